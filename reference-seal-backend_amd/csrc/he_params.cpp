@@ -1,0 +1,269 @@
+// he_params.cpp — see he_params.h.  Host-only C++17; no HIP calls here.
+#include "he_params.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+
+namespace he355 {
+
+ModU64 make_mod(u64 q)
+{
+    ModU64 m;
+    m.q = q;
+    const u128 one64 = (u128)1 << 64;
+    const u128 hi = one64 / q, rem = one64 % q;
+    m.cr1 = (u64)hi;
+    m.cr0 = (u64)((rem << 64) / q);
+    return m;
+}
+
+uint32_t bitrev(uint32_t x, int bits)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < bits; ++i, x >>= 1) r = (r << 1) | (x & 1);
+    return r;
+}
+
+static inline u64 mm(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+
+u64 Params::powmod(u64 b, u64 e, u64 q)
+{
+    u64 r = 1 % q;
+    b %= q;
+    for (; e; e >>= 1, b = mm(b, b, q))
+        if (e & 1) r = mm(r, b, q);
+    return r;
+}
+
+bool Params::is_prime(u64 n)
+{
+    // deterministic Miller-Rabin for 64-bit inputs
+    if (n < 2) return false;
+    for (u64 p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        if (n == p) return true;
+        if (n % p == 0) return false;
+    }
+    u64 d = n - 1;
+    int s = 0;
+    while ((d & 1) == 0) d >>= 1, ++s;
+    for (u64 a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+        u64 x = powmod(a, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool witness = true;
+        for (int k = 1; k < s && witness; ++k) {
+            x = mm(x, x, n);
+            if (x == n - 1) witness = false;
+        }
+        if (witness) return false;
+    }
+    return true;
+}
+
+// The search rule behind CoeffModulus::Create / PlainModulus::Batching: candidates = 1 (mod factor),
+// descending from just below 2^bit_size, down to 2^(bit_size-1).
+std::vector<u64> Params::get_primes(u64 factor, int bit_size, size_t count)
+{
+    std::vector<u64> out;
+    u64 v = (((u64)1 << bit_size) - 1) / factor * factor + 1;
+    const u64 floor_v = (u64)1 << (bit_size - 1);
+    for (; out.size() < count && v > floor_v; v -= factor)
+        if (is_prime(v)) out.push_back(v);
+    if (out.size() != count) throw std::logic_error("failed to find enough qualifying primes");
+    return out;
+}
+
+int Params::tc128_max_bits(size_t N)
+{
+    switch (N) {
+    case 1024: return 27;
+    case 2048: return 54;
+    case 4096: return 109;
+    case 8192: return 218;
+    case 16384: return 438;
+    case 32768: return 881;
+    default: return 0;
+    }
+}
+
+Params *Params::create(int scheme, size_t N, const std::vector<int> &bit_sizes, int plain_bits, bool sec128)
+{
+    if (bit_sizes.empty() || bit_sizes.size() >= (size_t)kMaxPrimes) throw std::invalid_argument("invalid coefficient modulus count");
+    if (sec128) {
+        int total = 0;
+        for (int b : bit_sizes) total += b;
+        const int cap = tc128_max_bits(N);
+        if (cap == 0 || total > cap) throw std::invalid_argument("encryption parameters are not set correctly: coefficient modulus too large for 128-bit security");
+    }
+    // one descending list per distinct bit size; slots are served from the back of the list
+    std::map<int, std::vector<u64>> lists;
+    for (int b : bit_sizes) {
+        if (b < 2 || b > 60) throw std::invalid_argument("coefficient modulus bit sizes must be in [2, 60]");
+        if (!lists.count(b)) lists[b] = get_primes(2 * (u64)N, b, (size_t)std::count(bit_sizes.begin(), bit_sizes.end(), b));
+    }
+    std::vector<u64> chain;
+    for (int b : bit_sizes) {
+        chain.push_back(lists[b].back());
+        lists[b].pop_back();
+    }
+    u64 t = 0;
+    if (scheme == kSchemeBFV) t = get_primes(2 * (u64)N, plain_bits, 1)[0];
+    return create_primes(scheme, N, chain, t);
+}
+
+Params *Params::create_primes(int scheme, size_t N, const std::vector<u64> &primes, u64 plain_modulus)
+{
+    Params *p = new Params();
+    try {
+        p->build(scheme, N, primes, plain_modulus);
+    } catch (...) {
+        delete p;
+        throw;
+    }
+    return p;
+}
+
+static u64 minimal_primitive_root(u64 two_n, u64 q)
+{
+    if ((q - 1) % two_n) throw std::invalid_argument("coefficient modulus is not NTT-friendly");
+    const u64 e = (q - 1) / two_n;
+    u64 root = 0;
+    for (u64 g = 2; g < 4096 && !root; ++g) {
+        u64 r = Params::powmod(g, e, q);
+        if (Params::powmod(r, two_n / 2, q) == q - 1) root = r;
+    }
+    if (!root) throw std::invalid_argument("no primitive root found");
+    // all primitive 2N-th roots are the odd powers of one of them; keep the smallest
+    const u64 step = mm(root, root, q);
+    u64 cur = root, best = root;
+    for (u64 i = 1; i < two_n / 2; ++i) {
+        cur = mm(cur, step, q);
+        best = std::min(best, cur);
+    }
+    return best;
+}
+
+static Tw16 make_tw(u64 w, u64 q, bool f64)
+{
+    Tw16 t;
+    if (f64) {
+        double wd = (double)w, wi = (double)w / (double)q;
+        std::memcpy(&t.a, &wd, 8);
+        std::memcpy(&t.b, &wi, 8);
+    } else {
+        t.a = w;
+        t.b = (u64)(((u128)w << 64) / q);
+    }
+    return t;
+}
+
+ArU64 PrimeTables::aru() const
+{
+    ArU64 a;
+    a.q = q;
+    a.two_q = 2 * q;
+    a.ninv = ninv;
+    a.ninv_q = (u64)(((u128)ninv << 64) / q);
+    return a;
+}
+ArF64 PrimeTables::arf() const
+{
+    ArF64 a;
+    a.q = (double)q;
+    a.qinv = 1.0 / (double)q;
+    a.ninv = (double)ninv;
+    a.ninv_i = (double)ninv / (double)q;
+    return a;
+}
+
+void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t)
+{
+    if (scheme_ != kSchemeBFV && scheme_ != kSchemeCKKS) throw std::invalid_argument("unsupported scheme");
+    int ln = 0;
+    while (((size_t)1 << ln) < N_) ++ln;
+    if (((size_t)1 << ln) != N_ || N_ < 1024 || N_ > 32768) throw std::invalid_argument("poly_modulus_degree must be a power of two in [1024, 32768]");
+    if (chain.empty() || chain.size() >= (size_t)kMaxPrimes) throw std::invalid_argument("invalid coefficient modulus count");
+    scheme = scheme_;
+    N = N_;
+    logn = ln;
+    logn1 = ln - 10;
+    K = chain.size();
+    Ltop = K > 1 ? K - 1 : 1;
+    plain_modulus = t;
+    if (scheme == kSchemeBFV && t < 2) throw std::invalid_argument("BFV needs a plain modulus");
+    const char *force = std::getenv("HE355_FORCE_U64");
+    const bool force_u64 = force && force[0] == '1';
+    primes.resize(K);
+    for (size_t i = 0; i < K; ++i) {
+        const u64 q = chain[i];
+        for (size_t k = 0; k < i; ++k)
+            if (chain[k] == q) throw std::invalid_argument("coefficient moduli must be distinct");
+        if (q >> 61 || !is_prime(q)) throw std::invalid_argument("coefficient modulus must be a prime below 2^61");
+        PrimeTables &pt = primes[i];
+        pt.q = q;
+        pt.bits = 64 - __builtin_clzll(q);
+        pt.mod = make_mod(q);
+        pt.root = minimal_primitive_root(2 * (u64)N, q);
+        pt.f64 = !force_u64 && (q >> 47) == 0;
+        pt.ninv = invmod((u64)N % q, q);
+        pt.fwd.resize(N);
+        pt.inv.resize(N);
+        pt.fwd_u64.resize(N);
+        const u64 iroot = invmod(pt.root, q);
+        u64 pw = 1, ipw = 1;
+        std::vector<u64> inv_u64(N);
+        for (size_t e = 0; e < N; ++e) {
+            const uint32_t k = bitrev((uint32_t)e, logn);
+            pt.fwd_u64[k] = pw;
+            inv_u64[k] = ipw;
+            pt.fwd[k] = make_tw(pw, q, pt.f64);
+            pt.inv[k] = make_tw(ipw, q, pt.f64);
+            pw = mm(pw, pt.root, q);
+            ipw = mm(ipw, iroot, q);
+        }
+        pt.inv_w0_scaled = make_tw(mm(inv_u64[1], pt.ninv, q), q, pt.f64);
+    }
+}
+
+uint32_t Params::galois_elt_from_step(int step) const
+{
+    const uint32_t n = (uint32_t)N, m = 2 * n;
+    if (step == 0) return m - 1; // column swap / conjugation
+    const uint32_t mag = (uint32_t)(step < 0 ? -(long)step : step);
+    if (mag >= n / 2) return 0;
+    const uint32_t k = step < 0 ? n / 2 - mag : mag;
+    u64 g = 1;
+    for (uint32_t i = 0; i < k; ++i) g = (g * 3) & (m - 1);
+    return (uint32_t)g;
+}
+
+std::vector<uint32_t> Params::galois_elts_all() const
+{
+    const u64 m = 2 * (u64)N;
+    std::vector<uint32_t> out{(uint32_t)(m - 1)};
+    u64 pos = 3, neg = 1;
+    for (u64 x = 1; x < m; x += 2)
+        if (((x * 3) & (m - 1)) == 1) { neg = x; break; }
+    for (int i = 0; i < logn - 1; ++i) {
+        out.push_back((uint32_t)pos);
+        out.push_back((uint32_t)neg);
+        pos = (pos * pos) & (m - 1);
+        neg = (neg * neg) & (m - 1);
+    }
+    return out;
+}
+
+std::vector<uint32_t> Params::galois_perm_ntt(uint32_t elt) const
+{
+    std::vector<uint32_t> perm(N);
+    for (size_t i = 0; i < N; ++i) {
+        const u64 odd = 2 * (u64)bitrev((uint32_t)i, logn) + 1; // exponent of psi evaluated at slot i
+        const u64 src = ((odd * elt) & (2 * N - 1)) >> 1;
+        perm[i] = bitrev((uint32_t)src, logn);
+    }
+    return perm;
+}
+
+} // namespace he355

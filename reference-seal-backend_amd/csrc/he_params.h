@@ -1,0 +1,73 @@
+// he_params.h — encryption-parameter object of the MI355X backend (host side).
+//
+// Mirrors what SEALContextWrapper::initCKKS / initBFV build through SEAL
+// (/root/reference/src/engine/seal_context.cpp:72-127): the prime chain for {60, bits x (depth-1), 60},
+// the BFV batching plain modulus, the 128-bit security gate, the NTT tables and the Galois element rules.
+// It owns only host memory; device copies are made by DeviceContext (device_context.h).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "modarith.h"
+
+namespace he355 {
+
+constexpr int kSchemeBFV = 1;  // seal::scheme_type::bfv
+constexpr int kSchemeCKKS = 2; // seal::scheme_type::ckks
+constexpr int kMaxPrimes = 64;
+
+struct PrimeTables {
+    u64 q = 0;
+    int bits = 0;
+    ModU64 mod{};
+    u64 root = 0;       // minimal primitive 2N-th root of unity
+    bool f64 = false;   // true: ArF64 engine (q < 2^47), false: ArU64
+    u64 ninv = 0;       // N^-1 mod q
+    std::vector<Tw16> fwd; // N entries, engine format, index = bit-reversed exponent
+    std::vector<Tw16> inv; // inverse of fwd entry-wise, same indexing
+    Tw16 inv_w0_scaled{};  // inv[1] * N^-1 (last inverse stage)
+    std::vector<u64> fwd_u64; // plain residues of fwd (for host-side client code / checks)
+    ArU64 aru() const;
+    ArF64 arf() const;
+};
+
+class Params {
+public:
+    // bit_sizes is the key-level chain; sec128 enforces SEAL's tc128 cap.  Throws std::invalid_argument.
+    static Params *create(int scheme, size_t N, const std::vector<int> &bit_sizes, int plain_bits, bool sec128);
+    static Params *create_primes(int scheme, size_t N, const std::vector<u64> &primes, u64 plain_modulus);
+
+    int scheme = 0;
+    size_t N = 0;
+    int logn = 0;
+    int logn1 = 0;      // N = 2^logn1 * 1024
+    size_t K = 0;       // all primes; the special prime is last
+    size_t Ltop = 0;    // data residues at the first level
+    u64 plain_modulus = 0;
+    std::vector<PrimeTables> primes;
+
+    u64 modulus(size_t i) const { return primes[i].q; }
+    // GaloisTool rules (generator 3)
+    uint32_t galois_elt_from_step(int step) const;        // 0 if |step| >= N/2 (SEAL throws)
+    std::vector<uint32_t> galois_elts_all() const;
+    // permutation tables: out[i] = in[perm[i]] (NTT form); coefficient form: out[idx[i]] = +-in[i]
+    std::vector<uint32_t> galois_perm_ntt(uint32_t elt) const;
+
+    // number theory helpers (also used by the client-side code)
+    static bool is_prime(u64 v);
+    static std::vector<u64> get_primes(u64 factor, int bit_size, size_t count);
+    static u64 powmod(u64 b, u64 e, u64 q);
+    static u64 invmod(u64 a, u64 q) { return powmod(a, q - 2, q); }
+    static int tc128_max_bits(size_t N);
+
+private:
+    Params() = default;
+    void build(int scheme, size_t N, const std::vector<u64> &primes, u64 plain_modulus);
+};
+
+ModU64 make_mod(u64 q);
+uint32_t bitrev(uint32_t x, int bits);
+
+} // namespace he355

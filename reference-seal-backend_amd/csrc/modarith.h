@@ -1,0 +1,217 @@
+// modarith.h — modular arithmetic for RNS residues on CDNA4 (gfx950).
+//
+// Two arithmetic engines, both producing the same canonical residues:
+//   ArU64 : 64-bit integer Harvey/Shoup lazy arithmetic for any prime < 2^61 (v_mad_u64_u32 chains).
+//           Measured on MI355X: 1.55 T butterflies/s (profiles/r01_alu_rates_mi355x.txt).
+//   ArF64 : exact integer arithmetic carried in fp64 for primes < 2^47 (the 40/45-bit primes the
+//           reference's parameter rule produces, seal_context.cpp:79-82).  v_fma_f64 / v_mul_f64 /
+//           v_rndne_f64 are full rate on MI355X; a butterfly is 8 fp64 instructions: 4.33 T butterflies/s.
+//           Every intermediate is an integer of magnitude < 2^53, every product is split exactly with
+//           one FMA, so results are bit-exact — fp64 is the ALU, not a precision choice.
+//
+// The functions are plain inline code with no HIP dependence so that tests/csim can run the identical
+// lane program on the CPU (test-only lane simulator); under hipcc they are __host__ __device__.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define HE_HD __host__ __device__ __forceinline__
+#else
+#define HE_HD inline
+#endif
+
+namespace he355 {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef unsigned __int128 u128;
+
+HE_HD u64 mulhi64(u64 a, u64 b) { return (u64)(((u128)a * b) >> 64); }
+
+// ---- Barrett constants for a modulus (floor(2^128/q) as two words) ---------------------------------
+struct ModU64 {
+    u64 q;
+    u64 cr0, cr1; // floor(2^128/q) low/high
+};
+
+// x < 2^64 -> [0,q)
+HE_HD u64 barrett64(u64 x, const ModU64 &m)
+{
+    u64 t = mulhi64(x, m.cr1);
+    u64 r = x - t * m.q;
+    return r >= m.q ? r - m.q : r;
+}
+// x < 2^128 -> [0,q)
+HE_HD u64 barrett128(u128 x, const ModU64 &m)
+{
+    u64 x0 = (u64)x, x1 = (u64)(x >> 64);
+    u64 carry = mulhi64(x0, m.cr0);
+    u128 t2 = (u128)x0 * m.cr1;
+    u128 s = (u128)(u64)t2 + carry;
+    u64 tmp1 = (u64)s;
+    u64 tmp3 = (u64)(t2 >> 64) + (u64)(s >> 64);
+    t2 = (u128)x1 * m.cr0;
+    s = (u128)tmp1 + (u64)t2;
+    carry = (u64)(t2 >> 64) + (u64)(s >> 64);
+    u64 quo = x1 * m.cr1 + tmp3 + carry;
+    u64 r = x0 - quo * m.q;
+    return r >= m.q ? r - m.q : r;
+}
+HE_HD u64 mulmod(u64 a, u64 b, const ModU64 &m) { return barrett128((u128)a * b, m); }
+HE_HD u64 addmod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s - q : s; }
+HE_HD u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+// x * w mod q with Shoup quotient wq = floor(w*2^64/q); result in [0,2q)
+HE_HD u64 mul_shoup_lazy(u64 x, u64 w, u64 wq, u64 q) { return w * x - mulhi64(x, wq) * q; }
+HE_HD u64 mul_shoup(u64 x, u64 w, u64 wq, u64 q)
+{
+    u64 r = mul_shoup_lazy(x, w, wq, q);
+    return r >= q ? r - q : r;
+}
+
+// One twiddle-table entry is 16 bytes for both engines (one dwordx4 / one s_load_dwordx4).
+struct alignas(16) Tw16 {
+    u64 a, b;
+};
+
+// ====================================================================================================
+// ArU64 — Harvey lazy butterflies, values in [0,4q) forward / [0,2q) inverse
+// ====================================================================================================
+struct ArU64 {
+    typedef u64 T;
+    u64 q, two_q;
+    u64 ninv, ninv_q; // N^-1 and its Shoup quotient (inverse transform scaling)
+
+    HE_HD T from_canon(u64 x) const { return x; }
+    HE_HD T from_raw(u64 bits) const { return bits; }
+    HE_HD u64 to_raw(T x) const { return x; }
+    // [0,4q) -> [0,q)
+    HE_HD u64 to_canon(T x) const
+    {
+        if (x >= two_q) x -= two_q;
+        if (x >= q) x -= q;
+        return x;
+    }
+    // forward (Cooley-Tukey): X,Y in [0,4q) -> [0,4q)
+    HE_HD void bfly_fwd(T &X, T &Y, const Tw16 &w) const
+    {
+        u64 u = X >= two_q ? X - two_q : X;
+        u64 v = mul_shoup_lazy(Y, w.a, w.b, q);
+        X = u + v;
+        Y = u + two_q - v;
+    }
+    // inverse (Gentleman-Sande): X,Y in [0,2q) -> [0,2q)
+    HE_HD void bfly_inv(T &X, T &Y, const Tw16 &w) const
+    {
+        u64 s = X + Y;
+        u64 d = X + two_q - Y;
+        X = s >= two_q ? s - two_q : s;
+        Y = mul_shoup_lazy(d, w.a, w.b, q);
+    }
+    // last inverse stage with N^-1 folded in: w must already be (w * N^-1) in Shoup form
+    HE_HD void bfly_inv_last(T &X, T &Y, const Tw16 &w_scaled) const
+    {
+        u64 s = X + Y;
+        u64 d = X + two_q - Y;
+        s = s >= two_q ? s - two_q : s;
+        X = mul_shoup_lazy(s, ninv, ninv_q, q);
+        Y = mul_shoup_lazy(d, w_scaled.a, w_scaled.b, q);
+    }
+    // scale by N^-1 only (N1 == 1 rings have no column pass)
+    HE_HD T scale_ninv(T x) const { return mul_shoup_lazy(x, ninv, ninv_q, q); }
+    // bring a forward-lazy value into the inverse-lazy range (and vice versa these are no-ops)
+    HE_HD T renorm(T x) const { return x >= two_q ? x - two_q : x; }
+    static constexpr bool kNeedsRenormInv = false;
+};
+
+// ====================================================================================================
+// ArF64 — exact arithmetic in doubles, centred lazy residues, q < 2^47
+// ====================================================================================================
+HE_HD double u52_to_f64(u64 x) // exact for x < 2^52
+{
+    union { u64 u; double d; } c;
+    c.u = x | 0x4330000000000000ull;
+    return c.d - 4503599627370496.0;
+}
+HE_HD u64 f64_to_u52(double x) // exact for integer 0 <= x < 2^52
+{
+    union { u64 u; double d; } c;
+    c.d = x + 4503599627370496.0;
+    return c.u & 0x000FFFFFFFFFFFFFull;
+}
+
+struct ArF64 {
+    typedef double T;
+    double q, qinv;     // q and fl(1/q)
+    double ninv, ninv_i; // N^-1 mod q (as double) and fl(ninv/q)
+
+    HE_HD T from_canon(u64 x) const { return u52_to_f64(x); }
+    HE_HD T from_raw(u64 bits) const
+    {
+        union { u64 u; double d; } c;
+        c.u = bits;
+        return c.d;
+    }
+    HE_HD u64 to_raw(T x) const
+    {
+        union { u64 u; double d; } c;
+        c.d = x;
+        return c.u;
+    }
+    // any integer |x| < 2^52 -> canonical [0,q)
+    HE_HD u64 to_canon(T x) const
+    {
+        double c = __builtin_floor(x * qinv);
+        double r = __builtin_fma(-c, q, x);
+        if (r < 0.0) r += q;
+        if (r >= q) r -= q;
+        return f64_to_u52(r);
+    }
+    // y*w mod q, centred: |result| <= q*(1/2 + |y|*2^-51); tw.a = w, tw.b = fl(w/q) as doubles
+    HE_HD T mulmod_c(T y, double w, double winv) const
+    {
+        double h = y * w;
+        double l = __builtin_fma(y, w, -h);
+        double c = __builtin_rint(y * winv);
+        double d = __builtin_fma(-c, q, h);
+        return d + l;
+    }
+    HE_HD static double tw_w(const Tw16 &t)
+    {
+        union { u64 u; double d; } c;
+        c.u = t.a;
+        return c.d;
+    }
+    HE_HD static double tw_wi(const Tw16 &t)
+    {
+        union { u64 u; double d; } c;
+        c.u = t.b;
+        return c.d;
+    }
+    HE_HD void bfly_fwd(T &X, T &Y, const Tw16 &w) const
+    {
+        double t = mulmod_c(Y, tw_w(w), tw_wi(w));
+        double x = X;
+        X = x + t;
+        Y = x - t;
+    }
+    HE_HD void bfly_inv(T &X, T &Y, const Tw16 &w) const
+    {
+        double s = X + Y;
+        double d = X - Y;
+        X = s;
+        Y = mulmod_c(d, tw_w(w), tw_wi(w));
+    }
+    HE_HD void bfly_inv_last(T &X, T &Y, const Tw16 &w_scaled) const
+    {
+        double s = X + Y;
+        double d = X - Y;
+        X = mulmod_c(s, ninv, ninv_i);
+        Y = mulmod_c(d, tw_w(w_scaled), tw_wi(w_scaled));
+    }
+    HE_HD T scale_ninv(T x) const { return mulmod_c(x, ninv, ninv_i); }
+    // recentre to |x| <= q/2 (+1): needed on the sum path of the inverse transform, which doubles per stage
+    HE_HD T renorm(T x) const { return __builtin_fma(-__builtin_rint(x * qinv), q, x); }
+    static constexpr bool kNeedsRenormInv = true;
+};
+
+} // namespace he355

@@ -1,0 +1,174 @@
+// sim_ntt.cpp — TEST-ONLY lane simulator.  Runs the product's lane programs (ntt_core.h / modarith.h,
+// the very code the HIP kernels execute) on the CPU, one 64-lane wave at a time with a simulated LDS,
+// so that the index maps, twiddle addressing and fp64 magnitude bounds can be checked against the oracle
+// without a GPU.  It is compiled only into tests/csim/_build/libcsim.so; the product never contains it.
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "../../reference-seal-backend_amd/csrc/he_params.h"
+#include "../../reference-seal-backend_amd/csrc/ntt_core.h"
+
+using namespace he355;
+
+static double g_maxmag = 0; // largest |value| seen by the fp64 engine at phase boundaries
+
+template <class T> static void track(const T *, int) {}
+template <> void track<double>(const double *x, int n)
+{
+    for (int i = 0; i < n; ++i) g_maxmag = std::max(g_maxmag, std::fabs(x[i]));
+}
+
+template <class Ar, int LOGN1> static void cols_fwd(const Ar &ar, const PrimeTables &pt, const u64 *in, u64 *raw)
+{
+    constexpr int N1 = 1 << LOGN1;
+    for (int b = 0; b < kRowN; ++b) {
+        typename Ar::T x[N1];
+        for (int a = 0; a < N1; ++a) x[a] = ar.from_canon(in[a * kRowN + b]);
+        col_fwd<Ar, LOGN1>(ar, x, pt.fwd.data());
+        track(x, N1);
+        for (int a = 0; a < N1; ++a) raw[a * kRowN + b] = ar.to_raw(x[a]);
+    }
+}
+template <class Ar, int LOGN1> static void cols_inv(const Ar &ar, const PrimeTables &pt, const u64 *raw, u64 *out)
+{
+    constexpr int N1 = 1 << LOGN1;
+    for (int b = 0; b < kRowN; ++b) {
+        typename Ar::T x[N1];
+        for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(raw[a * kRowN + b]);
+        col_inv<Ar, LOGN1>(ar, x, pt.inv.data(), pt.inv_w0_scaled);
+        track(x, N1);
+        for (int a = 0; a < N1; ++a) out[a * kRowN + b] = ar.to_canon(x[a]);
+    }
+}
+
+template <class Ar> static void rows_fwd(const Ar &ar, const PrimeTables &pt, int n1, bool in_raw, const u64 *in, u64 *out)
+{
+    typedef typename Ar::T T;
+    std::vector<T> lds(kLdsRow);
+    static T regs[64][kRowE];
+    for (int a = 0; a < n1; ++a) {
+        const u32 rowbase = (u32)(n1 + a);
+        const u64 *src = in + (size_t)a * kRowN;
+        for (int lane = 0; lane < 64; ++lane) {
+            T *x = regs[lane];
+            for (int r = 0; r < kRowE; ++r) x[r] = in_raw ? ar.from_raw(src[elemA(lane, r)]) : ar.from_canon(src[elemA(lane, r)]);
+            row_fwd_A(ar, x, pt.fwd.data(), rowbase);
+            track(x, kRowE);
+        }
+        for (int lane = 0; lane < 64; ++lane) lds_store_A(lds.data(), lane, regs[lane]);
+        for (int lane = 0; lane < 64; ++lane) lds_load_B(lds.data(), lane, regs[lane]);
+        for (int lane = 0; lane < 64; ++lane) { row_fwd_B(ar, regs[lane], pt.fwd.data(), rowbase, lane); track(regs[lane], kRowE); }
+        for (int lane = 0; lane < 64; ++lane) lds_store_B(lds.data(), lane, regs[lane]);
+        for (int lane = 0; lane < 64; ++lane) lds_load_C(lds.data(), lane, regs[lane]);
+        for (int lane = 0; lane < 64; ++lane) {
+            T *x = regs[lane];
+            row_fwd_C(ar, x, pt.fwd.data(), rowbase, lane);
+            track(x, kRowE);
+            for (int r = 0; r < kRowE; ++r) out[(size_t)a * kRowN + elemC(lane, r)] = ar.to_canon(x[r]);
+        }
+    }
+}
+template <class Ar> static void rows_inv(const Ar &ar, const PrimeTables &pt, int n1, const u64 *in, u64 *out)
+{
+    typedef typename Ar::T T;
+    std::vector<T> lds(kLdsRow);
+    static T regs[64][kRowE];
+    for (int a = 0; a < n1; ++a) {
+        const u32 rowbase = (u32)(n1 + a);
+        for (int lane = 0; lane < 64; ++lane) {
+            T *x = regs[lane];
+            for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(in[(size_t)a * kRowN + elemC(lane, r)]);
+            row_inv_C(ar, x, pt.inv.data(), rowbase, lane);
+            track(x, kRowE);
+        }
+        for (int lane = 0; lane < 64; ++lane) lds_store_C(lds.data(), lane, regs[lane]);
+        for (int lane = 0; lane < 64; ++lane) lds_load_B(lds.data(), lane, regs[lane]);
+        for (int lane = 0; lane < 64; ++lane) { row_inv_B(ar, regs[lane], pt.inv.data(), rowbase, lane); track(regs[lane], kRowE); }
+        for (int lane = 0; lane < 64; ++lane) lds_store_B(lds.data(), lane, regs[lane]);
+        for (int lane = 0; lane < 64; ++lane) lds_load_A(lds.data(), lane, regs[lane]);
+        for (int lane = 0; lane < 64; ++lane) {
+            T *x = regs[lane];
+            if (n1 == 1) row_inv_A<Ar, true>(ar, x, pt.inv.data(), rowbase, pt.inv_w0_scaled);
+            else row_inv_A<Ar, false>(ar, x, pt.inv.data(), rowbase, pt.inv_w0_scaled);
+            track(x, kRowE);
+            for (int r = 0; r < kRowE; ++r)
+                out[(size_t)a * kRowN + elemA(lane, r)] = (n1 == 1) ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
+        }
+    }
+}
+
+template <class Ar> static void fwd_any(const Ar &ar, const Params &P, const PrimeTables &pt, u64 *poly)
+{
+    const int n1 = 1 << P.logn1;
+    std::vector<u64> raw(P.N), out(P.N);
+    switch (P.logn1) {
+    case 0: break;
+    case 1: cols_fwd<Ar, 1>(ar, pt, poly, raw.data()); break;
+    case 2: cols_fwd<Ar, 2>(ar, pt, poly, raw.data()); break;
+    case 3: cols_fwd<Ar, 3>(ar, pt, poly, raw.data()); break;
+    case 4: cols_fwd<Ar, 4>(ar, pt, poly, raw.data()); break;
+    case 5: cols_fwd<Ar, 5>(ar, pt, poly, raw.data()); break;
+    }
+    rows_fwd(ar, pt, n1, P.logn1 > 0, P.logn1 > 0 ? raw.data() : poly, out.data());
+    std::memcpy(poly, out.data(), P.N * 8);
+}
+template <class Ar> static void inv_any(const Ar &ar, const Params &P, const PrimeTables &pt, u64 *poly)
+{
+    const int n1 = 1 << P.logn1;
+    std::vector<u64> raw(P.N), out(P.N);
+    rows_inv(ar, pt, n1, poly, raw.data());
+    switch (P.logn1) {
+    case 0: std::memcpy(out.data(), raw.data(), P.N * 8); break;
+    case 1: cols_inv<Ar, 1>(ar, pt, raw.data(), out.data()); break;
+    case 2: cols_inv<Ar, 2>(ar, pt, raw.data(), out.data()); break;
+    case 3: cols_inv<Ar, 3>(ar, pt, raw.data(), out.data()); break;
+    case 4: cols_inv<Ar, 4>(ar, pt, raw.data(), out.data()); break;
+    case 5: cols_inv<Ar, 5>(ar, pt, raw.data(), out.data()); break;
+    }
+    std::memcpy(poly, out.data(), P.N * 8);
+}
+
+extern "C" {
+void *sim_params_create(int scheme, size_t N, const int *bits, size_t n, int plain_bits, int sec128)
+{
+    try {
+        return Params::create(scheme, N, std::vector<int>(bits, bits + n), plain_bits, sec128 != 0);
+    } catch (std::exception &) {
+        return nullptr;
+    }
+}
+void sim_params_destroy(void *p) { delete (Params *)p; }
+uint64_t sim_modulus(void *p, size_t i) { return ((Params *)p)->primes[i].q; }
+uint64_t sim_root(void *p, size_t i) { return ((Params *)p)->primes[i].root; }
+int sim_is_f64(void *p, size_t i) { return ((Params *)p)->primes[i].f64; }
+size_t sim_K(void *p) { return ((Params *)p)->K; }
+double sim_maxmag_reset(void) { double m = g_maxmag; g_maxmag = 0; return m; }
+void sim_ntt_forward(void *p, size_t i, uint64_t *poly)
+{
+    const Params &P = *(Params *)p;
+    const PrimeTables &pt = P.primes[i];
+    if (pt.f64) fwd_any(pt.arf(), P, pt, poly);
+    else fwd_any(pt.aru(), P, pt, poly);
+}
+void sim_ntt_inverse(void *p, size_t i, uint64_t *poly)
+{
+    const Params &P = *(Params *)p;
+    const PrimeTables &pt = P.primes[i];
+    if (pt.f64) inv_any(pt.arf(), P, pt, poly);
+    else inv_any(pt.aru(), P, pt, poly);
+}
+uint32_t sim_galois_elt(void *p, int step) { return ((Params *)p)->galois_elt_from_step(step); }
+size_t sim_galois_elts_all(void *p, uint32_t *out)
+{
+    auto v = ((Params *)p)->galois_elts_all();
+    std::memcpy(out, v.data(), v.size() * 4);
+    return v.size();
+}
+void sim_galois_perm(void *p, uint32_t elt, uint32_t *out)
+{
+    auto v = ((Params *)p)->galois_perm_ntt(elt);
+    std::memcpy(out, v.data(), v.size() * 4);
+}
+}
