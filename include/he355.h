@@ -1,0 +1,122 @@
+/*
+ * he355.h — C ABI of the MI355X hot path ("thin extern C FFI" of the backend).
+ *
+ * These are the entry points a host in any language binds (cgo / JNI / ctypes / the C++ HEBench classes in
+ * reference-seal-backend_amd/csrc/bridge) in place of the seal::Evaluator calls the reference makes inside its
+ * timed operate() bodies.  Plain pointers and sizes only; no C++ or torch types.  All `d_*` pointers are
+ * device (HBM) pointers obtained from he355_malloc; ciphertext slabs are arrays of SEAL-layout ciphertexts
+ * [n][size][L][N] of uint64 residues (CKKS: NTT form), i.e. byte-compatible with seal::Ciphertext::data().
+ *
+ * Reference interface replaced (file:line under /root/reference):
+ *   he355_ctx_create            SEALContextWrapper::createCKKSContext/createBFVContext  include/engine/seal_context.h:32-50,
+ *                               parameter rule src/engine/seal_context.cpp:79-90,107-119
+ *   he355_set_relin_key         KeyGenerator::create_relin_keys                         src/engine/seal_context.cpp:53
+ *   he355_set_galois_key        KeyGenerator::create_galois_keys                        src/engine/seal_context.cpp:69
+ *   he355_add                   evaluator()->add          src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:340,
+ *                                                         src/benchmarks/bfv/seal_bfv_element_wise_benchmark.cpp:322
+ *   he355_multiply              evaluator()->multiply     src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:343
+ *   he355_multiply_relin        multiply + relinearize_inplace                src/benchmarks/ckks/seal_ckks_dot_product_benchmark.cpp:325-329
+ *     (rescale = 1)             ... + rescale_to_next_inplace                 src/benchmarks/ckks/seal_ckks_matmultval_benchmark.cpp:253-255
+ *   he355_relinearize           evaluator()->relinearize_inplace              src/engine/seal_context.cpp:390,447
+ *   he355_rescale               evaluator()->rescale_to_next_inplace          src/engine/seal_context.cpp:391,448
+ *   he355_rotate                evaluator()->rotate_vector                    src/engine/seal_context.cpp:337
+ *   he355_accumulate            SEALContextWrapper::accumulateCKKS            src/engine/seal_context.cpp:321-347
+ *   the Indexer                 ParameterIndexer{value_index,batch_size} and the result order r = i*b1 + x
+ *                                                         src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:322-336
+ *
+ * Error convention: every function returns 0 on success or a non-zero code (HE355_E_*); the message is kept
+ * per thread and read with he355_last_error() — the same shape as the API Bridge's ErrorCode +
+ * getLastErrorDescription.  There is NO CPU fallback: without a HIP device every device call fails with
+ * HE355_E_DEVICE.
+ */
+#ifndef HE355_H
+#define HE355_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HE355_SCHEME_BFV 1
+#define HE355_SCHEME_CKKS 2
+
+#define HE355_OK 0
+#define HE355_E_INVALID_ARGS 1 /* same meaning as HEBENCH_ECODE_INVALID_ARGS   */
+#define HE355_E_PARAMS 2       /* parameter/context error; the reference reports these as HEBSEAL_ECODE_SEAL_ERROR = 2 */
+#define HE355_E_DEVICE 3       /* HIP error or no device                        */
+#define HE355_E_CRITICAL 0x7FFFFFFF
+
+typedef struct he355_ctx he355_ctx;
+
+/* operand selection for result r of a batch (see the Indexer row above) */
+typedef struct {
+    uint64_t a_base, b_base; /* value_index of operand 0 / operand 1                  */
+    uint64_t b1;             /* batch size of operand 1: a = a_base + r / b1, b = b_base + r % b1 */
+    int32_t pairwise;        /* 1: a = a_base + r, b = b_base + r                     */
+    int32_t reserved;
+} he355_indexer;
+
+const char *he355_last_error(void);
+
+/* ---- context (host only; no HIP call is made until he355_device_init) ---- */
+int he355_ctx_create(int scheme, uint64_t poly_modulus_degree, const int32_t *bit_sizes, uint64_t n_bit_sizes, int plain_modulus_bits,
+                     int enforce_sec128, he355_ctx **out);
+int he355_ctx_create_primes(int scheme, uint64_t poly_modulus_degree, const uint64_t *primes, uint64_t n_primes, uint64_t plain_modulus,
+                            he355_ctx **out);
+void he355_ctx_destroy(he355_ctx *ctx);
+uint64_t he355_poly_degree(const he355_ctx *ctx);
+uint64_t he355_key_modulus_count(const he355_ctx *ctx);  /* K, special prime last       */
+uint64_t he355_data_modulus_count(const he355_ctx *ctx); /* L at the first data level   */
+uint64_t he355_modulus(const he355_ctx *ctx, uint64_t i);
+uint64_t he355_plain_modulus(const he355_ctx *ctx);
+int he355_prime_uses_fp64(const he355_ctx *ctx, uint64_t i); /* which arithmetic engine owns prime i */
+uint32_t he355_galois_elt_from_step(const he355_ctx *ctx, int step);
+uint64_t he355_galois_elts_all(const he355_ctx *ctx, uint32_t *out, uint64_t cap);
+
+/* ---- device ---- */
+int he355_device_count(int *count);
+int he355_device_init(he355_ctx *ctx, int device_ordinal); /* uploads tables; creates the stream */
+int he355_malloc(he355_ctx *ctx, uint64_t bytes, void **d_ptr);
+int he355_free(he355_ctx *ctx, void *d_ptr);
+int he355_upload(he355_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+int he355_download(he355_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+int he355_sync(he355_ctx *ctx);
+/* synthetic data: fill n_polys residue polynomials with uniform residues, polynomial p using prime
+ * prime_of[p % period] (throughput-mode inputs) */
+int he355_fill_uniform(he355_ctx *ctx, uint64_t *d_dst, uint64_t n_polys, const uint8_t *prime_of, uint32_t period, uint64_t seed);
+
+/* ---- evaluation keys: host arrays [L_top digits][2][K][N], NTT form (SEAL KSwitchKeys layout) ---- */
+int he355_set_relin_key(he355_ctx *ctx, const uint64_t *h_key);
+int he355_set_galois_key(he355_ctx *ctx, uint32_t galois_elt, const uint64_t *h_key);
+int he355_set_relin_key_synthetic(he355_ctx *ctx, uint64_t seed);                       /* uniform residues, generated in HBM */
+int he355_set_galois_key_synthetic(he355_ctx *ctx, uint32_t galois_elt, uint64_t seed);
+
+/* ---- batched evaluator ops on device slabs; L = residues at the operands' level ---- */
+int he355_add(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, uint64_t *d_out);
+int he355_sub(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, uint64_t *d_out);
+/* CKKS multiply: [.][2][L][N] x [.][2][L][N] -> [n][3][L][N] */
+int he355_multiply(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, uint64_t *d_out);
+/* multiply -> relinearize (-> rescale): out [n][2][L][N] or [n][2][L-1][N] */
+int he355_multiply_relin(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, int rescale,
+                         uint64_t *d_out);
+int he355_relinearize(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_ct3, uint64_t *d_out);            /* [n][3][L][N] -> [n][2][L][N] */
+int he355_rescale(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_in, uint64_t *d_out);         /* -> [n][size][L-1][N] */
+int he355_apply_galois(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, uint32_t galois_elt, uint64_t *d_out);
+int he355_rotate(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, int step, uint64_t *d_out);
+/* accumulateCKKS: in place log-tree sum of the first `count` slots; d_tmp: scratch slab of the same size */
+int he355_accumulate(he355_ctx *ctx, int L, uint64_t n, uint64_t *d_inout, uint64_t count, uint64_t *d_tmp);
+/* transforms of n_polys residue polynomials, polynomial p under prime prime_of[p % period] (test / client use) */
+int he355_ntt_forward(he355_ctx *ctx, uint64_t *d_polys, uint64_t n_polys, const uint8_t *prime_of, uint32_t period);
+int he355_ntt_inverse(he355_ctx *ctx, uint64_t *d_polys, uint64_t n_polys, const uint8_t *prime_of, uint32_t period);
+
+/* ---- timing on the stream the kernels run on (HIP events) ---- */
+int he355_timer_begin(he355_ctx *ctx);
+int he355_timer_end(he355_ctx *ctx, float *elapsed_ms);
+/* ---- tuning ---- */
+int he355_set_chunk(he355_ctx *ctx, uint64_t ops_per_chunk); /* ops processed per kernel sequence (scratch ~ 117 MiB/op at N=2^15, L=16) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

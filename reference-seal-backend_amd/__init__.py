@@ -1,0 +1,284 @@
+"""MI355X-native HEBench backend — Python loader for the C ABI (include/he355.h).
+
+The product is the shared library ``lib/libhebench_mi355x_backend.so`` (HIP kernels + C++17 host + the
+HEBench API-Bridge entry points).  This module only binds its C ABI with ctypes so that tests, ``bench.py``
+and ``__graft_entry__`` can drive it; it contains no arithmetic and never imports ``oracle``.
+
+Import with ``importlib.import_module("reference-seal-backend_amd")`` (the directory name has a hyphen).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhebench_mi355x_backend.so")
+
+SCHEME_BFV, SCHEME_CKKS = 1, 2
+OK, E_INVALID_ARGS, E_PARAMS, E_DEVICE = 0, 1, 2, 3
+
+
+class HE355Error(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"he355 error {code}: {msg}")
+        self.code = code
+
+
+class Indexer(C.Structure):
+    _fields_ = [("a_base", C.c_uint64), ("b_base", C.c_uint64), ("b1", C.c_uint64),
+                ("pairwise", C.c_int32), ("reserved", C.c_int32)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the backend for gfx950 with hipcc (csrc/Makefile)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.run(["make", "-C", csrc, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", csrc, "-j8", "-s"], check=True)
+    return LIB_PATH
+
+
+_lib = None
+_u64p = C.POINTER(C.c_uint64)
+
+
+def lib():
+    """The loaded shared library.  Fails loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no fallback path)")
+        L = C.CDLL(LIB_PATH)
+        vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int, C.c_uint32
+        vpp = C.POINTER(vp)
+        u8p = C.POINTER(C.c_uint8)
+        sig = {
+            "he355_last_error": (C.c_char_p, []),
+            "he355_ctx_create": (i32, [i32, u64, C.POINTER(C.c_int32), u64, i32, i32, vpp]),
+            "he355_ctx_create_primes": (i32, [i32, u64, _u64p, u64, u64, vpp]),
+            "he355_ctx_destroy": (None, [vp]),
+            "he355_poly_degree": (u64, [vp]), "he355_key_modulus_count": (u64, [vp]),
+            "he355_data_modulus_count": (u64, [vp]), "he355_modulus": (u64, [vp, u64]),
+            "he355_plain_modulus": (u64, [vp]), "he355_prime_uses_fp64": (i32, [vp, u64]),
+            "he355_galois_elt_from_step": (u32, [vp, i32]),
+            "he355_galois_elts_all": (u64, [vp, C.POINTER(u32), u64]),
+            "he355_device_count": (i32, [C.POINTER(i32)]),
+            "he355_device_init": (i32, [vp, i32]),
+            "he355_malloc": (i32, [vp, u64, vpp]), "he355_free": (i32, [vp, vp]),
+            "he355_upload": (i32, [vp, vp, vp, u64]), "he355_download": (i32, [vp, vp, vp, u64]),
+            "he355_sync": (i32, [vp]),
+            "he355_fill_uniform": (i32, [vp, vp, u64, u8p, u32, u64]),
+            "he355_set_relin_key": (i32, [vp, _u64p]), "he355_set_galois_key": (i32, [vp, u32, _u64p]),
+            "he355_set_relin_key_synthetic": (i32, [vp, u64]),
+            "he355_set_galois_key_synthetic": (i32, [vp, u32, u64]),
+            "he355_add": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
+            "he355_sub": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
+            "he355_multiply": (i32, [vp, i32, u64, vp, vp, Indexer, vp]),
+            "he355_multiply_relin": (i32, [vp, i32, u64, vp, vp, Indexer, i32, vp]),
+            "he355_relinearize": (i32, [vp, i32, u64, vp, vp]),
+            "he355_rescale": (i32, [vp, i32, i32, u64, vp, vp]),
+            "he355_apply_galois": (i32, [vp, i32, u64, vp, u32, vp]),
+            "he355_rotate": (i32, [vp, i32, u64, vp, i32, vp]),
+            "he355_accumulate": (i32, [vp, i32, u64, vp, u64, vp]),
+            "he355_ntt_forward": (i32, [vp, vp, u64, u8p, u32]),
+            "he355_ntt_inverse": (i32, [vp, vp, u64, u8p, u32]),
+            "he355_timer_begin": (i32, [vp]), "he355_timer_end": (i32, [vp, C.POINTER(C.c_float)]),
+            "he355_set_chunk": (i32, [vp, u64]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+C_ABI_SYMBOLS = [
+    "he355_last_error", "he355_ctx_create", "he355_ctx_create_primes", "he355_ctx_destroy", "he355_poly_degree",
+    "he355_key_modulus_count", "he355_data_modulus_count", "he355_modulus", "he355_plain_modulus",
+    "he355_prime_uses_fp64", "he355_galois_elt_from_step", "he355_galois_elts_all", "he355_device_count",
+    "he355_device_init", "he355_malloc", "he355_free", "he355_upload", "he355_download", "he355_sync",
+    "he355_fill_uniform", "he355_set_relin_key", "he355_set_galois_key", "he355_set_relin_key_synthetic",
+    "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_multiply_relin",
+    "he355_relinearize", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_accumulate",
+    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_set_chunk",
+]
+
+
+def _check(code: int):
+    if code != 0:
+        raise HE355Error(code, lib().he355_last_error().decode())
+
+
+def chain_bits(depth: int, coeff_bits: int) -> list[int]:
+    """{60, bits x (depth-1), 60}: the reference's rule (seal_context.cpp:79-82,107-110)."""
+    return [60] + [coeff_bits] * (depth - 1) + [60]
+
+
+class DeviceBuffer:
+    """A slab of uint64 in HBM owned by a Context."""
+
+    def __init__(self, ctx: "Context", n_u64: int):
+        self.ctx, self.n = ctx, int(n_u64)
+        p = C.c_void_p()
+        _check(lib().he355_malloc(ctx.h, self.n * 8, C.byref(p)))
+        self.ptr = p
+
+    def upload(self, arr: np.ndarray):
+        a = np.ascontiguousarray(arr, dtype=np.uint64)
+        assert a.size == self.n, (a.size, self.n)
+        _check(lib().he355_upload(self.ctx.h, self.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return self
+
+    def download(self, shape=None) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.uint64)
+        _check(lib().he355_download(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes))
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if self.ptr:
+            lib().he355_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """Host mirror of the reference's SEALContextWrapper for the hot path: parameters + device state."""
+
+    def __init__(self, scheme: int, N: int, bit_sizes=None, primes=None, plain_bits: int = 0,
+                 plain_modulus: int = 0, sec128: bool = True, device: int | None = None):
+        L = lib()
+        h = C.c_void_p()
+        if primes is not None:
+            arr = np.asarray(primes, dtype=np.uint64)
+            _check(L.he355_ctx_create_primes(scheme, N, arr.ctypes.data_as(_u64p), len(arr), plain_modulus, C.byref(h)))
+        else:
+            bs = (C.c_int32 * len(bit_sizes))(*bit_sizes)
+            _check(L.he355_ctx_create(scheme, N, bs, len(bit_sizes), plain_bits, int(sec128), C.byref(h)))
+        self.h = h
+        self.scheme, self.N = scheme, N
+        self.K = L.he355_key_modulus_count(h)
+        self.L = L.he355_data_modulus_count(h)
+        self.moduli = [L.he355_modulus(h, i) for i in range(self.K)]
+        self.fp64 = [bool(L.he355_prime_uses_fp64(h, i)) for i in range(self.K)]
+        self.t = L.he355_plain_modulus(h)
+        self._bufs = []
+        if device is not None:
+            self.device_init(device)
+
+    def device_init(self, device: int = 0):
+        _check(lib().he355_device_init(self.h, device))
+
+    def close(self):
+        if self.h:
+            for b in self._bufs:
+                b.free()
+            self._bufs = []
+            lib().he355_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- memory ----------------------------------------------------------------------------------
+    def alloc(self, n_u64: int) -> DeviceBuffer:
+        b = DeviceBuffer(self, n_u64)
+        self._bufs.append(b)
+        return b
+
+    def to_device(self, arr: np.ndarray) -> DeviceBuffer:
+        return self.alloc(arr.size).upload(arr)
+
+    def fill_uniform(self, buf: DeviceBuffer, n_polys: int, prime_of, seed: int):
+        pm = (C.c_uint8 * len(prime_of))(*prime_of)
+        _check(lib().he355_fill_uniform(self.h, buf.ptr, n_polys, pm, len(prime_of), seed))
+
+    def sync(self):
+        _check(lib().he355_sync(self.h))
+
+    def set_chunk(self, ops: int):
+        _check(lib().he355_set_chunk(self.h, ops))
+
+    # -- keys ------------------------------------------------------------------------------------
+    def set_relin_key(self, key: np.ndarray):
+        k = np.ascontiguousarray(key, dtype=np.uint64)
+        assert k.size == self.L * 2 * self.K * self.N
+        _check(lib().he355_set_relin_key(self.h, k.ctypes.data_as(_u64p)))
+
+    def set_galois_key(self, elt: int, key: np.ndarray):
+        k = np.ascontiguousarray(key, dtype=np.uint64)
+        assert k.size == self.L * 2 * self.K * self.N
+        _check(lib().he355_set_galois_key(self.h, elt, k.ctypes.data_as(_u64p)))
+
+    def set_relin_key_synthetic(self, seed: int):
+        _check(lib().he355_set_relin_key_synthetic(self.h, seed))
+
+    def set_galois_key_synthetic(self, elt: int, seed: int):
+        _check(lib().he355_set_galois_key_synthetic(self.h, elt, seed))
+
+    def galois_elt(self, step: int) -> int:
+        return lib().he355_galois_elt_from_step(self.h, step)
+
+    def galois_elts_all(self):
+        buf = (C.c_uint32 * 64)()
+        n = lib().he355_galois_elts_all(self.h, buf, 64)
+        return [int(x) for x in buf[:n]]
+
+    # -- evaluator (device slabs) ----------------------------------------------------------------
+    @staticmethod
+    def outer(a_base: int, b0: int, b_base: int, b1: int) -> Indexer:
+        """HEBench indexers: result r = i*b1 + x uses operand0[a_base+i], operand1[b_base+x]."""
+        return Indexer(a_base, b_base, b1, 0, 0)
+
+    @staticmethod
+    def pairwise(a_base: int = 0, b_base: int = 0) -> Indexer:
+        return Indexer(a_base, b_base, 1, 1, 0)
+
+    def add(self, L, size, n, a, b, ix, out, sub=False):
+        f = lib().he355_sub if sub else lib().he355_add
+        _check(f(self.h, L, size, n, a.ptr, b.ptr, ix, out.ptr))
+
+    def multiply(self, L, n, a, b, ix, out):
+        _check(lib().he355_multiply(self.h, L, n, a.ptr, b.ptr, ix, out.ptr))
+
+    def multiply_relin(self, L, n, a, b, ix, out, rescale=False):
+        _check(lib().he355_multiply_relin(self.h, L, n, a.ptr, b.ptr, ix, int(rescale), out.ptr))
+
+    def relinearize(self, L, n, ct3, out):
+        _check(lib().he355_relinearize(self.h, L, n, ct3.ptr, out.ptr))
+
+    def rescale(self, L, size, n, inp, out):
+        _check(lib().he355_rescale(self.h, L, size, n, inp.ptr, out.ptr))
+
+    def apply_galois(self, L, n, inp, elt, out):
+        _check(lib().he355_apply_galois(self.h, L, n, inp.ptr, elt, out.ptr))
+
+    def rotate(self, L, n, inp, step, out):
+        _check(lib().he355_rotate(self.h, L, n, inp.ptr, step, out.ptr))
+
+    def accumulate(self, L, n, inout, count, tmp):
+        _check(lib().he355_accumulate(self.h, L, n, inout.ptr, count, tmp.ptr))
+
+    def ntt(self, buf, n_polys, prime_of, inverse=False):
+        pm = (C.c_uint8 * len(prime_of))(*prime_of)
+        f = lib().he355_ntt_inverse if inverse else lib().he355_ntt_forward
+        _check(f(self.h, buf.ptr, n_polys, pm, len(prime_of)))
+
+    # -- timing on the kernels' stream -----------------------------------------------------------
+    def timer_begin(self):
+        _check(lib().he355_timer_begin(self.h))
+
+    def timer_end(self) -> float:
+        ms = C.c_float()
+        _check(lib().he355_timer_end(self.h, C.byref(ms)))
+        return float(ms.value)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib().he355_device_count(C.byref(n))
+    return int(n.value)

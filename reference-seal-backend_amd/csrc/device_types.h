@@ -1,0 +1,40 @@
+// device_types.h — plain structs shared by host launch code and HIP kernels.
+#pragma once
+#include "modarith.h"
+
+namespace he355 {
+
+// Per-prime constants + table pointers, resident in HBM (array of K entries), read wave-uniformly.
+struct PrimeDev {
+    u64 q, cr0, cr1;      // Barrett (u64 engine and element-wise reductions)
+    u64 ninv, ninv_q;     // N^-1 and Shoup quotient
+    double qd, qinv;      // fp64 engine
+    double ninv_d, ninv_i;
+    const Tw16 *fwd;      // N entries
+    const Tw16 *inv;      // N entries
+    Tw16 inv_w0_scaled;
+    int f64;              // 1: ArF64 engine owns this prime
+    int pad_;
+};
+
+// How result r picks its operands (HEBench outer product, ckks eltwise .cpp:334-336, or pairwise)
+struct Indexer {
+    u64 a_base, b_base; // value_index of operand 0 / 1
+    u64 b1;             // batch size of operand 1 (row length of the outer product)
+    int pairwise;       // 1: a = a_base + r, b = b_base + r
+    int pad_;
+};
+HE_HD u64 idx_a(const Indexer &ix, u64 r) { return ix.pairwise ? ix.a_base + r : ix.a_base + r / ix.b1; }
+HE_HD u64 idx_b(const Indexer &ix, u64 r) { return ix.pairwise ? ix.b_base + r : ix.b_base + r % ix.b1; }
+
+// A batch of residue polynomials for the generic transform kernels:
+// poly p of item it lives at base + it*item_stride + p*N and belongs to prime prime_of[p] (255 = skip).
+struct PolyView {
+    u64 *base;
+    u64 item_stride;
+    int polys_per_item;
+    int pad_;
+    unsigned char prime_of[64];
+};
+
+} // namespace he355

@@ -1,0 +1,712 @@
+// he355_api.hip — device context, per-op kernel sequences and the C ABI declared in include/he355.h.
+// Host code is C++17; the only way into the GPU is through the launchers of he355_kernels.h.
+// There is no CPU implementation of any evaluator op in this library: without a HIP device every device
+// entry point fails with HE355_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/he355.h"
+#include "he355_kernels.h"
+#include "he_params.h"
+#include "ntt_core.h"
+
+namespace he355 {
+
+struct DeviceError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+#define HIPCHECK(expr)                                                                                             \
+    do {                                                                                                           \
+        hipError_t e__ = (expr);                                                                                   \
+        if (e__ != hipSuccess)                                                                                     \
+            throw DeviceError(std::string("HIP error: ") + hipGetErrorString(e__) + " in " #expr " (" __FILE__ ":" + \
+                              std::to_string(__LINE__) + ")");                                                     \
+    } while (0)
+
+namespace {
+
+__device__ __forceinline__ u64 splitmix64(u64 x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+struct PrimeMap {
+    unsigned char prime_of[64];
+    u32 period;
+};
+
+// uniform-looking residues in [0, q): counter-based generator, value = floor(rand64 * q / 2^64)
+__global__ void k_fill_uniform(u64 *dst, u64 n_polys, int logN, const PrimeDev *primes, PrimeMap pm, u64 seed)
+{
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 poly = gid >> logN;
+    if (poly >= n_polys) return;
+    const u64 q = primes[pm.prime_of[poly % pm.period]].q;
+    dst[gid] = mulhi64(splitmix64(seed ^ splitmix64(gid)), q);
+}
+// key residues of fp64-engine primes are kept as doubles in HBM (exact: q < 2^47)
+__global__ void k_key_to_engine(u64 *key, u64 n_polys, int logN, const PrimeDev *primes, int K)
+{
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 poly = gid >> logN;
+    if (poly >= n_polys) return;
+    if (primes[poly % K].f64) {
+        union { u64 u; double d; } c;
+        c.d = u52_to_f64(key[gid]);
+        key[gid] = c.u;
+    }
+}
+
+} // namespace
+
+class DeviceContext {
+public:
+    DeviceContext(const Params &p, int device) : P(p), device_(device)
+    {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0) throw DeviceError("no HIP device available (the MI355X backend has no CPU fallback)");
+        if (device < 0 || device >= count) throw DeviceError("invalid device ordinal");
+        HIPCHECK(hipSetDevice(device));
+        HIPCHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        HIPCHECK(hipEventCreate(&ev0_));
+        HIPCHECK(hipEventCreate(&ev1_));
+        const size_t N = P.N, K = P.K;
+        std::vector<PrimeDev> pd(K);
+        for (size_t i = 0; i < K; ++i) {
+            const PrimeTables &pt = P.primes[i];
+            Tw16 *dfwd = nullptr, *dinv = nullptr;
+            HIPCHECK(hipMalloc(&dfwd, N * sizeof(Tw16)));
+            owned_.push_back(dfwd);
+            HIPCHECK(hipMalloc(&dinv, N * sizeof(Tw16)));
+            owned_.push_back(dinv);
+            HIPCHECK(hipMemcpy(dfwd, pt.fwd.data(), N * sizeof(Tw16), hipMemcpyHostToDevice));
+            HIPCHECK(hipMemcpy(dinv, pt.inv.data(), N * sizeof(Tw16), hipMemcpyHostToDevice));
+            PrimeDev &d = pd[i];
+            const ArU64 au = pt.aru();
+            const ArF64 af = pt.arf();
+            d.q = pt.q; d.cr0 = pt.mod.cr0; d.cr1 = pt.mod.cr1;
+            d.ninv = au.ninv; d.ninv_q = au.ninv_q;
+            d.qd = af.q; d.qinv = af.qinv; d.ninv_d = af.ninv; d.ninv_i = af.ninv_i;
+            d.fwd = dfwd; d.inv = dinv; d.inv_w0_scaled = pt.inv_w0_scaled;
+            d.f64 = pt.f64 ? 1 : 0; d.pad_ = 0;
+            env_.prime_f64[i] = pt.f64 ? 1 : 0;
+        }
+        HIPCHECK(hipMalloc(&d_primes_, K * sizeof(PrimeDev)));
+        HIPCHECK(hipMemcpy(d_primes_, pd.data(), K * sizeof(PrimeDev), hipMemcpyHostToDevice));
+        std::vector<FloorConst> fc(K * K);
+        for (size_t s = 0; s < K; ++s)
+            for (size_t i = 0; i < K; ++i) {
+                FloorConst &f = fc[s * K + i];
+                std::memset(&f, 0, sizeof(f));
+                if (s == i) continue;
+                const u64 qi = P.primes[i].q, qs = P.primes[s].q;
+                const u64 inv = Params::invmod(qs % qi, qi);
+                f.inv = inv;
+                f.inv_shoup = (u64)(((u128)inv << 64) / qi);
+                f.inv_d = (double)inv;
+                f.inv_i = (double)inv / (double)qi;
+                f.half_mod = (qs >> 1) % qi;
+            }
+        HIPCHECK(hipMalloc(&d_floor_, K * K * sizeof(FloorConst)));
+        HIPCHECK(hipMemcpy(d_floor_, fc.data(), K * K * sizeof(FloorConst), hipMemcpyHostToDevice));
+        env_.primes = d_primes_;
+        env_.floor_consts = d_floor_;
+        env_.N = (int)N; env_.logn1 = P.logn1; env_.K = (int)K; env_.Ltop = (int)P.Ltop; env_.scheme = P.scheme;
+        env_.stream = stream_;
+        const char *bs = std::getenv("HE355_BLOCK_SYNC");
+        set_block_sync(bs && bs[0] == '1');
+        const char *ch = std::getenv("HE355_CHUNK");
+        if (ch && std::atoi(ch) > 0) chunk_ = (size_t)std::atoi(ch);
+    }
+    ~DeviceContext()
+    {
+        (void)hipSetDevice(device_);
+        (void)hipStreamSynchronize(stream_);
+        for (void *p : owned_) (void)hipFree(p);
+        (void)hipFree(d_primes_);
+        (void)hipFree(d_floor_);
+        (void)hipFree(d_relin_);
+        for (auto &kv : d_galois_) (void)hipFree(kv.second);
+        for (auto &kv : d_perm_) (void)hipFree(kv.second);
+        (void)hipFree(scratch_);
+        (void)hipFree(rot_tmp_);
+        (void)hipEventDestroy(ev0_);
+        (void)hipEventDestroy(ev1_);
+        (void)hipStreamDestroy(stream_);
+    }
+
+    void use() { HIPCHECK(hipSetDevice(device_)); }
+    hipStream_t stream() const { return stream_; }
+    const KernelEnv &env() const { return env_; }
+    void set_chunk(size_t c) { chunk_ = c ? c : 1; }
+
+    size_t key_elems() const { return P.Ltop * 2 * P.K * P.N; }
+
+    void key_from_host(u64 **slot, const u64 *h_key)
+    {
+        use();
+        if (!*slot) HIPCHECK(hipMalloc(slot, key_elems() * 8));
+        HIPCHECK(hipMemcpyAsync(*slot, h_key, key_elems() * 8, hipMemcpyHostToDevice, stream_));
+        key_finish(*slot);
+    }
+    void key_synthetic(u64 **slot, u64 seed)
+    {
+        use();
+        if (!*slot) HIPCHECK(hipMalloc(slot, key_elems() * 8));
+        PrimeMap pm;
+        pm.period = (u32)P.K;
+        for (size_t i = 0; i < P.K; ++i) pm.prime_of[i] = (unsigned char)i;
+        const u64 n_polys = P.Ltop * 2 * P.K, total = n_polys * P.N;
+        hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, *slot, n_polys, P.logn, d_primes_, pm, seed);
+        key_finish(*slot);
+    }
+    void key_finish(u64 *d_key)
+    {
+        const u64 n_polys = P.Ltop * 2 * P.K, total = n_polys * P.N;
+        hipLaunchKernelGGL(k_key_to_engine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, d_key, n_polys, P.logn, d_primes_, (int)P.K);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(stream_));
+    }
+    u64 **relin_slot() { return &d_relin_; }
+    u64 **galois_slot(uint32_t elt) { return &d_galois_[elt]; }
+    const u64 *relin_key() const { return d_relin_; }
+    const u64 *galois_key(uint32_t elt) const
+    {
+        auto it = d_galois_.find(elt);
+        return it == d_galois_.end() ? nullptr : it->second;
+    }
+    const uint32_t *perm(uint32_t elt)
+    {
+        auto it = d_perm_.find(elt);
+        if (it != d_perm_.end()) return it->second;
+        const std::vector<uint32_t> h = P.galois_perm_ntt(elt);
+        uint32_t *d = nullptr;
+        HIPCHECK(hipMalloc(&d, P.N * 4));
+        HIPCHECK(hipMemcpy(d, h.data(), P.N * 4, hipMemcpyHostToDevice));
+        d_perm_[elt] = d;
+        return d;
+    }
+
+    void fill_uniform(u64 *dst, u64 n_polys, const uint8_t *prime_of, u32 period, u64 seed)
+    {
+        use();
+        if (period == 0 || period > 64) throw std::invalid_argument("prime map period must be in [1, 64]");
+        PrimeMap pm;
+        pm.period = period;
+        for (u32 i = 0; i < period; ++i) {
+            if (prime_of[i] >= P.K) throw std::invalid_argument("prime index out of range");
+            pm.prime_of[i] = prime_of[i];
+        }
+        const u64 total = n_polys * P.N;
+        hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, dst, n_polys, P.logn, d_primes_, pm, seed);
+        HIPCHECK(hipGetLastError());
+    }
+
+    // ---- per-op sequences ------------------------------------------------------------------------------
+    void check_level(int L) const
+    {
+        if (L < 1 || (size_t)L > P.Ltop) throw std::invalid_argument("level out of range");
+    }
+    void addsub(int L, int size, u64 n, const u64 *a, const u64 *b, Indexer ix, u64 *out, bool sub)
+    {
+        use();
+        check_level(L);
+        launch_addsub(env_, L, size, n, a, b, ix, out, sub);
+        HIPCHECK(hipGetLastError());
+    }
+    void multiply(int L, u64 n, const u64 *a, const u64 *b, Indexer ix, u64 *out)
+    {
+        use();
+        check_level(L);
+        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_multiply implements the CKKS (NTT-form) product");
+        launch_mul3(env_, L, n, a, b, ix, out);
+        HIPCHECK(hipGetLastError());
+    }
+
+    struct Scratch {
+        KsBuffers ks;
+        u64 *rlr; // [C][3][N]  tail of the rescale prime after the inverse row pass
+        u64 *f;   // [C][3][L][N]
+    };
+    // layout of the scratch arena for `c` ops at level L
+    Scratch scratch(size_t c, int L)
+    {
+        const size_t N = P.N, LN = (size_t)L * N;
+        const size_t per_op = 2 * LN + LN + LN + (size_t)(L + 1) * LN + 2 * LN + 2 * N + 2 * LN + 3 * N + 3 * LN;
+        const size_t need = per_op * c * 8;
+        if (need > scratch_bytes_) {
+            HIPCHECK(hipStreamSynchronize(stream_));
+            if (scratch_) HIPCHECK(hipFree(scratch_));
+            scratch_ = nullptr;
+            scratch_bytes_ = 0;
+            HIPCHECK(hipMalloc(&scratch_, need));
+            scratch_bytes_ = need;
+        }
+        Scratch s;
+        u64 *p = scratch_;
+        s.ks.c01 = p; p += c * 2 * LN; s.ks.c01_item_stride = 2 * LN;
+        s.ks.c2n = p; p += c * LN;
+        s.ks.c2r = p; p += c * LN;
+        s.ks.d = p; p += c * (size_t)(L + 1) * LN;
+        s.ks.t = p; p += c * 2 * LN;
+        s.ks.tpr = p; p += c * 2 * N;
+        s.ks.e = p; p += c * 2 * LN;
+        s.rlr = p; p += c * 3 * N;
+        s.f = p;
+        return s;
+    }
+
+    // K2, K3, mod-down; result added into B.c01.  with_tail: also start the rescale (tail of prime L-1)
+    void key_switch_tail(int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail)
+    {
+        const size_t N = P.N, LN = (size_t)L * N;
+        const int SP = (int)P.K - 1;
+        launch_k2(env_, L, nc, B);
+        launch_k3(env_, L, nc, B, key);
+        launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
+        FloorRowsArgs fr;
+        fr.src_prime = SP; fr.n_tgt = L; fr.n_src = 2;
+        fr.cols = B.e;
+        fr.tsrc = B.t; fr.tsrc_op_stride = 2 * LN; fr.tsrc_poly_stride = LN;
+        fr.addend = B.c01; fr.add_op_stride = B.c01_item_stride; fr.add_poly_stride = LN;
+        fr.out = B.c01; fr.out_op_stride = B.c01_item_stride; fr.out_poly_stride = LN;
+        fr.tail_prime = with_tail ? L - 1 : -1;
+        fr.tail = S.rlr;
+        launch_floor_rows(env_, nc, fr);
+    }
+    void rescale_tail(int L, int size, u64 nc, const Scratch &S, const u64 *src, u64 src_op_stride, u64 *out)
+    {
+        const size_t N = P.N, LN = (size_t)L * N, L1N = (size_t)(L - 1) * N;
+        launch_floor_cols(env_, L - 1, L - 1, nc * size, S.rlr, S.f);
+        FloorRowsArgs fr;
+        fr.src_prime = L - 1; fr.n_tgt = L - 1; fr.n_src = size;
+        fr.cols = S.f;
+        fr.tsrc = src; fr.tsrc_op_stride = src_op_stride; fr.tsrc_poly_stride = LN;
+        fr.addend = nullptr; fr.add_op_stride = 0; fr.add_poly_stride = 0;
+        fr.out = out; fr.out_op_stride = (u64)size * L1N; fr.out_poly_stride = L1N;
+        fr.tail_prime = -1; fr.tail = nullptr;
+        launch_floor_rows(env_, nc, fr);
+    }
+    void require_keyswitch() const
+    {
+        if (P.K < 2) throw std::invalid_argument("encryption parameters do not support key switching");
+    }
+
+    void multiply_relin(int L, u64 n, const u64 *a, const u64 *b, Indexer ix, bool rescale, u64 *out)
+    {
+        use();
+        check_level(L);
+        require_keyswitch();
+        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_multiply_relin implements the CKKS pipeline");
+        if (!d_relin_) throw std::invalid_argument("relinearization key not set");
+        if (rescale && L < 2) throw std::invalid_argument("cannot rescale at the last level");
+        const size_t N = P.N, LN = (size_t)L * N;
+        for (u64 off = 0; off < n; off += chunk_) {
+            const u64 nc = std::min<u64>(chunk_, n - off);
+            Scratch S = scratch(chunk_, L);
+            KsBuffers B = S.ks;
+            if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
+            launch_k1(env_, L, K1_MUL, nc, off, a, b, ix, nullptr, B);
+            key_switch_tail(L, nc, S, B, d_relin_, rescale);
+            if (rescale) rescale_tail(L, 2, nc, S, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N);
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    void relinearize(int L, u64 n, const u64 *ct3, u64 *out)
+    {
+        use();
+        check_level(L);
+        require_keyswitch();
+        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_relinearize: BFV path not available in this build");
+        if (!d_relin_) throw std::invalid_argument("relinearization key not set");
+        const size_t N = P.N, LN = (size_t)L * N;
+        Indexer ix{};
+        for (u64 off = 0; off < n; off += chunk_) {
+            const u64 nc = std::min<u64>(chunk_, n - off);
+            Scratch S = scratch(chunk_, L);
+            KsBuffers B = S.ks;
+            B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
+            launch_k1(env_, L, K1_CT3, nc, off, ct3, nullptr, ix, nullptr, B);
+            key_switch_tail(L, nc, S, B, d_relin_, false);
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    void rescale(int L, int size, u64 n, const u64 *in, u64 *out)
+    {
+        use();
+        check_level(L);
+        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_rescale is a CKKS operation");
+        if (L < 2) throw std::invalid_argument("cannot rescale at the last level");
+        if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
+        const size_t N = P.N, LN = (size_t)L * N;
+        for (u64 off = 0; off < n; off += chunk_) {
+            const u64 nc = std::min<u64>(chunk_, n - off);
+            Scratch S = scratch(chunk_, L);
+            const u64 *src = in + off * size * LN;
+            launch_rows_inv_select(env_, L - 1, nc * size, src + (size_t)(L - 1) * N, LN, S.rlr);
+            rescale_tail(L, size, nc, S, src, (u64)size * LN, out + off * size * (size_t)(L - 1) * N);
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    void apply_galois(int L, u64 n, const u64 *in, uint32_t elt, u64 *out)
+    {
+        use();
+        check_level(L);
+        require_keyswitch();
+        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_apply_galois: BFV path not available in this build");
+        if (!(elt & 1) || elt >= 2 * P.N) throw std::invalid_argument("Galois element is not valid");
+        const u64 *key = galois_key(elt);
+        if (!key) throw std::invalid_argument("Galois key not present");
+        if (in == out) throw std::invalid_argument("apply_galois cannot run in place");
+        const uint32_t *pm = perm(elt);
+        const size_t N = P.N, LN = (size_t)L * N;
+        Indexer ix{};
+        for (u64 off = 0; off < n; off += chunk_) {
+            const u64 nc = std::min<u64>(chunk_, n - off);
+            Scratch S = scratch(chunk_, L);
+            KsBuffers B = S.ks;
+            B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
+            launch_k1(env_, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B);
+            key_switch_tail(L, nc, S, B, key, false);
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    // Evaluator::rotate_internal: use the key of the step if present, otherwise the NAF decomposition
+    void rotate(int L, u64 n, const u64 *in, int step, u64 *out)
+    {
+        use();
+        const size_t bytes = n * 2 * (size_t)L * P.N * 8;
+        if (step == 0) {
+            if (in != out) HIPCHECK(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, stream_));
+            return;
+        }
+        const uint32_t elt = P.galois_elt_from_step(step);
+        if (!elt) throw std::invalid_argument("step count too large");
+        if (galois_key(elt)) { apply_galois(L, n, in, elt, out); return; }
+        std::vector<int> naf;
+        {
+            const bool neg = step < 0;
+            long v = neg ? -(long)step : step;
+            for (int i = 0; v; ++i) {
+                const int zi = (v & 1) ? 2 - (int)(v & 3) : 0;
+                v = (v - zi) >> 1;
+                if (zi) naf.push_back((neg ? -zi : zi) * (1 << i));
+            }
+        }
+        if (naf.size() == 1) throw std::invalid_argument("Galois key not present");
+        if (in == out) throw std::invalid_argument("rotate cannot run in place");
+        std::vector<int> steps;
+        for (int s : naf)
+            if ((size_t)(s < 0 ? -s : s) != P.N / 2) steps.push_back(s); // a term of N/2 is no rotation
+        if (steps.empty()) {
+            HIPCHECK(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, stream_));
+            return;
+        }
+        if (steps.size() > 1 && bytes > rot_tmp_bytes_) {
+            HIPCHECK(hipStreamSynchronize(stream_));
+            if (rot_tmp_) HIPCHECK(hipFree(rot_tmp_));
+            rot_tmp_ = nullptr; rot_tmp_bytes_ = 0;
+            HIPCHECK(hipMalloc(&rot_tmp_, bytes));
+            rot_tmp_bytes_ = bytes;
+        }
+        // ping-pong between out and the temporary so that the last rotation lands in out
+        const u64 *cur = in;
+        const size_t m = steps.size();
+        for (size_t t = 0; t < m; ++t) {
+            u64 *dst = ((m - 1 - t) % 2 == 0) ? out : rot_tmp_;
+            const uint32_t e = P.galois_elt_from_step(steps[t]);
+            if (!e || !galois_key(e)) throw std::invalid_argument("Galois key not present");
+            apply_galois(L, n, cur, e, dst);
+            cur = dst;
+        }
+    }
+    // SEALContextWrapper::accumulateCKKS (seal_context.cpp:321-347), count > 0
+    void accumulate(int L, u64 n, u64 *inout, u64 count, u64 *tmp)
+    {
+        if (count == 0) throw std::invalid_argument("accumulate with count 0 needs a fresh encryption of zero (client side)");
+        const u64 slots = P.N / 2;
+        if (count > slots) count = slots;
+        int rotations = 64 - __builtin_clzll(count);
+        if (((u64)1 << (rotations - 1)) == count) --rotations;
+        Indexer ix{};
+        ix.pairwise = 1;
+        for (int i = 0; i < rotations; ++i) {
+            rotate(L, n, inout, 1 << i, tmp);
+            addsub(L, 2, n, inout, tmp, ix, inout, false);
+        }
+    }
+    void ntt(u64 *polys, u64 n_polys, const uint8_t *prime_of, u32 period, bool inverse)
+    {
+        use();
+        if (period == 0 || period > 64) throw std::invalid_argument("prime map period must be in [1, 64]");
+        if (n_polys % period) throw std::invalid_argument("polynomial count must be a multiple of the prime map period");
+        PolyView v;
+        v.base = polys; v.item_stride = (u64)period * P.N; v.polys_per_item = (int)period; v.pad_ = 0;
+        for (u32 i = 0; i < period; ++i) {
+            if (prime_of[i] >= P.K) throw std::invalid_argument("prime index out of range");
+            v.prime_of[i] = prime_of[i];
+        }
+        if (inverse) launch_ntt_inverse(env_, v, (u32)(n_polys / period));
+        else launch_ntt_forward(env_, v, (u32)(n_polys / period));
+        HIPCHECK(hipGetLastError());
+    }
+    void timer_begin() { use(); HIPCHECK(hipEventRecord(ev0_, stream_)); }
+    float timer_end()
+    {
+        use();
+        HIPCHECK(hipEventRecord(ev1_, stream_));
+        HIPCHECK(hipEventSynchronize(ev1_));
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
+        return ms;
+    }
+    void sync() { use(); HIPCHECK(hipStreamSynchronize(stream_)); }
+
+private:
+    const Params &P;
+    int device_;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    KernelEnv env_{};
+    PrimeDev *d_primes_ = nullptr;
+    FloorConst *d_floor_ = nullptr;
+    std::vector<void *> owned_;
+    u64 *d_relin_ = nullptr;
+    std::map<uint32_t, u64 *> d_galois_;
+    std::map<uint32_t, uint32_t *> d_perm_;
+    u64 *scratch_ = nullptr;
+    size_t scratch_bytes_ = 0;
+    u64 *rot_tmp_ = nullptr;
+    size_t rot_tmp_bytes_ = 0;
+    size_t chunk_ = 32;
+};
+
+} // namespace he355
+
+// =========================================================================================================
+// C ABI
+// =========================================================================================================
+using namespace he355;
+
+struct he355_ctx {
+    std::unique_ptr<Params> params;
+    std::unique_ptr<DeviceContext> dev;
+};
+
+static thread_local std::string g_last_error;
+
+template <class F> static int guarded(F &&f)
+{
+    try {
+        f();
+        return HE355_OK;
+    } catch (const DeviceError &e) {
+        g_last_error = e.what();
+        return HE355_E_DEVICE;
+    } catch (const std::invalid_argument &e) {
+        g_last_error = e.what();
+        return HE355_E_INVALID_ARGS;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return HE355_E_PARAMS;
+    } catch (...) {
+        g_last_error = "unknown error";
+        return HE355_E_CRITICAL;
+    }
+}
+static DeviceContext &dev(he355_ctx *c)
+{
+    if (!c) throw std::invalid_argument("null context");
+    if (!c->dev) throw DeviceError("device not initialised: call he355_device_init first (no CPU fallback exists)");
+    return *c->dev;
+}
+static Indexer to_ix(const he355_indexer &i)
+{
+    Indexer x;
+    x.a_base = i.a_base; x.b_base = i.b_base; x.b1 = i.b1 ? i.b1 : 1; x.pairwise = i.pairwise; x.pad_ = 0;
+    return x;
+}
+
+extern "C" {
+
+const char *he355_last_error(void) { return g_last_error.c_str(); }
+
+int he355_ctx_create(int scheme, uint64_t N, const int32_t *bit_sizes, uint64_t n, int plain_bits, int sec128, he355_ctx **out)
+{
+    if (!out || !bit_sizes) { g_last_error = "null argument"; return HE355_E_INVALID_ARGS; }
+    *out = nullptr;
+    try {
+        std::unique_ptr<he355_ctx> c(new he355_ctx());
+        c->params.reset(Params::create(scheme, (size_t)N, std::vector<int>(bit_sizes, bit_sizes + n), plain_bits, sec128 != 0));
+        *out = c.release();
+        return HE355_OK;
+    } catch (const std::exception &e) { // SEAL exceptions are reported as code 2 by the reference (seal_context.cpp:94-97)
+        g_last_error = e.what();
+        return HE355_E_PARAMS;
+    }
+}
+int he355_ctx_create_primes(int scheme, uint64_t N, const uint64_t *primes, uint64_t n, uint64_t plain_modulus, he355_ctx **out)
+{
+    if (!out || !primes) { g_last_error = "null argument"; return HE355_E_INVALID_ARGS; }
+    *out = nullptr;
+    try {
+        std::unique_ptr<he355_ctx> c(new he355_ctx());
+        c->params.reset(Params::create_primes(scheme, (size_t)N, std::vector<u64>(primes, primes + n), plain_modulus));
+        *out = c.release();
+        return HE355_OK;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return HE355_E_PARAMS;
+    }
+}
+void he355_ctx_destroy(he355_ctx *ctx) { delete ctx; }
+uint64_t he355_poly_degree(const he355_ctx *c) { return c->params->N; }
+uint64_t he355_key_modulus_count(const he355_ctx *c) { return c->params->K; }
+uint64_t he355_data_modulus_count(const he355_ctx *c) { return c->params->Ltop; }
+uint64_t he355_modulus(const he355_ctx *c, uint64_t i) { return i < c->params->K ? c->params->primes[i].q : 0; }
+uint64_t he355_plain_modulus(const he355_ctx *c) { return c->params->plain_modulus; }
+int he355_prime_uses_fp64(const he355_ctx *c, uint64_t i) { return i < c->params->K ? (int)c->params->primes[i].f64 : 0; }
+uint32_t he355_galois_elt_from_step(const he355_ctx *c, int step) { return c->params->galois_elt_from_step(step); }
+uint64_t he355_galois_elts_all(const he355_ctx *c, uint32_t *out, uint64_t cap)
+{
+    const auto v = c->params->galois_elts_all();
+    for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+    return v.size();
+}
+
+int he355_device_count(int *count)
+{
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (count) *count = (e == hipSuccess) ? n : 0;
+    if (e != hipSuccess) { g_last_error = std::string("HIP error: ") + hipGetErrorString(e); return HE355_E_DEVICE; }
+    return HE355_OK;
+}
+int he355_device_init(he355_ctx *c, int device)
+{
+    return guarded([&] {
+        if (!c) throw std::invalid_argument("null context");
+        c->dev.reset(new DeviceContext(*c->params, device));
+    });
+}
+int he355_malloc(he355_ctx *c, uint64_t bytes, void **d_ptr)
+{
+    return guarded([&] {
+        dev(c).use();
+        if (!d_ptr) throw std::invalid_argument("null pointer");
+        HIPCHECK(hipMalloc(d_ptr, bytes ? bytes : 8));
+    });
+}
+int he355_free(he355_ctx *c, void *d_ptr)
+{
+    return guarded([&] {
+        dev(c).sync();
+        HIPCHECK(hipFree(d_ptr));
+    });
+}
+int he355_upload(he355_ctx *c, void *d_dst, const void *h_src, uint64_t bytes)
+{
+    return guarded([&] {
+        dev(c).use();
+        HIPCHECK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, dev(c).stream()));
+        HIPCHECK(hipStreamSynchronize(dev(c).stream()));
+    });
+}
+int he355_download(he355_ctx *c, void *h_dst, const void *d_src, uint64_t bytes)
+{
+    return guarded([&] {
+        dev(c).use();
+        HIPCHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, dev(c).stream()));
+        HIPCHECK(hipStreamSynchronize(dev(c).stream()));
+    });
+}
+int he355_sync(he355_ctx *c) { return guarded([&] { dev(c).sync(); }); }
+int he355_fill_uniform(he355_ctx *c, uint64_t *d_dst, uint64_t n_polys, const uint8_t *prime_of, uint32_t period, uint64_t seed)
+{
+    return guarded([&] { dev(c).fill_uniform(d_dst, n_polys, prime_of, period, seed); });
+}
+int he355_set_relin_key(he355_ctx *c, const uint64_t *h_key)
+{
+    return guarded([&] { dev(c).key_from_host(dev(c).relin_slot(), h_key); });
+}
+int he355_set_galois_key(he355_ctx *c, uint32_t elt, const uint64_t *h_key)
+{
+    return guarded([&] { dev(c).key_from_host(dev(c).galois_slot(elt), h_key); });
+}
+int he355_set_relin_key_synthetic(he355_ctx *c, uint64_t seed)
+{
+    return guarded([&] { dev(c).key_synthetic(dev(c).relin_slot(), seed); });
+}
+int he355_set_galois_key_synthetic(he355_ctx *c, uint32_t elt, uint64_t seed)
+{
+    return guarded([&] { dev(c).key_synthetic(dev(c).galois_slot(elt), seed); });
+}
+int he355_add(he355_ctx *c, int L, int size, uint64_t n, const uint64_t *a, const uint64_t *b, he355_indexer ix, uint64_t *out)
+{
+    return guarded([&] { dev(c).addsub(L, size, n, a, b, to_ix(ix), out, false); });
+}
+int he355_sub(he355_ctx *c, int L, int size, uint64_t n, const uint64_t *a, const uint64_t *b, he355_indexer ix, uint64_t *out)
+{
+    return guarded([&] { dev(c).addsub(L, size, n, a, b, to_ix(ix), out, true); });
+}
+int he355_multiply(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const uint64_t *b, he355_indexer ix, uint64_t *out)
+{
+    return guarded([&] { dev(c).multiply(L, n, a, b, to_ix(ix), out); });
+}
+int he355_multiply_relin(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const uint64_t *b, he355_indexer ix, int rescale, uint64_t *out)
+{
+    return guarded([&] { dev(c).multiply_relin(L, n, a, b, to_ix(ix), rescale != 0, out); });
+}
+int he355_relinearize(he355_ctx *c, int L, uint64_t n, const uint64_t *ct3, uint64_t *out)
+{
+    return guarded([&] { dev(c).relinearize(L, n, ct3, out); });
+}
+int he355_rescale(he355_ctx *c, int L, int size, uint64_t n, const uint64_t *in, uint64_t *out)
+{
+    return guarded([&] { dev(c).rescale(L, size, n, in, out); });
+}
+int he355_apply_galois(he355_ctx *c, int L, uint64_t n, const uint64_t *in, uint32_t elt, uint64_t *out)
+{
+    return guarded([&] { dev(c).apply_galois(L, n, in, elt, out); });
+}
+int he355_rotate(he355_ctx *c, int L, uint64_t n, const uint64_t *in, int step, uint64_t *out)
+{
+    return guarded([&] { dev(c).rotate(L, n, in, step, out); });
+}
+int he355_accumulate(he355_ctx *c, int L, uint64_t n, uint64_t *inout, uint64_t count, uint64_t *tmp)
+{
+    return guarded([&] { dev(c).accumulate(L, n, inout, count, tmp); });
+}
+int he355_ntt_forward(he355_ctx *c, uint64_t *polys, uint64_t n_polys, const uint8_t *prime_of, uint32_t period)
+{
+    return guarded([&] { dev(c).ntt(polys, n_polys, prime_of, period, false); });
+}
+int he355_ntt_inverse(he355_ctx *c, uint64_t *polys, uint64_t n_polys, const uint8_t *prime_of, uint32_t period)
+{
+    return guarded([&] { dev(c).ntt(polys, n_polys, prime_of, period, true); });
+}
+int he355_timer_begin(he355_ctx *c) { return guarded([&] { dev(c).timer_begin(); }); }
+int he355_timer_end(he355_ctx *c, float *ms)
+{
+    return guarded([&] {
+        const float v = dev(c).timer_end();
+        if (ms) *ms = v;
+    });
+}
+int he355_set_chunk(he355_ctx *c, uint64_t ops)
+{
+    return guarded([&] { dev(c).set_chunk((size_t)ops); });
+}
+
+} // extern "C"

@@ -1,0 +1,79 @@
+// he355_kernels.h — host-callable launchers of the HIP kernels (implemented in he355_kernels.hip).
+// All launchers enqueue on `stream` and return immediately; none allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+namespace he355 {
+
+// Per (source prime s, target prime i) constants of the RNS divide-and-round ("floor") step used by the
+// key-switch mod-down (s = special prime) and by rescale (s = last data prime).  Device array [K][K].
+struct FloorConst {
+    u64 inv, inv_shoup;   // s^-1 mod q_i (+ Shoup quotient)
+    double inv_d, inv_i;  // same for the fp64 engine: value and fl(value/q_i)
+    u64 half_mod;         // floor(s/2) mod q_i
+    u64 pad_;
+};
+
+struct KernelEnv {
+    const PrimeDev *primes; // device array [K]
+    const FloorConst *floor_consts; // device array [K*K], entry [s*K + i]
+    int N, logn1, K, Ltop, scheme;
+    hipStream_t stream;
+    unsigned char prime_f64[64]; // host copy: 1 if the fp64 engine owns prime i
+};
+// 0 (default): phases of a row transform are ordered by wavefront-scope fences only (each wave owns its LDS
+// region).  1: additionally use a workgroup barrier (debug aid).
+void set_block_sync(int enabled);
+
+// ---- generic transforms over a PolyView (in place) ---------------------------------------------------
+void launch_ntt_forward(const KernelEnv &env, const PolyView &v, u32 n_items);  // canonical -> canonical NTT form
+void launch_ntt_inverse(const KernelEnv &env, const PolyView &v, u32 n_items);  // canonical NTT form -> coefficients
+
+// ---- element-wise ------------------------------------------------------------------------------------
+// out[r][p][n] = a[ia(r)][p][n] (+|-) b[ib(r)][p][n] mod q_{p % L}; polys = size * L
+void launch_addsub(const KernelEnv &env, int L, int size, u64 n_results, const u64 *a, const u64 *b, Indexer ix, u64 *out, bool sub);
+// dyadic tensor (CKKS multiply): a,b size-2 level-L NTT form -> out size 3
+void launch_mul3(const KernelEnv &env, int L, u64 n_results, const u64 *a, const u64 *b, Indexer ix, u64 *out);
+
+// ---- key-switch pipeline pieces (see DESIGN.md "Key-switch pipeline") ---------------------------------
+struct KsBuffers {
+    u64 *c01;   // [C][2][L][N]   canonical: polys that receive the key-switched result (may be the output)
+    u64 c01_item_stride;
+    u64 *c2n;   // [C][L][N]      canonical NTT-form target (digit i==j operand, CKKS)
+    u64 *c2r;   // [C][L][N]      target after the inverse row pass (raw of prime j; canonical if N == 1024)
+    u64 *d;     // [C][L+1][L][N] digit j lifted to prime tt after the forward column pass (raw of prime tt)
+    u64 *t;     // [C][2][L][N]   accumulated key products, data primes, canonical NTT form
+    u64 *tpr;   // [C][2][N]      special-prime accumulations after the inverse row pass (raw)
+    u64 *e;     // [C][2][L][N]   mod-down corrections after the forward column pass (raw of prime i)
+};
+enum K1Mode { K1_MUL = 0, K1_CT3 = 1, K1_GALOIS = 2 };
+// K1: produce c01 / c2n / c2r for a chunk of ops.  MUL: a,b via indexer.  CT3: `a` is [n][3][L][N].
+// GALOIS: `a` is [n][2][L][N], perm = device permutation table (NTT-form gather).
+void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix,
+               const uint32_t *perm, const KsBuffers &buf);
+// K2: finish iNTT of each digit, lift to every key prime, forward column pass -> d
+void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf);
+// K3: forward row pass of every (tt, j) + multiply-accumulate with the key -> t (data primes) / tpr (special)
+void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key);
+// floor step, column half: src [n_ops*n_src][N] raw of prime s -> r = (x + floor(s/2)) mod s ->
+// (r mod q_i - floor(s/2) mod q_i) for i < n_tgt -> forward column pass -> dst [n_ops*n_src][n_tgt][N]
+void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst);
+// floor step, row half: out[(op,k,i)] = (tsrc[(op,k,i)] - NTT(dst_cols[(op,k,i)])) * s^-1 (+ addend) mod q_i.
+// Strides are in u64 elements.  If tail_prime >= 0 the rows of that prime additionally go through the
+// inverse row pass into tail[(op,k)] (next floor step's source).
+struct FloorRowsArgs {
+    int src_prime, n_tgt, n_src; // n_src polys per op (2)
+    const u64 *cols;             // [n_ops*n_src][n_tgt][N] raw
+    const u64 *tsrc; u64 tsrc_op_stride, tsrc_poly_stride;
+    const u64 *addend; u64 add_op_stride, add_poly_stride; // may be null
+    u64 *out; u64 out_op_stride, out_poly_stride;
+    int tail_prime;              // -1: none
+    u64 *tail;                   // [n_ops*n_src][N]
+};
+void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &args);
+// inverse row pass of one residue of each poly: src [(op,k)] residue `prime` -> tail [(op,k)][N]
+void launch_rows_inv_select(const KernelEnv &env, int prime, u64 n_polys, const u64 *src, u64 src_poly_stride, u64 *tail);
+
+} // namespace he355

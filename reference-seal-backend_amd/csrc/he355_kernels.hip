@@ -1,0 +1,893 @@
+// he355_kernels.hip — hand-written HIP kernels for gfx950 (CDNA4): RNS negacyclic NTT, dyadic arithmetic,
+// hybrid key switching (relinearize / rotate) and RNS divide-and-round (mod-down, rescale).
+//
+// Work decomposition (one residue polynomial = N = N1 x 1024 coefficients):
+//   * row kernels   : one 64-lane WAVE owns one 1024-element row, 16 elements per lane in VGPRs, the ten
+//                     stages run 4+4+2 in registers with two LDS exchanges (ntt_core.h); a workgroup is four
+//                     such waves (four rows of the same residue) and 34 KiB of LDS.
+//   * column kernels: one LANE owns one stride-1024 column (N1 <= 32 values in VGPRs); twiddles of a column
+//                     pass are wave-uniform, so they come through scalar loads.
+// Global accesses are coalesced: layout A reads/writes 512 contiguous bytes per wave instruction, layout C
+// moves 16 B per lane (two dwordx4 per 32-byte lane segment).
+// Reference semantics implemented here: SEAL Evaluator::{add, multiply (CKKS), relinearize_inplace,
+// rescale_to_next_inplace, rotate_vector} as called from /root/reference/src/benchmarks/ckks/*.cpp and
+// src/engine/seal_context.cpp (see include/he355.h for the call-site map).
+#include <hip/hip_runtime.h>
+
+#include "he355_kernels.h"
+#include "ntt_core.h"
+
+namespace he355 {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = 4;
+
+// Each wave exchanges data only inside its own LDS region: LDS instructions of one wave execute in
+// order, so a wavefront-scope release/acquire pair (compiler ordering only) is all the hand-off needs.
+// Every wave of a block still runs the same number of phases (invalid jobs are clamped, not skipped), so
+// the optional workgroup barrier (g_block_sync, debug aid) stays legal.
+__device__ int g_block_sync = 0;
+#define HE_WAVE_SYNC()                                             \
+    do {                                                           \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+        __builtin_amdgcn_wave_barrier();                           \
+        if (g_block_sync) __syncthreads();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+    } while (0)
+
+__device__ __forceinline__ ArU64 make_ar(const PrimeDev &p, ArU64 *)
+{
+    ArU64 a;
+    a.q = p.q; a.two_q = p.q * 2; a.ninv = p.ninv; a.ninv_q = p.ninv_q; a.cr0 = p.cr0; a.cr1 = p.cr1;
+    return a;
+}
+__device__ __forceinline__ ArF64 make_ar(const PrimeDev &p, ArF64 *)
+{
+    ArF64 a;
+    a.q = p.qd; a.qinv = p.qinv; a.ninv = p.ninv_d; a.ninv_i = p.ninv_i;
+    return a;
+}
+__device__ __forceinline__ ModU64 make_modu(const PrimeDev &p)
+{
+    ModU64 m;
+    m.q = p.q; m.cr0 = p.cr0; m.cr1 = p.cr1;
+    return m;
+}
+
+// ---- row <-> register moves ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_rowA(const u64 *row, int lane, u64 v[kRowE])
+{
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) v[r] = row[(r << 6) | lane];
+}
+__device__ __forceinline__ void store_rowA(u64 *row, int lane, const u64 v[kRowE])
+{
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) row[(r << 6) | lane] = v[r];
+}
+__device__ __forceinline__ void load_rowC(const u64 *row, int lane, u64 v[kRowE])
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(row + (c << 8) + (lane << 2));
+        const ulonglong2 lo = p[0], hi = p[1];
+        v[4 * c + 0] = lo.x; v[4 * c + 1] = lo.y; v[4 * c + 2] = hi.x; v[4 * c + 3] = hi.y;
+    }
+}
+__device__ __forceinline__ void store_rowC(u64 *row, int lane, const u64 v[kRowE])
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        ulonglong2 *p = reinterpret_cast<ulonglong2 *>(row + (c << 8) + (lane << 2));
+        p[0] = make_ulonglong2(v[4 * c + 0], v[4 * c + 1]);
+        p[1] = make_ulonglong2(v[4 * c + 2], v[4 * c + 3]);
+    }
+}
+
+// ---- wave-level row transforms (x in: layout A for forward, layout C for inverse) ---------------------
+template <class Ar>
+__device__ __forceinline__ void wave_rows_fwd(const Ar &ar, const Tw16 *tw, u32 rowbase, int lane, u64 *lds_w, typename Ar::T x[kRowE])
+{
+    typedef typename Ar::T T;
+    T *lds = reinterpret_cast<T *>(lds_w);
+    row_fwd_A(ar, x, tw, rowbase);
+    lds_store_A(lds, lane, x);
+    HE_WAVE_SYNC();
+    lds_load_B(lds, lane, x);
+    HE_WAVE_SYNC();
+    row_fwd_B(ar, x, tw, rowbase, lane);
+    lds_store_B(lds, lane, x);
+    HE_WAVE_SYNC();
+    lds_load_C(lds, lane, x);
+    HE_WAVE_SYNC();
+    row_fwd_C(ar, x, tw, rowbase, lane);
+}
+template <class Ar>
+__device__ __forceinline__ void wave_rows_inv(const Ar &ar, const PrimeDev &P, bool last, u32 rowbase, int lane, u64 *lds_w, typename Ar::T x[kRowE])
+{
+    typedef typename Ar::T T;
+    T *lds = reinterpret_cast<T *>(lds_w);
+    row_inv_C(ar, x, P.inv, rowbase, lane);
+    lds_store_C(lds, lane, x);
+    HE_WAVE_SYNC();
+    lds_load_B(lds, lane, x);
+    HE_WAVE_SYNC();
+    row_inv_B(ar, x, P.inv, rowbase, lane);
+    lds_store_B(lds, lane, x);
+    HE_WAVE_SYNC();
+    lds_load_A(lds, lane, x);
+    HE_WAVE_SYNC();
+    if (last) row_inv_A<Ar, true>(ar, x, P.inv, rowbase, P.inv_w0_scaled);
+    else row_inv_A<Ar, false>(ar, x, P.inv, rowbase, P.inv_w0_scaled);
+}
+
+// =======================================================================================================
+// Generic transforms over a PolyView
+// =======================================================================================================
+template <class Ar>
+__device__ __forceinline__ void rows_fwd_job(const PrimeDev &P, u64 *row, bool in_raw, u32 rowbase, int lane, u64 *lds, bool valid)
+{
+    const Ar ar = make_ar(P, (Ar *)nullptr);
+    typename Ar::T x[kRowE];
+    u64 v[kRowE];
+    load_rowA(row, lane, v);
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) x[r] = in_raw ? ar.from_raw(v[r]) : ar.from_canon(v[r]);
+    wave_rows_fwd(ar, P.fwd, rowbase, lane, lds, x);
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) v[r] = ar.to_canon(x[r]);
+    if (valid) store_rowC(row, lane, v);
+}
+
+__global__ void __launch_bounds__(kBlock) k_rows_fwd(PolyView view, const PrimeDev *primes, u64 total_jobs, int logn1, int in_raw)
+{
+    __shared__ u64 lds[kWaves][kLdsRow];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 n1 = 1u << logn1;
+    u64 job = (u64)blockIdx.x * kWaves + wave;
+    bool valid = job < total_jobs;
+    if (!valid) job = total_jobs - 1;
+    const u32 a = (u32)(job & (n1 - 1));
+    const u64 pj = job >> logn1;
+    const int p = (int)(pj % view.polys_per_item);
+    const u64 item = pj / view.polys_per_item;
+    int prime = view.prime_of[p];
+    if (prime == 255) { valid = false; prime = 0; }
+    u64 *row = view.base + item * view.item_stride + ((u64)p << (logn1 + kRowLog)) + ((u64)a << kRowLog);
+    const PrimeDev &P = primes[prime];
+    if (P.f64) rows_fwd_job<ArF64>(P, row, in_raw != 0, n1 + a, lane, lds[wave], valid);
+    else rows_fwd_job<ArU64>(P, row, in_raw != 0, n1 + a, lane, lds[wave], valid);
+}
+
+template <class Ar>
+__device__ __forceinline__ void rows_inv_job(const PrimeDev &P, const u64 *src, u64 *dst, bool last, u32 rowbase, int lane, u64 *lds, bool valid)
+{
+    const Ar ar = make_ar(P, (Ar *)nullptr);
+    typename Ar::T x[kRowE];
+    u64 v[kRowE];
+    load_rowC(src, lane, v);
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
+    wave_rows_inv(ar, P, last, rowbase, lane, lds, x);
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
+    if (valid) store_rowA(dst, lane, v);
+}
+
+__global__ void __launch_bounds__(kBlock) k_rows_inv(PolyView view, const PrimeDev *primes, u64 total_jobs, int logn1)
+{
+    __shared__ u64 lds[kWaves][kLdsRow];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 n1 = 1u << logn1;
+    u64 job = (u64)blockIdx.x * kWaves + wave;
+    bool valid = job < total_jobs;
+    if (!valid) job = total_jobs - 1;
+    const u32 a = (u32)(job & (n1 - 1));
+    const u64 pj = job >> logn1;
+    const int p = (int)(pj % view.polys_per_item);
+    const u64 item = pj / view.polys_per_item;
+    int prime = view.prime_of[p];
+    if (prime == 255) { valid = false; prime = 0; }
+    u64 *row = view.base + item * view.item_stride + ((u64)p << (logn1 + kRowLog)) + ((u64)a << kRowLog);
+    const PrimeDev &P = primes[prime];
+    if (P.f64) rows_inv_job<ArF64>(P, row, row, logn1 == 0, n1 + a, lane, lds[wave], valid);
+    else rows_inv_job<ArU64>(P, row, row, logn1 == 0, n1 + a, lane, lds[wave], valid);
+}
+
+// inverse row pass of one selected residue per poly into a compact tail buffer
+__global__ void __launch_bounds__(kBlock) k_rows_inv_select(const u64 *src, u64 src_poly_stride, u64 *tail, const PrimeDev *primes, int prime,
+                                                            u64 total_jobs, int logn1)
+{
+    __shared__ u64 lds[kWaves][kLdsRow];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 n1 = 1u << logn1;
+    u64 job = (u64)blockIdx.x * kWaves + wave;
+    bool valid = job < total_jobs;
+    if (!valid) job = total_jobs - 1;
+    const u32 a = (u32)(job & (n1 - 1));
+    const u64 poly = job >> logn1;
+    const u64 *s = src + poly * src_poly_stride + ((u64)a << kRowLog);
+    u64 *d = tail + (poly << (logn1 + kRowLog)) + ((u64)a << kRowLog);
+    const PrimeDev &P = primes[prime];
+    if (P.f64) rows_inv_job<ArF64>(P, s, d, logn1 == 0, n1 + a, lane, lds[wave], valid);
+    else rows_inv_job<ArU64>(P, s, d, logn1 == 0, n1 + a, lane, lds[wave], valid);
+}
+
+template <int LOGN1>
+__global__ void __launch_bounds__(kBlock) k_cols_fwd(PolyView view, const PrimeDev *primes)
+{
+    constexpr int N1 = 1 << LOGN1;
+    const u64 pj = blockIdx.x >> 2;
+    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
+    const int p = (int)(pj % view.polys_per_item);
+    const u64 item = pj / view.polys_per_item;
+    const int prime = view.prime_of[p];
+    if (prime == 255) return;
+    u64 *poly = view.base + item * view.item_stride + ((u64)p << (LOGN1 + kRowLog));
+    const PrimeDev &P = primes[prime];
+    if (P.f64) {
+        const ArF64 ar = make_ar(P, (ArF64 *)nullptr);
+        double x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = ar.from_canon(poly[(a << kRowLog) + col]);
+        col_fwd<ArF64, LOGN1>(ar, x, P.fwd);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = ar.to_raw(x[a]);
+    } else {
+        const ArU64 ar = make_ar(P, (ArU64 *)nullptr);
+        u64 x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = poly[(a << kRowLog) + col];
+        col_fwd<ArU64, LOGN1>(ar, x, P.fwd);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = x[a];
+    }
+}
+
+template <int LOGN1>
+__global__ void __launch_bounds__(kBlock) k_cols_inv(PolyView view, const PrimeDev *primes)
+{
+    constexpr int N1 = 1 << LOGN1;
+    const u64 pj = blockIdx.x >> 2;
+    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
+    const int p = (int)(pj % view.polys_per_item);
+    const u64 item = pj / view.polys_per_item;
+    const int prime = view.prime_of[p];
+    if (prime == 255) return;
+    u64 *poly = view.base + item * view.item_stride + ((u64)p << (LOGN1 + kRowLog));
+    const PrimeDev &P = primes[prime];
+    if (P.f64) {
+        const ArF64 ar = make_ar(P, (ArF64 *)nullptr);
+        double x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(poly[(a << kRowLog) + col]);
+        col_inv<ArF64, LOGN1>(ar, x, P.inv, P.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = ar.to_canon(x[a]);
+    } else {
+        const ArU64 ar = make_ar(P, (ArU64 *)nullptr);
+        u64 x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = poly[(a << kRowLog) + col];
+        col_inv<ArU64, LOGN1>(ar, x, P.inv, P.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = ar.to_canon(x[a]);
+    }
+}
+
+// =======================================================================================================
+// Element-wise kernels (HBM-bound): 16 bytes per lane per access
+// =======================================================================================================
+// Evaluator::add / sub: one thread = 2 coefficients of one residue polynomial of one result.
+__global__ void __launch_bounds__(kBlock) k_addsub(const u64 *a, const u64 *b, u64 *out, Indexer ix, const PrimeDev *primes, int L, int polys,
+                                                   int logN, u64 n_results, int sub)
+{
+    const u64 pairs_per_poly = (u64)1 << (logN - 1);
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 pp = gid >> (logN - 1);            // (result, poly)
+    const u64 e2 = gid & (pairs_per_poly - 1);   // pair index inside the residue polynomial
+    const u64 r = pp / polys;
+    if (r >= n_results) return;
+    const int p = (int)(pp % polys);
+    const u64 q = primes[p % L].q;
+    const u64 ct = (u64)polys << logN;
+    const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(a + idx_a(ix, r) * ct + ((u64)p << logN))[e2];
+    const ulonglong2 y = reinterpret_cast<const ulonglong2 *>(b + idx_b(ix, r) * ct + ((u64)p << logN))[e2];
+    ulonglong2 z;
+    if (sub) { z.x = submod(x.x, y.x, q); z.y = submod(x.y, y.y, q); }
+    else { z.x = addmod(x.x, y.x, q); z.y = addmod(x.y, y.y, q); }
+    reinterpret_cast<ulonglong2 *>(out + r * ct + ((u64)p << logN))[e2] = z;
+}
+
+// Evaluator::multiply, CKKS, size 2 x 2 -> 3 (dyadic tensor).  One thread = 2 coefficients of one residue.
+template <class Ar>
+__device__ __forceinline__ void mul3_pair(const Ar &ar, const ulonglong2 a0, const ulonglong2 a1, const ulonglong2 b0, const ulonglong2 b1,
+                                          ulonglong2 &c0, ulonglong2 &c1, ulonglong2 &c2)
+{
+    typename Ar::T x0 = ar.dy_in(a0.x), x1 = ar.dy_in(a1.x), y0 = ar.dy_in(b0.x), y1 = ar.dy_in(b1.x);
+    c0.x = ar.dy_out(ar.dy_mul(x0, y0));
+    c1.x = ar.dy_out(ar.dy_add(ar.dy_mul(x0, y1), ar.dy_mul(x1, y0)));
+    c2.x = ar.dy_out(ar.dy_mul(x1, y1));
+    x0 = ar.dy_in(a0.y); x1 = ar.dy_in(a1.y); y0 = ar.dy_in(b0.y); y1 = ar.dy_in(b1.y);
+    c0.y = ar.dy_out(ar.dy_mul(x0, y0));
+    c1.y = ar.dy_out(ar.dy_add(ar.dy_mul(x0, y1), ar.dy_mul(x1, y0)));
+    c2.y = ar.dy_out(ar.dy_mul(x1, y1));
+}
+
+__global__ void __launch_bounds__(kBlock) k_mul3(const u64 *a, const u64 *b, u64 *out, Indexer ix, const PrimeDev *primes, int L, int logN,
+                                                 u64 n_results)
+{
+    const u64 pairs_per_poly = (u64)1 << (logN - 1);
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 ri = gid >> (logN - 1);
+    const u64 e2 = gid & (pairs_per_poly - 1);
+    const u64 r = ri / L;
+    if (r >= n_results) return;
+    const int i = (int)(ri % L);
+    const u64 poly = (u64)1 << logN, P1 = (u64)L << logN;
+    const u64 *pa = a + idx_a(ix, r) * 2 * P1 + i * poly, *pb = b + idx_b(ix, r) * 2 * P1 + i * poly;
+    const ulonglong2 a0 = reinterpret_cast<const ulonglong2 *>(pa)[e2], a1 = reinterpret_cast<const ulonglong2 *>(pa + P1)[e2];
+    const ulonglong2 b0 = reinterpret_cast<const ulonglong2 *>(pb)[e2], b1 = reinterpret_cast<const ulonglong2 *>(pb + P1)[e2];
+    ulonglong2 c0, c1, c2;
+    const PrimeDev &P = primes[i];
+    if (P.f64) mul3_pair(make_ar(P, (ArF64 *)nullptr), a0, a1, b0, b1, c0, c1, c2);
+    else mul3_pair(make_ar(P, (ArU64 *)nullptr), a0, a1, b0, b1, c0, c1, c2);
+    u64 *po = out + r * 3 * P1 + i * poly;
+    reinterpret_cast<ulonglong2 *>(po)[e2] = c0;
+    reinterpret_cast<ulonglong2 *>(po + P1)[e2] = c1;
+    reinterpret_cast<ulonglong2 *>(po + 2 * P1)[e2] = c2;
+}
+
+// =======================================================================================================
+// K1: (multiply | take ct3 | Galois-permute) + inverse row pass of the key-switch target
+// =======================================================================================================
+struct K1Args {
+    const u64 *a, *b;
+    Indexer ix;
+    const uint32_t *perm;
+    u64 *c01; u64 c01_item_stride;
+    u64 *c2n, *c2r;
+    u64 n_ops, op_offset;
+    int L, logn1, mode;
+};
+
+template <class Ar>
+__device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 op, int i, u32 a_row, int lane, u64 *lds, bool valid)
+{
+    typedef typename Ar::T T;
+    const Ar ar = make_ar(P, (Ar *)nullptr);
+    const u32 n1 = 1u << A.logn1;
+    const u64 N = (u64)n1 << kRowLog, P1 = (u64)A.L * N;
+    const u64 roff = (u64)i * N + ((u64)a_row << kRowLog);
+    u64 *c0p = A.c01 + op * A.c01_item_stride + roff;
+    u64 *c1p = c0p + P1;
+    u64 *c2np = A.c2n + op * P1 + roff;
+    u64 *c2rp = A.c2r + op * P1 + roff;
+    T x[kRowE];
+    u64 v0[kRowE], v1[kRowE];
+    if (A.mode == K1_MUL) {
+        const u64 r = A.op_offset + op;
+        const u64 *pa = A.a + idx_a(A.ix, r) * 2 * P1 + roff, *pb = A.b + idx_b(A.ix, r) * 2 * P1 + roff;
+        u64 a0[kRowE], a1[kRowE], b0[kRowE], b1[kRowE];
+        load_rowC(pa, lane, a0); load_rowC(pa + P1, lane, a1);
+        load_rowC(pb, lane, b0); load_rowC(pb + P1, lane, b1);
+        u64 v2[kRowE];
+#pragma unroll
+        for (int r2 = 0; r2 < kRowE; ++r2) {
+            const T x0 = ar.dy_in(a0[r2]), x1 = ar.dy_in(a1[r2]), y0 = ar.dy_in(b0[r2]), y1 = ar.dy_in(b1[r2]);
+            v0[r2] = ar.dy_out(ar.dy_mul(x0, y0));
+            v1[r2] = ar.dy_out(ar.dy_add(ar.dy_mul(x0, y1), ar.dy_mul(x1, y0)));
+            v2[r2] = ar.dy_out(ar.dy_mul(x1, y1));
+            x[r2] = ar.from_canon(v2[r2]);
+        }
+        if (valid) { store_rowC(c0p, lane, v0); store_rowC(c1p, lane, v1); store_rowC(c2np, lane, v2); }
+    } else if (A.mode == K1_CT3) {
+        const u64 *pa = A.a + (A.op_offset + op) * 3 * P1 + roff;
+        u64 v2[kRowE];
+        load_rowC(pa, lane, v0); load_rowC(pa + P1, lane, v1); load_rowC(pa + 2 * P1, lane, v2);
+#pragma unroll
+        for (int r2 = 0; r2 < kRowE; ++r2) x[r2] = ar.from_canon(v2[r2]);
+        if (valid) { store_rowC(c0p, lane, v0); store_rowC(c1p, lane, v1); store_rowC(c2np, lane, v2); }
+    } else { // K1_GALOIS: out[idx] = in[perm[idx]] on both polys; c1 := 0; key-switch target = permuted c1
+        const u64 *p0 = A.a + (A.op_offset + op) * 2 * P1 + (u64)i * N;
+        const uint32_t *pm = A.perm + ((u64)a_row << kRowLog);
+        u64 v2[kRowE];
+#pragma unroll
+        for (int r2 = 0; r2 < kRowE; ++r2) {
+            const uint32_t src = pm[elemC(lane, r2)];
+            v0[r2] = p0[src];
+            v2[r2] = p0[P1 + src];
+            v1[r2] = 0;
+            x[r2] = ar.from_canon(v2[r2]);
+        }
+        if (valid) { store_rowC(c0p, lane, v0); store_rowC(c1p, lane, v1); store_rowC(c2np, lane, v2); }
+    }
+    const bool last = A.logn1 == 0;
+    wave_rows_inv(ar, P, last, n1 + a_row, lane, lds, x);
+#pragma unroll
+    for (int r2 = 0; r2 < kRowE; ++r2) v0[r2] = last ? ar.to_canon(x[r2]) : ar.to_raw(x[r2]);
+    if (valid) store_rowA(c2rp, lane, v0);
+}
+
+__global__ void __launch_bounds__(kBlock) k_k1(K1Args A, const PrimeDev *primes)
+{
+    __shared__ u64 lds[kWaves][kLdsRow];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 n1 = 1u << A.logn1;
+    const u64 total = A.n_ops * A.L * n1;
+    u64 job = (u64)blockIdx.x * kWaves + wave;
+    const bool valid = job < total;
+    if (!valid) job = total - 1;
+    const u32 a_row = (u32)(job & (n1 - 1));
+    const u64 oi = job >> A.logn1;
+    const int i = (int)(oi % A.L);
+    const u64 op = oi / A.L;
+    const PrimeDev &P = primes[i];
+    if (P.f64) k1_job<ArF64>(A, P, op, i, a_row, lane, lds[wave], valid);
+    else k1_job<ArU64>(A, P, op, i, a_row, lane, lds[wave], valid);
+}
+
+// =======================================================================================================
+// K2: per (op, digit j, column): finish the inverse transform, lift to every key prime, forward column pass
+// =======================================================================================================
+struct K2Args {
+    const u64 *c2r;
+    u64 *d;
+    u64 n_ops;
+    int L, K, ckks;
+};
+
+// lift canonical c (mod q_j) to a value usable as forward-transform input under prime t
+template <int LOGN1>
+__device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt, const u64 c[1 << LOGN1], u64 *dst, int col)
+{
+    constexpr int N1 = 1 << LOGN1;
+    if (Pt.f64) {
+        const ArF64 ar = make_ar(Pt, (ArF64 *)nullptr);
+        double x[N1];
+        if (Pj.q >> 52) { // digit too wide for an exact double: reduce with integers first
+            const ModU64 mt = make_modu(Pt);
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(barrett64(c[a], mt));
+        } else if (Pj.q > 2 * Pt.q) {
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = ar.renorm(u52_to_f64(c[a]));
+        } else {
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(c[a]);
+        }
+        col_fwd<ArF64, LOGN1>(ar, x, Pt.fwd);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = ar.to_raw(x[a]);
+    } else {
+        const ArU64 ar = make_ar(Pt, (ArU64 *)nullptr);
+        u64 x[N1];
+        if (Pj.q > Pt.q) {
+            const ModU64 mt = make_modu(Pt);
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = barrett64(c[a], mt);
+        } else {
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = c[a];
+        }
+        col_fwd<ArU64, LOGN1>(ar, x, Pt.fwd);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = x[a];
+    }
+}
+
+template <int LOGN1>
+__global__ void __launch_bounds__(kBlock) k_k2(K2Args A, const PrimeDev *primes)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    const u64 oj = blockIdx.x >> 2;
+    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
+    const int j = (int)(oj % A.L);
+    const u64 op = oj / A.L;
+    const u64 *src = A.c2r + (op * A.L + j) * N;
+    const PrimeDev &Pj = primes[j];
+    u64 c[N1];
+    if (LOGN1 == 0) {
+        c[0] = src[col]; // the row pass was the whole inverse transform: already canonical coefficients
+    } else if (Pj.f64) {
+        const ArF64 ar = make_ar(Pj, (ArF64 *)nullptr);
+        double x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
+        col_inv<ArF64, LOGN1>(ar, x, Pj.inv, Pj.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
+    } else {
+        const ArU64 ar = make_ar(Pj, (ArU64 *)nullptr);
+        u64 x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
+        col_inv<ArU64, LOGN1>(ar, x, Pj.inv, Pj.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
+    }
+    for (int tt = 0; tt <= A.L; ++tt) {
+        if (A.ckks && tt == j) continue; // CKKS: digit j under its own prime is the NTT-form input itself
+        const int t = (tt == A.L) ? A.K - 1 : tt;
+        u64 *dst = A.d + ((op * (A.L + 1) + tt) * A.L + j) * N;
+        k2_target<LOGN1>(Pj, primes[t], c, dst, col);
+    }
+}
+
+// =======================================================================================================
+// K3: per (op, key prime tt, row): sum over digits j of NTT_tt(digit j) * key_j[k][tt]
+// =======================================================================================================
+struct K3Args {
+    const u64 *d, *c2n, *key;
+    u64 *t, *tpr;
+    u64 n_ops;
+    int L, K, logn1, ckks;
+    int n_tt;
+    unsigned char tt_list[64];
+};
+
+template <class Ar>
+__global__ void __launch_bounds__(kBlock) k_k3(K3Args A, const PrimeDev *primes)
+{
+    typedef typename Ar::T T;
+    typedef typename Ar::Acc Acc;
+    __shared__ u64 lds[kWaves][kLdsRow];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 n1 = 1u << A.logn1;
+    const u64 N = (u64)n1 << kRowLog;
+    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so all op-groups of one
+    // (tt,row) tile are placed on the same XCD back to back: its 2*L key rows stay in that XCD's L2.
+    const u64 n_og = (A.n_ops + kWaves - 1) / kWaves;
+    const u64 total_tiles = (u64)A.n_tt * n1;
+    const u64 s = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const u64 tile = (s / n_og) * 8 + xcd;
+    if (tile >= total_tiles) return; // whole block exits together
+    const u64 og = s % n_og;
+    u64 op = og * kWaves + wave;
+    const bool valid = op < A.n_ops;
+    if (!valid) op = A.n_ops - 1;
+    const int tt = A.tt_list[tile >> A.logn1];
+    const u32 a_row = (u32)(tile & (n1 - 1));
+    const int t = (tt == A.L) ? A.K - 1 : tt;
+    const PrimeDev &P = primes[t];
+    const Ar ar = make_ar(P, (Ar *)nullptr);
+    const u64 rowoff = (u64)a_row << kRowLog;
+    Acc acc0[kRowE], acc1[kRowE];
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) { acc0[r] = 0; acc1[r] = 0; }
+    for (int j = 0; j < A.L; ++j) {
+        T x[kRowE];
+        u64 v[kRowE];
+        if (A.ckks && tt == j) {
+            load_rowC(A.c2n + (op * A.L + j) * N + rowoff, lane, v);
+#pragma unroll
+            for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
+        } else {
+            load_rowA(A.d + ((op * (A.L + 1) + tt) * A.L + j) * N + rowoff, lane, v);
+#pragma unroll
+            for (int r = 0; r < kRowE; ++r) x[r] = ar.from_raw(v[r]);
+            wave_rows_fwd(ar, P.fwd, n1 + a_row, lane, lds[wave], x);
+        }
+        const u64 *k0 = A.key + (((u64)j * 2 + 0) * A.K + t) * N + rowoff;
+        const u64 *k1 = A.key + (((u64)j * 2 + 1) * A.K + t) * N + rowoff;
+        load_rowC(k0, lane, v);
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc0[r], x[r], ar.key_in(v[r]));
+        load_rowC(k1, lane, v);
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc1[r], x[r], ar.key_in(v[r]));
+    }
+    u64 v[kRowE];
+    if (tt < A.L) {
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc0[r]);
+        if (valid) store_rowC(A.t + ((op * 2 + 0) * A.L + tt) * N + rowoff, lane, v);
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc1[r]);
+        if (valid) store_rowC(A.t + ((op * 2 + 1) * A.L + tt) * N + rowoff, lane, v);
+    } else {
+        // special prime: start the inverse transform right here (row pass), mod-down finishes it
+        const bool last = A.logn1 == 0;
+        T x[kRowE];
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(ar.acc_canon(acc0[r]));
+        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
+        if (valid) store_rowA(A.tpr + (op * 2 + 0) * N + rowoff, lane, v);
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(ar.acc_canon(acc1[r]));
+        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
+        if (valid) store_rowA(A.tpr + (op * 2 + 1) * N + rowoff, lane, v);
+    }
+}
+
+// =======================================================================================================
+// Floor step, column half (key-switch mod-down and rescale): finish the inverse transform of the source
+// residue, add floor(s/2), reduce into every target prime, subtract floor(s/2), forward column pass.
+// =======================================================================================================
+struct FloorColsArgs {
+    const u64 *src;
+    u64 *dst;
+    int src_prime, n_tgt, K;
+    const FloorConst *fc;
+};
+
+template <int LOGN1>
+__global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const PrimeDev *primes)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    const u64 poly = blockIdx.x >> 2;
+    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
+    const u64 *src = A.src + poly * N;
+    const PrimeDev &Ps = primes[A.src_prime];
+    u64 c[N1];
+    if (LOGN1 == 0) {
+        c[0] = src[col];
+    } else if (Ps.f64) {
+        const ArF64 ar = make_ar(Ps, (ArF64 *)nullptr);
+        double x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
+        col_inv<ArF64, LOGN1>(ar, x, Ps.inv, Ps.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
+    } else {
+        const ArU64 ar = make_ar(Ps, (ArU64 *)nullptr);
+        u64 x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
+        col_inv<ArU64, LOGN1>(ar, x, Ps.inv, Ps.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
+    }
+    const u64 qs = Ps.q, half = qs >> 1;
+#pragma unroll
+    for (int a = 0; a < N1; ++a) c[a] = addmod(c[a], half, qs);
+    for (int i = 0; i < A.n_tgt; ++i) {
+        const PrimeDev &Pi = primes[i];
+        const u64 qi = Pi.q;
+        const u64 half_i = A.fc[A.src_prime * A.K + i].half_mod;
+        const ModU64 mi = make_modu(Pi);
+        u64 *dst = A.dst + (poly * A.n_tgt + i) * N;
+        u64 dl[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) dl[a] = submod(qs > qi ? barrett64(c[a], mi) : c[a], half_i, qi);
+        if (Pi.f64) {
+            const ArF64 ar = make_ar(Pi, (ArF64 *)nullptr);
+            double x[N1];
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(dl[a]);
+            col_fwd<ArF64, LOGN1>(ar, x, Pi.fwd);
+#pragma unroll
+            for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = ar.to_raw(x[a]);
+        } else {
+            const ArU64 ar = make_ar(Pi, (ArU64 *)nullptr);
+            col_fwd<ArU64, LOGN1>(ar, dl, Pi.fwd);
+#pragma unroll
+            for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = dl[a];
+        }
+    }
+}
+
+// =======================================================================================================
+// Floor step, row half: out = (tsrc - NTT(cols)) * s^-1 (+ addend) mod q_i; optional inverse-row-pass tail
+// =======================================================================================================
+struct FloorRowsDev {
+    FloorRowsArgs a;
+    const FloorConst *fc;
+    u64 n_ops;
+    int K, logn1;
+    int n_i;
+    unsigned char i_list[64];
+};
+
+template <class Ar>
+__global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const PrimeDev *primes)
+{
+    typedef typename Ar::T T;
+    __shared__ u64 lds[kWaves][kLdsRow];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 n1 = 1u << A.logn1;
+    const u64 N = (u64)n1 << kRowLog;
+    // jobs of one target prime are contiguous and padded to a multiple of kWaves: a block never mixes primes
+    const u64 per_i = (A.n_ops * A.a.n_src) << A.logn1;
+    const u64 per_i_pad = (per_i + kWaves - 1) / kWaves * kWaves;
+    const u64 job = (u64)blockIdx.x * kWaves + wave;
+    const int i = A.i_list[job / per_i_pad];
+    u64 w = job % per_i_pad;
+    const bool valid = w < per_i;
+    if (!valid) w = per_i - 1;
+    const u32 a_row = (u32)(w & (n1 - 1));
+    const u64 rest = w >> A.logn1;
+    const int k = (int)(rest % A.a.n_src);
+    const u64 op = rest / A.a.n_src;
+    const PrimeDev &P = primes[i];
+    const Ar ar = make_ar(P, (Ar *)nullptr);
+    const FloorConst fc = A.fc[A.a.src_prime * A.K + i];
+    const u64 rowoff = (u64)a_row << kRowLog;
+    T x[kRowE];
+    u64 v[kRowE], tv[kRowE], av[kRowE];
+    load_rowA(A.a.cols + ((op * A.a.n_src + k) * A.a.n_tgt + i) * N + rowoff, lane, v);
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) x[r] = ar.from_raw(v[r]);
+    wave_rows_fwd(ar, P.fwd, n1 + a_row, lane, lds[wave], x);
+    load_rowC(A.a.tsrc + op * A.a.tsrc_op_stride + k * A.a.tsrc_poly_stride + (u64)i * N + rowoff, lane, tv);
+    if (A.a.addend) load_rowC(A.a.addend + op * A.a.add_op_stride + k * A.a.add_poly_stride + (u64)i * N + rowoff, lane, av);
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin(tv[r], x[r], fc.inv, fc.inv_shoup, fc.inv_d, fc.inv_i, A.a.addend ? av[r] : 0);
+    if (valid && A.a.out) store_rowC(A.a.out + op * A.a.out_op_stride + k * A.a.out_poly_stride + (u64)i * N + rowoff, lane, v);
+    if (i == A.a.tail_prime) { // wave-uniform
+        const bool last = A.logn1 == 0;
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
+        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
+        if (valid) store_rowA(A.a.tail + (op * A.a.n_src + k) * N + rowoff, lane, v);
+    }
+}
+
+inline unsigned grid_for(u64 jobs, u64 per_block) { return (unsigned)((jobs + per_block - 1) / per_block); }
+
+} // namespace
+
+void set_block_sync(int enabled)
+{
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_block_sync), &enabled, sizeof(int));
+}
+
+// =======================================================================================================
+// Launchers
+// =======================================================================================================
+void launch_ntt_forward(const KernelEnv &env, const PolyView &v, u32 n_items)
+{
+    const u64 polys = (u64)n_items * v.polys_per_item;
+    if (!polys) return;
+    if (env.logn1 > 0) {
+        const unsigned g = (unsigned)(polys * 4);
+        switch (env.logn1) {
+        case 1: hipLaunchKernelGGL(k_cols_fwd<1>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+        case 2: hipLaunchKernelGGL(k_cols_fwd<2>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+        case 3: hipLaunchKernelGGL(k_cols_fwd<3>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+        case 4: hipLaunchKernelGGL(k_cols_fwd<4>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+        case 5: hipLaunchKernelGGL(k_cols_fwd<5>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+        }
+    }
+    const u64 jobs = polys << env.logn1;
+    hipLaunchKernelGGL(k_rows_fwd, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, v, env.primes, jobs, env.logn1, env.logn1 > 0 ? 1 : 0);
+}
+
+void launch_ntt_inverse(const KernelEnv &env, const PolyView &v, u32 n_items)
+{
+    const u64 polys = (u64)n_items * v.polys_per_item;
+    if (!polys) return;
+    const u64 jobs = polys << env.logn1;
+    hipLaunchKernelGGL(k_rows_inv, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, v, env.primes, jobs, env.logn1);
+    if (env.logn1 > 0) {
+        const unsigned g = (unsigned)(polys * 4);
+        switch (env.logn1) {
+        case 1: hipLaunchKernelGGL(k_cols_inv<1>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+        case 2: hipLaunchKernelGGL(k_cols_inv<2>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+        case 3: hipLaunchKernelGGL(k_cols_inv<3>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+        case 4: hipLaunchKernelGGL(k_cols_inv<4>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+        case 5: hipLaunchKernelGGL(k_cols_inv<5>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+        }
+    }
+}
+
+void launch_addsub(const KernelEnv &env, int L, int size, u64 n_results, const u64 *a, const u64 *b, Indexer ix, u64 *out, bool sub)
+{
+    if (!n_results) return;
+    const int logN = env.logn1 + kRowLog, polys = size * L;
+    const u64 threads = (n_results * polys) << (logN - 1);
+    hipLaunchKernelGGL(k_addsub, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, a, b, out, ix, env.primes, L, polys, logN, n_results,
+                       sub ? 1 : 0);
+}
+
+void launch_mul3(const KernelEnv &env, int L, u64 n_results, const u64 *a, const u64 *b, Indexer ix, u64 *out)
+{
+    if (!n_results) return;
+    const int logN = env.logn1 + kRowLog;
+    const u64 threads = (n_results * L) << (logN - 1);
+    hipLaunchKernelGGL(k_mul3, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, a, b, out, ix, env.primes, L, logN, n_results);
+}
+
+void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
+               const KsBuffers &buf)
+{
+    if (!n_ops) return;
+    K1Args A;
+    A.a = a; A.b = b; A.ix = ix; A.perm = perm;
+    A.c01 = buf.c01; A.c01_item_stride = buf.c01_item_stride; A.c2n = buf.c2n; A.c2r = buf.c2r;
+    A.n_ops = n_ops; A.op_offset = op_offset; A.L = L; A.logn1 = env.logn1; A.mode = (int)mode;
+    const u64 jobs = (n_ops * L) << env.logn1;
+    hipLaunchKernelGGL(k_k1, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes);
+}
+
+void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf)
+{
+    if (!n_ops) return;
+    K2Args A;
+    A.c2r = buf.c2r; A.d = buf.d; A.n_ops = n_ops; A.L = L; A.K = env.K; A.ckks = env.scheme == 2;
+    const unsigned g = (unsigned)(n_ops * L * 4);
+    switch (env.logn1) {
+    case 0: hipLaunchKernelGGL(k_k2<0>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 1: hipLaunchKernelGGL(k_k2<1>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 2: hipLaunchKernelGGL(k_k2<2>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 3: hipLaunchKernelGGL(k_k2<3>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 4: hipLaunchKernelGGL(k_k2<4>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 5: hipLaunchKernelGGL(k_k2<5>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    }
+}
+
+void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key)
+{
+    const unsigned char *prime_f64 = env.prime_f64;
+    if (!n_ops) return;
+    for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine primes, pass 1: u64-engine primes
+        K3Args A;
+        A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tpr = buf.tpr;
+        A.n_ops = n_ops; A.L = L; A.K = env.K; A.logn1 = env.logn1; A.ckks = env.scheme == 2;
+        A.n_tt = 0;
+        for (int tt = 0; tt <= L; ++tt) {
+            const int t = (tt == L) ? env.K - 1 : tt;
+            if ((prime_f64[t] != 0) == (pass == 0)) A.tt_list[A.n_tt++] = (unsigned char)tt;
+        }
+        if (!A.n_tt) continue;
+        const u64 n_og = (n_ops + kWaves - 1) / kWaves;
+        const u64 tiles = (u64)A.n_tt << env.logn1;
+        const unsigned g = (unsigned)(((tiles + 7) / 8) * 8 * n_og);
+        if (pass == 0) hipLaunchKernelGGL(k_k3<ArF64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+        else hipLaunchKernelGGL(k_k3<ArU64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+    }
+}
+
+void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst)
+{
+    if (!n_polys) return;
+    FloorColsArgs A;
+    A.src = src; A.dst = dst; A.src_prime = src_prime; A.n_tgt = n_tgt; A.K = env.K; A.fc = env.floor_consts;
+    const unsigned g = (unsigned)(n_polys * 4);
+    switch (env.logn1) {
+    case 0: hipLaunchKernelGGL(k_floor_cols<0>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 1: hipLaunchKernelGGL(k_floor_cols<1>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 2: hipLaunchKernelGGL(k_floor_cols<2>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 3: hipLaunchKernelGGL(k_floor_cols<3>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 4: hipLaunchKernelGGL(k_floor_cols<4>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 5: hipLaunchKernelGGL(k_floor_cols<5>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    }
+}
+
+void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &args)
+{
+    const unsigned char *prime_f64 = env.prime_f64;
+    if (!n_ops) return;
+    for (int pass = 0; pass < 2; ++pass) {
+        FloorRowsDev A;
+        A.a = args; A.fc = env.floor_consts; A.n_ops = n_ops; A.K = env.K; A.logn1 = env.logn1;
+        A.n_i = 0;
+        for (int i = 0; i < args.n_tgt; ++i)
+            if ((prime_f64[i] != 0) == (pass == 0)) A.i_list[A.n_i++] = (unsigned char)i;
+        if (!A.n_i) continue;
+        const u64 per_i = (n_ops * args.n_src) << env.logn1;
+        const u64 jobs = (per_i + kWaves - 1) / kWaves * kWaves * A.n_i;
+        if (pass == 0) hipLaunchKernelGGL(k_floor_rows<ArF64>, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes);
+        else hipLaunchKernelGGL(k_floor_rows<ArU64>, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes);
+    }
+}
+
+void launch_rows_inv_select(const KernelEnv &env, int prime, u64 n_polys, const u64 *src, u64 src_poly_stride, u64 *tail)
+{
+    if (!n_polys) return;
+    const u64 jobs = n_polys << env.logn1;
+    hipLaunchKernelGGL(k_rows_inv_select, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, src, src_poly_stride, tail, env.primes, prime, jobs,
+                       env.logn1);
+}
+
+} // namespace he355

@@ -166,6 +166,8 @@ ArU64 PrimeTables::aru() const
     a.two_q = 2 * q;
     a.ninv = ninv;
     a.ninv_q = (u64)(((u128)ninv << 64) / q);
+    a.cr0 = mod.cr0;
+    a.cr1 = mod.cr1;
     return a;
 }
 ArF64 PrimeTables::arf() const

@@ -14,8 +14,8 @@
 #pragma once
 #include <cstdint>
 
-#if defined(__HIPCC__)
-#define HE_HD __host__ __device__ __forceinline__
+#if defined(__HIP__)
+#define HE_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define HE_HD inline
 #endif
@@ -80,6 +80,25 @@ struct ArU64 {
     typedef u64 T;
     u64 q, two_q;
     u64 ninv, ninv_q; // N^-1 and its Shoup quotient (inverse transform scaling)
+    u64 cr0, cr1;     // Barrett constant floor(2^128/q)
+
+    HE_HD ModU64 mod() const { ModU64 m; m.q = q; m.cr0 = cr0; m.cr1 = cr1; return m; }
+    // ---- dyadic domain: canonical in, canonical out ----
+    typedef u64 Acc;
+    HE_HD T dy_in(u64 c) const { return c; }
+    HE_HD T dy_mul(T x, T y) const { return barrett128((u128)x * y, mod()); }
+    HE_HD T dy_add(T x, T y) const { return addmod(x, y, q); }
+    HE_HD u64 dy_out(T x) const { return x; }
+    HE_HD T key_in(u64 bits) const { return bits; }
+    // acc += x*key, x lazy (< 4q), key canonical
+    HE_HD void acc_mac(Acc &acc, T x, T key) const { acc = addmod(acc, barrett128((u128)x * key, mod()), q); }
+    HE_HD u64 acc_canon(Acc acc) const { return acc; }
+    // (t - x) * inv (+ addend): t, addend canonical, x lazy < 4q; inv given as Shoup pair
+    HE_HD u64 floor_fin(u64 t, T x, u64 inv, u64 inv_shoup, double, double, u64 addend) const
+    {
+        u64 r = mul_shoup(t + 2 * two_q - x, inv, inv_shoup, q);
+        return addmod(r, addend, q);
+    }
 
     HE_HD T from_canon(u64 x) const { return x; }
     HE_HD T from_raw(u64 bits) const { return bits; }
@@ -174,6 +193,39 @@ struct ArF64 {
         double c = __builtin_rint(y * winv);
         double d = __builtin_fma(-c, q, h);
         return d + l;
+    }
+    // x*y mod q for two variable operands (no precomputed quotient), centred; |x*y| < 2^100
+    HE_HD T mulmod_vv(T x, T y) const
+    {
+        double h = x * y;
+        double l = __builtin_fma(x, y, -h);
+        double c = __builtin_rint(h * qinv);
+        double d = __builtin_fma(-c, q, h);
+        return d + l;
+    }
+    // integer |x| < 2q -> canonical [0,q) as double
+    HE_HD T canon2(T x) const
+    {
+        if (x < 0.0) x += q;
+        if (x < 0.0) x += q;
+        if (x >= q) x -= q;
+        return x;
+    }
+    // canonical u64 of an arbitrary-size integer residue class is to_canon(); this one is for |x| < 2q
+    HE_HD u64 to_canon2(T x) const { return f64_to_u52(canon2(x)); }
+    // ---- dyadic domain ----
+    typedef double Acc;
+    HE_HD T dy_in(u64 c) const { return u52_to_f64(c); }
+    HE_HD T dy_mul(T x, T y) const { return mulmod_vv(x, y); }
+    HE_HD T dy_add(T x, T y) const { return x + y; }
+    HE_HD u64 dy_out(T x) const { return to_canon2(x); }
+    HE_HD T key_in(u64 bits) const { return from_raw(bits); }
+    HE_HD void acc_mac(Acc &acc, T x, T key) const { acc += mulmod_vv(x, key); }
+    HE_HD u64 acc_canon(Acc acc) const { return to_canon(acc); }
+    HE_HD u64 floor_fin(u64 t, T x, u64, u64, double inv_d, double inv_i, u64 addend) const
+    {
+        double m = mulmod_c(u52_to_f64(t) - x, inv_d, inv_i);
+        return to_canon2(m + u52_to_f64(addend));
     }
     HE_HD static double tw_w(const Tw16 &t)
     {
