@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CKKS multiply -> relinearize -> rescale, N=2^15, L=16, batch 1024 per GPU.
+
+Metric (BASELINE.json): ciphertext-ops/sec, one op = one result ciphertext of the per-pair pipeline
+(multiply, relinearize_inplace, rescale_to_next_inplace — the sequence at
+/root/reference/src/benchmarks/ckks/seal_ckks_matmultval_benchmark.cpp:253-255 applied per batch element with
+the HEBench outer-product indexing of seal_ckks_element_wise_benchmark.cpp:322-336, here 1024 x 1).
+
+A "step" is one pass of that pipeline over the whole resident batch.  Inputs (uniform residues — a uniformly
+random ciphertext is distribution-identical to a real one) and the relinearization key are
+generated in HBM before the timed region.  One process per GPU; the batch is sharded by replication of the
+workload (weak scaling: 1024 results per GPU), no data-path collective: the units are independent
+(SURVEY.md §8e).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N = 32768
+DEPTH = 16
+COEFF_BITS = 45
+BATCH = 1024
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_op(L: int, n: int, batch: int, K: int) -> float:
+    """read 2 cts + write 1 ct at L-1 + the relin key once per batch."""
+    ct_in = 2 * L * n * 8
+    ct_out = 2 * (L - 1) * n * 8
+    key = L * 2 * K * n * 8
+    return 2 * ct_in + ct_out + key / batch
+
+
+def cpu_baseline(be, sample_ops: int, bits):
+    """Oracle (CPU port of the SEAL-algorithm pipeline) timed on this host's cores on a bounded sample;
+    the same sample is pushed through the GPU path and compared bit-for-bit."""
+    import oracle as ho
+    o = ho.Context(ho.SCHEME_CKKS, N, bit_sizes=bits)
+    rng = np.random.default_rng(1234)
+    L = o.L
+    a = np.stack([o.random_poly(rng, L, 2) for _ in range(sample_ops)])
+    b = o.random_poly(rng, L, 2)[None]
+    rk = o.random_kswitch_key(rng)
+    threads = ho.lib().ho_max_threads()
+    idx_a = np.arange(sample_ops, dtype=np.uint32)
+    idx_b = np.zeros(sample_ops, dtype=np.uint32)
+    o.batch_op(ho.OP_MUL_RELIN_RESCALE, a[:threads], idx_a[:threads], b, idx_b[:threads], rk)  # warm-up (tables, pages)
+    t0 = time.perf_counter()
+    want = o.batch_op(ho.OP_MUL_RELIN_RESCALE, a, idx_a, b, idx_b, rk)
+    dt = time.perf_counter() - t0
+    return dict(value=sample_ops / dt, seconds=dt, cores=threads, a=a, b=b, rk=rk, want=want)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH, help="results per GPU per step")
+    ap.add_argument("--chunk", type=int, default=0, help="ops per kernel sequence (0: library default)")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="ops in the CPU-baseline sample (0: skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    be = importlib.import_module("reference-seal-backend_amd")
+    bits = be.chain_bits(DEPTH, COEFF_BITS)
+    ctx = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, device=local_rank)
+    L, K = ctx.L, ctx.K
+    n = args.batch
+    if args.chunk:
+        ctx.set_chunk(args.chunk)
+
+    # ---- resident inputs (HBM) ----
+    pm = list(range(L))
+    d_a = ctx.alloc(n * 2 * L * N)
+    d_b = ctx.alloc(1 * 2 * L * N)
+    d_out = ctx.alloc(n * 2 * (L - 1) * N)
+    ctx.fill_uniform(d_a, n * 2 * L, pm, 1234 + rank)
+    ctx.fill_uniform(d_b, 2 * L, pm, 99 + rank)
+    ctx.set_relin_key_synthetic(7)
+    ix = be.Context.outer(0, n, 0, 1)
+
+    def step():
+        ctx.multiply_relin(L, n, d_a, d_b, ix, d_out, rescale=True)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timer_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    gpu_ms = ctx.timer_end()  # HIP events on the stream the kernels run on
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_ops = n * args.steps * world
+    value = total_ops / elapsed
+
+    cpu = None
+    parity = None
+    if rank == 0 and args.cpu_sample > 0:
+        cb = cpu_baseline(be, args.cpu_sample, bits)
+        # push the identical sample through the GPU path: the measured path is the checked path
+        s = args.cpu_sample
+        da, db = ctx.to_device(cb["a"]), ctx.to_device(cb["b"])
+        ctx.set_relin_key(cb["rk"])
+        do = ctx.alloc(s * 2 * (L - 1) * N)
+        ctx.multiply_relin(L, s, da, db, be.Context.outer(0, s, 0, 1), do, rescale=True)
+        parity = bool(np.array_equal(do.download(cb["want"].shape), cb["want"]))
+        cpu = {"value": round(cb["value"], 3), "unit": "ciphertext-ops/sec", "cores": cb["cores"], "kind": "port",
+               "sample": f"{s} of the {n} results of one step (same parameters, uniform residues), "
+                         f"{cb['seconds']:.2f} s wall on {cb['cores']} OpenMP threads; "
+                         "in-repo SEAL-algorithm restatement, SEAL v3.7.2 unavailable offline"}
+
+    if rank == 0:
+        bytes_op = algorithmic_bytes_per_op(L, N, n, K)
+        gpu_s = gpu_ms / 1e3
+        achieved = bytes_op * n * args.steps / gpu_s / 1e9
+        out = {
+            "metric": "ciphertext-ops/sec (CKKS ct x ct mul+relin+rescale, N=2^15, L=16)",
+            "value": round(value, 2),
+            "unit": "ciphertext-ops/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64 (exact fp64-FMA engine for the 45-bit primes, u64 Harvey for the 60-bit primes)",
+            "data": "synthetic (uniform residues generated in HBM; synthetic relinearization key)",
+            "config": {"workload": "CKKS EltwiseMult + relinearize + rescale, N=2^15, depth 16 (L=16 data primes + 1 special), "
+                                   f"batch {n}x1 per GPU (BASELINE.json configs[2])",
+                       "poly_modulus_degree": N, "coeff_modulus_bits": bits, "batch_per_gpu": n, "global_batch": n * world,
+                       "parallelism": f"batch-sharded x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": None,
+                         "kernel": "mul->relin->rescale kernel sequence (k_k1, k_k2, k_k3 x2, k_floor_cols x2, k_floor_rows x4 per chunk)",
+                         "algorithmic_bytes_per_op": bytes_op,
+                         "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 3),
+                         "note": "expected binding resource is the VALU (64-bit modular butterflies), not HBM: SURVEY.md §0.6"},
+            "cpu_baseline": cpu,
+            "parity_checked_in_run": parity,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

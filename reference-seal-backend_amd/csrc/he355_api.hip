@@ -79,6 +79,9 @@ public:
         if (device < 0 || device >= count) throw DeviceError("invalid device ordinal");
         HIPCHECK(hipSetDevice(device));
         HIPCHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        HIPCHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+        HIPCHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
         HIPCHECK(hipEventCreate(&ev0_));
         HIPCHECK(hipEventCreate(&ev1_));
         const size_t N = P.N, K = P.K;
@@ -124,8 +127,8 @@ public:
         env_.floor_consts = d_floor_;
         env_.N = (int)N; env_.logn1 = P.logn1; env_.K = (int)K; env_.Ltop = (int)P.Ltop; env_.scheme = P.scheme;
         env_.stream = stream_;
-        const char *bs = std::getenv("HE355_BLOCK_SYNC");
-        set_block_sync(bs && bs[0] == '1');
+        const char *ds = std::getenv("HE355_DUAL_STREAM");
+        if (ds) dual_stream_ = ds[0] != '0';
         const char *ch = std::getenv("HE355_CHUNK");
         if (ch && std::atoi(ch) > 0) chunk_ = (size_t)std::atoi(ch);
     }
@@ -139,8 +142,13 @@ public:
         (void)hipFree(d_relin_);
         for (auto &kv : d_galois_) (void)hipFree(kv.second);
         for (auto &kv : d_perm_) (void)hipFree(kv.second);
+        (void)hipStreamSynchronize(stream2_);
         (void)hipFree(scratch_);
+        (void)hipFree(scratch2_);
         (void)hipFree(rot_tmp_);
+        (void)hipEventDestroy(ev_fork_);
+        (void)hipEventDestroy(ev_join_);
+        (void)hipStreamDestroy(stream2_);
         (void)hipEventDestroy(ev0_);
         (void)hipEventDestroy(ev1_);
         (void)hipStreamDestroy(stream_);
@@ -239,22 +247,25 @@ public:
         u64 *rlr; // [C][3][N]  tail of the rescale prime after the inverse row pass
         u64 *f;   // [C][3][L][N]
     };
-    // layout of the scratch arena for `c` ops at level L
-    Scratch scratch(size_t c, int L)
+    // layout of the scratch arena (one per stream) for `c` ops at level L
+    Scratch scratch(size_t c, int L, int which = 0)
     {
         const size_t N = P.N, LN = (size_t)L * N;
         const size_t per_op = 2 * LN + LN + LN + (size_t)(L + 1) * LN + 2 * LN + 2 * N + 2 * LN + 3 * N + 3 * LN;
         const size_t need = per_op * c * 8;
-        if (need > scratch_bytes_) {
+        u64 *&arena = which ? scratch2_ : scratch_;
+        size_t &arena_bytes = which ? scratch2_bytes_ : scratch_bytes_;
+        if (need > arena_bytes) {
             HIPCHECK(hipStreamSynchronize(stream_));
-            if (scratch_) HIPCHECK(hipFree(scratch_));
-            scratch_ = nullptr;
-            scratch_bytes_ = 0;
-            HIPCHECK(hipMalloc(&scratch_, need));
-            scratch_bytes_ = need;
+            HIPCHECK(hipStreamSynchronize(stream2_));
+            if (arena) HIPCHECK(hipFree(arena));
+            arena = nullptr;
+            arena_bytes = 0;
+            HIPCHECK(hipMalloc(&arena, need));
+            arena_bytes = need;
         }
         Scratch s;
-        u64 *p = scratch_;
+        u64 *p = arena;
         s.ks.c01 = p; p += c * 2 * LN; s.ks.c01_item_stride = 2 * LN;
         s.ks.c2n = p; p += c * LN;
         s.ks.c2r = p; p += c * LN;
@@ -268,7 +279,7 @@ public:
     }
 
     // K2, K3, mod-down; result added into B.c01.  with_tail: also start the rescale (tail of prime L-1)
-    void key_switch_tail(int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail)
+    void key_switch_tail(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail)
     {
         const size_t N = P.N, LN = (size_t)L * N;
         const int SP = (int)P.K - 1;
@@ -285,7 +296,7 @@ public:
         fr.tail = S.rlr;
         launch_floor_rows(env_, nc, fr);
     }
-    void rescale_tail(int L, int size, u64 nc, const Scratch &S, const u64 *src, u64 src_op_stride, u64 *out)
+    void rescale_tail(const KernelEnv &env_, int L, int size, u64 nc, const Scratch &S, const u64 *src, u64 src_op_stride, u64 *out)
     {
         const size_t N = P.N, LN = (size_t)L * N, L1N = (size_t)(L - 1) * N;
         launch_floor_cols(env_, L - 1, L - 1, nc * size, S.rlr, S.f);
@@ -312,14 +323,31 @@ public:
         if (!d_relin_) throw std::invalid_argument("relinearization key not set");
         if (rescale && L < 2) throw std::invalid_argument("cannot rescale at the last level");
         const size_t N = P.N, LN = (size_t)L * N;
-        for (u64 off = 0; off < n; off += chunk_) {
+        // Alternate chunks between two streams, each with its own scratch arena: the ALU-bound key-product kernel
+        // of one chunk overlaps the HBM-bound multiply / digit-lift / floor kernels of the other.
+        const bool dual = dual_stream_ && n > chunk_;
+        if (dual) {
+            (void)scratch(chunk_, L, 0);
+            (void)scratch(chunk_, L, 1);
+            HIPCHECK(hipEventRecord(ev_fork_, stream_));
+            HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+        }
+        u64 ci = 0;
+        for (u64 off = 0; off < n; off += chunk_, ++ci) {
             const u64 nc = std::min<u64>(chunk_, n - off);
-            Scratch S = scratch(chunk_, L);
+            const int which = dual ? (int)(ci & 1) : 0;
+            KernelEnv env = env_;
+            env.stream = which ? stream2_ : stream_;
+            Scratch S = scratch(chunk_, L, which);
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
-            launch_k1(env_, L, K1_MUL, nc, off, a, b, ix, nullptr, B);
-            key_switch_tail(L, nc, S, B, d_relin_, rescale);
-            if (rescale) rescale_tail(L, 2, nc, S, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N);
+            launch_k1(env, L, K1_MUL, nc, off, a, b, ix, nullptr, B);
+            key_switch_tail(env, L, nc, S, B, d_relin_, rescale);
+            if (rescale) rescale_tail(env, L, 2, nc, S, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N);
+        }
+        if (dual) {
+            HIPCHECK(hipEventRecord(ev_join_, stream2_));
+            HIPCHECK(hipStreamWaitEvent(stream_, ev_join_, 0));
         }
         HIPCHECK(hipGetLastError());
     }
@@ -338,7 +366,7 @@ public:
             KsBuffers B = S.ks;
             B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
             launch_k1(env_, L, K1_CT3, nc, off, ct3, nullptr, ix, nullptr, B);
-            key_switch_tail(L, nc, S, B, d_relin_, false);
+            key_switch_tail(env_, L, nc, S, B, d_relin_, false);
         }
         HIPCHECK(hipGetLastError());
     }
@@ -355,7 +383,7 @@ public:
             Scratch S = scratch(chunk_, L);
             const u64 *src = in + off * size * LN;
             launch_rows_inv_select(env_, L - 1, nc * size, src + (size_t)(L - 1) * N, LN, S.rlr);
-            rescale_tail(L, size, nc, S, src, (u64)size * LN, out + off * size * (size_t)(L - 1) * N);
+            rescale_tail(env_, L, size, nc, S, src, (u64)size * LN, out + off * size * (size_t)(L - 1) * N);
         }
         HIPCHECK(hipGetLastError());
     }
@@ -378,7 +406,7 @@ public:
             KsBuffers B = S.ks;
             B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
             launch_k1(env_, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B);
-            key_switch_tail(L, nc, S, B, key, false);
+            key_switch_tail(env_, L, nc, S, B, key, false);
         }
         HIPCHECK(hipGetLastError());
     }
@@ -471,7 +499,7 @@ public:
         HIPCHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
         return ms;
     }
-    void sync() { use(); HIPCHECK(hipStreamSynchronize(stream_)); }
+    void sync() { use(); HIPCHECK(hipStreamSynchronize(stream_)); HIPCHECK(hipStreamSynchronize(stream2_)); }
 
 private:
     const Params &P;
@@ -485,8 +513,11 @@ private:
     u64 *d_relin_ = nullptr;
     std::map<uint32_t, u64 *> d_galois_;
     std::map<uint32_t, uint32_t *> d_perm_;
-    u64 *scratch_ = nullptr;
-    size_t scratch_bytes_ = 0;
+    u64 *scratch_ = nullptr, *scratch2_ = nullptr;
+    size_t scratch_bytes_ = 0, scratch2_bytes_ = 0;
+    hipStream_t stream2_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    bool dual_stream_ = true;
     u64 *rot_tmp_ = nullptr;
     size_t rot_tmp_bytes_ = 0;
     size_t chunk_ = 32;

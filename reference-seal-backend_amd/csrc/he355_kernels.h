@@ -23,9 +23,7 @@ struct KernelEnv {
     hipStream_t stream;
     unsigned char prime_f64[64]; // host copy: 1 if the fp64 engine owns prime i
 };
-// 0 (default): phases of a row transform are ordered by wavefront-scope fences only (each wave owns its LDS
-// region).  1: additionally use a workgroup barrier (debug aid).
-void set_block_sync(int enabled);
+
 
 // ---- generic transforms over a PolyView (in place) ---------------------------------------------------
 void launch_ntt_forward(const KernelEnv &env, const PolyView &v, u32 n_items);  // canonical -> canonical NTT form

@@ -14,6 +14,10 @@
 // src/engine/seal_context.cpp (see include/he355.h for the call-site map).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
 #include "he355_kernels.h"
 #include "ntt_core.h"
 
@@ -26,15 +30,21 @@ constexpr int kWaves = 4;
 // Each wave exchanges data only inside its own LDS region: LDS instructions of one wave execute in
 // order, so a wavefront-scope release/acquire pair (compiler ordering only) is all the hand-off needs.
 // Every wave of a block still runs the same number of phases (invalid jobs are clamped, not skipped), so
-// the optional workgroup barrier (g_block_sync, debug aid) stays legal.
-__device__ int g_block_sync = 0;
+// building with -DHE355_BLOCK_SYNC (workgroup barriers instead, debug aid) stays legal.
+#if defined(HE355_BLOCK_SYNC)
+#define HE_WAVE_SYNC() __syncthreads()
+#else
 #define HE_WAVE_SYNC()                                             \
     do {                                                           \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
         __builtin_amdgcn_wave_barrier();                           \
-        if (g_block_sync) __syncthreads();                         \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
     } while (0)
+#endif
+
+// Twiddle tables are reached through pointers stored in PrimeDev (HBM), which the compiler would treat as
+// generic (flat_load + full s_waitcnt per access).  They are always global memory: say so.
+__device__ __forceinline__ gtw_t gtw(const Tw16 *p) { return (gtw_t)p; }
 
 __device__ __forceinline__ ArU64 make_ar(const PrimeDev &p, ArU64 *)
 {
@@ -85,41 +95,89 @@ __device__ __forceinline__ void store_rowC(u64 *row, int lane, const u64 v[kRowE
     }
 }
 
+// ---- LDS-DMA: one 8 KiB row, HBM -> this wave's LDS staging buffer, no VGPRs, asynchronous -------------
+// Each global_load_lds_dwordx4 moves 64 x 16 B; the LDS image is the row in natural element order.
+// Completion is covered by the issuing wave's vmcnt (s_waitcnt vmcnt(0) before the first ds_read).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+__device__ __forceinline__ void dma_row_to_lds(const u64 *grow, u64 *lds_row, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(grow + (k << 7) + (lane << 1)), (lds_void_t *)(lds_row + (k << 7)), 16, 0, 0);
+}
+__device__ __forceinline__ void lds_rowA(const u64 *lds_row, int lane, u64 v[kRowE])
+{
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) v[r] = lds_row[(r << 6) | lane];
+}
+__device__ __forceinline__ void lds_rowC(const u64 *lds_row, int lane, u64 v[kRowE])
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(lds_row + (c << 8) + (lane << 2));
+        const ulonglong2 lo = p[0], hi = p[1];
+        v[4 * c + 0] = lo.x; v[4 * c + 1] = lo.y; v[4 * c + 2] = hi.x; v[4 * c + 3] = hi.y;
+    }
+}
+
 // ---- wave-level row transforms (x in: layout A for forward, layout C for inverse) ---------------------
-template <class Ar>
-__device__ __forceinline__ void wave_rows_fwd(const Ar &ar, const Tw16 *tw, u32 rowbase, int lane, u64 *lds_w, typename Ar::T x[kRowE])
+// U rows of the same tile at once (shared twiddles, interleaved butterfly chains); lds_w: U exchange buffers.
+// The twiddles of phase B / C are gathered BEFORE the exchange that precedes the phase and pinned there with a
+// scheduling barrier, so their loads are in flight while the exchange round-trips through LDS.
+template <int U, class Ar, class TW>
+__device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int lane, u64 (*lds_w)[kLdsRow], typename Ar::T (*x)[kRowE])
 {
     typedef typename Ar::T T;
-    T *lds = reinterpret_cast<T *>(lds_w);
-    row_fwd_A(ar, x, tw, rowbase);
-    lds_store_A(lds, lane, x);
+    {
+        Tw16 wa[kTwA];
+        gather_A(tw, wa);
+        row_fwd_A<U>(ar, x, wa);
+    }
+    Tw16 wb[kTwB];
+    gather_B(tw, lane, wb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) lds_store_A(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
     HE_WAVE_SYNC();
-    lds_load_B(lds, lane, x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) lds_load_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
     HE_WAVE_SYNC();
-    row_fwd_B(ar, x, tw, rowbase, lane);
-    lds_store_B(lds, lane, x);
+    row_fwd_B<U>(ar, x, wb);
+    Tw16 wc[kTwC];
+    gather_C(tw, lane, wc);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) lds_store_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
     HE_WAVE_SYNC();
-    lds_load_C(lds, lane, x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) lds_load_C(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
     HE_WAVE_SYNC();
-    row_fwd_C(ar, x, tw, rowbase, lane);
+    row_fwd_C<U>(ar, x, wc);
+}
+template <class Ar, class TW>
+__device__ __forceinline__ void wave_rows_fwd(const Ar &ar, const TW &tw, int lane, u64 *lds_w, typename Ar::T x[kRowE])
+{
+    wave_rows_fwd_n<1>(ar, tw, lane, reinterpret_cast<u64(*)[kLdsRow]>(lds_w), reinterpret_cast<typename Ar::T(*)[kRowE]>(x));
 }
 template <class Ar>
 __device__ __forceinline__ void wave_rows_inv(const Ar &ar, const PrimeDev &P, bool last, u32 rowbase, int lane, u64 *lds_w, typename Ar::T x[kRowE])
 {
     typedef typename Ar::T T;
     T *lds = reinterpret_cast<T *>(lds_w);
-    row_inv_C(ar, x, P.inv, rowbase, lane);
+    const auto itw = tw_table(gtw(P.inv), rowbase);
+    row_inv_C(ar, x, itw, lane);
     lds_store_C(lds, lane, x);
     HE_WAVE_SYNC();
     lds_load_B(lds, lane, x);
     HE_WAVE_SYNC();
-    row_inv_B(ar, x, P.inv, rowbase, lane);
+    row_inv_B(ar, x, itw, lane);
     lds_store_B(lds, lane, x);
     HE_WAVE_SYNC();
     lds_load_A(lds, lane, x);
     HE_WAVE_SYNC();
-    if (last) row_inv_A<Ar, true>(ar, x, P.inv, rowbase, P.inv_w0_scaled);
-    else row_inv_A<Ar, false>(ar, x, P.inv, rowbase, P.inv_w0_scaled);
+    if (last) row_inv_A<Ar, true>(ar, x, itw, P.inv_w0_scaled);
+    else row_inv_A<Ar, false>(ar, x, itw, P.inv_w0_scaled);
 }
 
 // =======================================================================================================
@@ -134,7 +192,7 @@ __device__ __forceinline__ void rows_fwd_job(const PrimeDev &P, u64 *row, bool i
     load_rowA(row, lane, v);
 #pragma unroll
     for (int r = 0; r < kRowE; ++r) x[r] = in_raw ? ar.from_raw(v[r]) : ar.from_canon(v[r]);
-    wave_rows_fwd(ar, P.fwd, rowbase, lane, lds, x);
+    wave_rows_fwd(ar, tw_table(gtw(P.fwd), rowbase), lane, lds, x);
 #pragma unroll
     for (int r = 0; r < kRowE; ++r) v[r] = ar.to_canon(x[r]);
     if (valid) store_rowC(row, lane, v);
@@ -231,7 +289,7 @@ __global__ void __launch_bounds__(kBlock) k_cols_fwd(PolyView view, const PrimeD
         double x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = ar.from_canon(poly[(a << kRowLog) + col]);
-        col_fwd<ArF64, LOGN1>(ar, x, P.fwd);
+        col_fwd<ArF64, LOGN1>(ar, x, gtw(P.fwd));
 #pragma unroll
         for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = ar.to_raw(x[a]);
     } else {
@@ -239,7 +297,7 @@ __global__ void __launch_bounds__(kBlock) k_cols_fwd(PolyView view, const PrimeD
         u64 x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = poly[(a << kRowLog) + col];
-        col_fwd<ArU64, LOGN1>(ar, x, P.fwd);
+        col_fwd<ArU64, LOGN1>(ar, x, gtw(P.fwd));
 #pragma unroll
         for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = x[a];
     }
@@ -262,7 +320,7 @@ __global__ void __launch_bounds__(kBlock) k_cols_inv(PolyView view, const PrimeD
         double x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(poly[(a << kRowLog) + col]);
-        col_inv<ArF64, LOGN1>(ar, x, P.inv, P.inv_w0_scaled);
+        col_inv<ArF64, LOGN1>(ar, x, gtw(P.inv), P.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = ar.to_canon(x[a]);
     } else {
@@ -270,7 +328,7 @@ __global__ void __launch_bounds__(kBlock) k_cols_inv(PolyView view, const PrimeD
         u64 x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = poly[(a << kRowLog) + col];
-        col_inv<ArU64, LOGN1>(ar, x, P.inv, P.inv_w0_scaled);
+        col_inv<ArU64, LOGN1>(ar, x, gtw(P.inv), P.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = ar.to_canon(x[a]);
     }
@@ -457,7 +515,7 @@ __device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt
 #pragma unroll
             for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(c[a]);
         }
-        col_fwd<ArF64, LOGN1>(ar, x, Pt.fwd);
+        col_fwd<ArF64, LOGN1>(ar, x, gtw(Pt.fwd));
 #pragma unroll
         for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = ar.to_raw(x[a]);
     } else {
@@ -471,7 +529,7 @@ __device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt
 #pragma unroll
             for (int a = 0; a < N1; ++a) x[a] = c[a];
         }
-        col_fwd<ArU64, LOGN1>(ar, x, Pt.fwd);
+        col_fwd<ArU64, LOGN1>(ar, x, gtw(Pt.fwd));
 #pragma unroll
         for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = x[a];
     }
@@ -496,7 +554,7 @@ __global__ void __launch_bounds__(kBlock) k_k2(K2Args A, const PrimeDev *primes)
         double x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
-        col_inv<ArF64, LOGN1>(ar, x, Pj.inv, Pj.inv_w0_scaled);
+        col_inv<ArF64, LOGN1>(ar, x, gtw(Pj.inv), Pj.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     } else {
@@ -504,7 +562,7 @@ __global__ void __launch_bounds__(kBlock) k_k2(K2Args A, const PrimeDev *primes)
         u64 x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
-        col_inv<ArU64, LOGN1>(ar, x, Pj.inv, Pj.inv_w0_scaled);
+        col_inv<ArU64, LOGN1>(ar, x, gtw(Pj.inv), Pj.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     }
@@ -533,7 +591,13 @@ __global__ void __launch_bounds__(kBlock) k_k3(K3Args A, const PrimeDev *primes)
 {
     typedef typename Ar::T T;
     typedef typename Ar::Acc Acc;
-    __shared__ u64 lds[kWaves][kLdsRow];
+    constexpr int U = 2; // digits transformed together by one wave
+    constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
+    // One block per CU (one wave per SIMD): the wave gets its latency hiding from the two interleaved digits
+    // and from LDS-DMA prefetch, not from co-resident waves.  LDS: 64 KiB exchange + 64 KiB DMA landing + twiddles.
+    __shared__ u64 lds[kWaves][U][kLdsRow];
+    __shared__ __attribute__((aligned(16))) u64 stage[kWaves][U][kRowN];
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 n1 = 1u << A.logn1;
     const u64 N = (u64)n1 << kRowLog;
@@ -554,30 +618,78 @@ __global__ void __launch_bounds__(kBlock) k_k3(K3Args A, const PrimeDev *primes)
     const PrimeDev &P = primes[t];
     const Ar ar = make_ar(P, (Ar *)nullptr);
     const u64 rowoff = (u64)a_row << kRowLog;
+    // This block's 1023 forward twiddles of row (t, a_row), staged once in LDS: all four waves, all digits
+    // and all ops of the tile read them from there (ds_read, lane-dependent index) instead of L2.
+    typename std::conditional<kF64, TwRowF64, TwRow>::type twr;
+    {
+        const gtw_t gf = gtw(P.fwd);
+        if constexpr (kF64) {
+            double *twl = reinterpret_cast<double *>(twl_raw);
+            for (u32 i = threadIdx.x; i + 1 < (u32)kRowTw; i += kBlock) twl[i] = ArF64::tw_w(tw_load(gf, tw_row_source(n1 + a_row, i)));
+            twr.t = twl;
+            twr.qinv = ar.qinv;
+        } else {
+            Tw16 *twl = reinterpret_cast<Tw16 *>(twl_raw);
+            for (u32 i = threadIdx.x; i + 1 < (u32)kRowTw; i += kBlock) twl[i] = tw_load(gf, tw_row_source(n1 + a_row, i));
+            twr.t = twl;
+        }
+    }
+    __syncthreads();
     Acc acc0[kRowE], acc1[kRowE];
 #pragma unroll
     for (int r = 0; r < kRowE; ++r) { acc0[r] = 0; acc1[r] = 0; }
-    for (int j = 0; j < A.L; ++j) {
+    auto key_row = [&](int j, int k) -> const u64 * { return A.key + (((u64)j * 2 + k) * A.K + t) * N + rowoff; };
+    auto mac_digit = [&](const T x[kRowE], int j) {
+        u64 kv[kRowE], kw[kRowE];
+        load_rowC(key_row(j, 0), lane, kv);
+        load_rowC(key_row(j, 1), lane, kw);
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc0[r], x[r], ar.key_in(kv[r]));
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc1[r], x[r], ar.key_in(kw[r]));
+    };
+    // digits that go through the forward row pass: all of them, except (CKKS) the one that lives under this very
+    // prime -- that one is the NTT-form target itself and is multiplied in directly
+    const bool has_own = A.ckks && tt < A.L;
+    const int nd = A.L - (has_own ? 1 : 0);
+    auto digit = [&](int i) -> int { return (has_own && i >= tt) ? i + 1 : i; };
+    auto src_row = [&](int j) -> const u64 * { return A.d + ((op * (A.L + 1) + tt) * A.L + j) * N + rowoff; };
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (u < nd) dma_row_to_lds(src_row(digit(u)), stage[wave][u], lane);
+    if (has_own) {
         T x[kRowE];
         u64 v[kRowE];
-        if (A.ckks && tt == j) {
-            load_rowC(A.c2n + (op * A.L + j) * N + rowoff, lane, v);
+        load_rowC(A.c2n + (op * A.L + tt) * N + rowoff, lane, v);
 #pragma unroll
-            for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
-        } else {
-            load_rowA(A.d + ((op * (A.L + 1) + tt) * A.L + j) * N + rowoff, lane, v);
+        for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
+        mac_digit(x, tt);
+    }
+    for (int i = 0; i < nd; i += U) {
+        const int cnt = (nd - i) < U ? (nd - i) : U;
+        T x[U][kRowE];
+        u64 v[kRowE];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the rows of this step have landed in the staging buffers
 #pragma unroll
-            for (int r = 0; r < kRowE; ++r) x[r] = ar.from_raw(v[r]);
-            wave_rows_fwd(ar, P.fwd, n1 + a_row, lane, lds[wave], x);
+        for (int u = 0; u < U; ++u) {
+            if (u < cnt) {
+                lds_rowA(stage[wave][u], lane, v);
+#pragma unroll
+                for (int r = 0; r < kRowE; ++r) x[u][r] = ar.from_raw(v[r]);
+            }
         }
-        const u64 *k0 = A.key + (((u64)j * 2 + 0) * A.K + t) * N + rowoff;
-        const u64 *k1 = A.key + (((u64)j * 2 + 1) * A.K + t) * N + rowoff;
-        load_rowC(k0, lane, v);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffers drained into registers
 #pragma unroll
-        for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc0[r], x[r], ar.key_in(v[r]));
-        load_rowC(k1, lane, v);
+        for (int u = 0; u < U; ++u)
+            if (i + U + u < nd) dma_row_to_lds(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
+        if (cnt == U) {
+            wave_rows_fwd_n<U>(ar, twr, lane, lds[wave], x);
 #pragma unroll
-        for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc1[r], x[r], ar.key_in(v[r]));
+            for (int u = 0; u < U; ++u) mac_digit(x[u], digit(i + u));
+        } else {
+            wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x);
+            mac_digit(x[0], digit(i));
+        }
     }
     u64 v[kRowE];
     if (tt < A.L) {
@@ -593,13 +705,13 @@ __global__ void __launch_bounds__(kBlock) k_k3(K3Args A, const PrimeDev *primes)
         T x[kRowE];
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(ar.acc_canon(acc0[r]));
-        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
+        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave][0], x);
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
         if (valid) store_rowA(A.tpr + (op * 2 + 0) * N + rowoff, lane, v);
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(ar.acc_canon(acc1[r]));
-        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
+        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave][0], x);
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
         if (valid) store_rowA(A.tpr + (op * 2 + 1) * N + rowoff, lane, v);
@@ -634,7 +746,7 @@ __global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const Pr
         double x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
-        col_inv<ArF64, LOGN1>(ar, x, Ps.inv, Ps.inv_w0_scaled);
+        col_inv<ArF64, LOGN1>(ar, x, gtw(Ps.inv), Ps.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     } else {
@@ -642,7 +754,7 @@ __global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const Pr
         u64 x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
-        col_inv<ArU64, LOGN1>(ar, x, Ps.inv, Ps.inv_w0_scaled);
+        col_inv<ArU64, LOGN1>(ar, x, gtw(Ps.inv), Ps.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     }
@@ -663,12 +775,12 @@ __global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const Pr
             double x[N1];
 #pragma unroll
             for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(dl[a]);
-            col_fwd<ArF64, LOGN1>(ar, x, Pi.fwd);
+            col_fwd<ArF64, LOGN1>(ar, x, gtw(Pi.fwd));
 #pragma unroll
             for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = ar.to_raw(x[a]);
         } else {
             const ArU64 ar = make_ar(Pi, (ArU64 *)nullptr);
-            col_fwd<ArU64, LOGN1>(ar, dl, Pi.fwd);
+            col_fwd<ArU64, LOGN1>(ar, dl, gtw(Pi.fwd));
 #pragma unroll
             for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = dl[a];
         }
@@ -716,7 +828,7 @@ __global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const Pri
     load_rowA(A.a.cols + ((op * A.a.n_src + k) * A.a.n_tgt + i) * N + rowoff, lane, v);
 #pragma unroll
     for (int r = 0; r < kRowE; ++r) x[r] = ar.from_raw(v[r]);
-    wave_rows_fwd(ar, P.fwd, n1 + a_row, lane, lds[wave], x);
+    wave_rows_fwd(ar, tw_table(gtw(P.fwd), n1 + a_row), lane, lds[wave], x);
     load_rowC(A.a.tsrc + op * A.a.tsrc_op_stride + k * A.a.tsrc_poly_stride + (u64)i * N + rowoff, lane, tv);
     if (A.a.addend) load_rowC(A.a.addend + op * A.a.add_op_stride + k * A.a.add_poly_stride + (u64)i * N + rowoff, lane, av);
 #pragma unroll
@@ -737,10 +849,6 @@ inline unsigned grid_for(u64 jobs, u64 per_block) { return (unsigned)((jobs + pe
 
 } // namespace
 
-void set_block_sync(int enabled)
-{
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_block_sync), &enabled, sizeof(int));
-}
 
 // =======================================================================================================
 // Launchers
@@ -843,6 +951,15 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         const u64 n_og = (n_ops + kWaves - 1) / kWaves;
         const u64 tiles = (u64)A.n_tt << env.logn1;
         const unsigned g = (unsigned)(((tiles + 7) / 8) * 8 * n_og);
+        static bool printed = false;
+        if (!printed && getenv("HE355_DEBUG")) {
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_k3<ArF64>, kBlock, 0);
+            fprintf(stderr, "[he355] k_k3<ArF64>: %d blocks/CU by the occupancy API\n", nb);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_k3<ArU64>, kBlock, 0);
+            fprintf(stderr, "[he355] k_k3<ArU64>: %d blocks/CU by the occupancy API\n", nb);
+            printed = true;
+        }
         if (pass == 0) hipLaunchKernelGGL(k_k3<ArF64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
         else hipLaunchKernelGGL(k_k3<ArU64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
     }

@@ -21,9 +21,11 @@ namespace he355 {
 constexpr int kRowLog = 10;
 constexpr int kRowN = 1 << kRowLog; // 1024 elements per row
 constexpr int kRowE = 16;           // elements per lane
-constexpr int kLdsRow = kRowN + (kRowN >> 6) * 4; // 1088: +4 elements per 64 to spread banks
+constexpr int kLdsRow = kRowN; // exchange buffer: exactly one row (8 KiB); bank spreading by XOR swizzle
 
-HE_HD int lds_pad(int e) { return e + ((e >> 6) << 2); }
+// element e lives at e ^ (((e >> 6) & 15) << 2): the 4-element group index inside each 64-element block is
+// XORed with the block number, so layout-B accesses (stride 64 elements) spread over all banks.
+HE_HD int lds_pad(int e) { return e ^ (((e >> 6) & 15) << 2); }
 
 // element index held in register r of lane `lane` under the three layouts
 HE_HD int elemA(int lane, int r) { return (r << 6) | lane; }                                   // r = bits 9..6
@@ -62,10 +64,102 @@ template <class T> HE_HD void lds_load_C(const T *lds, int lane, T x[kRowE])
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Row pass, forward.  rowbase = N1 + a for row a: stage s' (0..9) uses tw[(rowbase << s') + (e >> (10-s'))]
+// Twiddle accessors for the row pass.  Stage s' (0..9) of row a needs entry (rowbase << s') + g of the prime's
+// table, g = e >> (10-s') in [0, 2^s'), rowbase = N1 + a.
+//   TwTable : straight from the table (any pointer type, e.g. an address_space(1) pointer)
+//   TwRow   : from a row-local copy of those 1023 entries (index 2^s' - 1 + g), e.g. staged in LDS
 // ---------------------------------------------------------------------------------------------------
+HE_HD Tw16 tw_load(const Tw16 *p, u32 i) { return p[i]; }
+#if defined(__HIP__)
+// explicit global-memory twiddle pointer: one global_load_dwordx4 per entry, never a flat load
+typedef unsigned long long he_u64x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) he_u64x2 *gtw_t;
+HE_HD Tw16 tw_load(gtw_t p, u32 i)
+{
+    const he_u64x2 v = p[i];
+    Tw16 t;
+    t.a = v.x;
+    t.b = v.y;
+    return t;
+}
+#endif
+template <class P> struct TwTable {
+    P base;
+    u32 rowbase;
+    HE_HD Tw16 get(int s, u32 g) const { return tw_load(base, (rowbase << s) + g); }
+};
+template <class P> HE_HD TwTable<P> tw_table(P base, u32 rowbase)
+{
+    TwTable<P> t;
+    t.base = base;
+    t.rowbase = rowbase;
+    return t;
+}
+constexpr int kRowTw = kRowN; // 1023 entries used
+struct TwRow {
+    const Tw16 *t;
+    HE_HD Tw16 get(int s, u32 g) const { return t[(1u << s) - 1u + g]; }
+};
+// fp64 engine: the row-local copy keeps only w (8 bytes); w/q is rebuilt as fl(w * fl(1/q)), which differs from
+// the table's fl(w/q) by at most one ulp -- the quotient estimate may move by one, the residue class does not.
+struct TwRowF64 {
+    const double *t;
+    double qinv;
+    HE_HD Tw16 get(int s, u32 g) const
+    {
+        const double w = t[(1u << s) - 1u + g], wi = w * qinv;
+        Tw16 r;
+        union { u64 u; double d; } c;
+        c.d = w; r.a = c.u;
+        c.d = wi; r.b = c.u;
+        return r;
+    }
+};
+// global index of row-local entry i (0..1022): stage s = floor(log2(i+1)), g = i + 1 - 2^s
+HE_HD u32 tw_row_source(u32 rowbase, u32 i)
+{
+    const u32 v = i + 1;
+    int s = 0;
+    while ((v >> (s + 1)) != 0) ++s;
+    return (rowbase << s) + (v - (1u << s));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row pass, forward
+// ---------------------------------------------------------------------------------------------------
+// A phase (A: stages 0-3, B: 4-7, C: 8-9) runs entirely from registers: its twiddles are gathered up front
+// (gather_*) so that a kernel can issue those loads BEFORE the LDS exchange that precedes the phase and have
+// them land while the exchange is in flight.  Per lane: phase A 15 (lane-uniform), B 15, C 12 entries.
+// U rows of the SAME (prime, row index) can be transformed together (x[u][..]): they share every twiddle, and
+// their independent butterfly chains give one wave the instruction-level parallelism to cover latencies.
+constexpr int kTwA = 15, kTwB = 15, kTwC = 12;
+template <class TW> HE_HD void gather_A(const TW &tw, Tw16 w[kTwA])
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int g = 0; g < (1 << s); ++g) w[(1 << s) - 1 + g] = tw.get(s, (u32)g);
+}
+template <class TW> HE_HD void gather_B(const TW &tw, int lane, Tw16 w[kTwB])
+{
+    const u32 hi4 = (u32)lane >> 2;
+#pragma unroll
+    for (int s = 4; s < 8; ++s)
+#pragma unroll
+        for (int g = 0; g < (1 << (s - 4)); ++g) w[(1 << (s - 4)) - 1 + g] = tw.get(s, (hi4 << (s - 4)) | (u32)g);
+}
+template <class TW> HE_HD void gather_C(const TW &tw, int lane, Tw16 w[kTwC])
+{
+    // stage 8: e >> 2 = c*64 + lane for chunk c = r >> 2 (4 entries); stage 9: e >> 1 = c*128 + lane*2 + h (8 entries)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = tw.get(8, ((u32)c << 6) | (u32)lane);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) w[4 + 2 * c + h] = tw.get(9, ((u32)c << 7) | ((u32)lane << 1) | (u32)h);
+}
 // stages 0..3 on layout A (register bit 3-s' is the butterfly bit); twiddles are lane-uniform
-template <class Ar> HE_HD void row_fwd_A(const Ar &ar, typename Ar::T x[kRowE], const Tw16 *tw, u32 rowbase)
+template <int U, class Ar> HE_HD void row_fwd_A(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwA])
 {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -73,61 +167,86 @@ template <class Ar> HE_HD void row_fwd_A(const Ar &ar, typename Ar::T x[kRowE], 
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) {
             if (r & (1 << bit)) continue;
-            const Tw16 w = tw[(rowbase << s) + (r >> (4 - s))];
-            ar.bfly_fwd(x[r], x[r | (1 << bit)], w);
+#pragma unroll
+            for (int u = 0; u < U; ++u) ar.bfly_fwd(x[u][r], x[u][r | (1 << bit)], w[(1 << s) - 1 + (r >> (4 - s))]);
         }
     }
 }
-// stages 4..7 on layout B
-template <class Ar> HE_HD void row_fwd_B(const Ar &ar, typename Ar::T x[kRowE], const Tw16 *tw, u32 rowbase, int lane)
+// stages 4..7 on layout B: e >> (10-s) = (hi4 << (s-4)) | (r >> (8-s))
+template <int U, class Ar> HE_HD void row_fwd_B(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwB])
 {
-    const u32 hi4 = (u32)lane >> 2;
 #pragma unroll
     for (int s = 4; s < 8; ++s) {
         const int bit = 7 - s; // register bit
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) {
             if (r & (1 << bit)) continue;
-            // e >> (10-s) = (hi4 << (s-4)) | (r >> (8-s))
-            const Tw16 w = tw[(rowbase << s) + ((hi4 << (s - 4)) | ((u32)r >> (8 - s)))];
-            ar.bfly_fwd(x[r], x[r | (1 << bit)], w);
+#pragma unroll
+            for (int u = 0; u < U; ++u) ar.bfly_fwd(x[u][r], x[u][r | (1 << bit)], w[(1 << (s - 4)) - 1 + (r >> (8 - s))]);
         }
     }
 }
-// stages 8,9 on layout C (register bits 1,0)
-template <class Ar> HE_HD void row_fwd_C(const Ar &ar, typename Ar::T x[kRowE], const Tw16 *tw, u32 rowbase, int lane)
+// stages 8,9 on layout C (register bits 1,0); r = 4c + lo2
+template <int U, class Ar> HE_HD void row_fwd_C(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwC])
 {
 #pragma unroll
-    for (int s = 8; s < 10; ++s) {
-        const int bit = 9 - s;
+    for (int r = 0; r < kRowE; ++r) { // stage 8: pairs (r, r|2), twiddle of chunk c
+        if (r & 2) continue;
 #pragma unroll
-        for (int r = 0; r < kRowE; ++r) {
-            if (r & (1 << bit)) continue;
-            const u32 e = (u32)elemC(lane, r);
-            const Tw16 w = tw[(rowbase << s) + (e >> (10 - s))];
-            ar.bfly_fwd(x[r], x[r | (1 << bit)], w);
-        }
+        for (int u = 0; u < U; ++u) ar.bfly_fwd(x[u][r], x[u][r | 2], w[r >> 2]);
     }
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) { // stage 9: pairs (r, r|1), twiddle (c, h = bit 1 of r)
+        if (r & 1) continue;
+#pragma unroll
+        for (int u = 0; u < U; ++u) ar.bfly_fwd(x[u][r], x[u][r | 1], w[4 + 2 * (r >> 2) + ((r >> 1) & 1)]);
+    }
+}
+// single-row forms that gather and run in one go
+template <class Ar, class TW> HE_HD void row_fwd_A(const Ar &ar, typename Ar::T x[kRowE], const TW &tw)
+{
+    Tw16 w[kTwA];
+    gather_A(tw, w);
+    row_fwd_A<1>(ar, reinterpret_cast<typename Ar::T(*)[kRowE]>(x), w);
+}
+template <class Ar, class TW> HE_HD void row_fwd_B(const Ar &ar, typename Ar::T x[kRowE], const TW &tw, int lane)
+{
+    Tw16 w[kTwB];
+    gather_B(tw, lane, w);
+    row_fwd_B<1>(ar, reinterpret_cast<typename Ar::T(*)[kRowE]>(x), w);
+}
+template <class Ar, class TW> HE_HD void row_fwd_C(const Ar &ar, typename Ar::T x[kRowE], const TW &tw, int lane)
+{
+    Tw16 w[kTwC];
+    gather_C(tw, lane, w);
+    row_fwd_C<1>(ar, reinterpret_cast<typename Ar::T(*)[kRowE]>(x), w);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Row pass, inverse: stages 9,8 (layout C), 7..4 (layout B), 3..0 (layout A)
 // ---------------------------------------------------------------------------------------------------
-template <class Ar> HE_HD void row_inv_C(const Ar &ar, typename Ar::T x[kRowE], const Tw16 *itw, u32 rowbase, int lane)
+template <class Ar, class TW> HE_HD void row_inv_C(const Ar &ar, typename Ar::T x[kRowE], const TW &itw, int lane)
 {
 #pragma unroll
     for (int s = 9; s >= 8; --s) {
         const int bit = 9 - s;
+        Tw16 w[8];
+        int n = 0;
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) {
             if (r & (1 << bit)) continue;
-            const u32 e = (u32)elemC(lane, r);
-            const Tw16 w = itw[(rowbase << s) + (e >> (10 - s))];
-            ar.bfly_inv(x[r], x[r | (1 << bit)], w);
+            if (s == 8 && (r & 1)) continue;
+            w[n++] = itw.get(s, (u32)elemC(lane, r) >> (10 - s));
+        }
+        n = 0;
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) {
+            if (r & (1 << bit)) continue;
+            ar.bfly_inv(x[r], x[r | (1 << bit)], w[s == 8 ? (n++ >> 1) : n++]);
         }
     }
 }
-template <class Ar> HE_HD void row_inv_B(const Ar &ar, typename Ar::T x[kRowE], const Tw16 *itw, u32 rowbase, int lane)
+template <class Ar, class TW> HE_HD void row_inv_B(const Ar &ar, typename Ar::T x[kRowE], const TW &itw, int lane)
 {
     const u32 hi4 = (u32)lane >> 2;
     if (Ar::kNeedsRenormInv) {
@@ -137,16 +256,18 @@ template <class Ar> HE_HD void row_inv_B(const Ar &ar, typename Ar::T x[kRowE], 
 #pragma unroll
     for (int s = 7; s >= 4; --s) {
         const int bit = 7 - s;
+        Tw16 w[8];
+#pragma unroll
+        for (int g = 0; g < (1 << (s - 4)); ++g) w[g] = itw.get(s, (hi4 << (s - 4)) | (u32)g);
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) {
             if (r & (1 << bit)) continue;
-            const Tw16 w = itw[(rowbase << s) + ((hi4 << (s - 4)) | ((u32)r >> (8 - s)))];
-            ar.bfly_inv(x[r], x[r | (1 << bit)], w);
+            ar.bfly_inv(x[r], x[r | (1 << bit)], w[r >> (8 - s)]);
         }
     }
 }
 // LAST = this is the final stage of the whole transform (N1 == 1): fold N^-1 using itw_scaled for stage 0
-template <class Ar, bool LAST> HE_HD void row_inv_A(const Ar &ar, typename Ar::T x[kRowE], const Tw16 *itw, u32 rowbase, const Tw16 &w0_scaled)
+template <class Ar, bool LAST, class TW> HE_HD void row_inv_A(const Ar &ar, typename Ar::T x[kRowE], const TW &itw, const Tw16 &w0_scaled)
 {
     if (Ar::kNeedsRenormInv) {
 #pragma unroll
@@ -155,15 +276,14 @@ template <class Ar, bool LAST> HE_HD void row_inv_A(const Ar &ar, typename Ar::T
 #pragma unroll
     for (int s = 3; s >= 0; --s) {
         const int bit = 3 - s;
+        Tw16 w[8];
+#pragma unroll
+        for (int g = 0; g < (1 << s); ++g) w[g] = itw.get(s, (u32)g);
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) {
             if (r & (1 << bit)) continue;
-            if (LAST && s == 0) {
-                ar.bfly_inv_last(x[r], x[r | (1 << bit)], w0_scaled);
-            } else {
-                const Tw16 w = itw[(rowbase << s) + (r >> (4 - s))];
-                ar.bfly_inv(x[r], x[r | (1 << bit)], w);
-            }
+            if (LAST && s == 0) ar.bfly_inv_last(x[r], x[r | (1 << bit)], w0_scaled);
+            else ar.bfly_inv(x[r], x[r | (1 << bit)], w[r >> (4 - s)]);
         }
     }
 }
@@ -171,7 +291,7 @@ template <class Ar, bool LAST> HE_HD void row_inv_A(const Ar &ar, typename Ar::T
 // ---------------------------------------------------------------------------------------------------
 // Column pass: LOGN1 stages over N1 = 2^LOGN1 registers (row index a = register index)
 // ---------------------------------------------------------------------------------------------------
-template <class Ar, int LOGN1> HE_HD void col_fwd(const Ar &ar, typename Ar::T x[1 << LOGN1], const Tw16 *tw)
+template <class Ar, int LOGN1, class TW> HE_HD void col_fwd(const Ar &ar, typename Ar::T x[1 << LOGN1], TW tw)
 {
     constexpr int N1 = 1 << LOGN1;
 #pragma unroll
@@ -180,13 +300,13 @@ template <class Ar, int LOGN1> HE_HD void col_fwd(const Ar &ar, typename Ar::T x
 #pragma unroll
         for (int a = 0; a < N1; ++a) {
             if (a & gap) continue;
-            const Tw16 w = tw[(1 << s) + (a / (2 * gap))];
+            const Tw16 w = tw_load(tw, (u32)((1 << s) + (a / (2 * gap))));
             ar.bfly_fwd(x[a], x[a + gap], w);
         }
     }
 }
 // inverse column pass; the very last stage (s == 0) folds N^-1: w0_scaled = itw[1] * N^-1
-template <class Ar, int LOGN1> HE_HD void col_inv(const Ar &ar, typename Ar::T x[1 << LOGN1], const Tw16 *itw, const Tw16 &w0_scaled)
+template <class Ar, int LOGN1, class TW> HE_HD void col_inv(const Ar &ar, typename Ar::T x[1 << LOGN1], TW itw, const Tw16 &w0_scaled)
 {
     constexpr int N1 = 1 << LOGN1;
     if (Ar::kNeedsRenormInv) {
@@ -202,7 +322,7 @@ template <class Ar, int LOGN1> HE_HD void col_inv(const Ar &ar, typename Ar::T x
             if (s == 0) {
                 ar.bfly_inv_last(x[a], x[a + gap], w0_scaled);
             } else {
-                const Tw16 w = itw[(1 << s) + (a / (2 * gap))];
+                const Tw16 w = tw_load(itw, (u32)((1 << s) + (a / (2 * gap))));
                 ar.bfly_inv(x[a], x[a + gap], w);
             }
         }

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
+#include <type_traits>
 #include <vector>
 
 #include "../../reference-seal-backend_amd/csrc/he_params.h"
@@ -51,22 +52,52 @@ template <class Ar> static void rows_fwd(const Ar &ar, const PrimeTables &pt, in
     for (int a = 0; a < n1; ++a) {
         const u32 rowbase = (u32)(n1 + a);
         const u64 *src = in + (size_t)a * kRowN;
+        // the row-local twiddle copy (what K3 stages in LDS) must be equivalent to the table
+        std::vector<Tw16> rowtw(kRowTw);
+        for (u32 i = 0; i + 1 < (u32)kRowTw; ++i) rowtw[i] = pt.fwd[tw_row_source(rowbase, i)];
+        TwRow twr; twr.t = rowtw.data();
+        std::vector<double> roww(kRowTw);
+        for (u32 i = 0; i + 1 < (u32)kRowTw; ++i) std::memcpy(&roww[i], &rowtw[i].a, 8);
+        TwRowF64 twf; twf.t = roww.data(); twf.qinv = 1.0 / (double)pt.q;
+        const bool f64row = std::is_same<T, double>::value && (a & 2);
+        const auto twt = tw_table(pt.fwd.data(), rowbase);
+        const bool use_row = (a & 1) != 0;
+        // U=2 path (two rows sharing twiddles, as K3 runs it): second copy starts from the element-reversed row
+        static T regs2[64][2][kRowE];
+        std::vector<T> lds2(kLdsRow);
+        const bool pair = (a % 3) == 1;
         for (int lane = 0; lane < 64; ++lane) {
             T *x = regs[lane];
             for (int r = 0; r < kRowE; ++r) x[r] = in_raw ? ar.from_raw(src[elemA(lane, r)]) : ar.from_canon(src[elemA(lane, r)]);
-            row_fwd_A(ar, x, pt.fwd.data(), rowbase);
+            if (pair) {
+                for (int r = 0; r < kRowE; ++r) { regs2[lane][0][r] = x[r]; regs2[lane][1][r] = in_raw ? ar.from_raw(src[kRowN - 1 - elemA(lane, r)]) : ar.from_canon(src[kRowN - 1 - elemA(lane, r)]); }
+                { Tw16 w[kTwA]; gather_A(twt, w); row_fwd_A<2>(ar, regs2[lane], w); }
+            }
+            if (f64row) row_fwd_A(ar, x, twf); else if (use_row) row_fwd_A(ar, x, twr); else row_fwd_A(ar, x, twt);
             track(x, kRowE);
+        }
+        if (pair) {
+            std::vector<T> ldsa(kLdsRow), ldsb(kLdsRow);
+            for (int lane = 0; lane < 64; ++lane) { lds_store_A(ldsa.data(), lane, regs2[lane][0]); lds_store_A(ldsb.data(), lane, regs2[lane][1]); }
+            for (int lane = 0; lane < 64; ++lane) { lds_load_B(ldsa.data(), lane, regs2[lane][0]); lds_load_B(ldsb.data(), lane, regs2[lane][1]); }
+            for (int lane = 0; lane < 64; ++lane) { Tw16 w[kTwB]; gather_B(twt, lane, w); row_fwd_B<2>(ar, regs2[lane], w); }
+            for (int lane = 0; lane < 64; ++lane) { lds_store_B(ldsa.data(), lane, regs2[lane][0]); lds_store_B(ldsb.data(), lane, regs2[lane][1]); }
+            for (int lane = 0; lane < 64; ++lane) { lds_load_C(ldsa.data(), lane, regs2[lane][0]); lds_load_C(ldsb.data(), lane, regs2[lane][1]); }
+            for (int lane = 0; lane < 64; ++lane) { Tw16 w[kTwC]; gather_C(twt, lane, w); row_fwd_C<2>(ar, regs2[lane], w); }
         }
         for (int lane = 0; lane < 64; ++lane) lds_store_A(lds.data(), lane, regs[lane]);
         for (int lane = 0; lane < 64; ++lane) lds_load_B(lds.data(), lane, regs[lane]);
-        for (int lane = 0; lane < 64; ++lane) { row_fwd_B(ar, regs[lane], pt.fwd.data(), rowbase, lane); track(regs[lane], kRowE); }
+        for (int lane = 0; lane < 64; ++lane) { if (f64row) row_fwd_B(ar, regs[lane], twf, lane); else if (use_row) row_fwd_B(ar, regs[lane], twr, lane); else row_fwd_B(ar, regs[lane], twt, lane); track(regs[lane], kRowE); }
         for (int lane = 0; lane < 64; ++lane) lds_store_B(lds.data(), lane, regs[lane]);
         for (int lane = 0; lane < 64; ++lane) lds_load_C(lds.data(), lane, regs[lane]);
         for (int lane = 0; lane < 64; ++lane) {
             T *x = regs[lane];
-            row_fwd_C(ar, x, pt.fwd.data(), rowbase, lane);
+            if (f64row) row_fwd_C(ar, x, twf, lane); else if (use_row) row_fwd_C(ar, x, twr, lane); else row_fwd_C(ar, x, twt, lane);
             track(x, kRowE);
             for (int r = 0; r < kRowE; ++r) out[(size_t)a * kRowN + elemC(lane, r)] = ar.to_canon(x[r]);
+            if (pair) // the U=2 path's first row must agree with the single-row path
+                for (int r = 0; r < kRowE; ++r)
+                    if (ar.to_canon(regs2[lane][0][r]) != ar.to_canon(x[r])) throw std::runtime_error("U=2 row transform differs from U=1");
         }
     }
 }
@@ -77,21 +108,22 @@ template <class Ar> static void rows_inv(const Ar &ar, const PrimeTables &pt, in
     static T regs[64][kRowE];
     for (int a = 0; a < n1; ++a) {
         const u32 rowbase = (u32)(n1 + a);
+        const auto itw = tw_table(pt.inv.data(), rowbase);
         for (int lane = 0; lane < 64; ++lane) {
             T *x = regs[lane];
             for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(in[(size_t)a * kRowN + elemC(lane, r)]);
-            row_inv_C(ar, x, pt.inv.data(), rowbase, lane);
+            row_inv_C(ar, x, itw, lane);
             track(x, kRowE);
         }
         for (int lane = 0; lane < 64; ++lane) lds_store_C(lds.data(), lane, regs[lane]);
         for (int lane = 0; lane < 64; ++lane) lds_load_B(lds.data(), lane, regs[lane]);
-        for (int lane = 0; lane < 64; ++lane) { row_inv_B(ar, regs[lane], pt.inv.data(), rowbase, lane); track(regs[lane], kRowE); }
+        for (int lane = 0; lane < 64; ++lane) { row_inv_B(ar, regs[lane], itw, lane); track(regs[lane], kRowE); }
         for (int lane = 0; lane < 64; ++lane) lds_store_B(lds.data(), lane, regs[lane]);
         for (int lane = 0; lane < 64; ++lane) lds_load_A(lds.data(), lane, regs[lane]);
         for (int lane = 0; lane < 64; ++lane) {
             T *x = regs[lane];
-            if (n1 == 1) row_inv_A<Ar, true>(ar, x, pt.inv.data(), rowbase, pt.inv_w0_scaled);
-            else row_inv_A<Ar, false>(ar, x, pt.inv.data(), rowbase, pt.inv_w0_scaled);
+            if (n1 == 1) row_inv_A<Ar, true>(ar, x, itw, pt.inv_w0_scaled);
+            else row_inv_A<Ar, false>(ar, x, itw, pt.inv_w0_scaled);
             track(x, kRowE);
             for (int r = 0; r < kRowE; ++r)
                 out[(size_t)a * kRowN + elemA(lane, r)] = (n1 == 1) ? ar.to_canon(x[r]) : ar.to_raw(x[r]);

@@ -195,6 +195,14 @@ int main()
     RUNB(0, q60, Wp60, "bfly_shoup_u64")
     RUNB(1, q60, inv64(q60), "bfly_mont_u64")
     RUNB(2, q45, 0, "bfly_fp64_q45")
+    // occupancy sweep: waves per SIMD = blocks per CU (256-thread blocks -> 1 wave per SIMD per block)
+    for (int bpc = 1; bpc <= 8; bpc *= 2) {
+        const int blk = p.multiProcessorCount * bpc;
+        double ms2 = time_ms([&] { hipLaunchKernelGGL(k_bfly<2>, dim3(blk), dim3(threads), 0, 0, out, seed, q45, 0); });
+        double ms0 = time_ms([&] { hipLaunchKernelGGL(k_bfly<0>, dim3(blk), dim3(threads), 0, 0, out, seed, q60, Wp60); });
+        double ops = (double)blk * threads * (ILP / 2) * (double)ITERS;
+        printf("waves/SIMD=%d  fp64 %8.1f Gbfly/s   u64 %8.1f Gbfly/s\n", bpc, ops / ms2 / 1e6, ops / ms0 / 1e6);
+    }
     hipFree(out);
     return 0;
 }
