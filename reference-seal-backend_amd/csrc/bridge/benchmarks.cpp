@@ -1,0 +1,264 @@
+// benchmarks.cpp — see benchmarks.h
+#include "benchmarks.h"
+
+#include <cassert>
+#include <cmath>
+#include <sstream>
+
+using namespace mi355x;
+using hebench::cpp::HEBenchError;
+namespace AB = hebench::APIBridge;
+
+//------------------------
+// class VectorBenchmarkDescription
+//------------------------
+VectorBenchmarkDescription::VectorBenchmarkDescription(Scheme scheme, AB::Category category, AB::Workload op) : m_scheme(scheme)
+{
+    const bool ok = op == AB::Workload::EltwiseAdd || (scheme == Scheme::CKKS && (op == AB::Workload::EltwiseMultiply || op == AB::Workload::DotProduct));
+    if (!ok) throw HEBenchError(HEBERROR_MSG_CLASS("Workload operation not supported."), HEBENCH_ECODE_CRITICAL_ERROR);
+    // initialize the descriptor for this benchmark (ckks eltwise .cpp:32-56)
+    std::memset(&m_descriptor, 0, sizeof(AB::BenchmarkDescriptor));
+    m_descriptor.workload = op;
+    m_descriptor.data_type = scheme == Scheme::CKKS ? AB::DataType::Float64 : AB::DataType::Int64;
+    m_descriptor.category = category;
+    switch (category) {
+    case AB::Category::Latency:
+        m_descriptor.cat_params.min_test_time_ms = 0; // any
+        m_descriptor.cat_params.latency.warmup_iterations_count = 1;
+        break;
+    case AB::Category::Offline:
+        m_descriptor.cat_params.offline.data_count[0] = 0; // flexible
+        m_descriptor.cat_params.offline.data_count[1] = 0;
+        break;
+    default:
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid category received."), HEBENCH_ECODE_CRITICAL_ERROR);
+    }
+    m_descriptor.cipher_param_mask = HEBENCH_HE_PARAM_FLAGS_ALL_CIPHER;
+    m_descriptor.scheme = scheme == Scheme::CKKS ? HEBENCH_HE_SCHEME_CKKS : HEBENCH_HE_SCHEME_BFV;
+    m_descriptor.security = HEBENCH_HE_SECURITY_128;
+    m_descriptor.other = 0; // no extra parameters
+
+    // defaults: SURVEY.md App. C (ckks eltwise .h:23-29, bfv eltwise .h:23-26, ckks dot .cpp:53-60)
+    const bool dot = op == AB::Workload::DotProduct;
+    hebench::cpp::WorkloadParams::VectorSize w;
+    w.n() = dot ? 100 : 1000;
+    w.add<std::uint64_t>(8192, "PolyModulusDegree");
+    w.add<std::uint64_t>(2, "MultiplicativeDepth");
+    w.add<std::uint64_t>(scheme == Scheme::CKKS ? (dot ? 40 : 45) : 40, "CoefficientModulusBits");
+    if (scheme == Scheme::CKKS) w.add<std::uint64_t>(dot ? 40 : 45, "ScaleBits");
+    else w.add<std::uint64_t>(20, "PlainModulusBits");
+    w.add<std::uint64_t>(0, "NumThreads"); // kept so existing HEBench YAML configs load; the GPU path ignores it
+    this->addDefaultParameters(w);
+}
+
+hebench::cpp::BaseBenchmark *VectorBenchmarkDescription::createBenchmark(hebench::cpp::BaseEngine &engine, const AB::WorkloadParams *p_params)
+{
+    return new VectorBenchmark(engine, m_descriptor, *p_params, m_scheme);
+}
+void VectorBenchmarkDescription::destroyBenchmark(hebench::cpp::BaseBenchmark *p_bench)
+{
+    if (p_bench) delete p_bench;
+}
+
+std::string VectorBenchmarkDescription::getBenchmarkDescription(const AB::WorkloadParams *p_w_params) const
+{
+    std::stringstream ss;
+    std::string s_tmp = BenchmarkDescription::getBenchmarkDescription(p_w_params);
+    if (!p_w_params)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid null workload parameters `p_w_params`"), HEBENCH_ECODE_INVALID_ARGS);
+    const std::uint64_t poly_modulus_degree = p_w_params->params[Index_PolyModulusDegree].u_param;
+    const std::uint64_t multiplicative_depth = p_w_params->params[Index_NumCoefficientModuli].u_param;
+    const std::uint64_t coeff_modulus_bits = p_w_params->params[Index_CoefficientModulusBits].u_param;
+    const std::uint64_t extra_bits = p_w_params->params[Index_ScaleExponentBits].u_param;
+    if (!s_tmp.empty()) ss << s_tmp << std::endl;
+    ss << ", Encryption Parameters" << std::endl
+       << ", , Poly modulus degree, " << poly_modulus_degree << std::endl
+       << ", , Coefficient Modulus, 60";
+    for (std::size_t i = 1; i < multiplicative_depth; ++i) ss << ", " << coeff_modulus_bits;
+    ss << ", 60" << std::endl;
+    if (m_scheme == Scheme::CKKS) ss << ", , Scale, 2^" << extra_bits << std::endl;
+    else ss << ", , Plain modulus bits, " << extra_bits << std::endl;
+    ss << ", Algorithm, " << AlgorithmName << ", " << AlgorithmDescription << std::endl
+       << ", Device, AMD Instinct MI355X (HIP; batch mapped to the grid, no host threads)";
+    return ss.str();
+}
+
+//------------------------
+// class VectorBenchmark
+//------------------------
+VectorBenchmark::VectorBenchmark(hebench::cpp::BaseEngine &engine, const AB::BenchmarkDescriptor &bench_desc, const AB::WorkloadParams &bench_params,
+                                 Scheme scheme)
+    : hebench::cpp::BaseBenchmark(engine, bench_desc, bench_params), m_scheme(scheme), m_w_params(bench_params)
+{
+    if (bench_params.count < VectorBenchmarkDescription::NumWorkloadParams)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid workload parameters."), HEBENCH_ECODE_INVALID_ARGS);
+    if (m_w_params.n() <= 0)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Vector size must be greater than 0."), HEBENCH_ECODE_INVALID_ARGS);
+    const std::uint64_t poly_modulus_degree = m_w_params.get<std::uint64_t>(VectorBenchmarkDescription::Index_PolyModulusDegree);
+    const std::uint64_t multiplicative_depth = m_w_params.get<std::uint64_t>(VectorBenchmarkDescription::Index_NumCoefficientModuli);
+    const std::uint64_t coeff_modulus_bits = m_w_params.get<std::uint64_t>(VectorBenchmarkDescription::Index_CoefficientModulusBits);
+    const std::uint64_t extra_bits = m_w_params.get<std::uint64_t>(VectorBenchmarkDescription::Index_ScaleExponentBits);
+    if (coeff_modulus_bits < 1)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Multiplicative depth must be greater than 0."), HEBENCH_ECODE_INVALID_ARGS);
+    if (m_scheme == Scheme::CKKS)
+        m_p_ctx_wrapper = HeContextWrapper::createCKKSContext(poly_modulus_degree, multiplicative_depth, (int)coeff_modulus_bits, (int)extra_bits);
+    else
+        m_p_ctx_wrapper = HeContextWrapper::createBFVContext(poly_modulus_degree, multiplicative_depth, (int)coeff_modulus_bits, (int)extra_bits);
+    const std::size_t slot_count = m_p_ctx_wrapper->slot_count();
+    if (m_w_params.n() > slot_count)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Vector size cannot be greater than " + std::to_string(slot_count) + "."), HEBENCH_ECODE_INVALID_ARGS);
+}
+
+AB::Handle VectorBenchmark::encode(const AB::DataPackCollection *p_parameters)
+{
+    if (p_parameters->pack_count != VectorBenchmarkDescription::NumOpParams)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid number of parameters detected in parameter pack. Expected 2."), HEBENCH_ECODE_INVALID_ARGS);
+    std::vector<std::vector<Plain>> params(p_parameters->pack_count);
+    for (std::size_t x = 0; x < params.size(); ++x) {
+        const AB::DataPack &parameter = p_parameters->p_data_packs[x];
+        params[x].resize(parameter.buffer_count);
+        for (std::size_t y = 0; y < params[x].size(); ++y) {
+            const AB::NativeDataBuffer &sample = parameter.p_buffers[y];
+            if (!sample.p || sample.size < m_w_params.n() * 8)
+                throw HEBenchError(HEBERROR_MSG_CLASS("Invalid sample buffer."), HEBENCH_ECODE_INVALID_ARGS);
+            if (m_scheme == Scheme::CKKS) {
+                const double *p_row = reinterpret_cast<const double *>(sample.p);
+                params[x][y] = m_p_ctx_wrapper->encodeVector(std::vector<double>(p_row, p_row + m_w_params.n()));
+            } else {
+                const std::int64_t *p_row = reinterpret_cast<const std::int64_t *>(sample.p);
+                params[x][y] = m_p_ctx_wrapper->encodeVector(std::vector<std::int64_t>(p_row, p_row + m_w_params.n()));
+            }
+        }
+    }
+    return this->getEngine().createHandle<decltype(params)>(sizeof(params), 0, std::move(params));
+}
+
+void VectorBenchmark::decode(AB::Handle encoded_data, AB::DataPackCollection *p_native)
+{
+    const std::vector<Plain> &params = this->getEngine().retrieveFromHandle<std::vector<Plain>>(encoded_data);
+    if (p_native->pack_count < 1) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid output data pack."), HEBENCH_ECODE_INVALID_ARGS);
+    const bool dot = this->getDescriptor().workload == AB::Workload::DotProduct;
+    const std::size_t out_n = dot ? 1 : m_w_params.n();
+    for (std::size_t result_i = 0; result_i < params.size() && result_i < p_native->p_data_packs[0].buffer_count; ++result_i) {
+        void *loc = p_native->p_data_packs[0].p_buffers[result_i].p;
+        if (m_scheme == Scheme::CKKS) {
+            double *output_location = reinterpret_cast<double *>(loc);
+            std::vector<double> result_vec(m_p_ctx_wrapper->slot_count());
+            m_p_ctx_wrapper->client().ckks_decode(params[result_i].data.data(), (size_t)params[result_i].L, params[result_i].scale, result_vec.data());
+            for (std::size_t x = 0; x < out_n; ++x) // same clamp as ckks eltwise .cpp:222-225
+                output_location[x] = std::abs(result_vec[x]) < 0.00005 ? 0 : result_vec[x];
+        } else {
+            std::int64_t *output_location = reinterpret_cast<std::int64_t *>(loc);
+            std::vector<std::int64_t> result_vec(m_p_ctx_wrapper->slot_count());
+            m_p_ctx_wrapper->client().bfv_decode(params[result_i].data.data(), result_vec.data());
+            for (std::size_t x = 0; x < out_n; ++x) output_location[x] = result_vec[x];
+        }
+    }
+}
+
+AB::Handle VectorBenchmark::encrypt(AB::Handle encoded_data)
+{
+    const std::vector<std::vector<Plain>> &encoded = this->getEngine().retrieveFromHandle<std::vector<std::vector<Plain>>>(encoded_data);
+    std::vector<std::vector<Cipher>> encrypted(encoded.size());
+    for (std::size_t param_i = 0; param_i < encoded.size(); ++param_i) {
+        encrypted[param_i].resize(encoded[param_i].size());
+        for (std::size_t s = 0; s < encoded[param_i].size(); ++s) encrypted[param_i][s] = m_p_ctx_wrapper->encrypt(encoded[param_i][s]);
+    }
+    return this->getEngine().createHandle<decltype(encrypted)>(sizeof(encrypted), 0, std::move(encrypted));
+}
+
+AB::Handle VectorBenchmark::decrypt(AB::Handle encrypted_data)
+{
+    if ((encrypted_data.tag & hebench::cpp::EngineObject::tag) == 0)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid tag detected. Expected EngineObject::tag."), HEBENCH_ECODE_INVALID_ARGS);
+    const std::vector<Cipher> &encrypted = this->getEngine().retrieveFromHandle<std::vector<Cipher>>(encrypted_data);
+    std::vector<Plain> plaintext_data(encrypted.size());
+    for (std::size_t i = 0; i < encrypted.size(); ++i) plaintext_data[i] = m_p_ctx_wrapper->decrypt(encrypted[i]); // size-3 results included
+    return this->getEngine().createHandle<decltype(plaintext_data)>(sizeof(plaintext_data), 0, std::move(plaintext_data));
+}
+
+// load(): the host -> HBM boundary.  The reference only duplicates the handle (ckks eltwise .cpp:277-289) because
+// its "remote" is the host; here each operand becomes one device slab of its samples, and the evaluation keys the
+// workload needs are generated and uploaded.
+AB::Handle VectorBenchmark::load(const AB::Handle *p_local_data, std::uint64_t count)
+{
+    if (count != 1)
+        // we do all ops in ciphertext, so, we should get only one pack of data
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid number of handles. Expected 1."), HEBENCH_ECODE_INVALID_ARGS);
+    assert(p_local_data);
+    const std::vector<std::vector<Cipher>> &local = this->getEngine().retrieveFromHandle<std::vector<std::vector<Cipher>>>(p_local_data[0]);
+    std::vector<std::shared_ptr<DeviceCiphers>> remote;
+    for (const auto &operand : local) remote.push_back(m_p_ctx_wrapper->upload(operand));
+    if (this->getDescriptor().workload == AB::Workload::DotProduct) {
+        m_p_ctx_wrapper->needRelinKey();
+        // accumulateCKKS(n): rotations by 2^i, i < bit_count(n) (seal_context.cpp:331-339)
+        std::uint64_t cnt = std::min<std::uint64_t>(m_w_params.n(), m_p_ctx_wrapper->slot_count());
+        int rotations = 64 - __builtin_clzll(cnt);
+        if (((std::uint64_t)1 << (rotations - 1)) == cnt) --rotations;
+        for (int i = 0; i < rotations; ++i) m_p_ctx_wrapper->needRotationKey(1 << i);
+    }
+    return this->getEngine().createHandle<decltype(remote)>(sizeof(remote), 0, std::move(remote));
+}
+
+// store(): HBM -> host
+void VectorBenchmark::store(AB::Handle remote_data, AB::Handle *p_local_data, std::uint64_t count)
+{
+    assert(count == 0 || p_local_data);
+    if (count > 0) {
+        // pad with zeros any excess local handles as per specifications
+        std::memset(p_local_data, 0, sizeof(AB::Handle) * count);
+        const std::shared_ptr<DeviceCiphers> &remote = this->getEngine().retrieveFromHandle<std::shared_ptr<DeviceCiphers>>(remote_data);
+        std::vector<Cipher> local = m_p_ctx_wrapper->download(*remote);
+        p_local_data[0] = this->getEngine().createHandle<decltype(local)>(sizeof(local), 0, std::move(local));
+    }
+}
+
+// operate(): the timed hot path.  Result r = i * batch1 + x  <-  op(operand0[value_index0 + i], operand1[value_index1 + x])
+// (ckks eltwise .cpp:322-336).  One kernel sequence over the whole batch instead of an OpenMP loop.
+AB::Handle VectorBenchmark::operate(AB::Handle h_remote_packed, const AB::ParameterIndexer *p_param_indexers, std::uint64_t indexers_count)
+{
+    if (indexers_count < VectorBenchmarkDescription::NumOpParams) {
+        std::stringstream ss;
+        ss << "Invalid number of indexers. Expected " << VectorBenchmarkDescription::NumOpParams << ", but " << indexers_count << " received." << std::endl;
+        throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
+    }
+    const std::vector<std::shared_ptr<DeviceCiphers>> &params =
+        this->getEngine().retrieveFromHandle<std::vector<std::shared_ptr<DeviceCiphers>>>(h_remote_packed);
+    if (params.size() < 2) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid remote operand pack."), HEBENCH_ECODE_INVALID_ARGS);
+    const DeviceCiphers &p0 = *params[0], &p1 = *params[1];
+    const std::uint64_t b0 = p_param_indexers[0].batch_size, b1 = p_param_indexers[1].batch_size;
+    if (p_param_indexers[0].value_index + b0 > p0.n || p_param_indexers[1].value_index + b1 > p1.n)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Parameter indexer out of range."), HEBENCH_ECODE_INVALID_ARGS);
+    const std::uint64_t n = b0 * b1;
+    he355_indexer ix;
+    ix.a_base = p_param_indexers[0].value_index;
+    ix.b_base = p_param_indexers[1].value_index;
+    ix.b1 = b1 ? b1 : 1;
+    ix.pairwise = 0;
+    ix.reserved = 0;
+    he355_ctx *ctx = m_p_ctx_wrapper->raw();
+    const int L = p0.L;
+    std::shared_ptr<DeviceCiphers> result;
+    switch (this->getDescriptor().workload) {
+    case AB::Workload::EltwiseAdd:
+        result = m_p_ctx_wrapper->allocResult(n, 2, L, p0.scale);
+        HeContextWrapper::check(he355_add(ctx, L, 2, n, p0.d, p1.d, ix, result->d), "add");
+        break;
+    case AB::Workload::EltwiseMultiply: // multiply only: the size-3 result is decrypted as is (ckks eltwise .cpp:342-344)
+        result = m_p_ctx_wrapper->allocResult(n, 3, L, p0.scale * p1.scale);
+        HeContextWrapper::check(he355_multiply(ctx, L, n, p0.d, p1.d, ix, result->d), "multiply");
+        break;
+    case AB::Workload::DotProduct: { // multiply -> relinearize_inplace -> accumulateCKKS(n)  (ckks dot .cpp:325-330)
+        result = m_p_ctx_wrapper->allocResult(n, 2, L, p0.scale * p1.scale);
+        HeContextWrapper::check(he355_multiply_relin(ctx, L, n, p0.d, p1.d, ix, 0, result->d), "multiply+relinearize");
+        std::shared_ptr<DeviceCiphers> tmp = m_p_ctx_wrapper->allocResult(n, 2, L, result->scale);
+        HeContextWrapper::check(he355_accumulate(ctx, L, n, result->d, m_w_params.n(), tmp->d), "accumulate");
+        HeContextWrapper::check(he355_sync(ctx), "synchronise");
+        break;
+    }
+    default:
+        throw HEBenchError(HEBERROR_MSG_CLASS("Operation not supported."), HEBENCH_ECODE_INVALID_ARGS);
+    }
+    HeContextWrapper::check(he355_sync(ctx), "synchronise"); // operate() returns with the result complete, as the reference's does
+    return this->getEngine().createHandle<decltype(result)>(sizeof(result), 0, std::move(result));
+}

@@ -1,0 +1,168 @@
+// he_context.cpp — see he_context.h
+#include "he_context.h"
+
+#include <cmath>
+
+#include "../he355_internal.h"
+
+namespace mi355x {
+
+using hebench::cpp::HEBenchError;
+
+void HeContextWrapper::check(int code, const char *what)
+{
+    if (code == HE355_OK) return;
+    const std::string msg = std::string(what) + ": " + he355_last_error();
+    switch (code) {
+    case HE355_E_INVALID_ARGS: throw HEBenchError(msg, HEBENCH_ECODE_INVALID_ARGS);
+    case HE355_E_PARAMS: throw HEBenchError(msg, HEB355_ECODE_HE_ERROR);
+    case HE355_E_DEVICE: throw HEBenchError(msg, HEB355_ECODE_DEVICE_ERROR);
+    default: throw HEBenchError(msg, HEBENCH_ECODE_CRITICAL_ERROR);
+    }
+}
+
+DeviceCiphers::~DeviceCiphers()
+{
+    if (d && ctx) he355_free(ctx->raw(), d);
+}
+
+HeContextWrapper::~HeContextWrapper()
+{
+    m_client.reset();
+    if (m_ctx) he355_ctx_destroy(m_ctx);
+}
+
+void HeContextWrapper::init(int scheme, std::size_t N, std::size_t depth, int bits, int plain_bits)
+{
+    // std::vector<int> coeff_modulus = {60}; for i in 1..depth-1 push bits; push 60   (seal_context.cpp:79-82,107-110)
+    std::vector<int32_t> chain{60};
+    for (std::size_t i = 1; i < depth; ++i) chain.push_back(bits);
+    chain.push_back(60);
+    // any failure here is what the reference reports as HEBSEAL_ECODE_SEAL_ERROR (seal_context.cpp:94-97,123-126)
+    check(he355_ctx_create(scheme, N, chain.data(), chain.size(), plain_bits, 1, &m_ctx), "context creation");
+    m_params = he355_internal_params(m_ctx);
+    try {
+        m_client.reset(new he355::client::Client(*m_params, 0x5EA1C0DEull ^ (uint64_t)N ^ ((uint64_t)depth << 32)));
+    } catch (const std::exception &ex) {
+        throw HEBenchError(ex.what(), HEB355_ECODE_HE_ERROR);
+    }
+}
+
+HeContextWrapper::Ptr HeContextWrapper::createCKKSContext(std::size_t N, std::size_t depth, int bits, int scale_bits)
+{
+    Ptr p(new HeContextWrapper());
+    p->init(HE355_SCHEME_CKKS, N, depth, bits, 0);
+    const int sb = scale_bits < 0 ? 0 : scale_bits;
+    p->m_scale = sb == 0 ? 1.0 : std::pow(2.0, sb); // seal_context.cpp:83-84
+    return p;
+}
+HeContextWrapper::Ptr HeContextWrapper::createBFVContext(std::size_t N, std::size_t depth, int bits, int plain_bits)
+{
+    Ptr p(new HeContextWrapper());
+    p->init(HE355_SCHEME_BFV, N, depth, bits, plain_bits);
+    return p;
+}
+
+Plain HeContextWrapper::encodeVector(const std::vector<double> &values)
+{
+    if (values.size() > slot_count())
+        throw HEBenchError(HEBERROR_MSG_CLASS("Not enough slots available to create packed plaintext"), HEBENCH_ECODE_INVALID_ARGS);
+    Plain p;
+    p.data = m_client->ckks_encode(values.data(), values.size(), m_scale);
+    p.L = topLevel();
+    p.scale = m_scale;
+    return p;
+}
+Plain HeContextWrapper::encodeVector(const std::vector<std::int64_t> &values)
+{
+    if (values.size() > slot_count())
+        throw HEBenchError(HEBERROR_MSG_CLASS("Not enough slots available to create packed plaintext"), HEBENCH_ECODE_INVALID_ARGS);
+    Plain p;
+    p.data = m_client->bfv_encode(values.data(), values.size());
+    p.L = topLevel();
+    return p;
+}
+Cipher HeContextWrapper::encrypt(const Plain &plain)
+{
+    Cipher c;
+    c.data = m_client->encrypt(plain.data.data());
+    c.size = 2;
+    c.L = topLevel();
+    c.scale = plain.scale;
+    return c;
+}
+Plain HeContextWrapper::decrypt(const Cipher &cipher)
+{
+    try {
+        Plain p;
+        p.data = m_client->decrypt(cipher.data.data(), (size_t)cipher.size, (size_t)cipher.L);
+        p.L = cipher.L;
+        p.scale = cipher.scale;
+        return p;
+    } catch (const std::exception &ex) {
+        throw HEBenchError(ex.what(), HEB355_ECODE_HE_ERROR); // seal_context.cpp:166-169
+    }
+}
+
+void HeContextWrapper::ensureDevice()
+{
+    if (m_device) return;
+    check(he355_device_init(m_ctx, 0), "device initialisation");
+    m_device = true;
+}
+void HeContextWrapper::needRelinKey()
+{
+    ensureDevice();
+    if (m_relin) return;
+    const std::vector<uint64_t> k = m_client->make_relin_key();
+    check(he355_set_relin_key(m_ctx, k.data()), "relinearization key upload");
+    m_relin = true;
+}
+void HeContextWrapper::needRotationKey(int step)
+{
+    ensureDevice();
+    const uint32_t elt = he355_galois_elt_from_step(m_ctx, step);
+    if (!elt) throw HEBenchError(HEBERROR_MSG_CLASS("step count too large"), HEBENCH_ECODE_INVALID_ARGS);
+    if (m_galois.count(elt)) return;
+    const std::vector<uint64_t> k = m_client->make_galois_key(elt);
+    check(he355_set_galois_key(m_ctx, elt, k.data()), "Galois key upload");
+    m_galois[elt] = true;
+}
+
+std::shared_ptr<DeviceCiphers> HeContextWrapper::allocResult(uint64_t n, int size, int L, double scale)
+{
+    ensureDevice();
+    auto s = std::make_shared<DeviceCiphers>();
+    s->ctx = shared_from_this();
+    s->n = n; s->size = size; s->L = L; s->scale = scale;
+    void *d = nullptr;
+    check(he355_malloc(m_ctx, n * s->elems_per_ct(m_params->N) * 8, &d), "device allocation");
+    s->d = static_cast<uint64_t *>(d);
+    return s;
+}
+std::shared_ptr<DeviceCiphers> HeContextWrapper::upload(const std::vector<Cipher> &cts)
+{
+    if (cts.empty()) throw HEBenchError(HEBERROR_MSG_CLASS("empty operand"), HEBENCH_ECODE_INVALID_ARGS);
+    auto s = allocResult(cts.size(), cts[0].size, cts[0].L, cts[0].scale);
+    const uint64_t per = s->elems_per_ct(m_params->N);
+    for (size_t i = 0; i < cts.size(); ++i) {
+        if (cts[i].size != s->size || cts[i].L != s->L || cts[i].data.size() != per)
+            throw HEBenchError(HEBERROR_MSG_CLASS("operand ciphertexts differ in shape"), HEBENCH_ECODE_INVALID_ARGS);
+        check(he355_upload(m_ctx, s->d + i * per, cts[i].data.data(), per * 8), "upload");
+    }
+    return s;
+}
+std::vector<Cipher> HeContextWrapper::download(const DeviceCiphers &slab)
+{
+    const uint64_t per = slab.elems_per_ct(m_params->N);
+    std::vector<Cipher> out(slab.n);
+    check(he355_sync(m_ctx), "synchronise");
+    for (uint64_t i = 0; i < slab.n; ++i) {
+        out[i].data.resize(per);
+        out[i].size = slab.size; out[i].L = slab.L; out[i].scale = slab.scale;
+        check(he355_download(m_ctx, out[i].data.data(), slab.d + i * per, per * 8), "download");
+    }
+    return out;
+}
+
+} // namespace mi355x

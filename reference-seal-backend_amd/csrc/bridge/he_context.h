@@ -1,0 +1,89 @@
+// he_context.h — HeContextWrapper: the backend's counterpart of the reference's SEALContextWrapper
+// (/root/reference/include/engine/seal_context.h, src/engine/seal_context.cpp): parameters, keys, encoders,
+// encrypt/decrypt on the host, and the evaluator on the MI355X through the C ABI of include/he355.h.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/he355.h"
+#include "../client/he_client.h"
+#include "hebench_cpp.h"
+
+#define HEBENCH_HE_SECURITY_128 0   /* include/engine/seal_types.h:9 */
+#define HEB355_ECODE_HE_ERROR 2     /* same value and role as HEBSEAL_ECODE_SEAL_ERROR, seal_types.h:13 */
+#define HEB355_ECODE_DEVICE_ERROR 3 /* HIP / no device: this backend has no CPU fallback */
+
+namespace mi355x {
+
+// host-side objects behind the handles (the reference keeps seal::Plaintext / seal::Ciphertext there)
+struct Plain {
+    std::vector<uint64_t> data; // CKKS: [L][N] NTT form; BFV: [N] mod t
+    int L = 0;
+    double scale = 1.0;
+};
+struct Cipher {
+    std::vector<uint64_t> data; // [size][L][N]
+    int size = 2, L = 0;
+    double scale = 1.0;
+};
+// remote (HBM) slab of n ciphertexts of identical shape
+class HeContextWrapper;
+struct DeviceCiphers {
+    std::shared_ptr<HeContextWrapper> ctx;
+    uint64_t *d = nullptr;
+    uint64_t n = 0;
+    int size = 2, L = 0;
+    double scale = 1.0;
+    DeviceCiphers() = default;
+    DeviceCiphers(const DeviceCiphers &) = delete;
+    DeviceCiphers &operator=(const DeviceCiphers &) = delete;
+    ~DeviceCiphers();
+    uint64_t elems_per_ct(uint64_t N) const { return (uint64_t)size * L * N; }
+};
+
+class HeContextWrapper : public std::enable_shared_from_this<HeContextWrapper> {
+public:
+    HEBERROR_DECLARE_CLASS_NAME(HeContextWrapper)
+    typedef std::shared_ptr<HeContextWrapper> Ptr;
+    // seal_context.cpp:17-39 / 72-127: chain {60, bits x (depth-1), 60}, tc128
+    static Ptr createCKKSContext(std::size_t poly_modulus_degree, std::size_t num_coeff_moduli, int coeff_moduli_bits, int scale_bits);
+    static Ptr createBFVContext(std::size_t poly_modulus_degree, std::size_t num_coeff_moduli, int coeff_moduli_bits, int plaintext_modulus_bits);
+    ~HeContextWrapper();
+
+    he355_ctx *raw() { return m_ctx; }
+    he355::client::Client &client() { return *m_client; }
+    const he355::Params &params() const { return *m_params; }
+    std::size_t slot_count() const { return m_client->slot_count(); }
+    double scale() const { return m_scale; }
+    int topLevel() const { return (int)m_params->Ltop; }
+    bool isCKKS() const { return m_params->scheme == he355::kSchemeCKKS; }
+
+    // host side
+    Plain encodeVector(const std::vector<double> &values);
+    Plain encodeVector(const std::vector<std::int64_t> &values);
+    Cipher encrypt(const Plain &plain);
+    Plain decrypt(const Cipher &cipher);
+
+    // device side (lazy device init; uploads the keys a workload declared it needs)
+    void ensureDevice();
+    void needRelinKey();
+    void needRotationKey(int step);
+    std::shared_ptr<DeviceCiphers> upload(const std::vector<Cipher> &cts);
+    std::vector<Cipher> download(const DeviceCiphers &slab);
+    std::shared_ptr<DeviceCiphers> allocResult(uint64_t n, int size, int L, double scale);
+    static void check(int code, const char *what); // he355 error -> HEBenchError
+
+private:
+    HeContextWrapper() = default;
+    void init(int scheme, std::size_t N, std::size_t depth, int bits, int plain_bits);
+    he355_ctx *m_ctx = nullptr;
+    const he355::Params *m_params = nullptr;
+    std::unique_ptr<he355::client::Client> m_client;
+    double m_scale = 1.0;
+    bool m_device = false, m_relin = false;
+    std::map<uint32_t, bool> m_galois;
+};
+
+} // namespace mi355x

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/he355.h"
+#include "he355_internal.h"
 #include "he355_kernels.h"
 #include "he_params.h"
 #include "ntt_core.h"
@@ -568,6 +569,8 @@ static Indexer to_ix(const he355_indexer &i)
     x.a_base = i.a_base; x.b_base = i.b_base; x.b1 = i.b1 ? i.b1 : 1; x.pairwise = i.pairwise; x.pad_ = 0;
     return x;
 }
+
+const he355::Params *he355_internal_params(const he355_ctx *ctx) { return ctx ? ctx->params.get() : nullptr; }
 
 extern "C" {
 

@@ -203,30 +203,36 @@ void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t)
         for (size_t k = 0; k < i; ++k)
             if (chain[k] == q) throw std::invalid_argument("coefficient moduli must be distinct");
         if (q >> 61 || !is_prime(q)) throw std::invalid_argument("coefficient modulus must be a prime below 2^61");
-        PrimeTables &pt = primes[i];
-        pt.q = q;
-        pt.bits = 64 - __builtin_clzll(q);
-        pt.mod = make_mod(q);
-        pt.root = minimal_primitive_root(2 * (u64)N, q);
-        pt.f64 = !force_u64 && (q >> 47) == 0;
-        pt.ninv = invmod((u64)N % q, q);
-        pt.fwd.resize(N);
-        pt.inv.resize(N);
-        pt.fwd_u64.resize(N);
-        const u64 iroot = invmod(pt.root, q);
-        u64 pw = 1, ipw = 1;
-        std::vector<u64> inv_u64(N);
-        for (size_t e = 0; e < N; ++e) {
-            const uint32_t k = bitrev((uint32_t)e, logn);
-            pt.fwd_u64[k] = pw;
-            inv_u64[k] = ipw;
-            pt.fwd[k] = make_tw(pw, q, pt.f64);
-            pt.inv[k] = make_tw(ipw, q, pt.f64);
-            pw = mm(pw, pt.root, q);
-            ipw = mm(ipw, iroot, q);
-        }
-        pt.inv_w0_scaled = make_tw(mm(inv_u64[1], pt.ninv, q), q, pt.f64);
+        primes[i] = make_prime_tables(q, N, logn, !force_u64 && (q >> 47) == 0);
     }
+}
+
+PrimeTables Params::make_prime_tables(u64 q, size_t N, int logn, bool f64)
+{
+    PrimeTables pt;
+    pt.q = q;
+    pt.bits = 64 - __builtin_clzll(q);
+    pt.mod = make_mod(q);
+    pt.root = minimal_primitive_root(2 * (u64)N, q);
+    pt.f64 = f64;
+    pt.ninv = invmod((u64)N % q, q);
+    pt.fwd.resize(N);
+    pt.inv.resize(N);
+    pt.fwd_u64.resize(N);
+    pt.inv_u64.resize(N);
+    const u64 iroot = invmod(pt.root, q);
+    u64 pw = 1, ipw = 1;
+    for (size_t e = 0; e < N; ++e) {
+        const uint32_t k = bitrev((uint32_t)e, logn);
+        pt.fwd_u64[k] = pw;
+        pt.inv_u64[k] = ipw;
+        pt.fwd[k] = make_tw(pw, q, pt.f64);
+        pt.inv[k] = make_tw(ipw, q, pt.f64);
+        pw = mm(pw, pt.root, q);
+        ipw = mm(ipw, iroot, q);
+    }
+    pt.inv_w0_scaled = make_tw(mm(pt.inv_u64[1], pt.ninv, q), q, pt.f64);
+    return pt;
 }
 
 uint32_t Params::galois_elt_from_step(int step) const

@@ -29,6 +29,7 @@ struct PrimeTables {
     std::vector<Tw16> inv; // inverse of fwd entry-wise, same indexing
     Tw16 inv_w0_scaled{};  // inv[1] * N^-1 (last inverse stage)
     std::vector<u64> fwd_u64; // plain residues of fwd (for host-side client code / checks)
+    std::vector<u64> inv_u64; // plain residues of inv
     ArU64 aru() const;
     ArF64 arf() const;
 };
@@ -61,6 +62,8 @@ public:
     static u64 powmod(u64 b, u64 e, u64 q);
     static u64 invmod(u64 a, u64 q) { return powmod(a, q - 2, q); }
     static int tc128_max_bits(size_t N);
+    // NTT tables of one prime q = 1 (mod 2N) (also used for the BFV plain modulus on the client side)
+    static PrimeTables make_prime_tables(u64 q, size_t N, int logn, bool f64);
 
 private:
     Params() = default;

@@ -1,0 +1,108 @@
+"""HEBench API-Bridge boundary without a GPU: library loads, exports every bridge symbol, registers the
+descriptors with the reference's contents, validates arguments with the reference's error codes, does the
+client-side steps on the host, and fails loudly at load() (host->HBM boundary) when no device exists."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from hebench_harness import (Backend, BridgeError, ECODE_INVALID_ARGS, LATENCY, OFFLINE, SCHEME_BFV, SCHEME_CKKS, W_ADD, W_DOT, W_MUL,
+                             DT_FLOAT64, DT_INT64, Handle)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def backend():
+    be = importlib.import_module("reference-seal-backend_amd")
+    if not os.path.exists(be.LIB_PATH):
+        be.build()
+    b = Backend(be.LIB_PATH)
+    yield b
+    b.close()
+
+
+def test_exports_every_bridge_symbol():
+    be = importlib.import_module("reference-seal-backend_amd")
+    hdr = open(os.path.join(ROOT, "include", "hebench_api_bridge.h")).read()
+    decl = re.findall(r"^(?:ErrorCode|uint64_t)\s+(\w+)\(", hdr, re.M)
+    assert len(decl) == 20, decl
+    L = C.CDLL(be.LIB_PATH)
+    assert not [s for s in decl if not hasattr(L, s)]
+
+
+def test_engine_registration(backend):
+    assert backend.scheme_name(SCHEME_CKKS) == "CKKS" and backend.scheme_name(SCHEME_BFV) == "BFV"
+    assert backend.security_name(SCHEME_CKKS, 0) == "128 bits"  # seal_engine.cpp:105
+    bs = backend.benchmarks()
+    got = sorted((b["desc"].workload, b["desc"].scheme, b["desc"].category) for b in bs)
+    want = sorted([(W_ADD, SCHEME_BFV, LATENCY), (W_ADD, SCHEME_CKKS, LATENCY), (W_ADD, SCHEME_BFV, OFFLINE), (W_ADD, SCHEME_CKKS, OFFLINE),
+                   (W_MUL, SCHEME_CKKS, LATENCY), (W_MUL, SCHEME_CKKS, OFFLINE), (W_DOT, SCHEME_CKKS, LATENCY), (W_DOT, SCHEME_CKKS, OFFLINE)])
+    assert got == want
+    for b in bs:
+        d = b["desc"]
+        assert d.cipher_param_mask == 0xFFFFFFFF and d.security == 0 and d.other == 0
+        assert d.data_type == (DT_FLOAT64 if d.scheme == SCHEME_CKKS else DT_INT64)
+        if d.category == LATENCY:
+            assert d.cat_params.latency.warmup_iterations_count == 1 and d.cat_params.min_test_time_ms == 0
+    # default workload parameters: SURVEY.md App. C
+    ck = backend.find(W_MUL, SCHEME_CKKS, OFFLINE)["defaults"][0]
+    assert ck == [("n", 1000), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 2), ("CoefficientModulusBits", 45), ("ScaleBits", 45), ("NumThreads", 0)]
+    dot = backend.find(W_DOT, SCHEME_CKKS, LATENCY)["defaults"][0]
+    assert dot[0] == ("n", 100) and dot[3] == ("CoefficientModulusBits", 40)
+    bfv = backend.find(W_ADD, SCHEME_BFV, LATENCY)["defaults"][0]
+    assert bfv[3:5] == [("CoefficientModulusBits", 40), ("PlainModulusBits", 20)]
+
+
+def test_description_text(backend):
+    b = backend.find(W_ADD, SCHEME_CKKS, OFFLINE)
+    txt = backend.description_text(b, [("n", 10), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 3), ("CoefficientModulusBits", 45),
+                                       ("ScaleBits", 45), ("NumThreads", 0)])
+    assert ", , Poly modulus degree, 8192" in txt and ", , Coefficient Modulus, 60, 45, 45, 60" in txt and ", , Scale, 2^45" in txt
+    assert ", Algorithm, Vector, One vector per ciphertext" in txt
+
+
+def test_argument_validation_codes(backend):
+    b = backend.find(W_ADD, SCHEME_CKKS, LATENCY)
+    base = [("n", 10), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 2), ("CoefficientModulusBits", 45), ("ScaleBits", 45), ("NumThreads", 0)]
+    with pytest.raises(BridgeError) as ei:  # n <= 0 (ckks eltwise .cpp:129-131)
+        backend.create(b, [("n", 0)] + base[1:])
+    assert ei.value.code == ECODE_INVALID_ARGS and "Vector size must be greater than 0." in str(ei.value)
+    with pytest.raises(BridgeError) as ei:  # n > slot count (.cpp:152-155)
+        backend.create(b, [("n", 5000)] + base[1:])
+    assert ei.value.code == ECODE_INVALID_ARGS and "cannot be greater than 4096" in str(ei.value)
+    with pytest.raises(BridgeError) as ei:  # invalid parameters -> code 2, as HEBSEAL_ECODE_SEAL_ERROR (seal_context.cpp:94-97)
+        backend.create(b, [("n", 10), ("PolyModulusDegree", 4096), ("MultiplicativeDepth", 2), ("CoefficientModulusBits", 45), ("ScaleBits", 45), ("NumThreads", 0)])
+    assert ei.value.code == 2
+    assert backend.error_description(2) and backend.error_description(3)
+    hb = backend.create(b, base)
+    # pack_count != 2 (.cpp:165-167)
+    dpc, keep = backend.pack([np.zeros((1, 10))])
+    h = Handle()
+    code = backend.L.encode(hb, C.byref(dpc), C.byref(h))
+    assert code == ECODE_INVALID_ARGS and "Expected 2" in backend.last_error()
+    backend.destroy(hb)
+
+
+def test_client_side_then_loud_failure_at_load(backend):
+    be = importlib.import_module("reference-seal-backend_amd")
+    if be.device_count() > 0:
+        pytest.skip("a GPU is present")
+    b = backend.find(W_ADD, SCHEME_CKKS, OFFLINE)
+    hb = backend.create(b, [("n", 10), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 2), ("CoefficientModulusBits", 45), ("ScaleBits", 45),
+                            ("NumThreads", 0)], (2, 2))
+    rng = np.random.default_rng(0)
+    dpc, keep = backend.pack([rng.uniform(-1, 1, (2, 10)), rng.uniform(-1, 1, (2, 10))])
+    hp, hc, hr = Handle(), Handle(), Handle()
+    backend.chk(backend.L.encode(hb, C.byref(dpc), C.byref(hp)))   # host: CKKS encoder
+    backend.chk(backend.L.encrypt(hb, hp, C.byref(hc)))            # host: encryptor
+    code = backend.L.load(hb, C.byref(hc), 1, C.byref(hr))         # host -> HBM: must fail, loudly, with the device code
+    assert code == 3 and "no CPU fallback" in backend.last_error()
+    code = backend.L.load(hb, C.byref(hc), 2, C.byref(hr))         # count != 1 (.cpp:279-282)
+    assert code == ECODE_INVALID_ARGS
+    for h in (hp, hc):
+        backend.destroy(h)
+    backend.destroy(hb)
