@@ -1,0 +1,59 @@
+"""N > 1 path on the CPU: two gloo ranks shard an outer-product batch, exchange their shard descriptors and
+timings the way bench.py does (barrier, MAX over ranks), and check the shards tile the result range exactly."""
+import importlib.util
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_sharding():
+    spec = importlib.util.spec_from_file_location("he355_sharding", os.path.join(ROOT, "reference-seal-backend_amd", "sharding.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["he355_sharding"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _worker(rank, world, port, b0, b1, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = _load_sharding().shard_outer_product(b0, b1, world, rank, value_index0=3)
+    mine = torch.tensor([sh.first_result, sh.n_results, sh.a_base, sh.a_count], dtype=torch.int64)
+    gathered = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    dist.barrier()
+    t = torch.tensor([0.010 * (rank + 1)], dtype=torch.float64)  # pretend rank r took 10*(r+1) ms
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        q.put(([g.tolist() for g in gathered], float(t.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("b0,b1", [(1024, 1), (7, 3), (1, 5)])
+def test_two_rank_sharding(b0, b1):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000) + b0 % 7
+    procs = [ctx.Process(target=_worker, args=(r, world, port, b0, b1, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    shards, tmax = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert abs(tmax - 0.020) < 1e-12  # MAX over ranks
+    covered = []
+    for first, n, a_base, a_count in shards:
+        assert n == a_count * b1 and first == (a_base - 3) * b1
+        covered += list(range(first, first + n))
+    assert covered == list(range(b0 * b1))  # every result exactly once, in order, no overlap
+    mod = _load_sharding()
+    assert mod.aggregate_throughput([s[1] for s in shards], [0.01, 0.02]) == pytest.approx(b0 * b1 / 0.02)
