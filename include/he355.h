@@ -19,8 +19,9 @@
  *     (rescale = 1)             ... + rescale_to_next_inplace                 src/benchmarks/ckks/seal_ckks_matmultval_benchmark.cpp:253-255
  *   he355_relinearize           evaluator()->relinearize_inplace              src/engine/seal_context.cpp:390,447
  *   he355_rescale               evaluator()->rescale_to_next_inplace          src/engine/seal_context.cpp:391,448
- *   he355_rotate                evaluator()->rotate_vector                    src/engine/seal_context.cpp:337
- *   he355_accumulate            SEALContextWrapper::accumulateCKKS            src/engine/seal_context.cpp:321-347
+ *   he355_rotate                evaluator()->rotate_vector (CKKS) / rotate_rows (BFV)      src/engine/seal_context.cpp:337,302
+ *   he355_apply_galois(2N-1)    evaluator()->rotate_columns_inplace (BFV)                   src/engine/seal_context.cpp:308
+ *   he355_accumulate            SEALContextWrapper::accumulateCKKS / accumulateBFV          src/engine/seal_context.cpp:321-347,289-319
  *   the Indexer                 ParameterIndexer{value_index,batch_size} and the result order r = i*b1 + x
  *                                                         src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:322-336
  *
@@ -97,6 +98,9 @@ int he355_add(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_a, 
 int he355_sub(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, uint64_t *d_out);
 /* CKKS multiply: [.][2][L][N] x [.][2][L][N] -> [n][3][L][N] */
 int he355_multiply(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, uint64_t *d_out);
+/* BFV multiply (BEHZ, coefficient form): [.][2][L][N] x [.][2][L][N] -> [n][3][L][N]
+ * (evaluator()->multiply, src/benchmarks/bfv/seal_bfv_element_wise_benchmark.cpp:325, seal_bfv_dot_product_benchmark.cpp:311) */
+int he355_bfv_multiply(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, uint64_t *d_out);
 /* multiply -> relinearize (-> rescale): out [n][2][L][N] or [n][2][L-1][N] */
 int he355_multiply_relin(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, int rescale,
                          uint64_t *d_out);

@@ -77,6 +77,7 @@ def lib():
             "he355_add": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
             "he355_sub": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
             "he355_multiply": (i32, [vp, i32, u64, vp, vp, Indexer, vp]),
+            "he355_bfv_multiply": (i32, [vp, i32, u64, vp, vp, Indexer, vp]),
             "he355_multiply_relin": (i32, [vp, i32, u64, vp, vp, Indexer, i32, vp]),
             "he355_relinearize": (i32, [vp, i32, u64, vp, vp]),
             "he355_rescale": (i32, [vp, i32, i32, u64, vp, vp]),
@@ -101,7 +102,7 @@ C_ABI_SYMBOLS = [
     "he355_prime_uses_fp64", "he355_galois_elt_from_step", "he355_galois_elts_all", "he355_device_count",
     "he355_device_init", "he355_malloc", "he355_free", "he355_upload", "he355_download", "he355_sync",
     "he355_fill_uniform", "he355_set_relin_key", "he355_set_galois_key", "he355_set_relin_key_synthetic",
-    "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_multiply_relin",
+    "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
     "he355_relinearize", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_accumulate",
     "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_set_chunk",
 ]
@@ -244,6 +245,9 @@ class Context:
 
     def multiply(self, L, n, a, b, ix, out):
         _check(lib().he355_multiply(self.h, L, n, a.ptr, b.ptr, ix, out.ptr))
+
+    def bfv_multiply(self, L, n, a, b, ix, out):
+        _check(lib().he355_bfv_multiply(self.h, L, n, a.ptr, b.ptr, ix, out.ptr))
 
     def multiply_relin(self, L, n, a, b, ix, out, rescale=False):
         _check(lib().he355_multiply_relin(self.h, L, n, a.ptr, b.ptr, ix, int(rescale), out.ptr))

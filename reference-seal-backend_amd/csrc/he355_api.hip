@@ -86,9 +86,10 @@ public:
         HIPCHECK(hipEventCreate(&ev0_));
         HIPCHECK(hipEventCreate(&ev1_));
         const size_t N = P.N, K = P.K;
-        std::vector<PrimeDev> pd(K);
-        for (size_t i = 0; i < K; ++i) {
-            const PrimeTables &pt = P.primes[i];
+        const size_t n_all = K + P.aux.size(); // BFV: the BEHZ auxiliary primes follow the key chain
+        std::vector<PrimeDev> pd(n_all);
+        for (size_t i = 0; i < n_all; ++i) {
+            const PrimeTables &pt = i < K ? P.primes[i] : P.aux[i - K];
             Tw16 *dfwd = nullptr, *dinv = nullptr;
             HIPCHECK(hipMalloc(&dfwd, N * sizeof(Tw16)));
             owned_.push_back(dfwd);
@@ -106,8 +107,8 @@ public:
             d.f64 = pt.f64 ? 1 : 0; d.pad_ = 0;
             env_.prime_f64[i] = pt.f64 ? 1 : 0;
         }
-        HIPCHECK(hipMalloc(&d_primes_, K * sizeof(PrimeDev)));
-        HIPCHECK(hipMemcpy(d_primes_, pd.data(), K * sizeof(PrimeDev), hipMemcpyHostToDevice));
+        HIPCHECK(hipMalloc(&d_primes_, n_all * sizeof(PrimeDev)));
+        HIPCHECK(hipMemcpy(d_primes_, pd.data(), n_all * sizeof(PrimeDev), hipMemcpyHostToDevice));
         std::vector<FloorConst> fc(K * K);
         for (size_t s = 0; s < K; ++s)
             for (size_t i = 0; i < K; ++i) {
@@ -147,6 +148,8 @@ public:
         (void)hipFree(scratch_);
         (void)hipFree(scratch2_);
         (void)hipFree(rot_tmp_);
+        (void)hipFree(bfv_scratch_);
+        for (auto &kv : d_gather_) (void)hipFree(kv.second);
         (void)hipEventDestroy(ev_fork_);
         (void)hipEventDestroy(ev_join_);
         (void)hipStreamDestroy(stream2_);
@@ -204,6 +207,18 @@ public:
         HIPCHECK(hipMalloc(&d, P.N * 4));
         HIPCHECK(hipMemcpy(d, h.data(), P.N * 4, hipMemcpyHostToDevice));
         d_perm_[elt] = d;
+        return d;
+    }
+
+    const uint32_t *gather(uint32_t elt)
+    {
+        auto it = d_gather_.find(elt);
+        if (it != d_gather_.end()) return it->second;
+        const std::vector<uint32_t> h = P.galois_gather_coeff(elt);
+        uint32_t *d = nullptr;
+        HIPCHECK(hipMalloc(&d, P.N * 4));
+        HIPCHECK(hipMemcpy(d, h.data(), P.N * 4, hipMemcpyHostToDevice));
+        d_gather_[elt] = d;
         return d;
     }
 
@@ -357,9 +372,22 @@ public:
         use();
         check_level(L);
         require_keyswitch();
-        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_relinearize: BFV path not available in this build");
         if (!d_relin_) throw std::invalid_argument("relinearization key not set");
         const size_t N = P.N, LN = (size_t)L * N;
+        if (P.scheme == kSchemeBFV) {
+            for (u64 off = 0; off < n; off += chunk_) {
+                const u64 nc = std::min<u64>(chunk_, n - off);
+                Scratch S = scratch(chunk_, L);
+                KsBuffers B = S.ks;
+                B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
+                const u64 *src = ct3 + off * 3 * LN;
+                // (c0, c1) of each size-3 ciphertext -> out; c2 is the key-switch target
+                HIPCHECK(hipMemcpy2DAsync(B.c01, 2 * LN * 8, src, 3 * LN * 8, 2 * LN * 8, nc, hipMemcpyDeviceToDevice, stream_));
+                bfv_key_switch(L, nc, S, B, d_relin_, src + 2 * LN, 3 * LN);
+            }
+            HIPCHECK(hipGetLastError());
+            return;
+        }
         Indexer ix{};
         for (u64 off = 0; off < n; off += chunk_) {
             const u64 nc = std::min<u64>(chunk_, n - off);
@@ -393,11 +421,24 @@ public:
         use();
         check_level(L);
         require_keyswitch();
-        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_apply_galois: BFV path not available in this build");
         if (!(elt & 1) || elt >= 2 * P.N) throw std::invalid_argument("Galois element is not valid");
         const u64 *key = galois_key(elt);
         if (!key) throw std::invalid_argument("Galois key not present");
         if (in == out) throw std::invalid_argument("apply_galois cannot run in place");
+        if (P.scheme == kSchemeBFV) {
+            const uint32_t *gt = gather(elt);
+            const size_t LN = (size_t)L * P.N;
+            for (u64 off = 0; off < n; off += chunk_) {
+                const u64 nc = std::min<u64>(chunk_, n - off);
+                Scratch S = scratch(chunk_, L);
+                KsBuffers B = S.ks;
+                B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
+                launch_bfv_galois(env_, L, nc, in + off * 2 * LN, gt, B.c01, B.c01_item_stride, B.c2n);
+                bfv_key_switch(L, nc, S, B, key, B.c2n, LN);
+            }
+            HIPCHECK(hipGetLastError());
+            return;
+        }
         const uint32_t *pm = perm(elt);
         const size_t N = P.N, LN = (size_t)L * N;
         Indexer ix{};
@@ -464,6 +505,23 @@ public:
     void accumulate(int L, u64 n, u64 *inout, u64 count, u64 *tmp)
     {
         if (count == 0) throw std::invalid_argument("accumulate with count 0 needs a fresh encryption of zero (client side)");
+        if (P.scheme == kSchemeBFV) { // SEALContextWrapper::accumulateBFV (seal_context.cpp:289-319)
+            const u64 half = P.N / 2;
+            const u64 row_count = count > half ? half : count;
+            int rot = 64 - __builtin_clzll(row_count);
+            if (((u64)1 << (rot - 1)) == row_count) --rot;
+            Indexer ixb{};
+            ixb.pairwise = 1;
+            for (int i = 0; i < rot; ++i) {
+                rotate(L, n, inout, 1 << i, tmp); // rotate_rows
+                addsub(L, 2, n, inout, tmp, ixb, inout, false);
+            }
+            if (count > half) {
+                apply_galois(L, n, inout, (uint32_t)(2 * P.N - 1), tmp); // rotate_columns
+                addsub(L, 2, n, inout, tmp, ixb, inout, false);
+            }
+            return;
+        }
         const u64 slots = P.N / 2;
         if (count > slots) count = slots;
         int rotations = 64 - __builtin_clzll(count);
@@ -475,6 +533,93 @@ public:
             addsub(L, 2, n, inout, tmp, ix, inout, false);
         }
     }
+
+    // ---- BFV ------------------------------------------------------------------------------------------
+    const BehzDev &behz(int L)
+    {
+        auto it = behz_.find(L);
+        if (it != behz_.end()) return it->second;
+        if (L > kBehzMaxL) throw std::invalid_argument("BFV multiply supports at most 16 data primes in this build");
+        const BehzTables T = P.behz_tables(L);
+        std::vector<u64> blob;
+        auto push = [&](const std::vector<u64> &v) { const size_t off = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return off; };
+        std::vector<u64> cq(L);
+        for (int i = 0; i < L; ++i) cq[i] = (u64)(((u128)T.mtilde_q[i] * T.inv_punct_q[i]) % P.primes[i].q);
+        const size_t o_cq = push(cq), o_ip = push(T.inv_punct_q), o_q2b = push(T.q2bsk), o_q2m = push(T.q2mt), o_qmb = push(T.q_mod_bsk),
+                     o_imb = push(T.inv_mt_bsk), o_iqb = push(T.inv_q_bsk), o_tq = push(T.t_mod_q), o_tb = push(T.t_mod_bsk), o_ipB = push(T.inv_punct_B),
+                     o_B2q = push(T.B2q), o_B2m = push(T.B2msk), o_Bq = push(T.B_mod_q);
+        u64 *d = nullptr;
+        HIPCHECK(hipMalloc(&d, blob.size() * 8));
+        owned_.push_back(d);
+        HIPCHECK(hipMemcpy(d, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
+        BehzDev Z{};
+        Z.L = L;
+        Z.cq = d + o_cq; Z.inv_punct_q = d + o_ip; Z.q2bsk = d + o_q2b; Z.q2mt = d + o_q2m; Z.neg_inv_q_mod_mt = T.neg_inv_q_mod_mt;
+        Z.q_mod_bsk = d + o_qmb; Z.inv_mt_bsk = d + o_imb; Z.inv_q_bsk = d + o_iqb; Z.t_mod_q = d + o_tq; Z.t_mod_bsk = d + o_tb;
+        Z.inv_punct_B = d + o_ipB; Z.B2q = d + o_B2q; Z.B2msk = d + o_B2m; Z.inv_B_mod_msk = T.inv_B_mod_msk; Z.B_mod_q = d + o_Bq;
+        for (int j = 0; j < L; ++j) Z.bsk_prime[j] = (unsigned char)(P.K + 1 + j); // B_j
+        Z.bsk_prime[L] = (unsigned char)P.K;                                        // m_sk
+        return behz_[L] = Z;
+    }
+    // Evaluator::bfv_multiply (BEHZ), size 2 x 2 -> 3, coefficient form
+    void bfv_multiply(int L, u64 n, const u64 *a, const u64 *b, Indexer ix, u64 *out)
+    {
+        use();
+        check_level(L);
+        if (P.scheme != kSchemeBFV) throw std::invalid_argument("he355_bfv_multiply needs a BFV context");
+        const BehzDev &Z = behz(L);
+        const size_t N = P.N, S = (size_t)L + 1;
+        const size_t per_op = (4 * L + 4 * S + 3 * L + 3 * S) * N;
+        const size_t c = std::min<size_t>(chunk_, (size_t)n ? (size_t)n : 1);
+        if (per_op * c * 8 > bfv_bytes_) {
+            HIPCHECK(hipStreamSynchronize(stream_));
+            if (bfv_scratch_) HIPCHECK(hipFree(bfv_scratch_));
+            bfv_scratch_ = nullptr; bfv_bytes_ = 0;
+            HIPCHECK(hipMalloc(&bfv_scratch_, per_op * c * 8));
+            bfv_bytes_ = per_op * c * 8;
+        }
+        u64 *xq = bfv_scratch_, *xb = xq + c * 4 * L * N, *dq = xb + c * 4 * S * N, *ds = dq + c * 3 * L * N;
+        PolyView vq{}, vb{};
+        unsigned char pq[64], pb[64];
+        for (int i = 0; i < L; ++i) { pq[i] = (unsigned char)i; vq.prime_of[i] = pq[i]; }
+        for (size_t j = 0; j < S; ++j) { pb[j] = Z.bsk_prime[j]; vb.prime_of[j] = pb[j]; }
+        vq.polys_per_item = L; vq.item_stride = (u64)L * N;
+        vb.polys_per_item = (int)S; vb.item_stride = (u64)S * N;
+        for (u64 off = 0; off < n; off += c) {
+            const u64 nc = std::min<u64>(c, n - off);
+            launch_behz_extend_off(nc, off, a, b, ix, Z, xq, xb);
+            vq.base = xq; launch_ntt_forward(env_, vq, (u32)(nc * 4));
+            vb.base = xb; launch_ntt_forward(env_, vb, (u32)(nc * 4));
+            launch_tensor4(env_, L, pq, nc, xq, dq);
+            launch_tensor4(env_, (int)S, pb, nc, xb, ds);
+            vq.base = dq; launch_ntt_inverse(env_, vq, (u32)(nc * 3));
+            vb.base = ds; launch_ntt_inverse(env_, vb, (u32)(nc * 3));
+            launch_behz_floor_sk(env_, Z, nc, dq, ds, out + off * 3 * (size_t)L * N);
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    void launch_behz_extend_off(u64 nc, u64 off, const u64 *a, const u64 *b, Indexer ix, const BehzDev &Z, u64 *xq, u64 *xb)
+    {
+        // results off..off+nc-1: shift the indexer (outer product: r -> r + off needs the generic form, so pass the
+        // offset through a_base/b_base only when it stays exact; otherwise fold it by calling with a shifted view)
+        if (ix.pairwise) {
+            ix.a_base += off; ix.b_base += off;
+            launch_behz_extend(env_, Z, nc, a, b, ix, xq, xb);
+        } else if (off % ix.b1 == 0) {
+            ix.a_base += off / ix.b1;
+            launch_behz_extend(env_, Z, nc, a, b, ix, xq, xb);
+        } else {
+            throw std::invalid_argument("BFV multiply: chunk size must be a multiple of the operand-1 batch size");
+        }
+    }
+    // key switching for BFV: the target is in coefficient form; result added into c01 (coefficient form)
+    void bfv_key_switch(int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, const u64 *target, u64 target_op_stride)
+    {
+        launch_k2(env_, L, nc, B, target, target_op_stride);
+        launch_k3(env_, L, nc, B, key);
+        launch_bfv_tail_sp(env_, nc * 2, B.tpr, S.rlr);
+        launch_bfv_tail_fin(env_, L, nc, B.t, S.rlr, B.c01, B.c01_item_stride);
+    }
     void ntt(u64 *polys, u64 n_polys, const uint8_t *prime_of, u32 period, bool inverse)
     {
         use();
@@ -483,7 +628,7 @@ public:
         PolyView v;
         v.base = polys; v.item_stride = (u64)period * P.N; v.polys_per_item = (int)period; v.pad_ = 0;
         for (u32 i = 0; i < period; ++i) {
-            if (prime_of[i] >= P.K) throw std::invalid_argument("prime index out of range");
+            if (prime_of[i] >= P.K + P.aux.size()) throw std::invalid_argument("prime index out of range");
             v.prime_of[i] = prime_of[i];
         }
         if (inverse) launch_ntt_inverse(env_, v, (u32)(n_polys / period));
@@ -521,6 +666,10 @@ private:
     bool dual_stream_ = true;
     u64 *rot_tmp_ = nullptr;
     size_t rot_tmp_bytes_ = 0;
+    u64 *bfv_scratch_ = nullptr;
+    size_t bfv_bytes_ = 0;
+    std::map<int, BehzDev> behz_;
+    std::map<uint32_t, uint32_t *> d_gather_;
     size_t chunk_ = 32;
 };
 
@@ -697,6 +846,10 @@ int he355_sub(he355_ctx *c, int L, int size, uint64_t n, const uint64_t *a, cons
 int he355_multiply(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const uint64_t *b, he355_indexer ix, uint64_t *out)
 {
     return guarded([&] { dev(c).multiply(L, n, a, b, to_ix(ix), out); });
+}
+int he355_bfv_multiply(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const uint64_t *b, he355_indexer ix, uint64_t *out)
+{
+    return guarded([&] { dev(c).bfv_multiply(L, n, a, b, to_ix(ix), out); });
 }
 int he355_multiply_relin(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const uint64_t *b, he355_indexer ix, int rescale, uint64_t *out)
 {

@@ -52,8 +52,11 @@ enum K1Mode { K1_MUL = 0, K1_CT3 = 1, K1_GALOIS = 2 };
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix,
                const uint32_t *perm, const KsBuffers &buf);
 // K2: finish iNTT of each digit, lift to every key prime, forward column pass -> d
-void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf);
+// src_is_coeff (BFV): `src` already holds coefficient-form digits [op][L][N] (op stride src_op_stride) and every
+// (prime, digit) pair is lifted, including the digit's own prime
+void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *src = nullptr, u64 src_op_stride = 0);
 // K3: forward row pass of every (tt, j) + multiply-accumulate with the key -> t (data primes) / tpr (special)
+// BFV (env.scheme == 1): the products of ALL primes continue into the inverse row pass (t then holds raw rows)
 void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key);
 // floor step, column half: src [n_ops*n_src][N] raw of prime s -> r = (x + floor(s/2)) mod s ->
 // (r mod q_i - floor(s/2) mod q_i) for i < n_tgt -> forward column pass -> dst [n_ops*n_src][n_tgt][N]
@@ -71,6 +74,40 @@ struct FloorRowsArgs {
     u64 *tail;                   // [n_ops*n_src][N]
 };
 void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &args);
+// ---- BFV -------------------------------------------------------------------------------------------------
+// Device copy of BehzTables (he_params.h); all pointers are HBM.  Bsk order: B_0..B_{L-1}, m_sk.
+struct BehzDev {
+    int L, pad_;
+    const u64 *cq;          // [L]      2^32 * (Q/q_i)^-1 mod q_i  (fastbconv_m_tilde, merged constants)
+    const u64 *inv_punct_q; // [L]
+    const u64 *q2bsk;       // [L+1][L]
+    const u64 *q2mt;        // [L]
+    u64 neg_inv_q_mod_mt;
+    const u64 *q_mod_bsk, *inv_mt_bsk, *inv_q_bsk; // [L+1]
+    const u64 *t_mod_q;     // [L]
+    const u64 *t_mod_bsk;   // [L+1]
+    const u64 *inv_punct_B; // [L]
+    const u64 *B2q;         // [L][L]
+    const u64 *B2msk;       // [L]
+    u64 inv_B_mod_msk;
+    const u64 *B_mod_q;     // [L]
+    unsigned char bsk_prime[64]; // device prime index of Bsk element j
+};
+constexpr int kBehzMaxL = 16;
+// BEHZ steps (1)-(2): lift the four input polynomials of each pair to Bsk (fastbconv_m_tilde + sm_mrq) and copy them
+// for the base-q transform.  xq [n*4][L][N], xbsk [n*4][L+1][N], coefficient form.
+void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk);
+// dyadic tensor of NTT-form polys x [n*4][Lx][N] (a0,a1,b0,b1) -> d [n*3][Lx][N]; residue i under prime prime_of[i]
+void launch_tensor4(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d);
+// BEHZ steps (6)-(8): times t, fast floor, Shenoy-Kumaresan -> out [n][3][L][N]
+void launch_behz_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out);
+// coefficient-form Galois: c01[op][0] = sigma(in0), c01[op][1] = 0, tgt[op] = sigma(in1); gather table has the sign in bit 31
+void launch_bfv_galois(const KernelEnv &env, int L, u64 n_ops, const u64 *in, const uint32_t *gather, u64 *c01, u64 c01_item_stride, u64 *tgt);
+// BFV key-switch tails: finish the inverse transform of the special-prime sums and round (-> rp), then finish every data
+// prime's inverse transform, apply the floor step in coefficient form and add into c01
+void launch_bfv_tail_sp(const KernelEnv &env, u64 n_polys, const u64 *tpr, u64 *rp);
+void launch_bfv_tail_fin(const KernelEnv &env, int L, u64 n_ops, const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride);
+
 // inverse row pass of one residue of each poly: src [(op,k)] residue `prime` -> tail [(op,k)][N]
 void launch_rows_inv_select(const KernelEnv &env, int prime, u64 n_polys, const u64 *src, u64 src_poly_stride, u64 *tail);
 

@@ -491,9 +491,10 @@ __global__ void __launch_bounds__(kBlock) k_k1(K1Args A, const PrimeDev *primes)
 // =======================================================================================================
 struct K2Args {
     const u64 *c2r;
+    u64 src_op_stride;
     u64 *d;
     u64 n_ops;
-    int L, K, ckks;
+    int L, K, ckks, src_is_coeff;
 };
 
 // lift canonical c (mod q_j) to a value usable as forward-transform input under prime t
@@ -544,10 +545,13 @@ __global__ void __launch_bounds__(kBlock) k_k2(K2Args A, const PrimeDev *primes)
     const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
     const int j = (int)(oj % A.L);
     const u64 op = oj / A.L;
-    const u64 *src = A.c2r + (op * A.L + j) * N;
+    const u64 *src = A.c2r + op * A.src_op_stride + (u64)j * N;
     const PrimeDev &Pj = primes[j];
     u64 c[N1];
-    if (LOGN1 == 0) {
+    if (A.src_is_coeff) {
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = src[(a << kRowLog) + col]; // BFV: the target is in coefficient form already
+    } else if (LOGN1 == 0) {
         c[0] = src[col]; // the row pass was the whole inverse transform: already canonical coefficients
     } else if (Pj.f64) {
         const ArF64 ar = make_ar(Pj, (ArF64 *)nullptr);
@@ -692,7 +696,20 @@ __global__ void __launch_bounds__(kBlock) k_k3(K3Args A, const PrimeDev *primes)
         }
     }
     u64 v[kRowE];
-    if (tt < A.L) {
+    if (tt < A.L && !A.ckks) {
+        // BFV: the result must come back to coefficient form: every prime's sums start the inverse transform here
+        const bool last = A.logn1 == 0;
+        T x[kRowE];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(ar.acc_canon(k ? acc1[r] : acc0[r]));
+            wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave][0], x);
+#pragma unroll
+            for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
+            if (valid) store_rowA(A.t + ((op * 2 + k) * A.L + tt) * N + rowoff, lane, v);
+        }
+    } else if (tt < A.L) {
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc0[r]);
         if (valid) store_rowC(A.t + ((op * 2 + 0) * A.L + tt) * N + rowoff, lane, v);
@@ -845,6 +862,235 @@ __global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const Pri
     }
 }
 
+// =======================================================================================================
+// BFV: BEHZ base extension / floor kernels (one lane = one coefficient across all residues), coefficient-form Galois,
+// and the coefficient-form key-switch tails
+// =======================================================================================================
+__device__ __forceinline__ ModU64 mod_of(const PrimeDev *primes, int idx) { return make_modu(primes[idx]); }
+
+__global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDev *primes, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk,
+                                                        u64 n_ops, int logN)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 n = gid & (((u64)1 << logN) - 1);
+    const u64 pid = gid >> logN; // (op, which ct, which poly)
+    if (pid >= n_ops * 4) return;
+    const u64 r = pid >> 2;
+    const int c = (int)((pid >> 1) & 1), k = (int)(pid & 1);
+    const int L = Z.L, S = L + 1;
+    const u64 N = (u64)1 << logN, P1 = (u64)L * N;
+    const u64 *src = (c ? b + idx_b(ix, r) * 2 * P1 : a + idx_a(ix, r) * 2 * P1) + (u64)k * P1 + n;
+    u64 tmp[kBehzMaxL];
+    u64 mt_acc = 0;
+#pragma unroll
+    for (int i = 0; i < kBehzMaxL; ++i) {
+        if (i < L) {
+            const u64 x = src[(u64)i * N];
+            xq[(pid * L + i) * N + n] = x;
+            tmp[i] = mulmod(x, Z.cq[i], mod_of(primes, i)); // x * m_tilde * (Q/q_i)^-1 mod q_i
+            mt_acc += (tmp[i] & 0xFFFFFFFFull) * Z.q2mt[i];
+        }
+    }
+    const u64 MT = (u64)1 << 32;
+    const u64 rmt = (((mt_acc & 0xFFFFFFFFull) * Z.neg_inv_q_mod_mt) & 0xFFFFFFFFull); // -(x*m_tilde)_fast * Q^-1 mod m_tilde
+    for (int j = 0; j < S; ++j) {
+        const ModU64 mj = mod_of(primes, Z.bsk_prime[j]);
+        u128 acc = 0;
+#pragma unroll
+        for (int i = 0; i < kBehzMaxL; ++i)
+            if (i < L) acc += (u128)tmp[i] * Z.q2bsk[j * L + i];
+        const u64 conv = barrett128(acc, mj);
+        u64 rr = rmt;
+        if (rr >= (MT >> 1)) rr += mj.q - MT; // centred r as a residue mod p_j
+        const u64 v = barrett128((u128)rr * Z.q_mod_bsk[j] + conv, mj);
+        xbsk[(pid * S + j) * N + n] = mulmod(v, Z.inv_mt_bsk[j], mj);
+    }
+}
+
+struct PrimeMap64 {
+    unsigned char p[64];
+};
+// x [n*4][Lx][N] -> d [n*3][Lx][N], 2 coefficients per lane
+__global__ void __launch_bounds__(kBlock) k_tensor4(const u64 *x, u64 *d, const PrimeDev *primes, PrimeMap64 pm, int Lx, int logN, u64 n_ops)
+{
+    const u64 pairs_per_poly = (u64)1 << (logN - 1);
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 ri = gid >> (logN - 1);
+    const u64 e2 = gid & (pairs_per_poly - 1);
+    const u64 r = ri / Lx;
+    if (r >= n_ops) return;
+    const int i = (int)(ri % Lx);
+    const u64 N = (u64)1 << logN;
+    auto poly = [&](int which) { return reinterpret_cast<const ulonglong2 *>(x + ((r * 4 + which) * Lx + i) * N)[e2]; };
+    const ulonglong2 a0 = poly(0), a1 = poly(1), b0 = poly(2), b1 = poly(3);
+    ulonglong2 c0, c1, c2;
+    const PrimeDev &P = primes[pm.p[i]];
+    if (P.f64) mul3_pair(make_ar(P, (ArF64 *)nullptr), a0, a1, b0, b1, c0, c1, c2);
+    else mul3_pair(make_ar(P, (ArU64 *)nullptr), a0, a1, b0, b1, c0, c1, c2);
+    reinterpret_cast<ulonglong2 *>(d + ((r * 3 + 0) * Lx + i) * N)[e2] = c0;
+    reinterpret_cast<ulonglong2 *>(d + ((r * 3 + 1) * Lx + i) * N)[e2] = c1;
+    reinterpret_cast<ulonglong2 *>(d + ((r * 3 + 2) * Lx + i) * N)[e2] = c2;
+}
+
+__global__ void __launch_bounds__(kBlock) k_behz_floor_sk(BehzDev Z, const PrimeDev *primes, const u64 *dq, const u64 *ds, u64 *out, u64 n_polys, int logN)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 n = gid & (((u64)1 << logN) - 1);
+    const u64 pid = gid >> logN; // (op, k)
+    if (pid >= n_polys) return;
+    const int L = Z.L, S = L + 1;
+    const u64 N = (u64)1 << logN;
+    u64 tmp[kBehzMaxL], fl[kBehzMaxL + 1];
+    // (6) times t, then the base-q part prepared for the fast conversion
+#pragma unroll
+    for (int i = 0; i < kBehzMaxL; ++i)
+        if (i < L) {
+            const ModU64 mi = mod_of(primes, i);
+            tmp[i] = mulmod(mulmod(dq[(pid * L + i) * N + n], Z.t_mod_q[i], mi), Z.inv_punct_q[i], mi);
+        }
+    // (7) fast floor: (x_Bsk - FastBconv(x_q)) * Q^-1 mod p_j
+#pragma unroll
+    for (int j = 0; j < kBehzMaxL + 1; ++j)
+        if (j < S) {
+            const ModU64 mj = mod_of(primes, Z.bsk_prime[j]);
+            u128 acc = 0;
+#pragma unroll
+            for (int i = 0; i < kBehzMaxL; ++i)
+                if (i < L) acc += (u128)tmp[i] * Z.q2bsk[j * L + i];
+            const u64 conv = barrett128(acc, mj);
+            const u64 xs = mulmod(ds[(pid * S + j) * N + n], Z.t_mod_bsk[j], mj);
+            fl[j] = mulmod(submod(xs, conv, mj.q), Z.inv_q_bsk[j], mj);
+        }
+    // (8) Shenoy-Kumaresan: B -> q with the alpha_sk correction
+    const ModU64 msk = mod_of(primes, Z.bsk_prime[L]);
+    u128 accs = 0;
+#pragma unroll
+    for (int i = 0; i < kBehzMaxL; ++i)
+        if (i < L) {
+            tmp[i] = mulmod(fl[i], Z.inv_punct_B[i], mod_of(primes, Z.bsk_prime[i]));
+            accs += (u128)tmp[i] * Z.B2msk[i];
+        }
+    const u64 alpha = mulmod(submod(barrett128(accs, msk), fl[L], msk.q), Z.inv_B_mod_msk, msk);
+    const bool neg = alpha > (msk.q >> 1);
+    for (int j = 0; j < L; ++j) {
+        const ModU64 mj = mod_of(primes, j);
+        u128 acc = 0;
+#pragma unroll
+        for (int i = 0; i < kBehzMaxL; ++i)
+            if (i < L) acc += (u128)tmp[i] * Z.B2q[j * L + i];
+        const u64 conv = barrett128(acc, mj);
+        const u64 Bq = Z.B_mod_q[j];
+        const u64 res = neg ? barrett128((u128)(msk.q - alpha) * Bq + conv, mj) : barrett128((u128)alpha * (Bq ? mj.q - Bq : 0) + conv, mj);
+        out[(pid * L + j) * N + n] = res;
+    }
+}
+
+// coefficient-form automorphism as a gather (2 polys of a size-2 ciphertext)
+__global__ void __launch_bounds__(kBlock) k_bfv_galois(const u64 *in, const uint32_t *gather, u64 *c01, u64 c01_item_stride, u64 *tgt,
+                                                       const PrimeDev *primes, int L, int logN, u64 n_ops)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 o = gid & (((u64)1 << logN) - 1);
+    const u64 oi = gid >> logN;
+    const u64 op = oi / L;
+    if (op >= n_ops) return;
+    const int i = (int)(oi % L);
+    const u64 N = (u64)1 << logN, P1 = (u64)L * N;
+    const u64 q = primes[i].q;
+    const uint32_t g = gather[o];
+    const u64 src = g & 0x7FFFFFFFu;
+    const u64 *p0 = in + op * 2 * P1 + (u64)i * N;
+    u64 v0 = p0[src], v1 = p0[P1 + src];
+    if (g >> 31) { v0 = v0 ? q - v0 : 0; v1 = v1 ? q - v1 : 0; }
+    u64 *o0 = c01 + op * c01_item_stride + (u64)i * N + o;
+    o0[0] = v0;
+    o0[P1] = 0;
+    tgt[(op * L + i) * N + o] = v1;
+}
+
+template <int LOGN1>
+__global__ void __launch_bounds__(kBlock) k_bfv_tail_sp(const u64 *tpr, u64 *rp, const PrimeDev *primes, int sp)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    const u64 poly = blockIdx.x >> 2;
+    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
+    const u64 *src = tpr + poly * N;
+    const PrimeDev &Ps = primes[sp];
+    u64 c[N1];
+    if (LOGN1 == 0) {
+        c[0] = src[col];
+    } else if (Ps.f64) {
+        const ArF64 ar = make_ar(Ps, (ArF64 *)nullptr);
+        double x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
+        col_inv<ArF64, LOGN1>(ar, x, gtw(Ps.inv), Ps.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
+    } else {
+        const ArU64 ar = make_ar(Ps, (ArU64 *)nullptr);
+        u64 x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
+        col_inv<ArU64, LOGN1>(ar, x, gtw(Ps.inv), Ps.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
+    }
+    const u64 half = Ps.q >> 1;
+#pragma unroll
+    for (int a = 0; a < N1; ++a) rp[poly * N + (a << kRowLog) + col] = addmod(c[a], half, Ps.q);
+}
+
+template <int LOGN1>
+__global__ void __launch_bounds__(kBlock) k_bfv_tail_fin(const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride, const PrimeDev *primes,
+                                                         const FloorConst *fcs, int L, int K)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    const u64 pid = blockIdx.x >> 2; // (op, k, i)
+    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
+    const int i = (int)(pid % L);
+    const u64 ok = pid / L;
+    const int k = (int)(ok & 1);
+    const u64 op = ok >> 1;
+    const u64 *src = t + pid * N;
+    const PrimeDev &Pi = primes[i];
+    const PrimeDev &Ps = primes[K - 1];
+    u64 c[N1];
+    if (LOGN1 == 0) {
+        c[0] = src[col];
+    } else if (Pi.f64) {
+        const ArF64 ar = make_ar(Pi, (ArF64 *)nullptr);
+        double x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
+        col_inv<ArF64, LOGN1>(ar, x, gtw(Pi.inv), Pi.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
+    } else {
+        const ArU64 ar = make_ar(Pi, (ArU64 *)nullptr);
+        u64 x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
+        col_inv<ArU64, LOGN1>(ar, x, gtw(Pi.inv), Pi.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
+    }
+    const FloorConst fc = fcs[(K - 1) * K + i];
+    const ModU64 mi = make_modu(Pi);
+    const u64 qi = Pi.q, qs = Ps.q;
+    u64 *dst = c01 + op * c01_item_stride + ((u64)k * L + i) * N;
+#pragma unroll
+    for (int a = 0; a < N1; ++a) {
+        const u64 r = rp[ok * N + (a << kRowLog) + col];
+        const u64 delta = submod(qs > qi ? barrett64(r, mi) : r, fc.half_mod, qi);
+        const u64 res = mul_shoup(submod(c[a], delta, qi), fc.inv, fc.inv_shoup, qi);
+        const u64 idx = (a << kRowLog) + col;
+        dst[idx] = addmod(dst[idx], res, qi);
+    }
+}
+
 inline unsigned grid_for(u64 jobs, u64 per_block) { return (unsigned)((jobs + per_block - 1) / per_block); }
 
 } // namespace
@@ -918,11 +1164,14 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
     hipLaunchKernelGGL(k_k1, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes);
 }
 
-void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf)
+void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *src, u64 src_op_stride)
 {
     if (!n_ops) return;
     K2Args A;
-    A.c2r = buf.c2r; A.d = buf.d; A.n_ops = n_ops; A.L = L; A.K = env.K; A.ckks = env.scheme == 2;
+    A.c2r = src ? src : buf.c2r;
+    A.src_op_stride = src ? src_op_stride : (u64)L * env.N;
+    A.src_is_coeff = src ? 1 : 0;
+    A.d = buf.d; A.n_ops = n_ops; A.L = L; A.K = env.K; A.ckks = env.scheme == 2;
     const unsigned g = (unsigned)(n_ops * L * 4);
     switch (env.logn1) {
     case 0: hipLaunchKernelGGL(k_k2<0>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
@@ -1005,6 +1254,65 @@ void launch_rows_inv_select(const KernelEnv &env, int prime, u64 n_polys, const 
     const u64 jobs = n_polys << env.logn1;
     hipLaunchKernelGGL(k_rows_inv_select, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, src, src_poly_stride, tail, env.primes, prime, jobs,
                        env.logn1);
+}
+
+void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk)
+{
+    if (!n_ops) return;
+    const int logN = env.logn1 + kRowLog;
+    const u64 threads = (n_ops * 4) << logN;
+    hipLaunchKernelGGL(k_behz_extend, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, a, b, ix, xq, xbsk, n_ops, logN);
+}
+void launch_tensor4(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d)
+{
+    if (!n_ops) return;
+    const int logN = env.logn1 + kRowLog;
+    PrimeMap64 pm;
+    for (int i = 0; i < Lx; ++i) pm.p[i] = prime_of[i];
+    const u64 threads = (n_ops * Lx) << (logN - 1);
+    hipLaunchKernelGGL(k_tensor4, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, x, d, env.primes, pm, Lx, logN, n_ops);
+}
+void launch_behz_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out)
+{
+    if (!n_ops) return;
+    const int logN = env.logn1 + kRowLog;
+    const u64 threads = (n_ops * 3) << logN;
+    hipLaunchKernelGGL(k_behz_floor_sk, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, dq, ds, out, n_ops * 3, logN);
+}
+void launch_bfv_galois(const KernelEnv &env, int L, u64 n_ops, const u64 *in, const uint32_t *gather, u64 *c01, u64 c01_item_stride, u64 *tgt)
+{
+    if (!n_ops) return;
+    const int logN = env.logn1 + kRowLog;
+    const u64 threads = (n_ops * L) << logN;
+    hipLaunchKernelGGL(k_bfv_galois, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, in, gather, c01, c01_item_stride, tgt, env.primes, L, logN,
+                       n_ops);
+}
+void launch_bfv_tail_sp(const KernelEnv &env, u64 n_polys, const u64 *tpr, u64 *rp)
+{
+    if (!n_polys) return;
+    const unsigned g = (unsigned)(n_polys * 4);
+    const int sp = env.K - 1;
+    switch (env.logn1) {
+    case 0: hipLaunchKernelGGL(k_bfv_tail_sp<0>, dim3(g), dim3(kBlock), 0, env.stream, tpr, rp, env.primes, sp); break;
+    case 1: hipLaunchKernelGGL(k_bfv_tail_sp<1>, dim3(g), dim3(kBlock), 0, env.stream, tpr, rp, env.primes, sp); break;
+    case 2: hipLaunchKernelGGL(k_bfv_tail_sp<2>, dim3(g), dim3(kBlock), 0, env.stream, tpr, rp, env.primes, sp); break;
+    case 3: hipLaunchKernelGGL(k_bfv_tail_sp<3>, dim3(g), dim3(kBlock), 0, env.stream, tpr, rp, env.primes, sp); break;
+    case 4: hipLaunchKernelGGL(k_bfv_tail_sp<4>, dim3(g), dim3(kBlock), 0, env.stream, tpr, rp, env.primes, sp); break;
+    case 5: hipLaunchKernelGGL(k_bfv_tail_sp<5>, dim3(g), dim3(kBlock), 0, env.stream, tpr, rp, env.primes, sp); break;
+    }
+}
+void launch_bfv_tail_fin(const KernelEnv &env, int L, u64 n_ops, const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride)
+{
+    if (!n_ops) return;
+    const unsigned g = (unsigned)(n_ops * 2 * L * 4);
+    switch (env.logn1) {
+    case 0: hipLaunchKernelGGL(k_bfv_tail_fin<0>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    case 1: hipLaunchKernelGGL(k_bfv_tail_fin<1>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    case 2: hipLaunchKernelGGL(k_bfv_tail_fin<2>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    case 3: hipLaunchKernelGGL(k_bfv_tail_fin<3>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    case 4: hipLaunchKernelGGL(k_bfv_tail_fin<4>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    case 5: hipLaunchKernelGGL(k_bfv_tail_fin<5>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    }
 }
 
 } // namespace he355

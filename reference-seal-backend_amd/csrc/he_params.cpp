@@ -205,6 +205,107 @@ void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t)
         if (q >> 61 || !is_prime(q)) throw std::invalid_argument("coefficient modulus must be a prime below 2^61");
         primes[i] = make_prime_tables(q, N, logn, !force_u64 && (q >> 47) == 0);
     }
+    if (scheme == kSchemeBFV) {
+        // RNSTool::initialize: get_primes(2N, 61, |B| + 2) -> m_sk, gamma, B...  with |B| = |q| at every level
+        // (the +1 case needs 32 + bits(t) + bits(q) >= 61|q| + 61, impossible for user primes <= 60 bits)
+        if (t >= ((u64)1 << 32)) throw std::invalid_argument("plain modulus too large for the BEHZ base");
+        const std::vector<u64> ap = get_primes(2 * (u64)N, 61, Ltop + 2);
+        gamma = ap[1];
+        aux.push_back(make_prime_tables(ap[0], N, logn, false));
+        for (size_t i = 0; i < Ltop; ++i) aux.push_back(make_prime_tables(ap[2 + i], N, logn, false));
+        if (K + aux.size() > (size_t)kMaxPrimes) throw std::invalid_argument("too many primes for the device prime table");
+    }
+}
+
+std::vector<uint32_t> Params::galois_gather_coeff(uint32_t elt) const
+{
+    // GaloisTool::apply_galois maps in[i] to out[(i*g mod 2N) mod N], negated when i*g mod 2N >= N; as a gather:
+    // i0 = o * g^-1 mod 2N; i0 < N -> +in[i0], else -in[i0 - N]
+    const u64 m = 2 * (u64)N;
+    u64 ginv = 1;
+    for (u64 x = 1; x < m; x += 2)
+        if (((x * elt) & (m - 1)) == 1) { ginv = x; break; }
+    std::vector<uint32_t> g(N);
+    for (size_t o = 0; o < N; ++o) {
+        const u64 i0 = ((u64)o * ginv) & (m - 1);
+        g[o] = i0 < N ? (uint32_t)i0 : ((uint32_t)(i0 - N) | 0x80000000u);
+    }
+    return g;
+}
+
+BehzTables Params::behz_tables(int L_) const
+{
+    if (scheme != kSchemeBFV || L_ < 1 || (size_t)L_ > Ltop) throw std::invalid_argument("BEHZ tables need a BFV level");
+    const size_t L = (size_t)L_, S = L + 1;
+    BehzTables T;
+    T.L = L_;
+    auto qv = [&](size_t i) { return primes[i].q; };
+    auto bsk = [&](size_t j) { return j < L ? aux[1 + j].q : aux[0].q; }; // B_0..B_{L-1}, m_sk
+    const u64 MT = (u64)1 << 32, t = plain_modulus;
+    T.inv_punct_q.resize(L); T.mtilde_q.resize(L); T.q2mt.resize(L); T.t_mod_q.resize(L); T.B_mod_q.resize(L);
+    T.q2bsk.resize(S * L); T.q_mod_bsk.resize(S); T.inv_mt_bsk.resize(S); T.inv_q_bsk.resize(S); T.t_mod_bsk.resize(S);
+    T.inv_punct_B.resize(L); T.B2q.resize(L * L); T.B2msk.resize(L);
+    for (size_t i = 0; i < L; ++i) {
+        u64 p = 1, pm = 1;
+        for (size_t k = 0; k < L; ++k)
+            if (k != i) {
+                p = mm(p, qv(k) % qv(i), qv(i));
+                pm = (pm * (qv(k) & 0xFFFFFFFFull)) & 0xFFFFFFFFull;
+            }
+        T.inv_punct_q[i] = invmod(p, qv(i));
+        T.q2mt[i] = pm;
+        T.mtilde_q[i] = MT % qv(i);
+        T.t_mod_q[i] = t % qv(i);
+    }
+    u64 qm = 1;
+    for (size_t k = 0; k < L; ++k) qm = (qm * (qv(k) & 0xFFFFFFFFull)) & 0xFFFFFFFFull;
+    u64 inv = qm;
+    for (int it = 0; it < 6; ++it) inv = (inv * (2 - qm * inv)) & 0xFFFFFFFFull;
+    T.neg_inv_q_mod_mt = (MT - inv) & 0xFFFFFFFFull;
+    for (size_t j = 0; j < S; ++j) {
+        const u64 pj = bsk(j);
+        u64 all = 1;
+        for (size_t k = 0; k < L; ++k) all = mm(all, qv(k) % pj, pj);
+        T.q_mod_bsk[j] = all;
+        T.inv_q_bsk[j] = invmod(all, pj);
+        T.inv_mt_bsk[j] = invmod(MT % pj, pj);
+        T.t_mod_bsk[j] = t % pj;
+        for (size_t i = 0; i < L; ++i) {
+            u64 p = 1;
+            for (size_t k = 0; k < L; ++k)
+                if (k != i) p = mm(p, qv(k) % pj, pj);
+            T.q2bsk[j * L + i] = p;
+        }
+    }
+    const u64 msk = aux[0].q;
+    {
+        u64 all = 1;
+        for (size_t k = 0; k < L; ++k) all = mm(all, aux[1 + k].q % msk, msk);
+        T.inv_B_mod_msk = invmod(all, msk);
+    }
+    for (size_t i = 0; i < L; ++i) {
+        const u64 bi = aux[1 + i].q;
+        u64 p = 1, pm = 1;
+        for (size_t k = 0; k < L; ++k)
+            if (k != i) {
+                p = mm(p, aux[1 + k].q % bi, bi);
+                pm = mm(pm, aux[1 + k].q % msk, msk);
+            }
+        T.inv_punct_B[i] = invmod(p, bi);
+        T.B2msk[i] = pm;
+    }
+    for (size_t j = 0; j < L; ++j) {
+        u64 all = 1;
+        for (size_t k = 0; k < L; ++k) all = mm(all, aux[1 + k].q % qv(j), qv(j));
+        T.B_mod_q[j] = all;
+        for (size_t i = 0; i < L; ++i) {
+            u64 p = 1;
+            for (size_t k = 0; k < L; ++k)
+                if (k != i) p = mm(p, aux[1 + k].q % qv(j), qv(j));
+            T.B2q[j * L + i] = p;
+        }
+    }
+    return T;
 }
 
 PrimeTables Params::make_prime_tables(u64 q, size_t N, int logn, bool f64)

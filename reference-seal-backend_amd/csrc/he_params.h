@@ -34,6 +34,26 @@ struct PrimeTables {
     ArF64 arf() const;
 };
 
+// Per-level constants of the BEHZ multiply (RNSTool of SEAL, restated): base q = first L primes, B = B_0..B_{L-1}.
+struct BehzTables {
+    int L = 0;
+    std::vector<u64> inv_punct_q;  // [L]        (Q/q_i)^-1 mod q_i
+    std::vector<u64> mtilde_q;     // [L]        2^32 mod q_i
+    std::vector<u64> q2bsk;        // [L+1][L]   (Q/q_i) mod p_j   (p_j: B_0..B_{L-1}, m_sk)
+    std::vector<u64> q2mt;         // [L]        (Q/q_i) mod 2^32
+    u64 neg_inv_q_mod_mt = 0;      //            -Q^-1 mod 2^32
+    std::vector<u64> q_mod_bsk;    // [L+1]
+    std::vector<u64> inv_mt_bsk;   // [L+1]      (2^32)^-1 mod p_j
+    std::vector<u64> inv_q_bsk;    // [L+1]      Q^-1 mod p_j
+    std::vector<u64> t_mod_q;      // [L]
+    std::vector<u64> t_mod_bsk;    // [L+1]
+    std::vector<u64> inv_punct_B;  // [L]        (B/b_i)^-1 mod b_i
+    std::vector<u64> B2q;          // [L][L]     (B/b_i) mod q_j
+    std::vector<u64> B2msk;        // [L]        (B/b_i) mod m_sk
+    u64 inv_B_mod_msk = 0;
+    std::vector<u64> B_mod_q;      // [L]
+};
+
 class Params {
 public:
     // bit_sizes is the key-level chain; sec128 enforces SEAL's tc128 cap.  Throws std::invalid_argument.
@@ -48,6 +68,11 @@ public:
     size_t Ltop = 0;    // data residues at the first level
     u64 plain_modulus = 0;
     std::vector<PrimeTables> primes;
+    // BFV only: auxiliary BEHZ base (61-bit NTT primes from the same search rule): m_sk, then B_0..B_{Ltop-1};
+    // gamma is the second prime of that search (used by SEAL's decryption, not on the device).
+    // Device prime index of m_sk is K, of B_i is K + 1 + i.
+    std::vector<PrimeTables> aux; // [0] = m_sk, [1 + i] = B_i
+    u64 gamma = 0;
 
     u64 modulus(size_t i) const { return primes[i].q; }
     // GaloisTool rules (generator 3)
@@ -55,6 +80,9 @@ public:
     std::vector<uint32_t> galois_elts_all() const;
     // permutation tables: out[i] = in[perm[i]] (NTT form); coefficient form: out[idx[i]] = +-in[i]
     std::vector<uint32_t> galois_perm_ntt(uint32_t elt) const;
+    // coefficient form: out[o] = (+/-) in[src & 0x7fffffff], negated when bit 31 of the entry is set
+    std::vector<uint32_t> galois_gather_coeff(uint32_t elt) const;
+    BehzTables behz_tables(int L) const;
 
     // number theory helpers (also used by the client-side code)
     static bool is_prime(u64 v);

@@ -239,9 +239,11 @@ struct ArF64 {
         c.u = t.b;
         return c.d;
     }
+    // Butterflies use only w: the quotient estimate comes from h * (1/q) (mulmod_vv), so a twiddle is ONE double
+    // in registers / LDS.  Same instruction count as the (w, w/q) form, same exactness, |t| <= q(1/2 + |Y| 2^-51).
     HE_HD void bfly_fwd(T &X, T &Y, const Tw16 &w) const
     {
-        double t = mulmod_c(Y, tw_w(w), tw_wi(w));
+        double t = mulmod_vv(Y, tw_w(w));
         double x = X;
         X = x + t;
         Y = x - t;
@@ -251,7 +253,7 @@ struct ArF64 {
         double s = X + Y;
         double d = X - Y;
         X = s;
-        Y = mulmod_c(d, tw_w(w), tw_wi(w));
+        Y = mulmod_vv(d, tw_w(w));
     }
     HE_HD void bfly_inv_last(T &X, T &Y, const Tw16 &w_scaled) const
     {

@@ -100,18 +100,18 @@ struct TwRow {
     const Tw16 *t;
     HE_HD Tw16 get(int s, u32 g) const { return t[(1u << s) - 1u + g]; }
 };
-// fp64 engine: the row-local copy keeps only w (8 bytes); w/q is rebuilt as fl(w * fl(1/q)), which differs from
-// the table's fl(w/q) by at most one ulp -- the quotient estimate may move by one, the residue class does not.
+// fp64 engine: the row-local copy keeps only w (8 bytes); its butterflies take the quotient estimate from
+// h * (1/q), so nothing else is needed.
 struct TwRowF64 {
     const double *t;
     double qinv;
     HE_HD Tw16 get(int s, u32 g) const
     {
-        const double w = t[(1u << s) - 1u + g], wi = w * qinv;
         Tw16 r;
         union { u64 u; double d; } c;
-        c.d = w; r.a = c.u;
-        c.d = wi; r.b = c.u;
+        c.d = t[(1u << s) - 1u + g];
+        r.a = c.u;
+        r.b = 0; // the fp64 butterflies do not use the second word
         return r;
     }
 };
