@@ -14,7 +14,7 @@ namespace AB = hebench::APIBridge;
 //------------------------
 VectorBenchmarkDescription::VectorBenchmarkDescription(Scheme scheme, AB::Category category, AB::Workload op) : m_scheme(scheme)
 {
-    const bool ok = op == AB::Workload::EltwiseAdd || (scheme == Scheme::CKKS && (op == AB::Workload::EltwiseMultiply || op == AB::Workload::DotProduct));
+    const bool ok = op == AB::Workload::EltwiseAdd || op == AB::Workload::EltwiseMultiply || op == AB::Workload::DotProduct;
     if (!ok) throw HEBenchError(HEBERROR_MSG_CLASS("Workload operation not supported."), HEBENCH_ECODE_CRITICAL_ERROR);
     // initialize the descriptor for this benchmark (ckks eltwise .cpp:32-56)
     std::memset(&m_descriptor, 0, sizeof(AB::BenchmarkDescriptor));
@@ -44,7 +44,7 @@ VectorBenchmarkDescription::VectorBenchmarkDescription(Scheme scheme, AB::Catego
     w.n() = dot ? 100 : 1000;
     w.add<std::uint64_t>(8192, "PolyModulusDegree");
     w.add<std::uint64_t>(2, "MultiplicativeDepth");
-    w.add<std::uint64_t>(scheme == Scheme::CKKS ? (dot ? 40 : 45) : 40, "CoefficientModulusBits");
+    w.add<std::uint64_t>(scheme == Scheme::CKKS ? (dot ? 40 : 45) : (dot ? 45 : 40), "CoefficientModulusBits"); // bfv dot .h:23-26: 45
     if (scheme == Scheme::CKKS) w.add<std::uint64_t>(dot ? 40 : 45, "ScaleBits");
     else w.add<std::uint64_t>(20, "PlainModulusBits");
     w.add<std::uint64_t>(0, "NumThreads"); // kept so existing HEBench YAML configs load; the GPU path ignores it
@@ -191,11 +191,14 @@ AB::Handle VectorBenchmark::load(const AB::Handle *p_local_data, std::uint64_t c
     for (const auto &operand : local) remote.push_back(m_p_ctx_wrapper->upload(operand));
     if (this->getDescriptor().workload == AB::Workload::DotProduct) {
         m_p_ctx_wrapper->needRelinKey();
-        // accumulateCKKS(n): rotations by 2^i, i < bit_count(n) (seal_context.cpp:331-339)
-        std::uint64_t cnt = std::min<std::uint64_t>(m_w_params.n(), m_p_ctx_wrapper->slot_count());
+        // accumulateCKKS(n) / accumulateBFV(n): rotations by 2^i, i < bit_count(count) (seal_context.cpp:331-339, 295-304);
+        // BFV counts within one batching row and adds the column swap when n exceeds a row (:305-310)
+        const std::uint64_t row = m_scheme == Scheme::CKKS ? m_p_ctx_wrapper->slot_count() : m_p_ctx_wrapper->slot_count() / 2;
+        std::uint64_t cnt = std::min<std::uint64_t>(m_w_params.n(), row);
         int rotations = 64 - __builtin_clzll(cnt);
         if (((std::uint64_t)1 << (rotations - 1)) == cnt) --rotations;
         for (int i = 0; i < rotations; ++i) m_p_ctx_wrapper->needRotationKey(1 << i);
+        if (m_scheme == Scheme::BFV && m_w_params.n() > row) m_p_ctx_wrapper->needRotationKey(0);
     }
     return this->getEngine().createHandle<decltype(remote)>(sizeof(remote), 0, std::move(remote));
 }
@@ -244,13 +247,21 @@ AB::Handle VectorBenchmark::operate(AB::Handle h_remote_packed, const AB::Parame
         result = m_p_ctx_wrapper->allocResult(n, 2, L, p0.scale);
         HeContextWrapper::check(he355_add(ctx, L, 2, n, p0.d, p1.d, ix, result->d), "add");
         break;
-    case AB::Workload::EltwiseMultiply: // multiply only: the size-3 result is decrypted as is (ckks eltwise .cpp:342-344)
+    case AB::Workload::EltwiseMultiply: // multiply only: the size-3 result is decrypted as is (ckks eltwise .cpp:342-344, bfv :324-326)
         result = m_p_ctx_wrapper->allocResult(n, 3, L, p0.scale * p1.scale);
-        HeContextWrapper::check(he355_multiply(ctx, L, n, p0.d, p1.d, ix, result->d), "multiply");
+        if (m_scheme == Scheme::CKKS) HeContextWrapper::check(he355_multiply(ctx, L, n, p0.d, p1.d, ix, result->d), "multiply");
+        else HeContextWrapper::check(he355_bfv_multiply(ctx, L, n, p0.d, p1.d, ix, result->d), "multiply");
         break;
-    case AB::Workload::DotProduct: { // multiply -> relinearize_inplace -> accumulateCKKS(n)  (ckks dot .cpp:325-330)
+    case AB::Workload::DotProduct: { // multiply -> relinearize_inplace -> accumulate(n)  (ckks dot .cpp:325-330, bfv dot .cpp:311-315)
         result = m_p_ctx_wrapper->allocResult(n, 2, L, p0.scale * p1.scale);
-        HeContextWrapper::check(he355_multiply_relin(ctx, L, n, p0.d, p1.d, ix, 0, result->d), "multiply+relinearize");
+        if (m_scheme == Scheme::CKKS) {
+            HeContextWrapper::check(he355_multiply_relin(ctx, L, n, p0.d, p1.d, ix, 0, result->d), "multiply+relinearize");
+        } else {
+            std::shared_ptr<DeviceCiphers> c3 = m_p_ctx_wrapper->allocResult(n, 3, L, 1.0);
+            HeContextWrapper::check(he355_bfv_multiply(ctx, L, n, p0.d, p1.d, ix, c3->d), "multiply");
+            HeContextWrapper::check(he355_relinearize(ctx, L, n, c3->d, result->d), "relinearize");
+            HeContextWrapper::check(he355_sync(ctx), "synchronise");
+        }
         std::shared_ptr<DeviceCiphers> tmp = m_p_ctx_wrapper->allocResult(n, 2, L, result->scale);
         HeContextWrapper::check(he355_accumulate(ctx, L, n, result->d, m_w_params.n(), tmp->d), "accumulate");
         HeContextWrapper::check(he355_sync(ctx), "synchronise");

@@ -2,6 +2,7 @@
 #include <sstream>
 
 #include "benchmarks.h"
+#include "matmult_row.h"
 
 #define HEBENCH_API_VERSION_NEEDED_MAJOR 0
 #define HEBENCH_API_VERSION_NEEDED_MINOR 8
@@ -34,10 +35,15 @@ public:
         addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::CKKS, AB::Category::Latency, AB::Workload::EltwiseAdd));
         addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::BFV, AB::Category::Offline, AB::Workload::EltwiseAdd));
         addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::CKKS, AB::Category::Offline, AB::Workload::EltwiseAdd));
+        addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::BFV, AB::Category::Latency, AB::Workload::EltwiseMultiply));
         addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::CKKS, AB::Category::Latency, AB::Workload::EltwiseMultiply));
+        addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::BFV, AB::Category::Offline, AB::Workload::EltwiseMultiply));
         addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::CKKS, AB::Category::Offline, AB::Workload::EltwiseMultiply));
+        addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::BFV, AB::Category::Latency, AB::Workload::DotProduct));
         addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::CKKS, AB::Category::Latency, AB::Workload::DotProduct));
+        addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::BFV, AB::Category::Offline, AB::Workload::DotProduct));
         addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::CKKS, AB::Category::Offline, AB::Workload::DotProduct));
+        addBenchmarkDescription(std::make_shared<MatMultRowBenchmarkDescription>());
     }
 };
 

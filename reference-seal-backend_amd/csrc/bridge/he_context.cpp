@@ -120,13 +120,23 @@ void HeContextWrapper::needRelinKey()
 }
 void HeContextWrapper::needRotationKey(int step)
 {
-    ensureDevice();
     const uint32_t elt = he355_galois_elt_from_step(m_ctx, step);
     if (!elt) throw HEBenchError(HEBERROR_MSG_CLASS("step count too large"), HEBENCH_ECODE_INVALID_ARGS);
+    needGaloisKey(elt);
+}
+void HeContextWrapper::needGaloisKey(uint32_t elt)
+{
+    ensureDevice();
     if (m_galois.count(elt)) return;
     const std::vector<uint64_t> k = m_client->make_galois_key(elt);
     check(he355_set_galois_key(m_ctx, elt, k.data()), "Galois key upload");
     m_galois[elt] = true;
+}
+void HeContextWrapper::needDefaultGaloisKeys()
+{
+    uint32_t elts[64];
+    const uint64_t n = he355_galois_elts_all(m_ctx, elts, 64);
+    for (uint64_t i = 0; i < n && i < 64; ++i) needGaloisKey(elts[i]);
 }
 
 std::shared_ptr<DeviceCiphers> HeContextWrapper::allocResult(uint64_t n, int size, int L, double scale)

@@ -70,6 +70,8 @@ public:
     void ensureDevice();
     void needRelinKey();
     void needRotationKey(int step);
+    void needGaloisKey(uint32_t galois_elt);
+    void needDefaultGaloisKeys(); // create_galois_keys(): all +-2^k steps and the column swap (seal_context.cpp:69)
     std::shared_ptr<DeviceCiphers> upload(const std::vector<Cipher> &cts);
     std::vector<Cipher> download(const DeviceCiphers &slab);
     std::shared_ptr<DeviceCiphers> allocResult(uint64_t n, int size, int L, double scale);

@@ -1,0 +1,235 @@
+// matmult_row.cpp — see matmult_row.h
+#include "matmult_row.h"
+
+#include <algorithm>
+#include <sstream>
+
+using namespace mi355x;
+using hebench::cpp::HEBenchError;
+namespace AB = hebench::APIBridge;
+
+MatMultRowBenchmarkDescription::MatMultRowBenchmarkDescription()
+{
+    std::memset(&m_descriptor, 0, sizeof(AB::BenchmarkDescriptor)); // bfv row .cpp:28-38
+    m_descriptor.workload = AB::Workload::MatrixMultiply;
+    m_descriptor.data_type = AB::DataType::Int64;
+    m_descriptor.category = AB::Category::Latency;
+    m_descriptor.cat_params.latency.warmup_iterations_count = 1;
+    m_descriptor.cat_params.min_test_time_ms = 0;
+    m_descriptor.cipher_param_mask = HEBENCH_HE_PARAM_FLAGS_ALL_CIPHER;
+    m_descriptor.scheme = HEBENCH_HE_SCHEME_BFV;
+    m_descriptor.security = HEBENCH_HE_SECURITY_128;
+    m_descriptor.other = MatMultRowOtherID;
+    hebench::cpp::WorkloadParams::Common w; // defaults: bfv row .cpp:41-48, .h:29-32
+    w.add<std::uint64_t>(10, "rows_M0");
+    w.add<std::uint64_t>(9, "cols_M0");
+    w.add<std::uint64_t>(8, "cols_M1");
+    w.add<std::uint64_t>(8192, "PolyModulusDegree");
+    w.add<std::uint64_t>(3, "MultiplicativeDepth");
+    w.add<std::uint64_t>(40, "CoefficientModulusBits");
+    w.add<std::uint64_t>(20, "PlainModulusBits");
+    w.add<std::uint64_t>(0, "NumThreads");
+    this->addDefaultParameters(w);
+}
+hebench::cpp::BaseBenchmark *MatMultRowBenchmarkDescription::createBenchmark(hebench::cpp::BaseEngine &engine, const AB::WorkloadParams *p_params)
+{
+    if (!p_params) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid empty workload parameters. This workload requires flexible parameters."), HEBENCH_ECODE_CRITICAL_ERROR);
+    return new MatMultRowLatencyBenchmark(engine, m_descriptor, *p_params);
+}
+void MatMultRowBenchmarkDescription::destroyBenchmark(hebench::cpp::BaseBenchmark *p_bench)
+{
+    if (p_bench) delete p_bench;
+}
+std::string MatMultRowBenchmarkDescription::getBenchmarkDescription(const AB::WorkloadParams *p_w_params) const
+{
+    std::stringstream ss;
+    std::string s_tmp = BenchmarkDescription::getBenchmarkDescription(p_w_params);
+    if (!p_w_params) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid null workload parameters `p_w_params`"), HEBENCH_ECODE_INVALID_ARGS);
+    if (!s_tmp.empty()) ss << s_tmp << std::endl;
+    ss << ", Encryption Parameters" << std::endl
+       << ", , Poly modulus degree, " << p_w_params->params[Index_PolyModulusDegree].u_param << std::endl
+       << ", , Coefficient Modulus, 60";
+    for (std::size_t i = 1; i < p_w_params->params[Index_NumCoefficientModuli].u_param; ++i) ss << ", " << p_w_params->params[Index_CoefficientModulusBits].u_param;
+    ss << ", 60" << std::endl
+       << ", , Plain Modulus, " << p_w_params->params[Index_PlainModulusBits].u_param << std::endl
+       << ", Algorithm, " << AlgorithmName << ", " << AlgorithmDescription << std::endl
+       << ", Device, AMD Instinct MI355X (HIP; row-pair ciphertexts batched on the grid)";
+    return ss.str();
+}
+
+MatMultRowLatencyBenchmark::MatMultRowLatencyBenchmark(hebench::cpp::BaseEngine &engine, const AB::BenchmarkDescriptor &bench_desc,
+                                                       const AB::WorkloadParams &bench_params)
+    : hebench::cpp::BaseBenchmark(engine, bench_desc, bench_params)
+{
+    if (bench_desc.workload != AB::Workload::MatrixMultiply || bench_desc.data_type != AB::DataType::Int64 || bench_desc.category != AB::Category::Latency
+        || ((bench_desc.cipher_param_mask & 0x03) != 0x03) || bench_desc.scheme != HEBENCH_HE_SCHEME_BFV || bench_desc.security != HEBENCH_HE_SECURITY_128
+        || bench_desc.other != MatMultRowBenchmarkDescription::MatMultRowOtherID)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Benchmark descriptor received is not supported."), HEBENCH_ECODE_INVALID_ARGS);
+    if (bench_params.count < MatMultRowBenchmarkDescription::NumWorkloadParams)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid workload parameters."), HEBENCH_ECODE_INVALID_ARGS);
+    for (std::uint64_t i = 0; i < bench_params.count; ++i) m_w.push_back(bench_params.params[i].u_param);
+    const std::uint64_t N = m_w[MatMultRowBenchmarkDescription::Index_PolyModulusDegree];
+    if (rows_M0() <= 0 || cols_M0() <= 0 || cols_M1() <= 0)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Matrix dimensions must be greater than 0."), HEBENCH_ECODE_INVALID_ARGS);
+    if (m_w[MatMultRowBenchmarkDescription::Index_CoefficientModulusBits] < 1)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Multiplicative depth must be greater than 0."), HEBENCH_ECODE_INVALID_ARGS);
+    if (cols_M0() > (N / 2) || cols_M0() * cols_M1() > (N / 2)) { // bfv row .cpp:141-147
+        std::stringstream ss;
+        ss << "Invalid workload parameters. This workload only supports matrices of dimensions (a x b) x (b x c) where 'b' and b * c is at max " << (N / 2)
+           << " (e.g. PolyModulusDegree / 2).";
+        throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
+    }
+    m_p_ctx_wrapper = HeContextWrapper::createBFVContext(N, m_w[MatMultRowBenchmarkDescription::Index_NumCoefficientModuli],
+                                                         (int)m_w[MatMultRowBenchmarkDescription::Index_CoefficientModulusBits],
+                                                         (int)m_w[MatMultRowBenchmarkDescription::Index_PlainModulusBits]);
+}
+
+const AB::DataPack &MatMultRowLatencyBenchmark::findDataPack(const AB::DataPackCollection &c, std::uint64_t param_position)
+{
+    for (std::uint64_t i = 0; i < c.pack_count; ++i)
+        if (c.p_data_packs[i].param_position == param_position) return c.p_data_packs[i];
+    throw HEBenchError(HEBERROR_MSG_CLASS("DataPack for component @ " + std::to_string(param_position) + " not found."), HEBENCH_ECODE_INVALID_ARGS);
+}
+
+AB::Handle MatMultRowLatencyBenchmark::encode(const AB::DataPackCollection *p_parameters)
+{
+    if (p_parameters->pack_count != MatMultRowBenchmarkDescription::NumOpParams)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Expected 2 parameter packs, but " + std::to_string(p_parameters->pack_count) + " received."),
+                           HEBENCH_ECODE_INVALID_ARGS);
+    const std::int64_t *mats[2];
+    for (std::uint64_t op = 0; op < 2; ++op) {
+        const std::uint64_t r = op ? cols_M0() : rows_M0(), cl = op ? cols_M1() : cols_M0();
+        const AB::DataPack &dp = findDataPack(*p_parameters, op);
+        if (dp.buffer_count < 1)
+            throw HEBenchError(HEBERROR_MSG_CLASS("Latency test requires, at least, 1 sample per operation parameter."), HEBENCH_ECODE_INVALID_ARGS);
+        if (!dp.p_buffers || !dp.p_buffers[0].p) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty buffer in data pack."), HEBENCH_ECODE_CRITICAL_ERROR);
+        if (dp.p_buffers[0].size / sizeof(std::int64_t) < r * cl)
+            throw HEBenchError(HEBERROR_MSG_CLASS("Insufficient data for parameter sample."), HEBENCH_ECODE_CRITICAL_ERROR);
+        mats[op] = reinterpret_cast<const std::int64_t *>(dp.p_buffers[0].p);
+    }
+    const std::size_t dim1 = rows_M0(), dim2 = cols_M0(), dim3 = cols_M1();
+    const std::size_t slots = m_p_ctx_wrapper->slot_count(), row_size = slots / 2, spacers = row_size / dim2;
+    PlainPack pack;
+    pack.a.rows = dim1; pack.a.cols = dim2; pack.b.rows = dim2; pack.b.cols = dim3;
+    // encodeM0 (.cpp:221-263): A[i][j] replicated dim3 times at slot spacers*j + k; row i in batching row 0, row i+1 in row 1.
+    // The cleartext vector is reused across row pairs, exactly as the reference does.
+    std::vector<std::int64_t> va(slots, 0);
+    for (std::size_t i = 0; i < dim1; i += 2) {
+        for (std::size_t j = 0; j < dim2; ++j)
+            for (std::size_t k = 0; k < dim3; ++k) {
+                va[spacers * j + k] = mats[0][i * dim2 + j];
+                if (i + 1 < dim1) va[row_size + spacers * j + k] = mats[0][(i + 1) * dim2 + j];
+            }
+        pack.A.push_back(m_p_ctx_wrapper->encodeVector(va));
+    }
+    // encodeM1 (.cpp:265-297): B[j][k] at spacers*j + k in both batching rows
+    std::vector<std::int64_t> vb(slots, 0);
+    for (std::size_t j = 0; j < dim2; ++j)
+        for (std::size_t k = 0; k < dim3; ++k) {
+            vb[spacers * j + k] = mats[1][j * dim3 + k];
+            vb[row_size + spacers * j + k] = mats[1][j * dim3 + k];
+        }
+    pack.B = m_p_ctx_wrapper->encodeVector(vb);
+    return this->getEngine().createHandle<decltype(pack)>(sizeof(pack), 0, std::move(pack));
+}
+
+void MatMultRowLatencyBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackCollection *p_native)
+{
+    if (p_native->pack_count == 0) return;
+    if (!p_native->p_data_packs) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty 'p_native->p_data_packs'."), HEBENCH_ECODE_CRITICAL_ERROR);
+    const AB::DataPack &rc = findDataPack(*p_native, 0);
+    if (rc.buffer_count == 0 || !rc.p_buffers[0].p) return;
+    const ResultPlain &enc = this->getEngine().retrieveFromHandle<ResultPlain>(h_encoded_data);
+    // decodeResult (.cpp:339-369): result row i = first dim3 slots of batching row (i mod 2) of ciphertext i/2
+    const std::size_t dim1 = enc.d.rows, dim3 = enc.d.cols, slots = m_p_ctx_wrapper->slot_count(), row_size = slots / 2;
+    std::int64_t *raw = reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p);
+    std::size_t room = rc.p_buffers[0].size / sizeof(std::int64_t), pos = 0;
+    std::vector<std::int64_t> v(slots);
+    for (std::size_t i = 0; i < dim1 && pos < room; ++i) {
+        if ((i & 1) == 0) m_p_ctx_wrapper->client().bfv_decode(enc.C.at(i / 2).data.data(), v.data());
+        const std::size_t off = (i & 1) ? row_size : 0;
+        for (std::size_t j = 0; j < dim3 && pos < room; ++j) raw[pos++] = v[off + j];
+    }
+}
+
+AB::Handle MatMultRowLatencyBenchmark::encrypt(AB::Handle h_encoded_data)
+{
+    const PlainPack &p = this->getEngine().retrieveFromHandle<PlainPack>(h_encoded_data);
+    CipherPack c;
+    c.a = p.a; c.b = p.b;
+    for (const Plain &pl : p.A) c.A.push_back(m_p_ctx_wrapper->encrypt(pl));
+    c.B = m_p_ctx_wrapper->encrypt(p.B);
+    return this->getEngine().createHandle<decltype(c)>(sizeof(c), 0, std::move(c));
+}
+
+AB::Handle MatMultRowLatencyBenchmark::decrypt(AB::Handle h_encrypted_data)
+{
+    const ResultCipher &c = this->getEngine().retrieveFromHandle<ResultCipher>(h_encrypted_data);
+    ResultPlain p;
+    p.d = c.d;
+    for (const Cipher &ct : c.C) p.C.push_back(m_p_ctx_wrapper->decrypt(ct));
+    return this->getEngine().createHandle<decltype(p)>(sizeof(p), 0, std::move(p));
+}
+
+AB::Handle MatMultRowLatencyBenchmark::load(const AB::Handle *p_h_local_data, std::uint64_t count)
+{
+    if (count != 1) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid number of handles. Expected 1."), HEBENCH_ECODE_INVALID_ARGS);
+    if (!p_h_local_data) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid null array of handles: \"p_h_local_data\""), HEBENCH_ECODE_INVALID_ARGS);
+    const CipherPack &c = this->getEngine().retrieveFromHandle<CipherPack>(p_h_local_data[0]);
+    RemotePack r;
+    r.a = c.a; r.b = c.b;
+    r.A = m_p_ctx_wrapper->upload(c.A);
+    r.B = m_p_ctx_wrapper->upload(std::vector<Cipher>{c.B});
+    m_p_ctx_wrapper->needRelinKey();
+    m_p_ctx_wrapper->needDefaultGaloisKeys(); // the reference creates the full default set (seal_context.cpp:69); rotations use its NAF terms
+    return this->getEngine().createHandle<decltype(r)>(sizeof(r), 0, std::move(r));
+}
+
+void MatMultRowLatencyBenchmark::store(AB::Handle h_remote_data, AB::Handle *p_h_local_data, std::uint64_t count)
+{
+    if (count > 0 && !p_h_local_data) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid null array of handles: \"p_h_local_data\""), HEBENCH_ECODE_INVALID_ARGS);
+    if (count > 0) {
+        std::memset(p_h_local_data, 0, sizeof(AB::Handle) * count);
+        const ResultRemote &r = this->getEngine().retrieveFromHandle<ResultRemote>(h_remote_data);
+        ResultCipher c;
+        c.d = r.d;
+        c.C = m_p_ctx_wrapper->download(*r.C);
+        p_h_local_data[0] = this->getEngine().createHandle<decltype(c)>(sizeof(c), 0, std::move(c));
+    }
+}
+
+AB::Handle MatMultRowLatencyBenchmark::operate(AB::Handle h_remote_packed, const AB::ParameterIndexer *p_param_indexers, std::uint64_t indexers_count)
+{
+    if (indexers_count < MatMultRowBenchmarkDescription::NumOpParams) {
+        std::stringstream ss;
+        ss << "Invalid number of indexers. Expected " << MatMultRowBenchmarkDescription::NumOpParams << ", but " << indexers_count << " received." << std::endl;
+        throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
+    }
+    for (std::size_t i = 0; i < MatMultRowBenchmarkDescription::NumOpParams; ++i) { // this method does not support indexing portions of the batch
+        if (p_param_indexers[i].value_index > 0) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected index in parameter indexer."), HEBENCH_ECODE_INVALID_ARGS);
+        if (p_param_indexers[i].batch_size != 1) throw HEBenchError(HEBERROR_MSG_CLASS("Batch size must be 1 for latency test."), HEBENCH_ECODE_INVALID_ARGS);
+    }
+    const RemotePack &in = this->getEngine().retrieveFromHandle<RemotePack>(h_remote_packed);
+    he355_ctx *ctx = m_p_ctx_wrapper->raw();
+    const int L = in.A->L;
+    const std::uint64_t nA = in.A->n, dim2 = in.a.cols;
+    const int spacers = (int)((m_p_ctx_wrapper->slot_count() / 2) / dim2);
+    // matmultrow (.cpp:486-539), all row-pair ciphertexts A[i] as one batch:
+    he355_indexer ix{0, 0, 1, 0, 0}; // result i <- (A[i], B)
+    std::shared_ptr<DeviceCiphers> c3 = m_p_ctx_wrapper->allocResult(nA, 3, L, 1.0);
+    std::shared_ptr<DeviceCiphers> base = m_p_ctx_wrapper->allocResult(nA, 2, L, 1.0);
+    std::shared_ptr<DeviceCiphers> rotated = m_p_ctx_wrapper->allocResult(nA, 2, L, 1.0);
+    ResultRemote res;
+    res.d.rows = in.a.rows; res.d.cols = in.b.cols;
+    res.C = m_p_ctx_wrapper->allocResult(nA, 2, L, 1.0);
+    HeContextWrapper::check(he355_bfv_multiply(ctx, L, nA, in.A->d, in.B->d, ix, c3->d), "multiply");                 // :515
+    HeContextWrapper::check(he355_relinearize(ctx, L, nA, c3->d, base->d), "relinearize");                             // :516
+    he355_indexer pw{0, 0, 1, 1, 0};
+    HeContextWrapper::check(he355_rotate(ctx, L, nA, base->d, 0, res.C->d), "copy");                                   // result[i] = base (:519)
+    for (std::uint64_t j = 1; j < dim2; ++j) {
+        HeContextWrapper::check(he355_rotate(ctx, L, nA, base->d, (int)j * spacers, rotated->d), "rotate_rows");      // :525-529
+        HeContextWrapper::check(he355_add(ctx, L, 2, nA, res.C->d, rotated->d, pw, res.C->d), "add_inplace");         // :531
+    }
+    HeContextWrapper::check(he355_sync(ctx), "synchronise");
+    return this->getEngine().createHandle<decltype(res)>(sizeof(res), 0, std::move(res));
+}

@@ -1,0 +1,66 @@
+// matmult_row.h — BFV MatrixMultiply, "row" packing (other = 2), Latency: mirrors sbe::bfv::MatMultRowLatencyBenchmark
+// (/root/reference/src/benchmarks/bfv/seal_bfv_matmult_row_benchmark.cpp, include/.../seal_bfv_matmult_row_benchmark.h).
+// Two rows of A per ciphertext (one per batching row), B in one ciphertext; per row-pair:
+// multiply -> relinearize -> sum over j of rotate_rows(base, j * spacers)  (.cpp:486-539).
+#pragma once
+#include "he_context.h"
+
+namespace mi355x {
+
+class MatMultRowBenchmarkDescription : public hebench::cpp::BenchmarkDescription {
+public:
+    HEBERROR_DECLARE_CLASS_NAME(MatMultRowBenchmarkDescription)
+    static constexpr std::int64_t MatMultRowOtherID = 2;
+    static constexpr const char *AlgorithmName = "MatMultRow";
+    static constexpr const char *AlgorithmDescription = "Two rows of the first matrix per ciphertext, second matrix in one ciphertext";
+    static constexpr std::size_t NumOpParams = 2;
+    enum : std::uint64_t { // bfv row .h:34-50
+        Index_rows_M0 = 0,
+        Index_cols_M0,
+        Index_cols_M1,
+        Index_PolyModulusDegree,
+        Index_NumCoefficientModuli,
+        Index_CoefficientModulusBits,
+        Index_PlainModulusBits,
+        Index_NumThreads,
+        NumWorkloadParams
+    };
+    MatMultRowBenchmarkDescription();
+    hebench::cpp::BaseBenchmark *createBenchmark(hebench::cpp::BaseEngine &engine, const hebench::APIBridge::WorkloadParams *p_params) override;
+    void destroyBenchmark(hebench::cpp::BaseBenchmark *p_bench) override;
+    std::string getBenchmarkDescription(const hebench::APIBridge::WorkloadParams *p_w_params) const override;
+};
+
+class MatMultRowLatencyBenchmark : public hebench::cpp::BaseBenchmark {
+public:
+    HEBERROR_DECLARE_CLASS_NAME(MatMultRowLatencyBenchmark)
+    static constexpr std::int64_t tag = 0x20 + MatMultRowBenchmarkDescription::MatMultRowOtherID;
+    MatMultRowLatencyBenchmark(hebench::cpp::BaseEngine &engine, const hebench::APIBridge::BenchmarkDescriptor &bench_desc,
+                               const hebench::APIBridge::WorkloadParams &bench_params);
+    hebench::APIBridge::Handle encode(const hebench::APIBridge::DataPackCollection *p_parameters) override;
+    void decode(hebench::APIBridge::Handle encoded_data, hebench::APIBridge::DataPackCollection *p_native) override;
+    hebench::APIBridge::Handle encrypt(hebench::APIBridge::Handle encoded_data) override;
+    hebench::APIBridge::Handle decrypt(hebench::APIBridge::Handle encrypted_data) override;
+    hebench::APIBridge::Handle load(const hebench::APIBridge::Handle *p_local_data, std::uint64_t count) override;
+    void store(hebench::APIBridge::Handle remote_data, hebench::APIBridge::Handle *p_local_data, std::uint64_t count) override;
+    hebench::APIBridge::Handle operate(hebench::APIBridge::Handle h_remote_packed, const hebench::APIBridge::ParameterIndexer *p_param_indexers,
+                                       std::uint64_t indexers_count) override;
+    std::int64_t classTag() const override { return BaseBenchmark::classTag() | MatMultRowLatencyBenchmark::tag; }
+
+private:
+    struct Dims { std::uint64_t rows = 0, cols = 0; };
+    struct PlainPack { Dims a, b; std::vector<Plain> A; Plain B; };      // encode() result
+    struct CipherPack { Dims a, b; std::vector<Cipher> A; Cipher B; };   // encrypt() result
+    struct RemotePack { Dims a, b; std::shared_ptr<DeviceCiphers> A, B; };
+    struct ResultRemote { Dims d; std::shared_ptr<DeviceCiphers> C; };
+    struct ResultCipher { Dims d; std::vector<Cipher> C; };
+    struct ResultPlain { Dims d; std::vector<Plain> C; };
+    static const hebench::APIBridge::DataPack &findDataPack(const hebench::APIBridge::DataPackCollection &c, std::uint64_t param_position);
+    std::uint64_t rows_M0() const { return m_w[0]; }
+    std::uint64_t cols_M0() const { return m_w[1]; }
+    std::uint64_t cols_M1() const { return m_w[2]; }
+    std::vector<std::uint64_t> m_w;
+    HeContextWrapper::Ptr m_p_ctx_wrapper;
+};
+
+} // namespace mi355x

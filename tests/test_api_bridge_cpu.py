@@ -39,12 +39,15 @@ def test_engine_registration(backend):
     assert backend.security_name(SCHEME_CKKS, 0) == "128 bits"  # seal_engine.cpp:105
     bs = backend.benchmarks()
     got = sorted((b["desc"].workload, b["desc"].scheme, b["desc"].category) for b in bs)
-    want = sorted([(W_ADD, SCHEME_BFV, LATENCY), (W_ADD, SCHEME_CKKS, LATENCY), (W_ADD, SCHEME_BFV, OFFLINE), (W_ADD, SCHEME_CKKS, OFFLINE),
-                   (W_MUL, SCHEME_CKKS, LATENCY), (W_MUL, SCHEME_CKKS, OFFLINE), (W_DOT, SCHEME_CKKS, LATENCY), (W_DOT, SCHEME_CKKS, OFFLINE)])
-    assert got == want
+    want = sorted([(w, s, c) for w in (W_ADD, W_MUL, W_DOT) for s in (SCHEME_BFV, SCHEME_CKKS) for c in (LATENCY, OFFLINE)] + [(0, SCHEME_BFV, LATENCY)])
+    assert got == want  # 13 of the reference's 20 descriptors (seal_engine.cpp:108-151)
+    mm = [b for b in bs if b["desc"].workload == 0][0]
+    assert mm["desc"].other == 2  # MatMultRowOtherID
+    assert mm["defaults"][0] == [("rows_M0", 10), ("cols_M0", 9), ("cols_M1", 8), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 3),
+                                 ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)]
     for b in bs:
         d = b["desc"]
-        assert d.cipher_param_mask == 0xFFFFFFFF and d.security == 0 and d.other == 0
+        assert d.cipher_param_mask == 0xFFFFFFFF and d.security == 0 and d.other == (2 if d.workload == 0 else 0)
         assert d.data_type == (DT_FLOAT64 if d.scheme == SCHEME_CKKS else DT_INT64)
         if d.category == LATENCY:
             assert d.cat_params.latency.warmup_iterations_count == 1 and d.cat_params.min_test_time_ms == 0
@@ -55,6 +58,7 @@ def test_engine_registration(backend):
     assert dot[0] == ("n", 100) and dot[3] == ("CoefficientModulusBits", 40)
     bfv = backend.find(W_ADD, SCHEME_BFV, LATENCY)["defaults"][0]
     assert bfv[3:5] == [("CoefficientModulusBits", 40), ("PlainModulusBits", 20)]
+    assert backend.find(W_DOT, SCHEME_BFV, OFFLINE)["defaults"][0][3] == ("CoefficientModulusBits", 45)
 
 
 def test_description_text(backend):

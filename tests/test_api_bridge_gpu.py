@@ -81,3 +81,61 @@ def test_bfv_eltwise_add(backend):
     want = (a[:, None, :] + b[None, :, :]).reshape(4, n)
     assert np.array_equal(res, want)  # BASELINE configs[0] plumbing case (at the reference's default parameters)
     backend.destroy(hb)
+
+
+def bfv_params(n, N=8192, depth=2, bits=40):
+    return [("n", n), ("PolyModulusDegree", N), ("MultiplicativeDepth", depth), ("CoefficientModulusBits", bits), ("PlainModulusBits", 20), ("NumThreads", 0)]
+
+
+def _centre(v, t):
+    v = np.mod(v, t)
+    return np.where(v > t // 2, v - t, v)
+
+
+def test_bfv_eltwise_multiply(backend):
+    rng = np.random.default_rng(5)
+    n, t = 1000, 1032193
+    a, b = rng.integers(-700, 700, (2, n)), rng.integers(-700, 700, (3, n))
+    hb = backend.create(backend.find(W_MUL, SCHEME_BFV, OFFLINE), bfv_params(n), (2, 3))
+    res = backend.run(hb, [a.astype(np.int64), b.astype(np.int64)], n, np.int64)
+    want = _centre((a[:, None, :] * b[None, :, :]).reshape(6, n), t)
+    assert np.array_equal(res, want)
+    backend.destroy(hb)
+
+
+@pytest.mark.parametrize("n", [100, 4096, 6000])
+def test_bfv_dot_product(backend, n):
+    """n = 6000 > N/2 exercises the rotate_columns branch of accumulateBFV (seal_context.cpp:305-310)."""
+    rng = np.random.default_rng(6 + n)
+    t = 1032193
+    a, b = rng.integers(-20, 20, (2, n)), rng.integers(-20, 20, (2, n))
+    hb = backend.create(backend.find(W_DOT, SCHEME_BFV, OFFLINE), bfv_params(n, bits=45), (2, 2))
+    res = backend.run(hb, [a.astype(np.int64), b.astype(np.int64)], 1, np.int64)
+    want = _centre((a @ b.T).reshape(4, 1), t)
+    assert np.array_equal(res, want)
+    backend.destroy(hb)
+
+
+def _matmul(backend, dims, N, depth):
+    from hebench_harness import Handle, ParameterIndexer
+    import ctypes as C
+    r0, c0, c1 = dims
+    rng = np.random.default_rng(sum(dims))
+    A, B = rng.integers(-8, 8, (r0, c0)).astype(np.int64), rng.integers(-8, 8, (c0, c1)).astype(np.int64)
+    bench = [b for b in backend.benchmarks() if b["desc"].workload == 0][0]
+    hb = backend.create(bench, [("rows_M0", r0), ("cols_M0", c0), ("cols_M1", c1), ("PolyModulusDegree", N), ("MultiplicativeDepth", depth),
+                                ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)])
+    res = backend.run(hb, [A.reshape(1, -1), B.reshape(1, -1)], r0 * c1, np.int64)
+    backend.destroy(hb)
+    t = 1032193 if N <= 8192 else 786433
+    assert np.array_equal(res.reshape(r0, c1), _centre(A @ B, t))
+
+
+def test_bfv_matmult_row_default_dims(backend):
+    _matmul(backend, (10, 9, 8), 8192, 3)  # the reference's defaults (bfv row .cpp:41-43)
+
+
+def test_bfv_matmult_row_cfg5_128(backend):
+    """BASELINE configs[4]: 128x128x128 at N=2^15 (b*c = N/2 exactly): 64 row-pair ciphertexts, 127 rotations each,
+    non-power-of-two steps through SEAL's NAF decomposition."""
+    _matmul(backend, (128, 128, 128), 32768, 3)

@@ -291,3 +291,40 @@ def test_cfg3_full_size_mul_relin_rescale(be, oracle):
     g.multiply_relin(L, 64, da, db, be.Context.outer(0, 64, 0, 1), out_c, rescale=True)
     assert np.array_equal(full[: 64 * stride_out], out_c.download())
     g.close()
+
+
+def test_cfg4_full_size_dot_product(be, oracle):
+    """configs[3]: CKKS DotProduct, vector length 4096, N=2^15, L=16: multiply -> relinearize -> accumulateCKKS(4096)
+    = 1 + 12 key switches per result (seal_context.cpp:331-339).  Two results checked bit-for-bit against the oracle."""
+    bits = be.chain_bits(16, 45)
+    g = be.Context(be.SCHEME_CKKS, 32768, bit_sizes=bits, device=0)
+    o = oracle.Context(oracle.SCHEME_CKKS, 32768, bit_sizes=bits)
+    L, N, K, n = g.L, g.N, g.K, 8
+    pm = list(range(L))
+    da, db = g.alloc(n * 2 * L * N), g.alloc(2 * L * N)
+    g.fill_uniform(da, n * 2 * L, pm, 11)
+    g.fill_uniform(db, 2 * L, pm, 12)
+    kbuf = g.alloc(L * 2 * K * N)
+
+    def key(seed):
+        g.fill_uniform(kbuf, L * 2 * K, list(range(K)), seed)
+        return kbuf.download((L, 2, K, N))
+    g.set_relin_key_synthetic(100)
+    rk = key(100)
+    gks = {}
+    for i in range(12):
+        e = o.galois_elt(1 << i)
+        g.set_galois_key_synthetic(e, 200 + i)
+        gks[e] = key(200 + i)
+    out, tmp = g.alloc(n * 2 * L * N), g.alloc(n * 2 * L * N)
+    g.multiply_relin(L, n, da, db, be.Context.outer(0, n, 0, 1), out)
+    g.accumulate(L, n, out, 4096, tmp)
+    a, b = da.download((n, 2, L, N)), db.download((1, 2, L, N))[0]
+    got = out.download((n, 2, L, N))
+    for r in (0, n - 1):
+        t = o.relinearize(o.multiply_ntt(a[r], b), rk)
+        for i in range(12):
+            e = o.galois_elt(1 << i)
+            t = o.add(t, o.apply_galois(t, e, gks[e]))
+        assert np.array_equal(got[r], t), r
+    g.close()
