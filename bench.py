@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH, help="results per GPU per step")
     ap.add_argument("--chunk", type=int, default=0, help="ops per kernel sequence (0: library default)")
-    ap.add_argument("--cpu-sample", type=int, default=64, help="ops in the CPU-baseline sample (0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="ops in the CPU-baseline sample (0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,6 +152,12 @@ def main():
     if rank == 0:
         bytes_op = algorithmic_bytes_per_op(L, N, n, K)
         gpu_s = gpu_ms / 1e3
+        # HBM bytes per op from the PMC passes of the same command (tools/profile_round.sh -> profiles/r01_hbm_traffic.json:
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath) and n == BATCH:
+            traffic = json.load(open(tpath))["hbm_bytes_per_op"] * n
         achieved = bytes_op * n * args.steps / gpu_s / 1e9
         out = {
             "metric": "ciphertext-ops/sec (CKKS ct x ct mul+relin+rescale, N=2^15, L=16)",
@@ -171,7 +177,8 @@ def main():
                        "poly_modulus_degree": N, "coeff_modulus_bits": bits, "batch_per_gpu": n, "global_batch": n * world,
                        "parallelism": f"batch-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": None,
+                         "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": traffic,
+                         "traffic_note": "HBM bytes per step (1024 ops) from PMC counters; algorithmic bytes per step = %d" % int(bytes_op * n),
                          "kernel": "mul->relin->rescale kernel sequence (k_k1, k_k2, k_k3 x2, k_floor_cols x2, k_floor_rows x4 per chunk)",
                          "algorithmic_bytes_per_op": bytes_op,
                          "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 3),

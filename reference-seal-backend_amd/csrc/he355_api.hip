@@ -267,7 +267,7 @@ public:
     Scratch scratch(size_t c, int L, int which = 0)
     {
         const size_t N = P.N, LN = (size_t)L * N;
-        const size_t per_op = 2 * LN + LN + LN + (size_t)(L + 1) * LN + 2 * LN + 2 * N + 2 * LN + 3 * N + 3 * LN;
+        const size_t per_op = 2 * LN + LN + LN + (size_t)(L + 1) * LN + 2 * LN + 2 * N + 2 * N + 2 * LN + 3 * N + 3 * LN;
         const size_t need = per_op * c * 8;
         u64 *&arena = which ? scratch2_ : scratch_;
         size_t &arena_bytes = which ? scratch2_bytes_ : scratch_bytes_;
@@ -287,6 +287,7 @@ public:
         s.ks.c2r = p; p += c * LN;
         s.ks.d = p; p += c * (size_t)(L + 1) * LN;
         s.ks.t = p; p += c * 2 * LN;
+        s.ks.tp = p; p += c * 2 * N;
         s.ks.tpr = p; p += c * 2 * N;
         s.ks.e = p; p += c * 2 * LN;
         s.rlr = p; p += c * 3 * N;
@@ -670,7 +671,7 @@ private:
     size_t bfv_bytes_ = 0;
     std::map<int, BehzDev> behz_;
     std::map<uint32_t, uint32_t *> d_gather_;
-    size_t chunk_ = 32;
+    size_t chunk_ = 128;
 };
 
 } // namespace he355

@@ -43,7 +43,8 @@ struct KsBuffers {
     u64 *c2r;   // [C][L][N]      target after the inverse row pass (raw of prime j; canonical if N == 1024)
     u64 *d;     // [C][L+1][L][N] digit j lifted to prime tt after the forward column pass (raw of prime tt)
     u64 *t;     // [C][2][L][N]   accumulated key products, data primes, canonical NTT form
-    u64 *tpr;   // [C][2][N]      special-prime accumulations after the inverse row pass (raw)
+    u64 *tp;    // [C][2][N]      special-prime accumulations, canonical NTT form
+    u64 *tpr;   // [C][2][N]      the same after the inverse row pass (raw)
     u64 *e;     // [C][2][L][N]   mod-down corrections after the forward column pass (raw of prime i)
 };
 enum K1Mode { K1_MUL = 0, K1_CT3 = 1, K1_GALOIS = 2 };

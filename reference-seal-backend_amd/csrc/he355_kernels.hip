@@ -408,9 +408,11 @@ struct K1Args {
     u64 *c2n, *c2r;
     u64 n_ops, op_offset;
     int L, logn1, mode;
+    int n_i;                   // residues handled by this launch (one arithmetic engine per launch)
+    unsigned char i_list[64];
 };
 
-template <class Ar>
+template <class Ar, int MODE>
 __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 op, int i, u32 a_row, int lane, u64 *lds, bool valid)
 {
     typedef typename Ar::T T;
@@ -424,7 +426,7 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
     u64 *c2rp = A.c2r + op * P1 + roff;
     T x[kRowE];
     u64 v0[kRowE], v1[kRowE];
-    if (A.mode == K1_MUL) {
+    if (MODE == K1_MUL) {
         const u64 r = A.op_offset + op;
         const u64 *pa = A.a + idx_a(A.ix, r) * 2 * P1 + roff, *pb = A.b + idx_b(A.ix, r) * 2 * P1 + roff;
         u64 a0[kRowE], a1[kRowE], b0[kRowE], b1[kRowE];
@@ -440,7 +442,7 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
             x[r2] = ar.from_canon(v2[r2]);
         }
         if (valid) { store_rowC(c0p, lane, v0); store_rowC(c1p, lane, v1); store_rowC(c2np, lane, v2); }
-    } else if (A.mode == K1_CT3) {
+    } else if (MODE == K1_CT3) {
         const u64 *pa = A.a + (A.op_offset + op) * 3 * P1 + roff;
         u64 v2[kRowE];
         load_rowC(pa, lane, v0); load_rowC(pa + P1, lane, v1); load_rowC(pa + 2 * P1, lane, v2);
@@ -468,22 +470,21 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
     if (valid) store_rowA(c2rp, lane, v0);
 }
 
+template <int MODE, class Ar>
 __global__ void __launch_bounds__(kBlock) k_k1(K1Args A, const PrimeDev *primes)
 {
     __shared__ u64 lds[kWaves][kLdsRow];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 n1 = 1u << A.logn1;
-    const u64 total = A.n_ops * A.L * n1;
+    const u64 total = A.n_ops * A.n_i * n1;
     u64 job = (u64)blockIdx.x * kWaves + wave;
     const bool valid = job < total;
     if (!valid) job = total - 1;
     const u32 a_row = (u32)(job & (n1 - 1));
     const u64 oi = job >> A.logn1;
-    const int i = (int)(oi % A.L);
-    const u64 op = oi / A.L;
-    const PrimeDev &P = primes[i];
-    if (P.f64) k1_job<ArF64>(A, P, op, i, a_row, lane, lds[wave], valid);
-    else k1_job<ArU64>(A, P, op, i, a_row, lane, lds[wave], valid);
+    const int i = A.i_list[oi % A.n_i];
+    const u64 op = oi / A.n_i;
+    k1_job<Ar, MODE>(A, primes[i], op, i, a_row, lane, lds[wave], valid);
 }
 
 // =======================================================================================================
@@ -583,19 +584,19 @@ __global__ void __launch_bounds__(kBlock) k_k2(K2Args A, const PrimeDev *primes)
 // =======================================================================================================
 struct K3Args {
     const u64 *d, *c2n, *key;
-    u64 *t, *tpr;
+    u64 *t, *tp;
     u64 n_ops;
     int L, K, logn1, ckks;
     int n_tt;
+    u32 og_per_block; // consecutive op-groups one block handles on its tile
     unsigned char tt_list[64];
 };
 
-template <class Ar>
+template <class Ar, int U>
 __global__ void __launch_bounds__(kBlock) k_k3(K3Args A, const PrimeDev *primes)
 {
     typedef typename Ar::T T;
     typedef typename Ar::Acc Acc;
-    constexpr int U = 2; // digits transformed together by one wave
     constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
     // One block per CU (one wave per SIMD): the wave gets its latency hiding from the two interleaved digits
     // and from LDS-DMA prefetch, not from co-resident waves.  LDS: 64 KiB exchange + 64 KiB DMA landing + twiddles.
@@ -607,15 +608,15 @@ __global__ void __launch_bounds__(kBlock) k_k3(K3Args A, const PrimeDev *primes)
     const u64 N = (u64)n1 << kRowLog;
     // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so all op-groups of one
     // (tt,row) tile are placed on the same XCD back to back: its 2*L key rows stay in that XCD's L2.
+    // A block stays on its tile for og_per_block consecutive op-groups (4 ops each): the twiddle staging and the block
+    // start-up are paid once per og_per_block * 4 ops instead of once per 4.
     const u64 n_og = (A.n_ops + kWaves - 1) / kWaves;
+    const u64 n_ogb = (n_og + A.og_per_block - 1) / A.og_per_block;
     const u64 total_tiles = (u64)A.n_tt * n1;
     const u64 s = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-    const u64 tile = (s / n_og) * 8 + xcd;
+    const u64 tile = (s / n_ogb) * 8 + xcd;
     if (tile >= total_tiles) return; // whole block exits together
-    const u64 og = s % n_og;
-    u64 op = og * kWaves + wave;
-    const bool valid = op < A.n_ops;
-    if (!valid) op = A.n_ops - 1;
+    const u64 og_first = (s % n_ogb) * A.og_per_block;
     const int tt = A.tt_list[tile >> A.logn1];
     const u32 a_row = (u32)(tile & (n1 - 1));
     const int t = (tt == A.L) ? A.K - 1 : tt;
@@ -629,109 +630,104 @@ __global__ void __launch_bounds__(kBlock) k_k3(K3Args A, const PrimeDev *primes)
         const gtw_t gf = gtw(P.fwd);
         if constexpr (kF64) {
             double *twl = reinterpret_cast<double *>(twl_raw);
-            for (u32 i = threadIdx.x; i + 1 < (u32)kRowTw; i += kBlock) twl[i] = ArF64::tw_w(tw_load(gf, tw_row_source(n1 + a_row, i)));
+            Tw16 tmp[kRowTw / kBlock];
+#pragma unroll
+            for (int k = 0; k < kRowTw / kBlock; ++k) { // all loads in flight together
+                const u32 i = threadIdx.x + k * kBlock;
+                tmp[k] = tw_load(gf, tw_row_source(n1 + a_row, i + 1 < (u32)kRowTw ? i : 0));
+            }
+#pragma unroll
+            for (int k = 0; k < kRowTw / kBlock; ++k) twl[threadIdx.x + k * kBlock] = ArF64::tw_w(tmp[k]);
             twr.t = twl;
             twr.qinv = ar.qinv;
         } else {
             Tw16 *twl = reinterpret_cast<Tw16 *>(twl_raw);
-            for (u32 i = threadIdx.x; i + 1 < (u32)kRowTw; i += kBlock) twl[i] = tw_load(gf, tw_row_source(n1 + a_row, i));
+            Tw16 tmp[kRowTw / kBlock];
+#pragma unroll
+            for (int k = 0; k < kRowTw / kBlock; ++k) {
+                const u32 i = threadIdx.x + k * kBlock;
+                tmp[k] = tw_load(gf, tw_row_source(n1 + a_row, i + 1 < (u32)kRowTw ? i : 0));
+            }
+#pragma unroll
+            for (int k = 0; k < kRowTw / kBlock; ++k) twl[threadIdx.x + k * kBlock] = tmp[k];
             twr.t = twl;
         }
     }
     __syncthreads();
-    Acc acc0[kRowE], acc1[kRowE];
+    for (u32 g = 0; g < A.og_per_block; ++g) {
+        const u64 og = og_first + g;
+        if (og >= n_og) break; // block-uniform
+        u64 op = og * kWaves + wave;
+        const bool valid = op < A.n_ops;
+        if (!valid) op = A.n_ops - 1;
+        Acc acc0[kRowE], acc1[kRowE];
 #pragma unroll
-    for (int r = 0; r < kRowE; ++r) { acc0[r] = 0; acc1[r] = 0; }
-    auto key_row = [&](int j, int k) -> const u64 * { return A.key + (((u64)j * 2 + k) * A.K + t) * N + rowoff; };
-    auto mac_digit = [&](const T x[kRowE], int j) {
-        u64 kv[kRowE], kw[kRowE];
-        load_rowC(key_row(j, 0), lane, kv);
-        load_rowC(key_row(j, 1), lane, kw);
+        for (int r = 0; r < kRowE; ++r) { acc0[r] = 0; acc1[r] = 0; }
+        auto key_row = [&](int j, int k) -> const u64 * { return A.key + (((u64)j * 2 + k) * A.K + t) * N + rowoff; };
+        auto mac_digit = [&](const T x[kRowE], int j) {
+            u64 kv[kRowE], kw[kRowE];
+            load_rowC(key_row(j, 0), lane, kv);
+            load_rowC(key_row(j, 1), lane, kw);
 #pragma unroll
-        for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc0[r], x[r], ar.key_in(kv[r]));
+            for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc0[r], x[r], ar.key_in(kv[r]));
 #pragma unroll
-        for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc1[r], x[r], ar.key_in(kw[r]));
-    };
-    // digits that go through the forward row pass: all of them, except (CKKS) the one that lives under this very
-    // prime -- that one is the NTT-form target itself and is multiplied in directly
-    const bool has_own = A.ckks && tt < A.L;
-    const int nd = A.L - (has_own ? 1 : 0);
-    auto digit = [&](int i) -> int { return (has_own && i >= tt) ? i + 1 : i; };
-    auto src_row = [&](int j) -> const u64 * { return A.d + ((op * (A.L + 1) + tt) * A.L + j) * N + rowoff; };
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        if (u < nd) dma_row_to_lds(src_row(digit(u)), stage[wave][u], lane);
-    if (has_own) {
-        T x[kRowE];
-        u64 v[kRowE];
-        load_rowC(A.c2n + (op * A.L + tt) * N + rowoff, lane, v);
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
-        mac_digit(x, tt);
-    }
-    for (int i = 0; i < nd; i += U) {
-        const int cnt = (nd - i) < U ? (nd - i) : U;
-        T x[U][kRowE];
-        u64 v[kRowE];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the rows of this step have landed in the staging buffers
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (u < cnt) {
-                lds_rowA(stage[wave][u], lane, v);
-#pragma unroll
-                for (int r = 0; r < kRowE; ++r) x[u][r] = ar.from_raw(v[r]);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffers drained into registers
+            for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc1[r], x[r], ar.key_in(kw[r]));
+        };
+        // digits that go through the forward row pass: all of them, except (CKKS) the one that lives under this very
+        // prime -- that one is the NTT-form target itself and is multiplied in directly
+        const bool has_own = A.ckks && tt < A.L;
+        const int nd = A.L - (has_own ? 1 : 0);
+        auto digit = [&](int i) -> int { return (has_own && i >= tt) ? i + 1 : i; };
+        auto src_row = [&](int j) -> const u64 * { return A.d + ((op * (A.L + 1) + tt) * A.L + j) * N + rowoff; };
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (i + U + u < nd) dma_row_to_lds(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
-        if (cnt == U) {
+            if (u < nd) dma_row_to_lds(src_row(digit(u)), stage[wave][u], lane);
+        if (has_own) {
+            T x[kRowE];
+            u64 v[kRowE];
+            load_rowC(A.c2n + (op * A.L + tt) * N + rowoff, lane, v);
+#pragma unroll
+            for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
+            mac_digit(x, tt);
+        }
+        for (int i = 0; i < nd; i += U) {
+            const int cnt = (nd - i) < U ? (nd - i) : U;
+            T x[U][kRowE];
+            u64 v[kRowE];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the rows of this step have landed in the staging buffers
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (u < cnt) {
+                    lds_rowA(stage[wave][u], lane, v);
+#pragma unroll
+                    for (int r = 0; r < kRowE; ++r) x[u][r] = ar.from_raw(v[r]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffers drained into registers
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (i + U + u < nd) dma_row_to_lds(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
+            if (U == 2 && cnt < U) { // odd digit count: the partner row is zeros (its products add nothing)
+#pragma unroll
+                for (int r = 0; r < kRowE; ++r) x[U - 1][r] = 0;
+            }
             wave_rows_fwd_n<U>(ar, twr, lane, lds[wave], x);
 #pragma unroll
-            for (int u = 0; u < U; ++u) mac_digit(x[u], digit(i + u));
-        } else {
-            wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x);
-            mac_digit(x[0], digit(i));
+            for (int u = 0; u < U; ++u)
+                if (u < cnt) mac_digit(x[u], digit(i + u));
         }
-    }
-    u64 v[kRowE];
-    if (tt < A.L && !A.ckks) {
-        // BFV: the result must come back to coefficient form: every prime's sums start the inverse transform here
-        const bool last = A.logn1 == 0;
-        T x[kRowE];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-#pragma unroll
-            for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(ar.acc_canon(k ? acc1[r] : acc0[r]));
-            wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave][0], x);
-#pragma unroll
-            for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
-            if (valid) store_rowA(A.t + ((op * 2 + k) * A.L + tt) * N + rowoff, lane, v);
-        }
-    } else if (tt < A.L) {
+        // Epilogue: canonical sums, NTT form, layout C.  Data primes -> t; special prime -> tp.  The inverse row passes
+        // that follow (special prime always, every prime for BFV) are separate small launches: keeping them out of this
+        // kernel keeps its loop inside the instruction cache.
+        u64 v[kRowE];
+        u64 *dst0 = tt < A.L ? A.t + ((op * 2 + 0) * A.L + tt) * N + rowoff : A.tp + (op * 2 + 0) * N + rowoff;
+        u64 *dst1 = tt < A.L ? A.t + ((op * 2 + 1) * A.L + tt) * N + rowoff : A.tp + (op * 2 + 1) * N + rowoff;
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc0[r]);
-        if (valid) store_rowC(A.t + ((op * 2 + 0) * A.L + tt) * N + rowoff, lane, v);
+        if (valid) store_rowC(dst0, lane, v);
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc1[r]);
-        if (valid) store_rowC(A.t + ((op * 2 + 1) * A.L + tt) * N + rowoff, lane, v);
-    } else {
-        // special prime: start the inverse transform right here (row pass), mod-down finishes it
-        const bool last = A.logn1 == 0;
-        T x[kRowE];
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(ar.acc_canon(acc0[r]));
-        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave][0], x);
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
-        if (valid) store_rowA(A.tpr + (op * 2 + 0) * N + rowoff, lane, v);
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(ar.acc_canon(acc1[r]));
-        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave][0], x);
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
-        if (valid) store_rowA(A.tpr + (op * 2 + 1) * N + rowoff, lane, v);
+        if (valid) store_rowC(dst1, lane, v);
     }
 }
 
@@ -1160,8 +1156,23 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
     A.a = a; A.b = b; A.ix = ix; A.perm = perm;
     A.c01 = buf.c01; A.c01_item_stride = buf.c01_item_stride; A.c2n = buf.c2n; A.c2r = buf.c2r;
     A.n_ops = n_ops; A.op_offset = op_offset; A.L = L; A.logn1 = env.logn1; A.mode = (int)mode;
-    const u64 jobs = (n_ops * L) << env.logn1;
-    hipLaunchKernelGGL(k_k1, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes);
+    for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine residues, pass 1: u64-engine residues
+        A.n_i = 0;
+        for (int i = 0; i < L; ++i)
+            if ((env.prime_f64[i] != 0) == (pass == 0)) A.i_list[A.n_i++] = (unsigned char)i;
+        if (!A.n_i) continue;
+        const u64 jobs = (n_ops * A.n_i) << env.logn1;
+        const dim3 grid(grid_for(jobs, kWaves));
+        if (pass == 0) {
+            if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArF64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
+            else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArF64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
+            else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArF64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
+        } else {
+            if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArU64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
+            else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArU64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
+            else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArU64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
+        }
+    }
 }
 
 void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *src, u64 src_op_stride)
@@ -1189,7 +1200,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     if (!n_ops) return;
     for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine primes, pass 1: u64-engine primes
         K3Args A;
-        A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tpr = buf.tpr;
+        A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tp = buf.tp;
         A.n_ops = n_ops; A.L = L; A.K = env.K; A.logn1 = env.logn1; A.ckks = env.scheme == 2;
         A.n_tt = 0;
         for (int tt = 0; tt <= L; ++tt) {
@@ -1199,18 +1210,24 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         if (!A.n_tt) continue;
         const u64 n_og = (n_ops + kWaves - 1) / kWaves;
         const u64 tiles = (u64)A.n_tt << env.logn1;
-        const unsigned g = (unsigned)(((tiles + 7) / 8) * 8 * n_og);
-        static bool printed = false;
-        if (!printed && getenv("HE355_DEBUG")) {
-            int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_k3<ArF64>, kBlock, 0);
-            fprintf(stderr, "[he355] k_k3<ArF64>: %d blocks/CU by the occupancy API\n", nb);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_k3<ArU64>, kBlock, 0);
-            fprintf(stderr, "[he355] k_k3<ArU64>: %d blocks/CU by the occupancy API\n", nb);
-            printed = true;
-        }
-        if (pass == 0) hipLaunchKernelGGL(k_k3<ArF64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
-        else hipLaunchKernelGGL(k_k3<ArU64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+        // enough blocks to keep every CU busy for several rounds, few enough that start-up costs are amortised
+        static const u32 og_env = getenv("HE355_K3_OG") ? (u32)atoi(getenv("HE355_K3_OG")) : 0;
+        u32 ogpb = og_env ? og_env : 4;
+        while (ogpb > 1 && tiles * ((n_og + ogpb - 1) / ogpb) < 256u * 6) ogpb >>= 1;
+        A.og_per_block = ogpb;
+        const u64 n_ogb = (n_og + ogpb - 1) / ogpb;
+        const unsigned g = (unsigned)(((tiles + 7) / 8) * 8 * n_ogb);
+        if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 2>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+        else hipLaunchKernelGGL((k_k3<ArU64, 1>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+    }
+    // special-prime sums: start the inverse transform (row pass) for the mod-down
+    launch_rows_inv_select(env, env.K - 1, n_ops * 2, buf.tp, (u64)env.N, buf.tpr);
+    if (env.scheme != 2) { // BFV: every data prime's sums go back to coefficient form as well
+        PolyView v;
+        v.base = buf.t; v.item_stride = (u64)L * env.N; v.polys_per_item = L; v.pad_ = 0;
+        for (int i = 0; i < L; ++i) v.prime_of[i] = (unsigned char)i;
+        const u64 jobs = (n_ops * 2 * L) << env.logn1;
+        hipLaunchKernelGGL(k_rows_inv, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, v, env.primes, jobs, env.logn1);
     }
 }
 

@@ -7,8 +7,9 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(k_\w+)(<[^>]*>)?", name)
-    return (m.group(1) + (m.group(2) or "")).replace("he355::", "") if m else name[:40]
+    name = name.replace("he355::", "").replace("(anonymous namespace)::", "")
+    m = re.search(r"(k_\w+)(<[^(]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")).replace(" ", "").replace(",", ";") if m else name[:40]
 
 
 def main(d):
