@@ -84,13 +84,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; HE355_BENCH_BACKEND=gloo lets several ranks share one GPU for rehearsals on a 1-GPU box
+    backend = os.environ.get("HE355_BENCH_BACKEND", "nccl")
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=backend)
 
     be = importlib.import_module("reference-seal-backend_amd")
     bits = be.chain_bits(DEPTH, COEFF_BITS)
-    ctx = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, device=local_rank)
+    ctx = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, device=device)
     L, K = ctx.L, ctx.K
     n = args.batch
     if args.chunk:
@@ -126,7 +132,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
