@@ -25,6 +25,9 @@ namespace he355 {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef K2_WAVES
+#define K2_WAVES 2
+#endif
 constexpr int kWaves = 4;
 
 // Each wave exchanges data only inside its own LDS region: LDS instructions of one wave execute in
@@ -538,7 +541,7 @@ __device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt
 }
 
 template <int LOGN1>
-__global__ void __launch_bounds__(kBlock) k_k2(K2Args A, const PrimeDev *primes)
+__global__ void __launch_bounds__(kBlock, K2_WAVES) k_k2(K2Args A, const PrimeDev *primes)
 {
     constexpr int N1 = 1 << LOGN1;
     constexpr u64 N = (u64)N1 << kRowLog;

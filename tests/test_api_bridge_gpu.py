@@ -122,7 +122,7 @@ def _matmul(backend, dims, N, depth):
     r0, c0, c1 = dims
     rng = np.random.default_rng(sum(dims))
     A, B = rng.integers(-8, 8, (r0, c0)).astype(np.int64), rng.integers(-8, 8, (c0, c1)).astype(np.int64)
-    bench = [b for b in backend.benchmarks() if b["desc"].workload == 0][0]
+    bench = [b for b in backend.benchmarks() if b["desc"].workload == 0 and b["desc"].other == 2][0]
     hb = backend.create(bench, [("rows_M0", r0), ("cols_M0", c0), ("cols_M1", c1), ("PolyModulusDegree", N), ("MultiplicativeDepth", depth),
                                 ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)])
     res = backend.run(hb, [A.reshape(1, -1), B.reshape(1, -1)], r0 * c1, np.int64)
@@ -139,3 +139,34 @@ def test_bfv_matmult_row_cfg5_128(backend):
     """BASELINE configs[4]: 128x128x128 at N=2^15 (b*c = N/2 exactly): 64 row-pair ciphertexts, 127 rotations each,
     non-power-of-two steps through SEAL's NAF decomposition."""
     _matmul(backend, (128, 128, 128), 32768, 3)
+
+
+def _matmul_val(backend, scheme, dims, N, depth, bits):
+    r0, c0, c1 = dims
+    rng = np.random.default_rng(sum(dims) + scheme)
+    bench = [b for b in backend.benchmarks() if b["desc"].workload == 0 and b["desc"].other == 0 and b["desc"].scheme == scheme][0]
+    last = ("ScaleBits", bits) if scheme == SCHEME_CKKS else ("PlainModulusBits", 20)
+    hb = backend.create(bench, [("rows_M0", r0), ("cols_M0", c0), ("cols_M1", c1), ("PolyModulusDegree", N), ("MultiplicativeDepth", depth),
+                                ("CoefficientModulusBits", bits), last, ("NumThreads", 0)])
+    if scheme == SCHEME_CKKS:
+        A, B = rng.uniform(-1, 1, (r0, c0)), rng.uniform(-1, 1, (c0, c1))
+        res = backend.run(hb, [A.reshape(1, -1), B.reshape(1, -1)], r0 * c1, np.float64)
+        assert np.allclose(res.reshape(r0, c1), A @ B, atol=1e-3)
+    else:
+        A, B = rng.integers(-8, 8, (r0, c0)).astype(np.int64), rng.integers(-8, 8, (c0, c1)).astype(np.int64)
+        res = backend.run(hb, [A.reshape(1, -1), B.reshape(1, -1)], r0 * c1, np.int64)
+        assert np.array_equal(res.reshape(r0, c1), _centre(A @ B, 1032193))
+    backend.destroy(hb)
+
+
+@pytest.mark.parametrize("dims", [(10, 9, 8), (3, 64, 5), (2, 1, 2)])
+def test_ckks_matmult_val(backend, dims):
+    """One row per ciphertext, (i, j) pairs as one outer-product batch (ckks matmultval .cpp:246-258); the
+    reference's default dimensions and parameters first."""
+    _matmul_val(backend, SCHEME_CKKS, dims, 8192, 2, 45)
+
+
+@pytest.mark.parametrize("dims", [(10, 9, 8), (3, 5000, 2)])
+def test_bfv_matmult_val(backend, dims):
+    """cols_M0 = 5000 > N/2 takes the rotate_columns branch of accumulateBFV."""
+    _matmul_val(backend, SCHEME_BFV, dims, 8192, 2, 40)
