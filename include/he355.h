@@ -18,6 +18,8 @@
  *   he355_multiply_relin        multiply + relinearize_inplace                src/benchmarks/ckks/seal_ckks_dot_product_benchmark.cpp:325-329
  *     (rescale = 1)             ... + rescale_to_next_inplace                 src/benchmarks/ckks/seal_ckks_matmultval_benchmark.cpp:253-255
  *   he355_relinearize           evaluator()->relinearize_inplace              src/engine/seal_context.cpp:390,447
+ *   he355_multiply_accumulate   multiply + add_inplace over the inner dimension  src/benchmarks/ckks/seal_ckks_matmult_cipherbatchaxis_benchmark.cpp:404-420
+ *   he355_relinearize_rescale   relinearize_inplace + rescale_to_next_inplace    same file :436-437
  *   he355_rescale               evaluator()->rescale_to_next_inplace          src/engine/seal_context.cpp:391,448
  *   he355_rotate                evaluator()->rotate_vector (CKKS) / rotate_rows (BFV)      src/engine/seal_context.cpp:337,302
  *   he355_apply_galois(2N-1)    evaluator()->rotate_columns_inplace (BFV)                   src/engine/seal_context.cpp:308
@@ -105,6 +107,13 @@ int he355_bfv_multiply(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, c
 int he355_multiply_relin(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, int rescale,
                          uint64_t *d_out);
 int he355_relinearize(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_ct3, uint64_t *d_out);            /* [n][3][L][N] -> [n][2][L][N] */
+/* CKKS: out(i,j) = sum_k multiply(a(i,k), b(k,j)), size-3 results [rows*cols][3][L][N]; ciphertext (i,k) of a is at index
+ * i*a_stride_i + k*a_stride_k, (k,j) of b at k*b_stride_k + j*b_stride_j — the multiply/add_inplace loop of
+ * src/benchmarks/ckks/seal_ckks_matmult_cipherbatchaxis_benchmark.cpp:404-420 */
+int he355_multiply_accumulate(he355_ctx *ctx, int L, uint64_t rows, uint64_t cols, uint64_t inner, const uint64_t *d_a, uint64_t a_stride_i,
+                              uint64_t a_stride_k, const uint64_t *d_b, uint64_t b_stride_k, uint64_t b_stride_j, uint64_t *d_out);
+/* relinearize_inplace + rescale_to_next_inplace of size-3 ciphertexts (same file :436-437): [n][3][L][N] -> [n][2][L-1][N] */
+int he355_relinearize_rescale(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_ct3, uint64_t *d_out);
 int he355_rescale(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_in, uint64_t *d_out);         /* -> [n][size][L-1][N] */
 int he355_apply_galois(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, uint32_t galois_elt, uint64_t *d_out);
 int he355_rotate(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, int step, uint64_t *d_out);

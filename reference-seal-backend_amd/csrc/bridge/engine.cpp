@@ -3,6 +3,7 @@
 
 #include "benchmarks.h"
 #include "matmult_row.h"
+#include "matmult_cba.h"
 #include "matmult_val.h"
 
 #define HEBENCH_API_VERSION_NEEDED_MAJOR 0
@@ -44,9 +45,12 @@ public:
         addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::CKKS, AB::Category::Latency, AB::Workload::DotProduct));
         addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::BFV, AB::Category::Offline, AB::Workload::DotProduct));
         addBenchmarkDescription(std::make_shared<VectorBenchmarkDescription>(Scheme::CKKS, AB::Category::Offline, AB::Workload::DotProduct));
+        addBenchmarkDescription(std::make_shared<MatMultCipherBatchAxisBenchmarkDescription>(Scheme::BFV));
+        addBenchmarkDescription(std::make_shared<MatMultCipherBatchAxisBenchmarkDescription>(Scheme::CKKS));
         addBenchmarkDescription(std::make_shared<MatMultValBenchmarkDescription>(Scheme::BFV));
         addBenchmarkDescription(std::make_shared<MatMultValBenchmarkDescription>(Scheme::CKKS));
-        addBenchmarkDescription(std::make_shared<MatMultRowBenchmarkDescription>());
+        addBenchmarkDescription(std::make_shared<MatMultRowBenchmarkDescription>(Scheme::BFV));
+        addBenchmarkDescription(std::make_shared<MatMultRowBenchmarkDescription>(Scheme::CKKS));
     }
 };
 

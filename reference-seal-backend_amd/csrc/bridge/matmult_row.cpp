@@ -2,39 +2,41 @@
 #include "matmult_row.h"
 
 #include <algorithm>
+#include <cmath>
 #include <sstream>
 
 using namespace mi355x;
 using hebench::cpp::HEBenchError;
 namespace AB = hebench::APIBridge;
 
-MatMultRowBenchmarkDescription::MatMultRowBenchmarkDescription()
+MatMultRowBenchmarkDescription::MatMultRowBenchmarkDescription(Scheme scheme) : m_scheme(scheme)
 {
     std::memset(&m_descriptor, 0, sizeof(AB::BenchmarkDescriptor)); // bfv row .cpp:28-38
     m_descriptor.workload = AB::Workload::MatrixMultiply;
-    m_descriptor.data_type = AB::DataType::Int64;
+    m_descriptor.data_type = scheme == Scheme::CKKS ? AB::DataType::Float64 : AB::DataType::Int64;
     m_descriptor.category = AB::Category::Latency;
     m_descriptor.cat_params.latency.warmup_iterations_count = 1;
     m_descriptor.cat_params.min_test_time_ms = 0;
     m_descriptor.cipher_param_mask = HEBENCH_HE_PARAM_FLAGS_ALL_CIPHER;
-    m_descriptor.scheme = HEBENCH_HE_SCHEME_BFV;
+    m_descriptor.scheme = scheme == Scheme::CKKS ? HEBENCH_HE_SCHEME_CKKS : HEBENCH_HE_SCHEME_BFV;
     m_descriptor.security = HEBENCH_HE_SECURITY_128;
     m_descriptor.other = MatMultRowOtherID;
-    hebench::cpp::WorkloadParams::Common w; // defaults: bfv row .cpp:41-48, .h:29-32
+    hebench::cpp::WorkloadParams::Common w; // defaults: bfv row .cpp:41-48, .h:29-32; ckks row .h:29-32
     w.add<std::uint64_t>(10, "rows_M0");
     w.add<std::uint64_t>(9, "cols_M0");
     w.add<std::uint64_t>(8, "cols_M1");
     w.add<std::uint64_t>(8192, "PolyModulusDegree");
     w.add<std::uint64_t>(3, "MultiplicativeDepth");
-    w.add<std::uint64_t>(40, "CoefficientModulusBits");
-    w.add<std::uint64_t>(20, "PlainModulusBits");
+    w.add<std::uint64_t>(scheme == Scheme::CKKS ? 45 : 40, "CoefficientModulusBits");
+    if (scheme == Scheme::CKKS) w.add<std::uint64_t>(45, "ScaleBits");
+    else w.add<std::uint64_t>(20, "PlainModulusBits");
     w.add<std::uint64_t>(0, "NumThreads");
     this->addDefaultParameters(w);
 }
 hebench::cpp::BaseBenchmark *MatMultRowBenchmarkDescription::createBenchmark(hebench::cpp::BaseEngine &engine, const AB::WorkloadParams *p_params)
 {
     if (!p_params) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid empty workload parameters. This workload requires flexible parameters."), HEBENCH_ECODE_CRITICAL_ERROR);
-    return new MatMultRowLatencyBenchmark(engine, m_descriptor, *p_params);
+    return new MatMultRowLatencyBenchmark(engine, m_descriptor, *p_params, m_scheme);
 }
 void MatMultRowBenchmarkDescription::destroyBenchmark(hebench::cpp::BaseBenchmark *p_bench)
 {
@@ -50,19 +52,22 @@ std::string MatMultRowBenchmarkDescription::getBenchmarkDescription(const AB::Wo
        << ", , Poly modulus degree, " << p_w_params->params[Index_PolyModulusDegree].u_param << std::endl
        << ", , Coefficient Modulus, 60";
     for (std::size_t i = 1; i < p_w_params->params[Index_NumCoefficientModuli].u_param; ++i) ss << ", " << p_w_params->params[Index_CoefficientModulusBits].u_param;
-    ss << ", 60" << std::endl
-       << ", , Plain Modulus, " << p_w_params->params[Index_PlainModulusBits].u_param << std::endl
-       << ", Algorithm, " << AlgorithmName << ", " << AlgorithmDescription << std::endl
+    ss << ", 60" << std::endl;
+    if (m_scheme == Scheme::CKKS) ss << ", , Scale, 2^" << p_w_params->params[Index_PlainModulusBits].u_param << std::endl;
+    else ss << ", , Plain Modulus, " << p_w_params->params[Index_PlainModulusBits].u_param << std::endl;
+    ss << ", Algorithm, " << AlgorithmName << ", " << AlgorithmDescription << std::endl
        << ", Device, AMD Instinct MI355X (HIP; row-pair ciphertexts batched on the grid)";
     return ss.str();
 }
 
 MatMultRowLatencyBenchmark::MatMultRowLatencyBenchmark(hebench::cpp::BaseEngine &engine, const AB::BenchmarkDescriptor &bench_desc,
-                                                       const AB::WorkloadParams &bench_params)
-    : hebench::cpp::BaseBenchmark(engine, bench_desc, bench_params)
+                                                       const AB::WorkloadParams &bench_params, Scheme scheme)
+    : hebench::cpp::BaseBenchmark(engine, bench_desc, bench_params), m_scheme(scheme)
 {
-    if (bench_desc.workload != AB::Workload::MatrixMultiply || bench_desc.data_type != AB::DataType::Int64 || bench_desc.category != AB::Category::Latency
-        || ((bench_desc.cipher_param_mask & 0x03) != 0x03) || bench_desc.scheme != HEBENCH_HE_SCHEME_BFV || bench_desc.security != HEBENCH_HE_SECURITY_128
+    if (bench_desc.workload != AB::Workload::MatrixMultiply || bench_desc.category != AB::Category::Latency
+        || bench_desc.data_type != (scheme == Scheme::CKKS ? AB::DataType::Float64 : AB::DataType::Int64)
+        || bench_desc.scheme != (scheme == Scheme::CKKS ? HEBENCH_HE_SCHEME_CKKS : HEBENCH_HE_SCHEME_BFV)
+        || ((bench_desc.cipher_param_mask & 0x03) != 0x03) || bench_desc.security != HEBENCH_HE_SECURITY_128
         || bench_desc.other != MatMultRowBenchmarkDescription::MatMultRowOtherID)
         throw HEBenchError(HEBERROR_MSG_CLASS("Benchmark descriptor received is not supported."), HEBENCH_ECODE_INVALID_ARGS);
     if (bench_params.count < MatMultRowBenchmarkDescription::NumWorkloadParams)
@@ -79,9 +84,9 @@ MatMultRowLatencyBenchmark::MatMultRowLatencyBenchmark(hebench::cpp::BaseEngine 
            << " (e.g. PolyModulusDegree / 2).";
         throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
     }
-    m_p_ctx_wrapper = HeContextWrapper::createBFVContext(N, m_w[MatMultRowBenchmarkDescription::Index_NumCoefficientModuli],
-                                                         (int)m_w[MatMultRowBenchmarkDescription::Index_CoefficientModulusBits],
-                                                         (int)m_w[MatMultRowBenchmarkDescription::Index_PlainModulusBits]);
+    const std::uint64_t depth = m_w[MatMultRowBenchmarkDescription::Index_NumCoefficientModuli];
+    const int bits = (int)m_w[MatMultRowBenchmarkDescription::Index_CoefficientModulusBits], extra = (int)m_w[MatMultRowBenchmarkDescription::Index_PlainModulusBits];
+    m_p_ctx_wrapper = scheme == Scheme::CKKS ? HeContextWrapper::createCKKSContext(N, depth, bits, extra) : HeContextWrapper::createBFVContext(N, depth, bits, extra);
 }
 
 const AB::DataPack &MatMultRowLatencyBenchmark::findDataPack(const AB::DataPackCollection &c, std::uint64_t param_position)
@@ -96,7 +101,7 @@ AB::Handle MatMultRowLatencyBenchmark::encode(const AB::DataPackCollection *p_pa
     if (p_parameters->pack_count != MatMultRowBenchmarkDescription::NumOpParams)
         throw HEBenchError(HEBERROR_MSG_CLASS("Expected 2 parameter packs, but " + std::to_string(p_parameters->pack_count) + " received."),
                            HEBENCH_ECODE_INVALID_ARGS);
-    const std::int64_t *mats[2];
+    const void *mats_raw[2];
     for (std::uint64_t op = 0; op < 2; ++op) {
         const std::uint64_t r = op ? cols_M0() : rows_M0(), cl = op ? cols_M1() : cols_M0();
         const AB::DataPack &dp = findDataPack(*p_parameters, op);
@@ -105,9 +110,26 @@ AB::Handle MatMultRowLatencyBenchmark::encode(const AB::DataPackCollection *p_pa
         if (!dp.p_buffers || !dp.p_buffers[0].p) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty buffer in data pack."), HEBENCH_ECODE_CRITICAL_ERROR);
         if (dp.p_buffers[0].size / sizeof(std::int64_t) < r * cl)
             throw HEBenchError(HEBERROR_MSG_CLASS("Insufficient data for parameter sample."), HEBENCH_ECODE_CRITICAL_ERROR);
-        mats[op] = reinterpret_cast<const std::int64_t *>(dp.p_buffers[0].p);
+        mats_raw[op] = dp.p_buffers[0].p;
     }
     const std::size_t dim1 = rows_M0(), dim2 = cols_M0(), dim3 = cols_M1();
+    if (m_scheme == Scheme::CKKS) { // encodeM0 / encodeM1, ckks row .cpp:215-283: one row per ciphertext, spacers = slots / dim2
+        const double *m0 = reinterpret_cast<const double *>(mats_raw[0]), *m1 = reinterpret_cast<const double *>(mats_raw[1]);
+        const std::size_t slots = m_p_ctx_wrapper->slot_count(), spacers = slots / dim2;
+        PlainPack pack;
+        pack.a.rows = dim1; pack.a.cols = dim2; pack.b.rows = dim2; pack.b.cols = dim3;
+        std::vector<double> va(slots, 0.0), vb(slots, 0.0);
+        for (std::size_t i = 0; i < dim1; ++i) {
+            for (std::size_t j = 0; j < dim2; ++j)
+                for (std::size_t k = 0; k < dim3; ++k) va[spacers * j + k] = m0[i * dim2 + j];
+            pack.A.push_back(m_p_ctx_wrapper->encodeVector(va));
+        }
+        for (std::size_t j = 0; j < dim2; ++j)
+            for (std::size_t k = 0; k < dim3; ++k) vb[spacers * j + k] = m1[j * dim3 + k];
+        pack.B = m_p_ctx_wrapper->encodeVector(vb);
+        return this->getEngine().createHandle<decltype(pack)>(sizeof(pack), 0, std::move(pack));
+    }
+    const std::int64_t *mats[2] = {reinterpret_cast<const std::int64_t *>(mats_raw[0]), reinterpret_cast<const std::int64_t *>(mats_raw[1])};
     const std::size_t slots = m_p_ctx_wrapper->slot_count(), row_size = slots / 2, spacers = row_size / dim2;
     PlainPack pack;
     pack.a.rows = dim1; pack.a.cols = dim2; pack.b.rows = dim2; pack.b.cols = dim3;
@@ -140,6 +162,16 @@ void MatMultRowLatencyBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackC
     const AB::DataPack &rc = findDataPack(*p_native, 0);
     if (rc.buffer_count == 0 || !rc.p_buffers[0].p) return;
     const ResultPlain &enc = this->getEngine().retrieveFromHandle<ResultPlain>(h_encoded_data);
+    if (m_scheme == Scheme::CKKS) { // decodeResult, ckks row .cpp:330-356: row i = first dim3 slots of ciphertext i, |x| < 0.00005 -> 0
+        double *raw = reinterpret_cast<double *>(rc.p_buffers[0].p);
+        std::size_t room = rc.p_buffers[0].size / sizeof(double), pos = 0;
+        std::vector<double> v(m_p_ctx_wrapper->slot_count());
+        for (std::size_t i = 0; i < enc.d.rows && i < enc.C.size() && pos < room; ++i) {
+            m_p_ctx_wrapper->client().ckks_decode(enc.C[i].data.data(), (size_t)enc.C[i].L, enc.C[i].scale, v.data());
+            for (std::size_t j = 0; j < enc.d.cols && pos < room; ++j) raw[pos++] = std::abs(v[j]) < 0.00005 ? 0.0 : v[j];
+        }
+        return;
+    }
     // decodeResult (.cpp:339-369): result row i = first dim3 slots of batching row (i mod 2) of ciphertext i/2
     const std::size_t dim1 = enc.d.rows, dim3 = enc.d.cols, slots = m_p_ctx_wrapper->slot_count(), row_size = slots / 2;
     std::int64_t *raw = reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p);
@@ -213,17 +245,24 @@ AB::Handle MatMultRowLatencyBenchmark::operate(AB::Handle h_remote_packed, const
     he355_ctx *ctx = m_p_ctx_wrapper->raw();
     const int L = in.A->L;
     const std::uint64_t nA = in.A->n, dim2 = in.a.cols;
-    const int spacers = (int)((m_p_ctx_wrapper->slot_count() / 2) / dim2);
+    const bool ckks = m_scheme == Scheme::CKKS;
+    const int spacers = (int)((ckks ? m_p_ctx_wrapper->slot_count() : m_p_ctx_wrapper->slot_count() / 2) / dim2);
+    const double sc = ckks ? in.A->scale * in.B->scale : 1.0;
     // matmultrow (.cpp:486-539), all row-pair ciphertexts A[i] as one batch:
     he355_indexer ix{0, 0, 1, 0, 0}; // result i <- (A[i], B)
-    std::shared_ptr<DeviceCiphers> c3 = m_p_ctx_wrapper->allocResult(nA, 3, L, 1.0);
-    std::shared_ptr<DeviceCiphers> base = m_p_ctx_wrapper->allocResult(nA, 2, L, 1.0);
-    std::shared_ptr<DeviceCiphers> rotated = m_p_ctx_wrapper->allocResult(nA, 2, L, 1.0);
+    std::shared_ptr<DeviceCiphers> base = m_p_ctx_wrapper->allocResult(nA, 2, L, sc);
+    std::shared_ptr<DeviceCiphers> rotated = m_p_ctx_wrapper->allocResult(nA, 2, L, sc);
     ResultRemote res;
     res.d.rows = in.a.rows; res.d.cols = in.b.cols;
-    res.C = m_p_ctx_wrapper->allocResult(nA, 2, L, 1.0);
-    HeContextWrapper::check(he355_bfv_multiply(ctx, L, nA, in.A->d, in.B->d, ix, c3->d), "multiply");                 // :515
-    HeContextWrapper::check(he355_relinearize(ctx, L, nA, c3->d, base->d), "relinearize");                             // :516
+    res.C = m_p_ctx_wrapper->allocResult(nA, 2, L, sc);
+    if (ckks) {
+        HeContextWrapper::check(he355_multiply_relin(ctx, L, nA, in.A->d, in.B->d, ix, 0, base->d), "multiply+relinearize"); // ckks row .cpp:499-500
+    } else {
+        std::shared_ptr<DeviceCiphers> c3 = m_p_ctx_wrapper->allocResult(nA, 3, L, 1.0);
+        HeContextWrapper::check(he355_bfv_multiply(ctx, L, nA, in.A->d, in.B->d, ix, c3->d), "multiply");             // :515
+        HeContextWrapper::check(he355_relinearize(ctx, L, nA, c3->d, base->d), "relinearize");                         // :516
+        HeContextWrapper::check(he355_sync(ctx), "synchronise");
+    }
     he355_indexer pw{0, 0, 1, 1, 0};
     HeContextWrapper::check(he355_rotate(ctx, L, nA, base->d, 0, res.C->d), "copy");                                   // result[i] = base (:519)
     for (std::uint64_t j = 1; j < dim2; ++j) {

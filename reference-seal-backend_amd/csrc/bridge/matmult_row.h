@@ -1,9 +1,12 @@
-// matmult_row.h — BFV MatrixMultiply, "row" packing (other = 2), Latency: mirrors sbe::bfv::MatMultRowLatencyBenchmark
-// (/root/reference/src/benchmarks/bfv/seal_bfv_matmult_row_benchmark.cpp, include/.../seal_bfv_matmult_row_benchmark.h).
-// Two rows of A per ciphertext (one per batching row), B in one ciphertext; per row-pair:
-// multiply -> relinearize -> sum over j of rotate_rows(base, j * spacers)  (.cpp:486-539).
+// matmult_row.h — MatrixMultiply, "row" packing (other = 2), Latency: mirrors sbe::bfv::MatMultRowLatencyBenchmark
+// (/root/reference/src/benchmarks/bfv/seal_bfv_matmult_row_benchmark.cpp) and sbe::ckks::MatMultRowLatencyBenchmark
+// (/root/reference/src/benchmarks/ckks/seal_ckks_matmult_row_benchmark.cpp).
+// BFV : two rows of A per ciphertext (one per batching row), B in one ciphertext; per row-pair:
+//       multiply -> relinearize -> sum over j of rotate_rows(base, j * spacers), spacers = (N/2)/dim2   (bfv .cpp:486-539)
+// CKKS: one row of A per ciphertext; multiply -> relinearize -> sum over j of rotate_vector(base, j * spacers),
+//       spacers = slots/dim2, no rescale                                                              (ckks .cpp:472-523)
 #pragma once
-#include "he_context.h"
+#include "benchmarks.h"
 
 namespace mi355x {
 
@@ -25,10 +28,13 @@ public:
         Index_NumThreads,
         NumWorkloadParams
     };
-    MatMultRowBenchmarkDescription();
+    explicit MatMultRowBenchmarkDescription(Scheme scheme = Scheme::BFV);
     hebench::cpp::BaseBenchmark *createBenchmark(hebench::cpp::BaseEngine &engine, const hebench::APIBridge::WorkloadParams *p_params) override;
     void destroyBenchmark(hebench::cpp::BaseBenchmark *p_bench) override;
     std::string getBenchmarkDescription(const hebench::APIBridge::WorkloadParams *p_w_params) const override;
+
+private:
+    Scheme m_scheme;
 };
 
 class MatMultRowLatencyBenchmark : public hebench::cpp::BaseBenchmark {
@@ -36,7 +42,7 @@ public:
     HEBERROR_DECLARE_CLASS_NAME(MatMultRowLatencyBenchmark)
     static constexpr std::int64_t tag = 0x20 + MatMultRowBenchmarkDescription::MatMultRowOtherID;
     MatMultRowLatencyBenchmark(hebench::cpp::BaseEngine &engine, const hebench::APIBridge::BenchmarkDescriptor &bench_desc,
-                               const hebench::APIBridge::WorkloadParams &bench_params);
+                               const hebench::APIBridge::WorkloadParams &bench_params, Scheme scheme = Scheme::BFV);
     hebench::APIBridge::Handle encode(const hebench::APIBridge::DataPackCollection *p_parameters) override;
     void decode(hebench::APIBridge::Handle encoded_data, hebench::APIBridge::DataPackCollection *p_native) override;
     hebench::APIBridge::Handle encrypt(hebench::APIBridge::Handle encoded_data) override;
@@ -56,6 +62,7 @@ private:
     struct ResultCipher { Dims d; std::vector<Cipher> C; };
     struct ResultPlain { Dims d; std::vector<Plain> C; };
     static const hebench::APIBridge::DataPack &findDataPack(const hebench::APIBridge::DataPackCollection &c, std::uint64_t param_position);
+    Scheme m_scheme;
     std::uint64_t rows_M0() const { return m_w[0]; }
     std::uint64_t cols_M0() const { return m_w[1]; }
     std::uint64_t cols_M1() const { return m_w[2]; }

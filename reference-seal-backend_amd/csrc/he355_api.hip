@@ -368,7 +368,7 @@ public:
         }
         HIPCHECK(hipGetLastError());
     }
-    void relinearize(int L, u64 n, const u64 *ct3, u64 *out)
+    void relinearize(int L, u64 n, const u64 *ct3, u64 *out, bool rescale = false)
     {
         use();
         check_level(L);
@@ -376,6 +376,7 @@ public:
         if (!d_relin_) throw std::invalid_argument("relinearization key not set");
         const size_t N = P.N, LN = (size_t)L * N;
         if (P.scheme == kSchemeBFV) {
+            if (rescale) throw std::invalid_argument("rescale is a CKKS operation");
             for (u64 off = 0; off < n; off += chunk_) {
                 const u64 nc = std::min<u64>(chunk_, n - off);
                 Scratch S = scratch(chunk_, L);
@@ -389,15 +390,28 @@ public:
             HIPCHECK(hipGetLastError());
             return;
         }
+        if (rescale && L < 2) throw std::invalid_argument("cannot rescale at the last level");
         Indexer ix{};
         for (u64 off = 0; off < n; off += chunk_) {
             const u64 nc = std::min<u64>(chunk_, n - off);
             Scratch S = scratch(chunk_, L);
             KsBuffers B = S.ks;
-            B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
+            if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
             launch_k1(env_, L, K1_CT3, nc, off, ct3, nullptr, ix, nullptr, B);
-            key_switch_tail(env_, L, nc, S, B, d_relin_, false);
+            key_switch_tail(env_, L, nc, S, B, d_relin_, rescale);
+            if (rescale) rescale_tail(env_, L, 2, nc, S, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N);
         }
+        HIPCHECK(hipGetLastError());
+    }
+    void multiply_accumulate(int L, u64 rows, u64 cols, u64 inner, const u64 *a, u64 a_stride_i, u64 a_stride_k, const u64 *b, u64 b_stride_k,
+                             u64 b_stride_j, u64 *out)
+    {
+        use();
+        check_level(L);
+        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_multiply_accumulate implements the CKKS (NTT-form) product");
+        if (inner < 1 || inner > 0x7fffffff) throw std::invalid_argument("inner dimension out of range");
+        if (rows * cols == 0) return;
+        launch_mul3_acc(env_, L, rows, cols, (int)inner, a, a_stride_i, a_stride_k, b, b_stride_k, b_stride_j, out);
         HIPCHECK(hipGetLastError());
     }
     void rescale(int L, int size, u64 n, const u64 *in, u64 *out)
@@ -855,6 +869,15 @@ int he355_bfv_multiply(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const
 int he355_multiply_relin(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const uint64_t *b, he355_indexer ix, int rescale, uint64_t *out)
 {
     return guarded([&] { dev(c).multiply_relin(L, n, a, b, to_ix(ix), rescale != 0, out); });
+}
+int he355_multiply_accumulate(he355_ctx *c, int L, uint64_t rows, uint64_t cols, uint64_t inner, const uint64_t *a, uint64_t a_stride_i,
+                              uint64_t a_stride_k, const uint64_t *b, uint64_t b_stride_k, uint64_t b_stride_j, uint64_t *out)
+{
+    return guarded([&] { dev(c).multiply_accumulate(L, rows, cols, inner, a, a_stride_i, a_stride_k, b, b_stride_k, b_stride_j, out); });
+}
+int he355_relinearize_rescale(he355_ctx *c, int L, uint64_t n, const uint64_t *ct3, uint64_t *out)
+{
+    return guarded([&] { dev(c).relinearize(L, n, ct3, out, true); });
 }
 int he355_relinearize(he355_ctx *c, int L, uint64_t n, const uint64_t *ct3, uint64_t *out)
 {

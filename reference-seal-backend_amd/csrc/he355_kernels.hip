@@ -400,6 +400,47 @@ __global__ void __launch_bounds__(kBlock) k_mul3(const u64 *a, const u64 *b, u64
     reinterpret_cast<ulonglong2 *>(po + 2 * P1)[e2] = c2;
 }
 
+// Sum over the inner dimension of size-3 dyadic tensors: out(i,j) = sum_k a(i,k) (x) b(k,j) — the multiply / add_inplace
+// loop of the CipherBatchAxis workloads (ckks cipherbatchaxis .cpp:404-420) kept in registers: 4 reads per term, 3 writes
+// per result.  One thread = 2 coefficients of one residue of one result.
+template <class Ar>
+__device__ __forceinline__ void mul3_acc_pair(const Ar &ar, u64 q, const u64 *pa, const u64 *pb, u64 a_step, u64 b_step, u64 P1, u64 e2, int inner,
+                                              ulonglong2 &s0, ulonglong2 &s1, ulonglong2 &s2)
+{
+    s0 = s1 = s2 = make_ulonglong2(0, 0);
+    for (int k = 0; k < inner; ++k, pa += a_step, pb += b_step) {
+        const ulonglong2 a0 = reinterpret_cast<const ulonglong2 *>(pa)[e2], a1 = reinterpret_cast<const ulonglong2 *>(pa + P1)[e2];
+        const ulonglong2 b0 = reinterpret_cast<const ulonglong2 *>(pb)[e2], b1 = reinterpret_cast<const ulonglong2 *>(pb + P1)[e2];
+        ulonglong2 c0, c1, c2;
+        mul3_pair(ar, a0, a1, b0, b1, c0, c1, c2);
+        s0.x = addmod(s0.x, c0.x, q); s0.y = addmod(s0.y, c0.y, q);
+        s1.x = addmod(s1.x, c1.x, q); s1.y = addmod(s1.y, c1.y, q);
+        s2.x = addmod(s2.x, c2.x, q); s2.y = addmod(s2.y, c2.y, q);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_mul3_acc(const u64 *a, const u64 *b, u64 *out, const PrimeDev *primes, int L, int logN, u64 rows, u64 cols,
+                                                     int inner, u64 a_stride_i, u64 a_stride_k, u64 b_stride_k, u64 b_stride_j)
+{
+    const u64 pairs_per_poly = (u64)1 << (logN - 1);
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 ri = gid >> (logN - 1);
+    const u64 e2 = gid & (pairs_per_poly - 1);
+    const u64 r = ri / L;
+    if (r >= rows * cols) return;
+    const int i = (int)(ri % L);
+    const u64 poly = (u64)1 << logN, P1 = (u64)L << logN, ct = 2 * P1;
+    const u64 *pa = a + (r / cols) * a_stride_i * ct + i * poly, *pb = b + (r % cols) * b_stride_j * ct + i * poly;
+    ulonglong2 s0, s1, s2;
+    const PrimeDev &P = primes[i];
+    if (P.f64) mul3_acc_pair(make_ar(P, (ArF64 *)nullptr), P.q, pa, pb, a_stride_k * ct, b_stride_k * ct, P1, e2, inner, s0, s1, s2);
+    else mul3_acc_pair(make_ar(P, (ArU64 *)nullptr), P.q, pa, pb, a_stride_k * ct, b_stride_k * ct, P1, e2, inner, s0, s1, s2);
+    u64 *po = out + r * 3 * P1 + i * poly;
+    reinterpret_cast<ulonglong2 *>(po)[e2] = s0;
+    reinterpret_cast<ulonglong2 *>(po + P1)[e2] = s1;
+    reinterpret_cast<ulonglong2 *>(po + 2 * P1)[e2] = s2;
+}
+
 // =======================================================================================================
 // K1: (multiply | take ct3 | Galois-permute) + inverse row pass of the key-switch target
 // =======================================================================================================
@@ -1141,6 +1182,15 @@ void launch_addsub(const KernelEnv &env, int L, int size, u64 n_results, const u
     const u64 threads = (n_results * polys) << (logN - 1);
     hipLaunchKernelGGL(k_addsub, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, a, b, out, ix, env.primes, L, polys, logN, n_results,
                        sub ? 1 : 0);
+}
+
+void launch_mul3_acc(const KernelEnv &env, int L, u64 rows, u64 cols, int inner, const u64 *a, u64 a_stride_i, u64 a_stride_k, const u64 *b,
+                     u64 b_stride_k, u64 b_stride_j, u64 *out)
+{
+    const int logN = env.logn1 + kRowLog;
+    const u64 threads = (rows * cols * (u64)L) << (logN - 1);
+    hipLaunchKernelGGL(k_mul3_acc, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, a, b, out, env.primes, L, logN, rows, cols, inner,
+                       a_stride_i, a_stride_k, b_stride_k, b_stride_j);
 }
 
 void launch_mul3(const KernelEnv &env, int L, u64 n_results, const u64 *a, const u64 *b, Indexer ix, u64 *out)

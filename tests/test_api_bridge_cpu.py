@@ -39,17 +39,24 @@ def test_engine_registration(backend):
     assert backend.security_name(SCHEME_CKKS, 0) == "128 bits"  # seal_engine.cpp:105
     bs = backend.benchmarks()
     got = sorted((b["desc"].workload, b["desc"].scheme, b["desc"].category) for b in bs)
-    want = sorted([(w, s, c) for w in (W_ADD, W_MUL, W_DOT) for s in (SCHEME_BFV, SCHEME_CKKS) for c in (LATENCY, OFFLINE)] + [(0, SCHEME_BFV, LATENCY)] * 2 + [(0, SCHEME_CKKS, LATENCY)])
-    assert got == want  # 15 of the reference's 20 descriptors (seal_engine.cpp:108-151)
+    want = sorted([(w, s, c) for w in (W_ADD, W_MUL, W_DOT) for s in (SCHEME_BFV, SCHEME_CKKS) for c in (LATENCY, OFFLINE)] + [(0, SCHEME_BFV, LATENCY)] * 3 + [(0, SCHEME_CKKS, LATENCY)] * 3)
+    assert got == want  # 18 of the reference's 20 descriptors (seal_engine.cpp:108-151); LogReg x2 missing
+    assert sorted((b["desc"].scheme, b["desc"].other) for b in bs if b["desc"].workload == 0) == sorted(
+        (s, o) for s in (SCHEME_BFV, SCHEME_CKKS) for o in (0, 1, 2))  # MatMultVal, CipherBatchAxis, Row
+    cba = sorted((b["desc"].scheme, b["defaults"][0][4:7]) for b in bs if b["desc"].workload == 0 and b["desc"].other == 1)
+    assert cba == sorted([(SCHEME_BFV, [("MultiplicativeDepth", 3), ("CoefficientModulusBits", 40), ("PlainModulusBits", 20)]),
+                          (SCHEME_CKKS, [("MultiplicativeDepth", 3), ("CoefficientModulusBits", 45), ("ScaleBits", 45)])])
     mv = sorted((b["desc"].scheme, b["defaults"][0][4:7]) for b in bs if b["desc"].workload == 0 and b["desc"].other == 0)  # MatMultValOtherID
     assert mv == sorted([(SCHEME_BFV, [("MultiplicativeDepth", 2), ("CoefficientModulusBits", 40), ("PlainModulusBits", 20)]),
                          (SCHEME_CKKS, [("MultiplicativeDepth", 2), ("CoefficientModulusBits", 45), ("ScaleBits", 45)])])
-    mm = [b for b in bs if b["desc"].workload == 0 and b["desc"].other == 2][0]  # MatMultRowOtherID
+    mm = [b for b in bs if b["desc"].workload == 0 and b["desc"].other == 2 and b["desc"].scheme == SCHEME_BFV][0]  # MatMultRowOtherID
+    mc = [b for b in bs if b["desc"].workload == 0 and b["desc"].other == 2 and b["desc"].scheme == SCHEME_CKKS][0]
+    assert mc["defaults"][0][4:7] == [("MultiplicativeDepth", 3), ("CoefficientModulusBits", 45), ("ScaleBits", 45)]
     assert mm["defaults"][0] == [("rows_M0", 10), ("cols_M0", 9), ("cols_M1", 8), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 3),
                                  ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)]
     for b in bs:
         d = b["desc"]
-        assert d.cipher_param_mask == 0xFFFFFFFF and d.security == 0 and d.other in ((0, 2) if d.workload == 0 else (0,))
+        assert d.cipher_param_mask == 0xFFFFFFFF and d.security == 0 and d.other in ((0, 1, 2) if d.workload == 0 else (0,))
         assert d.data_type == (DT_FLOAT64 if d.scheme == SCHEME_CKKS else DT_INT64)
         if d.category == LATENCY:
             assert d.cat_params.latency.warmup_iterations_count == 1 and d.cat_params.min_test_time_ms == 0

@@ -122,7 +122,7 @@ def _matmul(backend, dims, N, depth):
     r0, c0, c1 = dims
     rng = np.random.default_rng(sum(dims))
     A, B = rng.integers(-8, 8, (r0, c0)).astype(np.int64), rng.integers(-8, 8, (c0, c1)).astype(np.int64)
-    bench = [b for b in backend.benchmarks() if b["desc"].workload == 0 and b["desc"].other == 2][0]
+    bench = [b for b in backend.benchmarks() if b["desc"].workload == 0 and b["desc"].other == 2 and b["desc"].scheme == SCHEME_BFV][0]
     hb = backend.create(bench, [("rows_M0", r0), ("cols_M0", c0), ("cols_M1", c1), ("PolyModulusDegree", N), ("MultiplicativeDepth", depth),
                                 ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)])
     res = backend.run(hb, [A.reshape(1, -1), B.reshape(1, -1)], r0 * c1, np.int64)
@@ -141,10 +141,10 @@ def test_bfv_matmult_row_cfg5_128(backend):
     _matmul(backend, (128, 128, 128), 32768, 3)
 
 
-def _matmul_val(backend, scheme, dims, N, depth, bits):
+def _matmul_val(backend, scheme, dims, N, depth, bits, other=0):
     r0, c0, c1 = dims
     rng = np.random.default_rng(sum(dims) + scheme)
-    bench = [b for b in backend.benchmarks() if b["desc"].workload == 0 and b["desc"].other == 0 and b["desc"].scheme == scheme][0]
+    bench = [b for b in backend.benchmarks() if b["desc"].workload == 0 and b["desc"].other == other and b["desc"].scheme == scheme][0]
     last = ("ScaleBits", bits) if scheme == SCHEME_CKKS else ("PlainModulusBits", 20)
     hb = backend.create(bench, [("rows_M0", r0), ("cols_M0", c0), ("cols_M1", c1), ("PolyModulusDegree", N), ("MultiplicativeDepth", depth),
                                 ("CoefficientModulusBits", bits), last, ("NumThreads", 0)])
@@ -170,3 +170,22 @@ def test_ckks_matmult_val(backend, dims):
 def test_bfv_matmult_val(backend, dims):
     """cols_M0 = 5000 > N/2 takes the rotate_columns branch of accumulateBFV."""
     _matmul_val(backend, SCHEME_BFV, dims, 8192, 2, 40)
+
+
+@pytest.mark.parametrize("dims", [(10, 9, 8), (2, 1, 3), (1, 17, 1)])
+def test_ckks_matmult_cipher_batch_axis(backend, dims):
+    """One element per ciphertext: size-3 sum over the inner dimension, then relinearize + rescale
+    (ckks cipherbatchaxis .cpp:404-437), at the reference's defaults (depth 3)."""
+    _matmul_val(backend, SCHEME_CKKS, dims, 8192, 3, 45, other=1)
+
+
+@pytest.mark.parametrize("dims", [(10, 9, 8), (2, 1, 3)])
+def test_bfv_matmult_cipher_batch_axis(backend, dims):
+    _matmul_val(backend, SCHEME_BFV, dims, 8192, 3, 40, other=1)
+
+
+@pytest.mark.parametrize("dims", [(10, 9, 8), (3, 64, 64), (5, 1, 7)])
+def test_ckks_matmult_row(backend, dims):
+    """One row per ciphertext, rotate_vector by j * (slots / cols_M0) (ckks row .cpp:472-523); 64 x 64 fills
+    all 4096 slots and takes 63 rotations, most of them NAF-decomposed."""
+    _matmul_val(backend, SCHEME_CKKS, dims, 8192, 3, 45, other=2)

@@ -153,6 +153,43 @@ def test_relinearize_and_rescale_standalone(pair, be):
             assert np.array_equal(got[r], o.rescale(src[r])), (size, r)
 
 
+def test_multiply_accumulate_and_relinearize_rescale(pair, be):
+    """The CipherBatchAxis inner loop (multiply, then multiply + add_inplace over the inner dimension; ckks
+    cipherbatchaxis .cpp:404-420) and its relinearize + rescale tail (:436-437), with strided operand layouts."""
+    g, o, rng = pair
+    L = g.L
+    r0, c0, c1 = 3, 4, 2
+    a, b = rand_cts(o, rng, c0 * r0, L), rand_cts(o, rng, c0 * c1, L)  # a column-major [k][i], b row-major [k][j]
+    da, db = g.to_device(a), g.to_device(b)
+    d3 = g.alloc(r0 * c1 * 3 * L * g.N)
+    g.multiply_accumulate(L, r0, c1, c0, da, 1, r0, db, c1, 1, d3)
+    got = d3.download((r0 * c1, 3, L, g.N))
+    want = []
+    for i in range(r0):
+        for j in range(c1):
+            acc = o.multiply_ntt(a[0 * r0 + i], b[0 * c1 + j])
+            for k in range(1, c0):
+                acc = o.add(acc, o.multiply_ntt(a[k * r0 + i], b[k * c1 + j]))
+            want.append(acc)
+            assert np.array_equal(got[i * c1 + j], acc), (i, j)
+    # the transposed layouts give the same sums: a row-major [i][k], b column-major [j][k]
+    at = np.ascontiguousarray(a.reshape(c0, r0, *a.shape[1:]).swapaxes(0, 1)).reshape(a.shape)
+    bt = np.ascontiguousarray(b.reshape(c0, c1, *b.shape[1:]).swapaxes(0, 1)).reshape(b.shape)
+    d3t = g.alloc(r0 * c1 * 3 * L * g.N)
+    g.multiply_accumulate(L, r0, c1, c0, g.to_device(at), c0, 1, g.to_device(bt), 1, c0, d3t)
+    assert np.array_equal(d3t.download(got.shape), got)
+    if L >= 2:
+        rk = o.random_kswitch_key(rng)
+        g.set_relin_key(rk)
+        out = g.alloc(r0 * c1 * 2 * (L - 1) * g.N)
+        g.set_chunk(4)  # ragged tail: 6 results
+        g.relinearize_rescale(L, r0 * c1, d3, out)
+        g.set_chunk(32)
+        res = out.download((r0 * c1, 2, L - 1, g.N))
+        for r in range(r0 * c1):
+            assert np.array_equal(res[r], o.rescale(o.relinearize(want[r], rk))), r
+
+
 def test_galois_rotate_accumulate(pair, be):
     g, o, rng = pair
     L, N = g.L, g.N
