@@ -24,6 +24,12 @@
 namespace he355 {
 namespace {
 
+#ifndef HE355_K3_F64_SHAPE
+#define HE355_K3_F64_SHAPE 18
+#endif
+#ifndef HE355_K3_U64_SHAPE
+#define HE355_K3_U64_SHAPE 18
+#endif
 constexpr int kBlock = 256;
 #ifndef K2_WAVES
 #define K2_WAVES 2
@@ -636,9 +642,10 @@ struct K3Args {
     unsigned char tt_list[64];
 };
 
-template <class Ar, int U>
-__global__ void __launch_bounds__(kBlock) k_k3(K3Args A, const PrimeDev *primes)
+template <class Ar, int U, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *primes)
 {
+    constexpr int kWaves = WAVES, kBlock = WAVES * 64; // this kernel's own block shape (shadows the file-wide one)
     typedef typename Ar::T T;
     typedef typename Ar::Acc Acc;
     constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
@@ -1261,17 +1268,33 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             if ((prime_f64[t] != 0) == (pass == 0)) A.tt_list[A.n_tt++] = (unsigned char)tt;
         }
         if (!A.n_tt) continue;
-        const u64 n_og = (n_ops + kWaves - 1) / kWaves;
+        // block shape per engine: (interleaved digits per wave, waves per block).  HE355_K3_SHAPE=<u><w><u><w> overrides
+        // (fp64 pair, then u64 pair), e.g. 2418 = fp64 U=2 x 4 waves, u64 U=1 x 8 waves.
+        static const int shape_env = getenv("HE355_K3_SHAPE") ? atoi(getenv("HE355_K3_SHAPE")) : 0;
+        const int shape = pass == 0 ? (shape_env ? shape_env / 100 : HE355_K3_F64_SHAPE) : (shape_env ? shape_env % 100 : HE355_K3_U64_SHAPE);
+        const int waves = shape % 10;
+        const u64 n_og = (n_ops + waves - 1) / waves;
         const u64 tiles = (u64)A.n_tt << env.logn1;
         // enough blocks to keep every CU busy for several rounds, few enough that start-up costs are amortised
         static const u32 og_env = getenv("HE355_K3_OG") ? (u32)atoi(getenv("HE355_K3_OG")) : 0;
-        u32 ogpb = og_env ? og_env : 4;
+        u32 ogpb = og_env ? og_env : (waves == 8 ? 2 : 4);
         while (ogpb > 1 && tiles * ((n_og + ogpb - 1) / ogpb) < 256u * 6) ogpb >>= 1;
         A.og_per_block = ogpb;
         const u64 n_ogb = (n_og + ogpb - 1) / ogpb;
         const unsigned g = (unsigned)(((tiles + 7) / 8) * 8 * n_ogb);
-        if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 2>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
-        else hipLaunchKernelGGL((k_k3<ArU64, 1>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+        if (pass == 0) {
+            switch (shape) {
+            case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
+            case 18: hipLaunchKernelGGL((k_k3<ArF64, 1, 8>), dim3(g), dim3(512), 0, env.stream, A, env.primes); break;
+            default: throw std::runtime_error("unsupported K3 fp64 shape");
+            }
+        } else {
+            switch (shape) {
+            case 14: hipLaunchKernelGGL((k_k3<ArU64, 1, 4>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
+            case 18: hipLaunchKernelGGL((k_k3<ArU64, 1, 8>), dim3(g), dim3(512), 0, env.stream, A, env.primes); break;
+            default: throw std::runtime_error("unsupported K3 u64 shape");
+            }
+        }
     }
     // special-prime sums: start the inverse transform (row pass) for the mod-down
     launch_rows_inv_select(env, env.K - 1, n_ops * 2, buf.tp, (u64)env.N, buf.tpr);

@@ -20,6 +20,14 @@
 #define HE_HD inline
 #endif
 
+// Scheduling fence for hand-interleaved instruction groups (device code only): the machine scheduler may not move
+// anything across it, so independent operations written next to each other stay next to each other.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HE_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define HE_SCHED_FENCE() ((void)0)
+#endif
+
 namespace he355 {
 
 typedef uint64_t u64;
@@ -119,6 +127,12 @@ struct ArU64 {
         Y = u + two_q - v;
     }
     // inverse (Gentleman-Sande): X,Y in [0,2q) -> [0,2q)
+    // G independent butterflies (same meaning as G calls of bfly_fwd)
+    template <int G> HE_HD void bfly_fwd_g(T (&X)[G], T (&Y)[G], const Tw16 (&w)[G]) const
+    {
+#pragma unroll
+        for (int k = 0; k < G; ++k) bfly_fwd(X[k], Y[k], w[k]);
+    }
     HE_HD void bfly_inv(T &X, T &Y, const Tw16 &w) const
     {
         u64 s = X + Y;
@@ -247,6 +261,36 @@ struct ArF64 {
         double x = X;
         X = x + t;
         Y = x - t;
+    }
+    // G independent butterflies, written level by level: every instruction's operands were produced G or more
+    // instructions earlier, so one wave keeps the fp64 pipe busy without relying on other waves of the SIMD
+    // (dependent fp64 operations issued back to back stall; the compiler's own order is one serial chain per butterfly).
+    template <int G> HE_HD void bfly_fwd_g(T (&X)[G], T (&Y)[G], const Tw16 (&w)[G]) const
+    {
+        double h[G], l[G], c[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) h[k] = Y[k] * tw_w(w[k]);
+        HE_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < G; ++k) c[k] = h[k] * qinv;
+#pragma unroll
+        for (int k = 0; k < G; ++k) l[k] = __builtin_fma(Y[k], tw_w(w[k]), -h[k]);
+        HE_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < G; ++k) c[k] = __builtin_rint(c[k]);
+        HE_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < G; ++k) h[k] = __builtin_fma(-c[k], q, h[k]);
+        HE_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < G; ++k) l[k] = h[k] + l[k];
+        HE_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            Y[k] = X[k] - l[k];
+            X[k] = X[k] + l[k];
+        }
+        HE_SCHED_FENCE();
     }
     HE_HD void bfly_inv(T &X, T &Y, const Tw16 &w) const
     {

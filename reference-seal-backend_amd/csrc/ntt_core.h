@@ -21,11 +21,14 @@ namespace he355 {
 constexpr int kRowLog = 10;
 constexpr int kRowN = 1 << kRowLog; // 1024 elements per row
 constexpr int kRowE = 16;           // elements per lane
-constexpr int kLdsRow = kRowN; // exchange buffer: exactly one row (8 KiB); bank spreading by XOR swizzle
+constexpr int kLdsRow = kRowN + 64; // exchange buffer: one row plus 4 pad elements per 64-element block (8.5 KiB)
 
-// element e lives at e ^ (((e >> 6) & 15) << 2): the 4-element group index inside each 64-element block is
-// XORed with the block number, so layout-B accesses (stride 64 elements) spread over all banks.
-HE_HD int lds_pad(int e) { return e ^ (((e >> 6) & 15) << 2); }
+// element e lives at e + 4*(e >> 6): every 64-element block is followed by 4 pad elements (32 bytes), so layout-B
+// accesses (4 contiguous elements per 4-lane group, groups 64 elements apart) walk the banks in 32-byte steps.
+// The map is ADDITIVE in the lane part and the register part of e under all three layouts (the register part never
+// carries into the lane part), so every LDS address is one per-lane base plus a compile-time offset: three address
+// registers in all instead of one per element.
+HE_HD int lds_pad(int e) { return e + ((e >> 6) << 2); }
 
 // element index held in register r of lane `lane` under the three layouts
 HE_HD int elemA(int lane, int r) { return (r << 6) | lane; }                                   // r = bits 9..6
@@ -159,50 +162,54 @@ template <class TW> HE_HD void gather_C(const TW &tw, int lane, Tw16 w[kTwC])
         for (int h = 0; h < 2; ++h) w[4 + 2 * c + h] = tw.get(9, ((u32)c << 7) | ((u32)lane << 1) | (u32)h);
 }
 // stages 0..3 on layout A (register bit 3-s' is the butterfly bit); twiddles are lane-uniform
+// One radix-2 stage over the 16 registers of U rows: butterflies (r, r | 1<<BIT) with twiddle index widx(r), issued
+// in groups of kBflyGroup independent butterflies (Ar::bfly_fwd_g).
+#ifndef HE355_BFLY_GROUP
+#define HE355_BFLY_GROUP 8
+#endif
+constexpr int kBflyGroup = HE355_BFLY_GROUP;
+template <int U, int BIT, class Ar, class WIdx> HE_HD void row_fwd_stage(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 *w, WIdx widx)
+{
+    constexpr int kTotal = 8 * U, G = kBflyGroup < kTotal ? kBflyGroup : kTotal;
+    static_assert(kTotal % G == 0, "group size must divide the butterflies of a stage");
+#pragma unroll
+    for (int g0 = 0; g0 < kTotal; g0 += G) {
+        typename Ar::T X[G], Y[G];
+        Tw16 W[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int b = (g0 + k) / U, u = (g0 + k) % U;                        // butterfly b of row u
+            const int r = ((b >> BIT) << (BIT + 1)) | (b & ((1 << BIT) - 1));    // b with a 0 inserted at BIT
+            X[k] = x[u][r]; Y[k] = x[u][r | (1 << BIT)]; W[k] = w[widx(r)];
+        }
+        ar.template bfly_fwd_g<G>(X, Y, W);
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int b = (g0 + k) / U, u = (g0 + k) % U;
+            const int r = ((b >> BIT) << (BIT + 1)) | (b & ((1 << BIT) - 1));
+            x[u][r] = X[k]; x[u][r | (1 << BIT)] = Y[k];
+        }
+    }
+}
 template <int U, class Ar> HE_HD void row_fwd_A(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwA])
 {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int bit = 3 - s;
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) {
-            if (r & (1 << bit)) continue;
-#pragma unroll
-            for (int u = 0; u < U; ++u) ar.bfly_fwd(x[u][r], x[u][r | (1 << bit)], w[(1 << s) - 1 + (r >> (4 - s))]);
-        }
-    }
+    row_fwd_stage<U, 3>(ar, x, w, [](int r) { return 0 + (r >> 4); });
+    row_fwd_stage<U, 2>(ar, x, w, [](int r) { return 1 + (r >> 3); });
+    row_fwd_stage<U, 1>(ar, x, w, [](int r) { return 3 + (r >> 2); });
+    row_fwd_stage<U, 0>(ar, x, w, [](int r) { return 7 + (r >> 1); });
 }
-// stages 4..7 on layout B: e >> (10-s) = (hi4 << (s-4)) | (r >> (8-s))
 template <int U, class Ar> HE_HD void row_fwd_B(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwB])
 {
-#pragma unroll
-    for (int s = 4; s < 8; ++s) {
-        const int bit = 7 - s; // register bit
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) {
-            if (r & (1 << bit)) continue;
-#pragma unroll
-            for (int u = 0; u < U; ++u) ar.bfly_fwd(x[u][r], x[u][r | (1 << bit)], w[(1 << (s - 4)) - 1 + (r >> (8 - s))]);
-        }
-    }
+    row_fwd_stage<U, 3>(ar, x, w, [](int r) { return 0 + (r >> 4); });
+    row_fwd_stage<U, 2>(ar, x, w, [](int r) { return 1 + (r >> 3); });
+    row_fwd_stage<U, 1>(ar, x, w, [](int r) { return 3 + (r >> 2); });
+    row_fwd_stage<U, 0>(ar, x, w, [](int r) { return 7 + (r >> 1); });
 }
-// stages 8,9 on layout C (register bits 1,0); r = 4c + lo2
 template <int U, class Ar> HE_HD void row_fwd_C(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwC])
 {
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r) { // stage 8: pairs (r, r|2), twiddle of chunk c
-        if (r & 2) continue;
-#pragma unroll
-        for (int u = 0; u < U; ++u) ar.bfly_fwd(x[u][r], x[u][r | 2], w[r >> 2]);
-    }
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r) { // stage 9: pairs (r, r|1), twiddle (c, h = bit 1 of r)
-        if (r & 1) continue;
-#pragma unroll
-        for (int u = 0; u < U; ++u) ar.bfly_fwd(x[u][r], x[u][r | 1], w[4 + 2 * (r >> 2) + ((r >> 1) & 1)]);
-    }
+    row_fwd_stage<U, 1>(ar, x, w, [](int r) { return r >> 2; });                                  // stage 8: pairs (r, r|2), twiddle of chunk c
+    row_fwd_stage<U, 0>(ar, x, w, [](int r) { return 4 + 2 * (r >> 2) + ((r >> 1) & 1); });      // stage 9: pairs (r, r|1), twiddle (c, h = bit 1 of r)
 }
-// single-row forms that gather and run in one go
 template <class Ar, class TW> HE_HD void row_fwd_A(const Ar &ar, typename Ar::T x[kRowE], const TW &tw)
 {
     Tw16 w[kTwA];
