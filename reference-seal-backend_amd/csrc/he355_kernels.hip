@@ -632,6 +632,37 @@ __global__ void __launch_bounds__(kBlock, K2_WAVES) k_k2(K2Args A, const PrimeDe
 // =======================================================================================================
 // K3: per (op, key prime tt, row): sum over digits j of NTT_tt(digit j) * key_j[k][tt]
 // =======================================================================================================
+// Stage the 1023 forward twiddles of row `rowbase` of prime P in LDS (one copy per block): every wave, digit and op
+// of a (prime, row) tile reads them from there (ds_read, lane-dependent index) instead of L2.  fp64 engine: w only.
+// The caller synchronises the block before the first use.
+template <class Ar, int BLOCK>
+__device__ __forceinline__ typename std::conditional<std::is_same<Ar, ArF64>::value, TwRowF64, TwRow>::type
+stage_row_twiddles(const PrimeDev &P, const Ar &ar, u32 rowbase, unsigned char *twl_raw)
+{
+    constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
+    typename std::conditional<kF64, TwRowF64, TwRow>::type twr;
+    const gtw_t gf = gtw(P.fwd);
+    Tw16 tmp[kRowTw / BLOCK];
+#pragma unroll
+    for (int k = 0; k < kRowTw / BLOCK; ++k) { // all loads in flight together
+        const u32 i = threadIdx.x + k * BLOCK;
+        tmp[k] = tw_load(gf, tw_row_source(rowbase, i + 1 < (u32)kRowTw ? i : 0));
+    }
+    if constexpr (kF64) {
+        double *twl = reinterpret_cast<double *>(twl_raw);
+#pragma unroll
+        for (int k = 0; k < kRowTw / BLOCK; ++k) twl[threadIdx.x + k * BLOCK] = ArF64::tw_w(tmp[k]);
+        twr.t = twl;
+        twr.qinv = ar.qinv;
+    } else {
+        Tw16 *twl = reinterpret_cast<Tw16 *>(twl_raw);
+#pragma unroll
+        for (int k = 0; k < kRowTw / BLOCK; ++k) twl[threadIdx.x + k * BLOCK] = tmp[k];
+        twr.t = twl;
+    }
+    return twr;
+}
+
 struct K3Args {
     const u64 *d, *c2n, *key;
     u64 *t, *tp;
@@ -674,36 +705,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
     const PrimeDev &P = primes[t];
     const Ar ar = make_ar(P, (Ar *)nullptr);
     const u64 rowoff = (u64)a_row << kRowLog;
-    // This block's 1023 forward twiddles of row (t, a_row), staged once in LDS: all four waves, all digits
-    // and all ops of the tile read them from there (ds_read, lane-dependent index) instead of L2.
-    typename std::conditional<kF64, TwRowF64, TwRow>::type twr;
-    {
-        const gtw_t gf = gtw(P.fwd);
-        if constexpr (kF64) {
-            double *twl = reinterpret_cast<double *>(twl_raw);
-            Tw16 tmp[kRowTw / kBlock];
-#pragma unroll
-            for (int k = 0; k < kRowTw / kBlock; ++k) { // all loads in flight together
-                const u32 i = threadIdx.x + k * kBlock;
-                tmp[k] = tw_load(gf, tw_row_source(n1 + a_row, i + 1 < (u32)kRowTw ? i : 0));
-            }
-#pragma unroll
-            for (int k = 0; k < kRowTw / kBlock; ++k) twl[threadIdx.x + k * kBlock] = ArF64::tw_w(tmp[k]);
-            twr.t = twl;
-            twr.qinv = ar.qinv;
-        } else {
-            Tw16 *twl = reinterpret_cast<Tw16 *>(twl_raw);
-            Tw16 tmp[kRowTw / kBlock];
-#pragma unroll
-            for (int k = 0; k < kRowTw / kBlock; ++k) {
-                const u32 i = threadIdx.x + k * kBlock;
-                tmp[k] = tw_load(gf, tw_row_source(n1 + a_row, i + 1 < (u32)kRowTw ? i : 0));
-            }
-#pragma unroll
-            for (int k = 0; k < kRowTw / kBlock; ++k) twl[threadIdx.x + k * kBlock] = tmp[k];
-            twr.t = twl;
-        }
-    }
+    // this block's forward twiddles of row (t, a_row), staged once in LDS
+    const auto twr = stage_row_twiddles<Ar, kBlock>(P, ar, n1 + a_row, twl_raw);
     __syncthreads();
     for (u32 g = 0; g < A.og_per_block; ++g) {
         const u64 og = og_first + g;
@@ -860,52 +863,61 @@ struct FloorRowsDev {
     u64 n_ops;
     int K, logn1;
     int n_i;
+    u32 jobs_per_block; // multiple of kWaves
     unsigned char i_list[64];
 };
 
-template <class Ar>
+template <class Ar, bool TAIL>
 __global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const PrimeDev *primes)
 {
     typedef typename Ar::T T;
+    constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
     __shared__ u64 lds[kWaves][kLdsRow];
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 n1 = 1u << A.logn1;
     const u64 N = (u64)n1 << kRowLog;
-    // jobs of one target prime are contiguous and padded to a multiple of kWaves: a block never mixes primes
-    const u64 per_i = (A.n_ops * A.a.n_src) << A.logn1;
-    const u64 per_i_pad = (per_i + kWaves - 1) / kWaves * kWaves;
-    const u64 job = (u64)blockIdx.x * kWaves + wave;
-    const int i = A.i_list[job / per_i_pad];
-    u64 w = job % per_i_pad;
-    const bool valid = w < per_i;
-    if (!valid) w = per_i - 1;
-    const u32 a_row = (u32)(w & (n1 - 1));
-    const u64 rest = w >> A.logn1;
-    const int k = (int)(rest % A.a.n_src);
-    const u64 op = rest / A.a.n_src;
+    // A block owns one (target prime, row) tile and walks jobs_per_block consecutive (op, poly) jobs of it, one job per
+    // wave per step: the row's twiddles are staged in LDS once and every later access is a ds_read.
+    const u64 n_jobs = A.n_ops * A.a.n_src;
+    const u64 n_jb = (n_jobs + A.jobs_per_block - 1) / A.jobs_per_block;
+    const u64 tile = blockIdx.x / n_jb;
+    const u64 j_begin = (blockIdx.x % n_jb) * A.jobs_per_block;
+    const u64 j_end = j_begin + A.jobs_per_block < n_jobs ? j_begin + A.jobs_per_block : n_jobs;
+    const int i = A.i_list[tile >> A.logn1];
+    const u32 a_row = (u32)(tile & (n1 - 1));
     const PrimeDev &P = primes[i];
     const Ar ar = make_ar(P, (Ar *)nullptr);
     const FloorConst fc = A.fc[A.a.src_prime * A.K + i];
     const u64 rowoff = (u64)a_row << kRowLog;
-    T x[kRowE];
-    u64 v[kRowE], tv[kRowE], av[kRowE];
-    load_rowA(A.a.cols + ((op * A.a.n_src + k) * A.a.n_tgt + i) * N + rowoff, lane, v);
+    const auto twr = stage_row_twiddles<Ar, kBlock>(P, ar, n1 + a_row, twl_raw);
+    __syncthreads();
+    for (u64 j = j_begin + wave; j < j_end; j += kWaves) { // no block-level synchronisation inside: waves run independently
+        const int k = (int)(j % A.a.n_src);
+        const u64 op = j / A.a.n_src;
+        T x[kRowE];
+        u64 v[kRowE];
+        load_rowA(A.a.cols + ((op * A.a.n_src + k) * A.a.n_tgt + i) * N + rowoff, lane, v);
 #pragma unroll
-    for (int r = 0; r < kRowE; ++r) x[r] = ar.from_raw(v[r]);
-    wave_rows_fwd(ar, tw_table(gtw(P.fwd), n1 + a_row), lane, lds[wave], x);
-    load_rowC(A.a.tsrc + op * A.a.tsrc_op_stride + k * A.a.tsrc_poly_stride + (u64)i * N + rowoff, lane, tv);
-    if (A.a.addend) load_rowC(A.a.addend + op * A.a.add_op_stride + k * A.a.add_poly_stride + (u64)i * N + rowoff, lane, av);
+        for (int r = 0; r < kRowE; ++r) x[r] = ar.from_raw(v[r]);
+        wave_rows_fwd(ar, twr, lane, lds[wave], x);
+        {
+            u64 tv[kRowE], av[kRowE];
+            load_rowC(A.a.tsrc + op * A.a.tsrc_op_stride + k * A.a.tsrc_poly_stride + (u64)i * N + rowoff, lane, tv);
+            if (A.a.addend) load_rowC(A.a.addend + op * A.a.add_op_stride + k * A.a.add_poly_stride + (u64)i * N + rowoff, lane, av);
 #pragma unroll
-    for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin(tv[r], x[r], fc.inv, fc.inv_shoup, fc.inv_d, fc.inv_i, A.a.addend ? av[r] : 0);
-    if (valid && A.a.out) store_rowC(A.a.out + op * A.a.out_op_stride + k * A.a.out_poly_stride + (u64)i * N + rowoff, lane, v);
-    if (i == A.a.tail_prime) { // wave-uniform
-        const bool last = A.logn1 == 0;
+            for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin(tv[r], x[r], fc.inv, fc.inv_shoup, fc.inv_d, fc.inv_i, A.a.addend ? av[r] : 0);
+        }
+        if (A.a.out) store_rowC(A.a.out + op * A.a.out_op_stride + k * A.a.out_poly_stride + (u64)i * N + rowoff, lane, v);
+        if (TAIL) { // this prime is the next floor step's source: start its inverse transform right here
+            const bool last = A.logn1 == 0;
 #pragma unroll
-        for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
-        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
+            for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
+            wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
 #pragma unroll
-        for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
-        if (valid) store_rowA(A.a.tail + (op * A.a.n_src + k) * N + rowoff, lane, v);
+            for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
+            store_rowA(A.a.tail + (op * A.a.n_src + k) * N + rowoff, lane, v);
+        }
     }
 }
 
@@ -1327,17 +1339,24 @@ void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &arg
 {
     const unsigned char *prime_f64 = env.prime_f64;
     if (!n_ops) return;
-    for (int pass = 0; pass < 2; ++pass) {
+    const u64 n_jobs = n_ops * args.n_src;
+    // per block: up to 8 jobs per wave, fewer when that would leave CUs without blocks
+    u32 jpb = 8 * kWaves;
+    while (jpb > (u32)kWaves && (((u64)args.n_tgt << env.logn1) * ((n_jobs + jpb - 1) / jpb) < 256u * 8 || jpb / 2 >= n_jobs)) jpb >>= 1;
+    for (int pass = 0; pass < 4; ++pass) { // (engine, tail) combinations; the tail prime gets its own launch
+        const bool f64 = pass < 2, tail = pass & 1;
         FloorRowsDev A;
         A.a = args; A.fc = env.floor_consts; A.n_ops = n_ops; A.K = env.K; A.logn1 = env.logn1;
+        A.jobs_per_block = jpb;
         A.n_i = 0;
         for (int i = 0; i < args.n_tgt; ++i)
-            if ((prime_f64[i] != 0) == (pass == 0)) A.i_list[A.n_i++] = (unsigned char)i;
+            if ((prime_f64[i] != 0) == f64 && (i == args.tail_prime) == tail) A.i_list[A.n_i++] = (unsigned char)i;
         if (!A.n_i) continue;
-        const u64 per_i = (n_ops * args.n_src) << env.logn1;
-        const u64 jobs = (per_i + kWaves - 1) / kWaves * kWaves * A.n_i;
-        if (pass == 0) hipLaunchKernelGGL(k_floor_rows<ArF64>, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes);
-        else hipLaunchKernelGGL(k_floor_rows<ArU64>, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes);
+        const unsigned g = (unsigned)((((u64)A.n_i) << env.logn1) * ((n_jobs + jpb - 1) / jpb));
+        if (f64 && !tail) hipLaunchKernelGGL((k_floor_rows<ArF64, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+        else if (f64) hipLaunchKernelGGL((k_floor_rows<ArF64, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+        else if (!tail) hipLaunchKernelGGL((k_floor_rows<ArU64, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+        else hipLaunchKernelGGL((k_floor_rows<ArU64, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
     }
 }
 
