@@ -107,6 +107,18 @@ int he355_bfv_multiply(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, c
 int he355_multiply_relin(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, int rescale,
                          uint64_t *d_out);
 int he355_relinearize(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_ct3, uint64_t *d_out);            /* [n][3][L][N] -> [n][2][L][N] */
+/* CKKS plaintext operands: NTT-form plaintexts [.][L][N] at the ciphertexts' level; ciphertext r uses plaintext
+ * b_base + r % b1 (or b_base + r when pairwise), ciphertext operand a_base + r / b1 (the Indexer rule).
+ *   he355_multiply_plain: evaluator()->multiply_plain_inplace   src/engine/seal_context.cpp:390   (every polynomial x plain)
+ *   he355_add_plain     : evaluator()->add_plain_inplace        src/engine/seal_context.cpp:454   (c0 += plain)        */
+int he355_multiply_plain(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_ct, const uint64_t *d_plain, he355_indexer ix, uint64_t *d_out);
+int he355_add_plain(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_ct, const uint64_t *d_plain, he355_indexer ix, uint64_t *d_out);
+/* CKKS evaluator()->mod_switch_to_inplace / mod_switch_to_next_inplace (src/engine/seal_context.cpp:389,451 and matchLevel):
+ * the last residues of every polynomial are dropped; in [n_polys][L][N] -> out [n_polys][L_to][N] (n_polys = n * size for
+ * ciphertexts, n for plaintexts) */
+int he355_mod_switch_drop(he355_ctx *ctx, int L, int L_to, uint64_t n_polys, const uint64_t *d_in, uint64_t *d_out);
+/* out = in[0] + ... + in[n-1] (one ciphertext): the add_inplace accumulation of collapseCKKS, src/engine/seal_context.cpp:401 */
+int he355_sum(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_in, uint64_t *d_out);
 /* CKKS: out(i,j) = sum_k multiply(a(i,k), b(k,j)), size-3 results [rows*cols][3][L][N]; ciphertext (i,k) of a is at index
  * i*a_stride_i + k*a_stride_k, (k,j) of b at k*b_stride_k + j*b_stride_j — the multiply/add_inplace loop of
  * src/benchmarks/ckks/seal_ckks_matmult_cipherbatchaxis_benchmark.cpp:404-420 */

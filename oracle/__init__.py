@@ -67,6 +67,9 @@ def lib():
             "ho_multiply_ntt": (None, [vp, sz, _u64p, _u64p, _u64p]),
             "ho_switch_key": (None, [vp, sz, _u64p, _u64p, _u64p]),
             "ho_relinearize": (None, [vp, sz, _u64p, _u64p]),
+            "ho_multiply_plain": (None, [vp, sz, sz, _u64p, _u64p, _u64p]),
+            "ho_add_plain": (None, [vp, sz, sz, _u64p, _u64p, _u64p]),
+            "ho_mod_switch_drop": (None, [vp, sz, sz, sz, _u64p, _u64p]),
             "ho_rescale": (None, [vp, sz, sz, _u64p, _u64p]),
             "ho_mod_switch_coeff": (None, [vp, sz, sz, _u64p, _u64p]),
             "ho_galois_elt_from_step": (u32, [vp, i32]),
@@ -180,6 +183,24 @@ class Context:
         L = target.shape[0]
         out = np.ascontiguousarray(ct).copy()
         lib().ho_switch_key(self.h, L, _p(np.ascontiguousarray(target)), _p(key), _p(out))
+        return out
+
+    def multiply_plain(self, ct, plain):
+        size, L, _ = ct.shape
+        out = np.empty_like(ct)
+        lib().ho_multiply_plain(self.h, L, size, _p(np.ascontiguousarray(ct)), _p(np.ascontiguousarray(plain)), _p(out))
+        return out
+
+    def add_plain(self, ct, plain):
+        size, L, _ = ct.shape
+        out = np.empty_like(ct)
+        lib().ho_add_plain(self.h, L, size, _p(np.ascontiguousarray(ct)), _p(np.ascontiguousarray(plain)), _p(out))
+        return out
+
+    def mod_switch_drop(self, x, L_to):
+        size, L, _ = x.shape
+        out = np.empty((size, L_to, self.N), dtype=np.uint64)
+        lib().ho_mod_switch_drop(self.h, L, L_to, size, _p(np.ascontiguousarray(x)), _p(out))
         return out
 
     def relinearize(self, ct3, rk):

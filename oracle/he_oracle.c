@@ -415,6 +415,37 @@ void ho_multiply_ntt(const ho_ctx *c, size_t L, const u64 *a, const u64 *b, u64 
     }
 }
 
+/* evaluator.cpp Evaluator::multiply_plain_ntt: dyadic product of every ciphertext polynomial with the plaintext
+ * (seal_context.cpp:390 multiply_plain_inplace in collapseCKKS) */
+void ho_multiply_plain(const ho_ctx *c, size_t L, size_t size, const u64 *ct, const u64 *plain, u64 *out)
+{
+    const size_t N = c->N;
+    for (size_t k = 0; k < size; ++k)
+        for (size_t i = 0; i < L; ++i) {
+            const ho_mod *m = &c->t[i].m;
+            const size_t o = (k * L + i) * N;
+            for (size_t n = 0; n < N; ++n) out[o + n] = mulmod(ct[o + n], plain[i * N + n], m);
+        }
+}
+/* evaluator.cpp Evaluator::add_plain_inplace, CKKS branch: c0 += plain (seal_context.cpp:454) */
+void ho_add_plain(const ho_ctx *c, size_t L, size_t size, const u64 *ct, const u64 *plain, u64 *out)
+{
+    const size_t N = c->N;
+    for (size_t k = 0; k < size; ++k)
+        for (size_t i = 0; i < L; ++i) {
+            const u64 q = c->t[i].m.q;
+            const size_t o = (k * L + i) * N;
+            for (size_t n = 0; n < N; ++n) out[o + n] = k == 0 ? addmod(ct[o + n], plain[i * N + n], q) : ct[o + n];
+        }
+}
+/* evaluator.cpp Evaluator::mod_switch_drop_to_next, repeated: CKKS data just loses its last residues */
+void ho_mod_switch_drop(const ho_ctx *c, size_t L, size_t L_to, size_t size, const u64 *in, u64 *out)
+{
+    const size_t N = c->N;
+    for (size_t k = 0; k < size; ++k)
+        for (size_t i = 0; i < L_to; ++i) memcpy(out + (k * L_to + i) * N, in + (k * L + i) * N, N * sizeof(u64));
+}
+
 /* evaluator.cpp Evaluator::switch_key_inplace.  Reached from relinearize_inplace (ckks dot .cpp:329,
  * matmultval .cpp:254) and from apply_galois_inplace (rotate_vector/rotate_rows, seal_context.cpp:302,337).
  * target: L residues.  key digits j<L, each [2][K][N].  Result ADDED into ct[0], ct[1]. */

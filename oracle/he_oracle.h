@@ -73,6 +73,15 @@ void ho_add(const ho_ctx *c, size_t L, size_t size, const uint64_t *a, const uin
 void ho_sub(const ho_ctx *c, size_t L, size_t size, const uint64_t *a, const uint64_t *b, uint64_t *out);
 /* CKKS (and any NTT-form) dyadic tensor: a,b size 2 -> out size 3 */
 void ho_multiply_ntt(const ho_ctx *c, size_t L, const uint64_t *a, const uint64_t *b, uint64_t *out);
+/* Evaluator::multiply_plain (NTT-form plaintext [L][N]; every polynomial of ct is multiplied dyadically; SEAL
+ * multiply_plain_ntt; called from seal_context.cpp:390) and Evaluator::add_plain (CKKS: plain added to c0;
+ * seal_context.cpp:454).  ct: [size][L][N]. */
+void ho_multiply_plain(const ho_ctx *c, size_t L, size_t size, const uint64_t *ct, const uint64_t *plain, uint64_t *out);
+void ho_add_plain(const ho_ctx *c, size_t L, size_t size, const uint64_t *ct, const uint64_t *plain, uint64_t *out);
+/* CKKS Evaluator::mod_switch_to_next / mod_switch_to (ciphertexts and NTT-form plaintexts): the last residues are
+ * dropped, nothing is scaled (SEAL mod_switch_drop_to_next; seal_context.cpp:389,451 and matchLevel).
+ * in [size][L][N] -> out [size][L_to][N] */
+void ho_mod_switch_drop(const ho_ctx *c, size_t L, size_t L_to, size_t size, const uint64_t *in, uint64_t *out);
 /* Key switching (SEAL Evaluator::switch_key_inplace). target: [L][N] (CKKS: NTT form, BFV: coefficient
  * form).  key: [L_top digits][2][K][N] NTT form.  ct (size 2, [2][L][N]) gets the result ADDED in. */
 void ho_switch_key(const ho_ctx *c, size_t L, const uint64_t *target, const uint64_t *key, uint64_t *ct);

@@ -81,6 +81,10 @@ def lib():
             "he355_multiply_relin": (i32, [vp, i32, u64, vp, vp, Indexer, i32, vp]),
             "he355_relinearize": (i32, [vp, i32, u64, vp, vp]),
             "he355_relinearize_rescale": (i32, [vp, i32, u64, vp, vp]),
+            "he355_multiply_plain": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
+            "he355_add_plain": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
+            "he355_mod_switch_drop": (i32, [vp, i32, i32, u64, vp, vp]),
+            "he355_sum": (i32, [vp, i32, i32, u64, vp, vp]),
             "he355_multiply_accumulate": (i32, [vp, i32, u64, u64, u64, vp, u64, u64, vp, u64, u64, vp]),
             "he355_rescale": (i32, [vp, i32, i32, u64, vp, vp]),
             "he355_apply_galois": (i32, [vp, i32, u64, vp, u32, vp]),
@@ -105,7 +109,8 @@ C_ABI_SYMBOLS = [
     "he355_device_init", "he355_malloc", "he355_free", "he355_upload", "he355_download", "he355_sync",
     "he355_fill_uniform", "he355_set_relin_key", "he355_set_galois_key", "he355_set_relin_key_synthetic",
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
-    "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_accumulate",
+    "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",
+    "he355_mod_switch_drop", "he355_sum", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_accumulate",
     "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_set_chunk",
 ]
 
@@ -256,6 +261,18 @@ class Context:
 
     def relinearize(self, L, n, ct3, out):
         _check(lib().he355_relinearize(self.h, L, n, ct3.ptr, out.ptr))
+
+    def multiply_plain(self, L, size, n, ct, pt, ix, out):
+        _check(lib().he355_multiply_plain(self.h, L, size, n, ct.ptr, pt.ptr, ix, out.ptr))
+
+    def add_plain(self, L, size, n, ct, pt, ix, out):
+        _check(lib().he355_add_plain(self.h, L, size, n, ct.ptr, pt.ptr, ix, out.ptr))
+
+    def mod_switch_drop(self, L, L_to, n_polys, inp, out):
+        _check(lib().he355_mod_switch_drop(self.h, L, L_to, n_polys, inp.ptr, out.ptr))
+
+    def sum(self, L, size, n, inp, out):
+        _check(lib().he355_sum(self.h, L, size, n, inp.ptr, out.ptr))
 
     def relinearize_rescale(self, L, n, ct3, out):
         _check(lib().he355_relinearize_rescale(self.h, L, n, ct3.ptr, out.ptr))

@@ -3,6 +3,7 @@
 
 #include "benchmarks.h"
 #include "matmult_row.h"
+#include "logreg.h"
 #include "matmult_cba.h"
 #include "matmult_val.h"
 
@@ -51,6 +52,8 @@ public:
         addBenchmarkDescription(std::make_shared<MatMultValBenchmarkDescription>(Scheme::CKKS));
         addBenchmarkDescription(std::make_shared<MatMultRowBenchmarkDescription>(Scheme::BFV));
         addBenchmarkDescription(std::make_shared<MatMultRowBenchmarkDescription>(Scheme::CKKS));
+        addBenchmarkDescription(std::make_shared<LogRegHornerBenchmarkDescription>(hebench::APIBridge::Category::Latency));
+        addBenchmarkDescription(std::make_shared<LogRegHornerBenchmarkDescription>(hebench::APIBridge::Category::Offline, 0));
     }
 };
 

@@ -1,0 +1,310 @@
+// logreg.cpp — see logreg.h
+#include "logreg.h"
+
+#include <algorithm>
+#include <cmath>
+#include <sstream>
+
+using namespace mi355x;
+using hebench::cpp::HEBenchError;
+namespace AB = hebench::APIBridge;
+
+constexpr double LogRegHornerBenchmark::SigmoidPolyCoeff[4];
+
+LogRegHornerBenchmarkDescription::LogRegHornerBenchmarkDescription(AB::Category category, std::size_t batch_size)
+{
+    std::memset(&m_descriptor, 0, sizeof(AB::BenchmarkDescriptor)); // logreg .cpp:27-57
+    m_descriptor.data_type = AB::DataType::Float64;
+    m_descriptor.category = category;
+    switch (category) {
+    case AB::Category::Latency:
+        m_descriptor.cat_params.min_test_time_ms = 0;
+        m_descriptor.cat_params.latency.warmup_iterations_count = 1;
+        break;
+    case AB::Category::Offline:
+        if (batch_size > DefaultPolyModulusDegree / 2)
+            throw HEBenchError(HEBERROR_MSG_CLASS("Batch size must be under " + std::to_string(DefaultPolyModulusDegree / 2) + "."), HEBENCH_ECODE_INVALID_ARGS);
+        m_descriptor.cat_params.offline.data_count[0] = 1;
+        m_descriptor.cat_params.offline.data_count[1] = 1;
+        m_descriptor.cat_params.offline.data_count[2] = batch_size;
+        break;
+    default:
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid category received."), HEBENCH_ECODE_INVALID_ARGS);
+    }
+    m_descriptor.cipher_param_mask = HEBENCH_HE_PARAM_FLAGS_ALL_CIPHER;
+    m_descriptor.scheme = HEBENCH_HE_SCHEME_CKKS;
+    m_descriptor.security = HEBENCH_HE_SECURITY_128;
+    m_descriptor.other = LogRegOtherID;
+    m_descriptor.workload = AB::Workload::LogisticRegression_PolyD3;
+    hebench::cpp::WorkloadParams::Common w; // defaults: logreg .cpp:59-66, .h:57-61
+    w.add<std::uint64_t>(16, "n");
+    w.add<std::uint64_t>(DefaultPolyModulusDegree, "PolyModulusDegree");
+    w.add<std::uint64_t>(6, "MultiplicativeDepth");
+    w.add<std::uint64_t>(45, "CoefficientModulusBits");
+    w.add<std::uint64_t>(45, "ScaleBits");
+    w.add<std::uint64_t>(0, "NumThreads");
+    this->addDefaultParameters(w);
+}
+hebench::cpp::BaseBenchmark *LogRegHornerBenchmarkDescription::createBenchmark(hebench::cpp::BaseEngine &engine, const AB::WorkloadParams *p_params)
+{
+    if (!p_params) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid empty workload parameters. This workload requires flexible parameters."), HEBENCH_ECODE_CRITICAL_ERROR);
+    return new LogRegHornerBenchmark(engine, m_descriptor, *p_params);
+}
+void LogRegHornerBenchmarkDescription::destroyBenchmark(hebench::cpp::BaseBenchmark *p_bench)
+{
+    if (p_bench) delete p_bench;
+}
+std::string LogRegHornerBenchmarkDescription::getBenchmarkDescription(const AB::WorkloadParams *p_w_params) const
+{
+    std::stringstream ss;
+    std::string s_tmp = BenchmarkDescription::getBenchmarkDescription(p_w_params);
+    if (!p_w_params) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid null workload parameters `p_w_params`"), HEBENCH_ECODE_INVALID_ARGS);
+    if (!s_tmp.empty()) ss << s_tmp << std::endl;
+    ss << ", Encryption Parameters" << std::endl
+       << ", , Poly modulus degree, " << p_w_params->params[Index_PolyModulusDegree].u_param << std::endl
+       << ", , Coefficient Modulus, 60";
+    for (std::size_t i = 1; i < p_w_params->params[Index_NumCoefficientModuli].u_param; ++i) ss << ", " << p_w_params->params[Index_CoefficientModulusBits].u_param;
+    ss << ", 60" << std::endl
+       << ", , Scale, 2^" << p_w_params->params[Index_ScaleExponentBits].u_param << std::endl
+       << ", Algorithm, " << AlgorithmName << ", " << AlgorithmDescription << std::endl
+       << ", Device, AMD Instinct MI355X (HIP; input samples batched on the grid)";
+    return ss.str();
+}
+
+LogRegHornerBenchmark::LogRegHornerBenchmark(hebench::cpp::BaseEngine &engine, const AB::BenchmarkDescriptor &bench_desc, const AB::WorkloadParams &bench_params)
+    : hebench::cpp::BaseBenchmark(engine, bench_desc, bench_params)
+{
+    const AB::BenchmarkDescriptor &d = getDescriptor();
+    if (d.workload != AB::Workload::LogisticRegression_PolyD3 || d.data_type != AB::DataType::Float64
+        || (d.category != AB::Category::Latency && d.category != AB::Category::Offline) || ((d.cipher_param_mask & 0x03) != 0x03)
+        || d.scheme != HEBENCH_HE_SCHEME_CKKS || d.security != HEBENCH_HE_SECURITY_128 || d.other != LogRegHornerBenchmarkDescription::LogRegOtherID)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Benchmark descriptor received is not supported."), HEBENCH_ECODE_INVALID_ARGS);
+    if (d.category == AB::Category::Offline && (d.cat_params.offline.data_count[0] > 1 || d.cat_params.offline.data_count[1] > 1))
+        throw HEBenchError(HEBERROR_MSG_CLASS("Benchmark descriptor received is not supported."), HEBENCH_ECODE_INVALID_ARGS);
+    if (bench_params.count < LogRegHornerBenchmarkDescription::NumWorkloadParams)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid workload parameters."), HEBENCH_ECODE_INVALID_ARGS);
+    m_n = bench_params.params[LogRegHornerBenchmarkDescription::Index_n].u_param;
+    const std::uint64_t N = bench_params.params[LogRegHornerBenchmarkDescription::Index_PolyModulusDegree].u_param;
+    const std::uint64_t depth = bench_params.params[LogRegHornerBenchmarkDescription::Index_NumCoefficientModuli].u_param;
+    const std::uint64_t bits = bench_params.params[LogRegHornerBenchmarkDescription::Index_CoefficientModulusBits].u_param;
+    const std::uint64_t scale_bits = bench_params.params[LogRegHornerBenchmarkDescription::Index_ScaleExponentBits].u_param;
+    if (bits < 1) throw HEBenchError(HEBERROR_MSG_CLASS("Multiplicative depth must be greater than 0."), HEBENCH_ECODE_INVALID_ARGS);
+    m_p_ctx_wrapper = HeContextWrapper::createCKKSContext(N, depth, (int)bits, (int)scale_bits);
+    if (m_n > m_p_ctx_wrapper->slot_count())
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid workload parameter 'n'. Number of features must be under " + std::to_string(m_p_ctx_wrapper->slot_count()) + "."),
+                           HEBENCH_ECODE_INVALID_ARGS);
+    // the whole pipeline needs 5 levels below the first: dot product, collapse, three Horner steps
+    if (m_p_ctx_wrapper->topLevel() < 6)
+        throw HEBenchError(HEBERROR_MSG_CLASS("MultiplicativeDepth must be at least 6 for this workload."), HEBENCH_ECODE_INVALID_ARGS);
+    // sigmoid coefficients, one plaintext each, the value in every slot (.cpp:165-168)
+    for (double c : SigmoidPolyCoeff) m_plain_coeff.push_back(m_p_ctx_wrapper->encodeVector(std::vector<double>(m_p_ctx_wrapper->slot_count(), c)));
+}
+
+const AB::DataPack &LogRegHornerBenchmark::findDataPack(const AB::DataPackCollection &c, std::uint64_t pos)
+{
+    for (std::uint64_t i = 0; i < c.pack_count; ++i)
+        if (c.p_data_packs[i].param_position == pos) return c.p_data_packs[i];
+    throw HEBenchError(HEBERROR_MSG_CLASS("DataPack for Logistic Regression inference operation parameter " + std::to_string(pos) + " expected, but not found in 'p_parameters'."),
+                       HEBENCH_ECODE_INVALID_ARGS);
+}
+
+AB::Handle LogRegHornerBenchmark::encode(const AB::DataPackCollection *p_parameters)
+{
+    if (p_parameters->pack_count != LogRegHornerBenchmarkDescription::NumOpParams)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid number of operation parameters detected in parameter pack. Expected "
+                                              + std::to_string(LogRegHornerBenchmarkDescription::NumOpParams) + "."), HEBENCH_ECODE_INVALID_ARGS);
+    const AB::DataPack &pW = findDataPack(*p_parameters, LogRegHornerBenchmarkDescription::Index_W);
+    const AB::DataPack &pb = findDataPack(*p_parameters, LogRegHornerBenchmarkDescription::Index_b);
+    const AB::DataPack &pX = findDataPack(*p_parameters, LogRegHornerBenchmarkDescription::Index_X);
+    EncodedOpParams enc;
+    // encodeW (.cpp:202-224)
+    if (pW.buffer_count < 1 || !pW.p_buffers || !pW.p_buffers[0].p) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty DataPack for 'W'."), HEBENCH_ECODE_INVALID_ARGS);
+    if (pW.p_buffers[0].size / sizeof(double) < m_n) {
+        std::stringstream ss;
+        ss << "Insufficient features for 'W'. Expected " << m_n << ", but " << pW.p_buffers[0].size / sizeof(double) << " received.";
+        throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
+    }
+    {
+        const double *p = reinterpret_cast<const double *>(pW.p_buffers[0].p);
+        enc.W = m_p_ctx_wrapper->encodeVector(std::vector<double>(p, p + std::min<std::uint64_t>(pW.p_buffers[0].size / sizeof(double), m_p_ctx_wrapper->slot_count())));
+    }
+    // encodeBias (.cpp:226-242): the value in every slot
+    if (pb.buffer_count < 1 || !pb.p_buffers || !pb.p_buffers[0].p || pb.p_buffers[0].size < sizeof(double))
+        throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty DataPack for 'b'."), HEBENCH_ECODE_INVALID_ARGS);
+    enc.b = m_p_ctx_wrapper->encodeVector(std::vector<double>(m_p_ctx_wrapper->slot_count(), *reinterpret_cast<const double *>(pb.p_buffers[0].p)));
+    // encodeInputs (.cpp:244-290)
+    const std::uint64_t batch = getDescriptor().category == AB::Category::Offline ? getDescriptor().cat_params.offline.data_count[LogRegHornerBenchmarkDescription::Index_X] : 1;
+    if (!pX.p_buffers) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty DataPack for 'X'."), HEBENCH_ECODE_INVALID_ARGS);
+    if (pX.buffer_count < batch) {
+        std::stringstream ss;
+        ss << "Unexpected batch size for inputs. Expected, at least, " << batch << ", but " << pX.buffer_count << " received.";
+        throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
+    }
+    if (pX.buffer_count > m_p_ctx_wrapper->slot_count())
+        throw HEBenchError(HEBERROR_MSG_CLASS("Batch size must be under " + std::to_string(m_p_ctx_wrapper->slot_count()) + "."), HEBENCH_ECODE_INVALID_ARGS);
+    for (std::uint64_t s = 0; s < pX.buffer_count; ++s) {
+        if (!pX.p_buffers[s].p) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty input sample " + std::to_string(s) + "."), HEBENCH_ECODE_INVALID_ARGS);
+        const std::uint64_t cnt = pX.p_buffers[s].size / sizeof(double);
+        if (cnt < m_n) {
+            std::stringstream ss;
+            ss << "Invalid input sample size in sample " << s << ". Expected " << m_n << ", but " << cnt << " received.";
+            throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
+        }
+        const double *p = reinterpret_cast<const double *>(pX.p_buffers[s].p);
+        enc.X.push_back(m_p_ctx_wrapper->encodeVector(std::vector<double>(p, p + std::min<std::uint64_t>(cnt, m_p_ctx_wrapper->slot_count()))));
+    }
+    return this->getEngine().createHandle<decltype(enc)>(sizeof(enc), EncodedOpParamsTag, std::move(enc));
+}
+
+void LogRegHornerBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackCollection *p_native)
+{
+    const AB::DataPack &result = findDataPack(*p_native, 0); // only results of decrypt (.cpp:292-326)
+    std::uint64_t batch = 1;
+    if (getDescriptor().category == AB::Category::Offline)
+        batch = getDescriptor().cat_params.offline.data_count[LogRegHornerBenchmarkDescription::Index_X] > 0 ?
+                    getDescriptor().cat_params.offline.data_count[LogRegHornerBenchmarkDescription::Index_X] : result.buffer_count;
+    const std::uint64_t min_count = std::min(result.buffer_count, batch);
+    if (min_count == 0) return;
+    const Plain &encoded = this->getEngine().retrieveFromHandle<Plain>(h_encoded_data, EncodedResultTag);
+    std::vector<double> v(m_p_ctx_wrapper->slot_count());
+    m_p_ctx_wrapper->client().ckks_decode(encoded.data.data(), (size_t)encoded.L, encoded.scale, v.data());
+    for (std::uint64_t s = 0; s < min_count && s < v.size(); ++s)
+        if (result.p_buffers[s].p && result.p_buffers[s].size >= sizeof(double))
+            *reinterpret_cast<double *>(result.p_buffers[s].p) = std::abs(v[s]) < 0.00005 ? 0.0 : v[s];
+}
+
+AB::Handle LogRegHornerBenchmark::encrypt(AB::Handle h_encoded_data)
+{
+    const EncodedOpParams &p = this->getEngine().retrieveFromHandle<EncodedOpParams>(h_encoded_data, EncodedOpParamsTag);
+    EncryptedOpParams c;
+    c.W = m_p_ctx_wrapper->encrypt(p.W);
+    c.b = m_p_ctx_wrapper->encrypt(p.b);
+    for (const Plain &x : p.X) c.X.push_back(m_p_ctx_wrapper->encrypt(x));
+    return this->getEngine().createHandle<decltype(c)>(sizeof(c), EncryptedOpParamsTag, std::move(c));
+}
+
+AB::Handle LogRegHornerBenchmark::decrypt(AB::Handle h_encrypted_data)
+{
+    const Cipher &c = this->getEngine().retrieveFromHandle<Cipher>(h_encrypted_data, EncryptedResultTag);
+    Plain p = m_p_ctx_wrapper->decrypt(c);
+    return this->getEngine().createHandle<decltype(p)>(m_n, EncodedResultTag, std::move(p));
+}
+
+std::shared_ptr<DeviceCiphers> LogRegHornerBenchmark::uploadPlains(const std::vector<Plain> &p)
+{
+    std::vector<Cipher> tmp(p.size());
+    for (std::size_t i = 0; i < p.size(); ++i) {
+        tmp[i].data = p[i].data; tmp[i].size = 1; tmp[i].L = p[i].L; tmp[i].scale = p[i].scale;
+    }
+    return m_p_ctx_wrapper->upload(tmp);
+}
+
+AB::Handle LogRegHornerBenchmark::load(const AB::Handle *p_h_local_data, std::uint64_t count)
+{
+    if (count != 1) throw HEBenchError(HEBERROR_MSG_CLASS("Expected only 1 local handle to load."), HEBENCH_ECODE_INVALID_ARGS);
+    const EncryptedOpParams &c = this->getEngine().retrieveFromHandle<EncryptedOpParams>(p_h_local_data[0], EncryptedOpParamsTag);
+    RemoteOpParams r;
+    r.W = m_p_ctx_wrapper->upload(std::vector<Cipher>{c.W});
+    r.b = m_p_ctx_wrapper->upload(std::vector<Cipher>{c.b});
+    r.X = m_p_ctx_wrapper->upload(c.X);
+    // Operands the reference creates inside operate() on the host (identity masks seal_context.cpp:383-386, encrypt_zero :361,
+    // encrypt of the leading coefficient :437): they depend only on the batch size and the key, so they are prepared here.
+    const std::size_t batch = c.X.size();
+    std::vector<Plain> id;
+    for (std::size_t i = 0; i < batch; ++i) {
+        std::vector<double> e(batch, 0.0);
+        e[i] = 1.0;
+        id.push_back(m_p_ctx_wrapper->encodeVector(e));
+    }
+    r.identity = uploadPlains(id);
+    r.zero = m_p_ctx_wrapper->upload(std::vector<Cipher>{m_p_ctx_wrapper->encrypt(m_p_ctx_wrapper->encodeVector(std::vector<double>(1, 0.0)))});
+    r.coeff = uploadPlains(m_plain_coeff);
+    r.coeff3 = m_p_ctx_wrapper->upload(std::vector<Cipher>{m_p_ctx_wrapper->encrypt(m_plain_coeff.back())});
+    m_p_ctx_wrapper->needRelinKey();
+    m_p_ctx_wrapper->needDefaultGaloisKeys(); // accumulateCKKS steps 2^k and the collapse's rotations by -i (NAF terms of -i)
+    return this->getEngine().createHandle<decltype(r)>(sizeof(r), EncryptedOpParamsTag, std::move(r));
+}
+
+void LogRegHornerBenchmark::store(AB::Handle h_remote_data, AB::Handle *p_h_local_data, std::uint64_t count)
+{
+    if (count > 0) {
+        std::memset(p_h_local_data, 0, sizeof(AB::Handle) * count);
+        const std::shared_ptr<DeviceCiphers> &r = this->getEngine().retrieveFromHandle<std::shared_ptr<DeviceCiphers>>(h_remote_data, EncryptedResultTag);
+        Cipher local = m_p_ctx_wrapper->download(*r).at(0);
+        p_h_local_data[0] = this->getEngine().createHandle<decltype(local)>(sizeof(local), EncryptedResultTag, std::move(local));
+    }
+}
+
+std::shared_ptr<DeviceCiphers> LogRegHornerBenchmark::dropTo(const std::shared_ptr<DeviceCiphers> &x, int L_to)
+{
+    if (x->L == L_to) return x;
+    if (x->L < L_to) throw HEBenchError(HEBERROR_MSG_CLASS("cannot switch to a higher level"), HEB355_ECODE_HE_ERROR);
+    std::shared_ptr<DeviceCiphers> y = m_p_ctx_wrapper->allocResult(x->n, x->size, L_to, x->scale);
+    HeContextWrapper::check(he355_mod_switch_drop(m_p_ctx_wrapper->raw(), x->L, L_to, x->n * x->size, x->d, y->d), "mod_switch_to");
+    return y;
+}
+
+AB::Handle LogRegHornerBenchmark::operate(AB::Handle h_remote_packed, const AB::ParameterIndexer *p_param_indexers, std::uint64_t indexers_count)
+{
+    if (indexers_count < LogRegHornerBenchmarkDescription::NumOpParams) {
+        std::stringstream ss;
+        ss << "Invalid number of indexers. Expected " << LogRegHornerBenchmarkDescription::NumOpParams << ", but " << indexers_count << " received." << std::endl;
+        throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
+    }
+    const RemoteOpParams &in = this->getEngine().retrieveFromHandle<RemoteOpParams>(h_remote_packed, EncryptedOpParamsTag);
+    const AB::ParameterIndexer &ixX = p_param_indexers[LogRegHornerBenchmarkDescription::Index_X];
+    const std::uint64_t batch = in.X->n;
+    if (ixX.value_index != 0 || (getDescriptor().category == AB::Category::Offline && ixX.batch_size != batch)
+        || (getDescriptor().category == AB::Category::Latency && ixX.batch_size != 1))
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid indexer range for parameter " + std::to_string(LogRegHornerBenchmarkDescription::Index_X) + " detected."),
+                           HEBENCH_ECODE_INVALID_ARGS);
+    auto &cw = *m_p_ctx_wrapper;
+    he355_ctx *ctx = cw.raw();
+    const auto chk = HeContextWrapper::check;
+    const double scale = cw.scale();
+    const std::uint64_t N = cw.params().N;
+    const int L = in.W->L;
+    const he355_indexer pairwise{0, 0, 1, 1, 0};
+
+    // ---- linear part: dot_i = rescale(accumulate(relinearize(W * X_i), n))   (.cpp:413-416) -------------------------
+    std::shared_ptr<DeviceCiphers> dots = cw.allocResult(batch, 2, L, in.W->scale * in.X->scale), tmp = cw.allocResult(batch, 2, L, 1.0);
+    chk(he355_multiply_relin(ctx, L, batch, in.W->d, in.X->d, he355_indexer{0, 0, batch, 0, 0}, 0, dots->d), "multiply+relinearize");
+    chk(he355_accumulate(ctx, L, batch, dots->d, m_n, tmp->d), "accumulate");
+    std::shared_ptr<DeviceCiphers> dots1 = cw.allocResult(batch, 2, L - 1, dots->scale / (double)cw.params().primes[L - 1].q);
+    chk(he355_rescale(ctx, L, 2, batch, dots->d, dots1->d), "rescale");
+
+    // ---- collapseCKKS(dots, rotate) (seal_context.cpp:349-415): slot i of the result <- slot 0 of dot_i ---------------
+    const int L1 = L - 1, L2 = L - 2;
+    std::shared_ptr<DeviceCiphers> rot = cw.allocResult(batch, 2, L1, dots1->scale);
+    const std::uint64_t per1 = 2 * (std::uint64_t)L1 * N;
+    for (std::uint64_t i = 0; i < batch; ++i) // rotate_vector(dot_i, -i); i = 0 is the copy
+        chk(he355_rotate(ctx, L1, 1, dots1->d + i * per1, -(int)i, rot->d + i * per1), "rotate_vector");
+    std::shared_ptr<DeviceCiphers> id1 = dropTo(in.identity, L1);                         // mod_switch_to_inplace(plain, tmp.parms_id())
+    chk(he355_multiply_plain(ctx, L1, 2, batch, rot->d, id1->d, pairwise, rot->d), "multiply_plain"); // relinearize_inplace: size 2, nothing to do
+    // terms [0, batch) = rescaled masked rotations, term batch = Enc(0), term batch+1 = bias; all at level L2, scales pinned to `scale`
+    std::shared_ptr<DeviceCiphers> terms = cw.allocResult(batch + 2, 2, L2, scale);
+    const std::uint64_t per2 = 2 * (std::uint64_t)L2 * N;
+    chk(he355_rescale(ctx, L1, 2, batch, rot->d, terms->d), "rescale");
+    chk(he355_mod_switch_drop(ctx, in.zero->L, L2, 2, in.zero->d, terms->d + batch * per2), "matchLevel");       // retval: encrypt_zero, switched down
+    chk(he355_mod_switch_drop(ctx, in.b->L, L2, 2, in.b->d, terms->d + (batch + 1) * per2), "matchLevel");       // bias (.cpp:452-456)
+    std::shared_ptr<DeviceCiphers> lr = cw.allocResult(1, 2, L2, scale);
+    chk(he355_sum(ctx, L2, 2, batch + 2, terms->d, lr->d), "add");
+
+    // ---- evaluatePolynomial (seal_context.cpp:417-457), Horner: ((c3 x + c2) x + c1) x + c0 ----------------------------
+    std::shared_ptr<DeviceCiphers> x = lr, acc = in.coeff3;
+    const std::uint64_t coeffN = (std::uint64_t)in.coeff->L * N;
+    for (int k = 2; k >= 0; --k) {
+        const int lvl = std::min(x->L, acc->L); // matchLevel: the higher operand is switched down
+        x = dropTo(x, lvl);
+        acc = dropTo(acc, lvl);
+        std::shared_ptr<DeviceCiphers> nxt = cw.allocResult(1, 2, lvl - 1, scale); // scale pinned to the coefficient's (:452)
+        chk(he355_multiply_relin(ctx, lvl, 1, acc->d, x->d, pairwise, 1, nxt->d), "multiply+relinearize+rescale");
+        std::shared_ptr<DeviceCiphers> ck = cw.allocResult(1, 1, lvl - 1, scale);
+        chk(he355_mod_switch_drop(ctx, in.coeff->L, lvl - 1, 1, in.coeff->d + k * coeffN, ck->d), "mod_switch_to");
+        chk(he355_add_plain(ctx, lvl - 1, 2, 1, nxt->d, ck->d, pairwise, nxt->d), "add_plain");
+        chk(he355_sync(ctx), "synchronise"); // temporaries of this step are released below
+        acc = nxt;
+    }
+    chk(he355_sync(ctx), "synchronise");
+    return this->getEngine().createHandle<decltype(acc)>(sizeof(acc), EncryptedResultTag, std::move(acc));
+}

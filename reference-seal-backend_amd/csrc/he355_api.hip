@@ -403,6 +403,33 @@ public:
         }
         HIPCHECK(hipGetLastError());
     }
+    void plain_op(int L, int size, u64 n, const u64 *ct, const u64 *pt, Indexer ix, u64 *out, int mode)
+    {
+        use();
+        check_level(L);
+        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("plaintext operands are NTT-form CKKS plaintexts");
+        if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
+        launch_plain_op(env_, L, size, n, ct, pt, ix, out, mode);
+        HIPCHECK(hipGetLastError());
+    }
+    void mod_switch_drop(int L, int L_to, u64 n_polys, const u64 *in, u64 *out)
+    {
+        use();
+        check_level(L);
+        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_mod_switch_drop is the CKKS modulus switch");
+        if (L_to < 1 || L_to > L) throw std::invalid_argument("target level out of range");
+        launch_drop_residues(env_, L, L_to, n_polys, in, out);
+        HIPCHECK(hipGetLastError());
+    }
+    void sum(int L, int size, u64 n, const u64 *in, u64 *out)
+    {
+        use();
+        check_level(L);
+        if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
+        if (n < 1) throw std::invalid_argument("nothing to sum");
+        launch_sum_cts(env_, L, size, n, in, out);
+        HIPCHECK(hipGetLastError());
+    }
     void multiply_accumulate(int L, u64 rows, u64 cols, u64 inner, const u64 *a, u64 a_stride_i, u64 a_stride_k, const u64 *b, u64 b_stride_k,
                              u64 b_stride_j, u64 *out)
     {
@@ -869,6 +896,22 @@ int he355_bfv_multiply(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const
 int he355_multiply_relin(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const uint64_t *b, he355_indexer ix, int rescale, uint64_t *out)
 {
     return guarded([&] { dev(c).multiply_relin(L, n, a, b, to_ix(ix), rescale != 0, out); });
+}
+int he355_multiply_plain(he355_ctx *c, int L, int size, uint64_t n, const uint64_t *ct, const uint64_t *pt, he355_indexer ix, uint64_t *out)
+{
+    return guarded([&] { dev(c).plain_op(L, size, n, ct, pt, to_ix(ix), out, 0); });
+}
+int he355_add_plain(he355_ctx *c, int L, int size, uint64_t n, const uint64_t *ct, const uint64_t *pt, he355_indexer ix, uint64_t *out)
+{
+    return guarded([&] { dev(c).plain_op(L, size, n, ct, pt, to_ix(ix), out, 1); });
+}
+int he355_mod_switch_drop(he355_ctx *c, int L, int L_to, uint64_t n_polys, const uint64_t *in, uint64_t *out)
+{
+    return guarded([&] { dev(c).mod_switch_drop(L, L_to, n_polys, in, out); });
+}
+int he355_sum(he355_ctx *c, int L, int size, uint64_t n, const uint64_t *in, uint64_t *out)
+{
+    return guarded([&] { dev(c).sum(L, size, n, in, out); });
 }
 int he355_multiply_accumulate(he355_ctx *c, int L, uint64_t rows, uint64_t cols, uint64_t inner, const uint64_t *a, uint64_t a_stride_i,
                               uint64_t a_stride_k, const uint64_t *b, uint64_t b_stride_k, uint64_t b_stride_j, uint64_t *out)

@@ -34,6 +34,9 @@ void launch_ntt_inverse(const KernelEnv &env, const PolyView &v, u32 n_items);  
 void launch_addsub(const KernelEnv &env, int L, int size, u64 n_results, const u64 *a, const u64 *b, Indexer ix, u64 *out, bool sub);
 // dyadic tensor (CKKS multiply): a,b size-2 level-L NTT form -> out size 3
 void launch_mul3(const KernelEnv &env, int L, u64 n_results, const u64 *a, const u64 *b, Indexer ix, u64 *out);
+void launch_plain_op(const KernelEnv &env, int L, int size, u64 n_results, const u64 *ct, const u64 *pt, Indexer ix, u64 *out, int mode); // 0 mul, 1 add
+void launch_drop_residues(const KernelEnv &env, int L, int L_to, u64 n_polys, const u64 *in, u64 *out);
+void launch_sum_cts(const KernelEnv &env, int L, int size, u64 n_terms, const u64 *in, u64 *out);
 void launch_mul3_acc(const KernelEnv &env, int L, u64 rows, u64 cols, int inner, const u64 *a, u64 a_stride_i, u64 a_stride_k, const u64 *b,
                      u64 b_stride_k, u64 b_stride_j, u64 *out);
 

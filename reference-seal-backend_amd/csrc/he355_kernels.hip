@@ -367,6 +367,67 @@ __global__ void __launch_bounds__(kBlock) k_addsub(const u64 *a, const u64 *b, u
     reinterpret_cast<ulonglong2 *>(out + r * ct + ((u64)p << logN))[e2] = z;
 }
 
+// Evaluator::multiply_plain (mode 0: every polynomial times the NTT-form plaintext) and Evaluator::add_plain, CKKS
+// (mode 1: plaintext added to c0, the other polynomials copied).  One thread = 2 coefficients of one residue polynomial.
+__global__ void __launch_bounds__(kBlock) k_plain_op(const u64 *ct, const u64 *pt, u64 *out, Indexer ix, const PrimeDev *primes, int L, int size, int logN,
+                                                     u64 n_results, int mode)
+{
+    const u64 pairs_per_poly = (u64)1 << (logN - 1);
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 pp = gid >> (logN - 1);
+    const u64 e2 = gid & (pairs_per_poly - 1);
+    const int polys = size * L;
+    const u64 r = pp / polys;
+    if (r >= n_results) return;
+    const int p = (int)(pp % polys), i = p % L;
+    const PrimeDev &P = primes[i];
+    const u64 ctn = (u64)polys << logN;
+    const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(ct + idx_a(ix, r) * ctn + ((u64)p << logN))[e2];
+    ulonglong2 z = x;
+    if (mode == 0 || p < L) {
+        const ulonglong2 y = reinterpret_cast<const ulonglong2 *>(pt + (idx_b(ix, r) * L + i) * ((u64)1 << logN))[e2];
+        if (mode == 1) {
+            z.x = addmod(x.x, y.x, P.q); z.y = addmod(x.y, y.y, P.q);
+        } else if (P.f64) {
+            const ArF64 ar = make_ar(P, (ArF64 *)nullptr);
+            z.x = ar.dy_out(ar.dy_mul(ar.dy_in(x.x), ar.dy_in(y.x))); z.y = ar.dy_out(ar.dy_mul(ar.dy_in(x.y), ar.dy_in(y.y)));
+        } else {
+            const ArU64 ar = make_ar(P, (ArU64 *)nullptr);
+            z.x = ar.dy_mul(x.x, y.x); z.y = ar.dy_mul(x.y, y.y);
+        }
+    }
+    reinterpret_cast<ulonglong2 *>(out + r * ctn + ((u64)p << logN))[e2] = z;
+}
+
+// CKKS mod_switch_to (ciphertexts, NTT-form plaintexts): keep the first L_to residues of every polynomial.
+// in [n_polys][L][N] -> out [n_polys][L_to][N]; one thread = 2 coefficients.
+__global__ void __launch_bounds__(kBlock) k_drop_residues(const u64 *in, u64 *out, int L, int L_to, int logN, u64 n_polys)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 pp = gid >> (logN - 1), e2 = gid & (((u64)1 << (logN - 1)) - 1);
+    const u64 poly = pp / L_to;
+    if (poly >= n_polys) return;
+    const int i = (int)(pp % L_to);
+    reinterpret_cast<ulonglong2 *>(out + ((poly * L_to + i) << logN))[e2] = reinterpret_cast<const ulonglong2 *>(in + ((poly * L + i) << logN))[e2];
+}
+
+// Sum of n ciphertexts (the add_inplace accumulation of collapseCKKS, seal_context.cpp:401): out = sum_r in[r].
+// One thread = 2 coefficients of one residue polynomial of the result; it walks the n terms.
+__global__ void __launch_bounds__(kBlock) k_sum_cts(const u64 *in, u64 *out, const PrimeDev *primes, int L, int polys, int logN, u64 n_terms)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 p = gid >> (logN - 1), e2 = gid & (((u64)1 << (logN - 1)) - 1);
+    if (p >= (u64)polys) return;
+    const u64 q = primes[p % L].q;
+    const u64 ctn = (u64)polys << logN;
+    ulonglong2 s = make_ulonglong2(0, 0);
+    for (u64 r = 0; r < n_terms; ++r) {
+        const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(in + r * ctn + (p << logN))[e2];
+        s.x = addmod(s.x, x.x, q); s.y = addmod(s.y, x.y, q);
+    }
+    reinterpret_cast<ulonglong2 *>(out + (p << logN))[e2] = s;
+}
+
 // Evaluator::multiply, CKKS, size 2 x 2 -> 3 (dyadic tensor).  One thread = 2 coefficients of one residue.
 template <class Ar>
 __device__ __forceinline__ void mul3_pair(const Ar &ar, const ulonglong2 a0, const ulonglong2 a1, const ulonglong2 b0, const ulonglong2 b1,
@@ -1201,6 +1262,27 @@ void launch_addsub(const KernelEnv &env, int L, int size, u64 n_results, const u
     const u64 threads = (n_results * polys) << (logN - 1);
     hipLaunchKernelGGL(k_addsub, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, a, b, out, ix, env.primes, L, polys, logN, n_results,
                        sub ? 1 : 0);
+}
+
+void launch_plain_op(const KernelEnv &env, int L, int size, u64 n_results, const u64 *ct, const u64 *pt, Indexer ix, u64 *out, int mode)
+{
+    if (!n_results) return;
+    const int logN = env.logn1 + kRowLog;
+    const u64 threads = (n_results * size * L) << (logN - 1);
+    hipLaunchKernelGGL(k_plain_op, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, ct, pt, out, ix, env.primes, L, size, logN, n_results, mode);
+}
+void launch_drop_residues(const KernelEnv &env, int L, int L_to, u64 n_polys, const u64 *in, u64 *out)
+{
+    if (!n_polys) return;
+    const int logN = env.logn1 + kRowLog;
+    const u64 threads = (n_polys * L_to) << (logN - 1);
+    hipLaunchKernelGGL(k_drop_residues, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, in, out, L, L_to, logN, n_polys);
+}
+void launch_sum_cts(const KernelEnv &env, int L, int size, u64 n_terms, const u64 *in, u64 *out)
+{
+    const int logN = env.logn1 + kRowLog;
+    const u64 threads = ((u64)size * L) << (logN - 1);
+    hipLaunchKernelGGL(k_sum_cts, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, in, out, env.primes, L, size * L, logN, n_terms);
 }
 
 void launch_mul3_acc(const KernelEnv &env, int L, u64 rows, u64 cols, int inner, const u64 *a, u64 a_stride_i, u64 a_stride_k, const u64 *b,

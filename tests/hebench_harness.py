@@ -11,6 +11,7 @@ MAX_BUF, MAX_OP = 256, 32
 ECODE_INVALID_ARGS, ECODE_CRITICAL = 0x7FFFFFFE, 0x7FFFFFFF
 LATENCY, OFFLINE = 0, 1
 W_MATMUL, W_ADD, W_MUL, W_DOT = 0, 1, 2, 3
+W_LOGREG3 = 5  # LogisticRegression_PolyD3
 DT_INT64, DT_FLOAT64 = 1, 3
 SCHEME_CKKS, SCHEME_BFV = 100, 101
 
@@ -176,8 +177,8 @@ class Backend:
         self.chk(self.L.createBenchmark(self.engine, bench["handle"], C.byref(wp), C.byref(hb)))
         concrete = BenchmarkDescriptor.from_buffer_copy(bench["desc"])
         if concrete.category == OFFLINE:
-            concrete.cat_params.offline.data_count[0] = sample_counts[0]
-            concrete.cat_params.offline.data_count[1] = sample_counts[1]
+            for i, c in enumerate(sample_counts):
+                concrete.cat_params.offline.data_count[i] = c
         self.chk(self.L.initBenchmark(hb, C.byref(concrete)))
         return hb
 
@@ -217,17 +218,16 @@ class Backend:
         self.chk(L.encode(hb, C.byref(dpc), C.byref(h_plain)))
         self.chk(L.encrypt(hb, h_plain, C.byref(h_cipher)))
         self.chk(L.load(hb, C.byref(h_cipher), 1, C.byref(h_remote)))
-        b0, b1 = operands[0].shape[0], operands[1].shape[0]
         if indexers is None:
-            indexers = [(0, b0), (0, b1)]
-        pi = (ParameterIndexer * 2)(*[ParameterIndexer(v, b) for v, b in indexers])
-        self.chk(L.operate(hb, h_remote, pi, 2, C.byref(h_out)))
+            indexers = [(0, o.shape[0]) for o in operands]
+        pi = (ParameterIndexer * len(indexers))(*[ParameterIndexer(v, b) for v, b in indexers])
+        self.chk(L.operate(hb, h_remote, pi, len(indexers), C.byref(h_out)))
         local = (Handle * 2)()
         self.chk(L.store(hb, h_out, local, 2))
         assert local[1].p is None and local[1].size == 0  # excess handles are zero-filled (ckks eltwise .cpp:297-298)
         h_dec = Handle()
         self.chk(L.decrypt(hb, local[0], C.byref(h_dec)))
-        n_res = indexers[0][1] * indexers[1][1]
+        n_res = int(np.prod([b for _, b in indexers]))
         res = np.zeros((n_res, out_n), dtype=out_dtype)
         out_pack, keep2 = self.pack([res])
         self.chk(L.decode(hb, h_dec, C.byref(out_pack)))

@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from hebench_harness import (Backend, BridgeError, ECODE_INVALID_ARGS, LATENCY, OFFLINE, SCHEME_BFV, SCHEME_CKKS, W_ADD, W_DOT, W_MUL,
+from hebench_harness import (Backend, BridgeError, ECODE_INVALID_ARGS, LATENCY, OFFLINE, SCHEME_BFV, SCHEME_CKKS, W_ADD, W_DOT, W_MUL, W_LOGREG3,
                              DT_FLOAT64, DT_INT64, Handle)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,8 +39,16 @@ def test_engine_registration(backend):
     assert backend.security_name(SCHEME_CKKS, 0) == "128 bits"  # seal_engine.cpp:105
     bs = backend.benchmarks()
     got = sorted((b["desc"].workload, b["desc"].scheme, b["desc"].category) for b in bs)
-    want = sorted([(w, s, c) for w in (W_ADD, W_MUL, W_DOT) for s in (SCHEME_BFV, SCHEME_CKKS) for c in (LATENCY, OFFLINE)] + [(0, SCHEME_BFV, LATENCY)] * 3 + [(0, SCHEME_CKKS, LATENCY)] * 3)
-    assert got == want  # 18 of the reference's 20 descriptors (seal_engine.cpp:108-151); LogReg x2 missing
+    want = sorted([(w, s, c) for w in (W_ADD, W_MUL, W_DOT) for s in (SCHEME_BFV, SCHEME_CKKS) for c in (LATENCY, OFFLINE)] + [(0, SCHEME_BFV, LATENCY)] * 3 + [(0, SCHEME_CKKS, LATENCY)] * 3
+                  + [(W_LOGREG3, SCHEME_CKKS, LATENCY), (W_LOGREG3, SCHEME_CKKS, OFFLINE)])
+    assert got == want and len(bs) == 20  # all 20 of the reference's descriptors (seal_engine.cpp:108-151)
+    for c in (LATENCY, OFFLINE):
+        lr = backend.find(W_LOGREG3, SCHEME_CKKS, c)
+        assert lr["desc"].other == 1 and lr["desc"].data_type == DT_FLOAT64  # LogRegOtherID
+        assert lr["defaults"][0] == [("n", 16), ("PolyModulusDegree", 16384), ("MultiplicativeDepth", 6), ("CoefficientModulusBits", 45), ("ScaleBits", 45),
+                                     ("NumThreads", 0)]
+        if c == OFFLINE:
+            assert list(lr["desc"].cat_params.offline.data_count)[:3] == [1, 1, 0]
     assert sorted((b["desc"].scheme, b["desc"].other) for b in bs if b["desc"].workload == 0) == sorted(
         (s, o) for s in (SCHEME_BFV, SCHEME_CKKS) for o in (0, 1, 2))  # MatMultVal, CipherBatchAxis, Row
     cba = sorted((b["desc"].scheme, b["defaults"][0][4:7]) for b in bs if b["desc"].workload == 0 and b["desc"].other == 1)
@@ -56,7 +64,7 @@ def test_engine_registration(backend):
                                  ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)]
     for b in bs:
         d = b["desc"]
-        assert d.cipher_param_mask == 0xFFFFFFFF and d.security == 0 and d.other in ((0, 1, 2) if d.workload == 0 else (0,))
+        assert d.cipher_param_mask == 0xFFFFFFFF and d.security == 0 and d.other in ((0, 1, 2) if d.workload == 0 else (1,) if d.workload == W_LOGREG3 else (0,))
         assert d.data_type == (DT_FLOAT64 if d.scheme == SCHEME_CKKS else DT_INT64)
         if d.category == LATENCY:
             assert d.cat_params.latency.warmup_iterations_count == 1 and d.cat_params.min_test_time_ms == 0

@@ -189,3 +189,25 @@ def test_ckks_matmult_row(backend, dims):
     """One row per ciphertext, rotate_vector by j * (slots / cols_M0) (ckks row .cpp:472-523); 64 x 64 fills
     all 4096 slots and takes 63 rotations, most of them NAF-decomposed."""
     _matmul_val(backend, SCHEME_CKKS, dims, 8192, 3, 45, other=2)
+
+
+def _sigmoid_poly(x):
+    return 0.5 + 0.15012 * x - 0.0015930078125 * x ** 3  # SigmoidPolyCoeff, logreg .h:117
+
+
+@pytest.mark.parametrize("category,batch,n", [(LATENCY, 1, 16), (OFFLINE, 7, 16), (OFFLINE, 20, 5)])
+def test_ckks_logreg_horner(backend, category, batch, n):
+    """LogisticRegression_PolyD3 at the reference's default parameters (N=16384, depth 6, 45-bit): dot products as one
+    batch, collapse with rotations by -i, bias, degree-3 Horner (logreg .cpp:388-481).  Tolerance 1e-3: the scheme's
+    own approximation error after five rescales with manually pinned scales (seal_context.cpp:395,452)."""
+    from hebench_harness import W_LOGREG3
+    rng = np.random.default_rng(100 + batch + n)
+    W, b, X = rng.uniform(-1, 1, (1, n)), rng.uniform(-1, 1, (1, 1)), rng.uniform(-1, 1, (batch, n))
+    bench = backend.find(W_LOGREG3, SCHEME_CKKS, category)
+    hb = backend.create(bench, [("n", n), ("PolyModulusDegree", 16384), ("MultiplicativeDepth", 6), ("CoefficientModulusBits", 45), ("ScaleBits", 45),
+                                ("NumThreads", 0)], (1, 1, batch))
+    res = backend.run(hb, [W, b, X], 1, np.float64)
+    want = _sigmoid_poly(X @ W[0] + b[0, 0])
+    assert res.shape == (batch, 1)
+    assert np.allclose(res[:, 0], want, atol=1e-3), np.abs(res[:, 0] - want).max()
+    backend.destroy(hb)

@@ -190,6 +190,50 @@ def test_multiply_accumulate_and_relinearize_rescale(pair, be):
             assert np.array_equal(res[r], o.rescale(o.relinearize(want[r], rk))), r
 
 
+def test_plain_ops_mod_switch_and_sum(pair, be):
+    """multiply_plain / add_plain with per-op and broadcast plaintexts, CKKS mod_switch_to (drop residues) and the
+    collapse sum (seal_context.cpp:389-401, 451-454)."""
+    g, o, rng = pair
+    L, n = g.L, 5
+    cts = rand_cts(o, rng, n, L)
+    pts = np.stack([o.random_poly(rng, L, 1)[0] for _ in range(n)])  # [n, L, N] NTT-form plaintexts
+    dc, dp = g.to_device(cts), g.to_device(pts)
+    out = g.alloc(n * 2 * L * g.N)
+    g.multiply_plain(L, 2, n, dc, dp, be.Context.pairwise(), out)
+    got = out.download(cts.shape)
+    for r in range(n):
+        assert np.array_equal(got[r], o.multiply_plain(cts[r], pts[r])), r
+    g.multiply_plain(L, 2, n, dc, dp, be.Context.outer(0, n, 2, 1), out)  # one plaintext (index 2) for all
+    got = out.download(cts.shape)
+    for r in range(n):
+        assert np.array_equal(got[r], o.multiply_plain(cts[r], pts[2])), r
+    g.add_plain(L, 2, n, dc, dp, be.Context.pairwise(), out)
+    got = out.download(cts.shape)
+    for r in range(n):
+        assert np.array_equal(got[r], o.add_plain(cts[r], pts[r])), r
+    ct3 = rand_cts(o, rng, 2, L, size=3)
+    d3, o3 = g.to_device(ct3), g.alloc(2 * 3 * L * g.N)
+    g.multiply_plain(L, 3, 2, d3, dp, be.Context.pairwise(), o3)
+    assert np.array_equal(o3.download(ct3.shape)[1], o.multiply_plain(ct3[1], pts[1]))
+    # sum of the n ciphertexts
+    ds = g.alloc(2 * L * g.N)
+    g.sum(L, 2, n, dc, ds)
+    want = cts[0]
+    for r in range(1, n):
+        want = o.add(want, cts[r])
+    assert np.array_equal(ds.download(want.shape), want)
+    if L >= 2:
+        for L_to in range(1, L + 1):
+            dd = g.alloc(n * 2 * L_to * g.N)
+            g.mod_switch_drop(L, L_to, n * 2, dc, dd)
+            got = dd.download((n, 2, L_to, g.N))
+            for r in range(n):
+                assert np.array_equal(got[r], o.mod_switch_drop(cts[r], L_to)), (L_to, r)
+        dd = g.alloc(n * (L - 1) * g.N)
+        g.mod_switch_drop(L, L - 1, n, dp, dd)  # plaintexts: one polynomial each
+        assert np.array_equal(dd.download((n, L - 1, g.N)), pts[:, : L - 1])
+
+
 def test_galois_rotate_accumulate(pair, be):
     g, o, rng = pair
     L, N = g.L, g.N
