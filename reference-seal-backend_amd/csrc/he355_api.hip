@@ -68,6 +68,19 @@ __global__ void k_key_to_engine(u64 *key, u64 n_polys, int logN, const PrimeDev 
     }
 }
 
+// Shoup quotients of the key residues under the u64-engine primes, appended to the key: [L_top][2][n_q][N]
+__global__ void k_key_quotients(const u64 *key, u64 *keyq, u64 n_dk, int logN, const PrimeDev *primes, int K, int n_q, PrimeMap qmap)
+{
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 poly = gid >> logN; // (digit*2 + k) * n_q + slot
+    if (poly >= n_dk * n_q) return;
+    const int slot = (int)(poly % n_q), t = qmap.prime_of[slot];
+    const u64 dk = poly / n_q;
+    ArU64 ar;
+    ar.q = primes[t].q; ar.two_q = 2 * ar.q; ar.cr0 = primes[t].cr0; ar.cr1 = primes[t].cr1; ar.ninv = ar.ninv_q = 0;
+    keyq[gid] = ar.shoup_quotient_est(key[((dk * K + t) << logN) + (gid & (((u64)1 << logN) - 1))]);
+}
+
 } // namespace
 
 class DeviceContext {
@@ -164,18 +177,25 @@ public:
     void set_chunk(size_t c) { chunk_ = c ? c : 1; }
 
     size_t key_elems() const { return P.Ltop * 2 * P.K * P.N; }
+    size_t n_q_primes() const
+    {
+        size_t n = 0;
+        for (size_t i = 0; i < P.K; ++i) n += env_.prime_f64[i] == 0;
+        return n;
+    }
+    size_t key_alloc_elems() const { return key_elems() + P.Ltop * 2 * n_q_primes() * P.N; } // key + Shoup quotients (u64-engine primes)
 
     void key_from_host(u64 **slot, const u64 *h_key)
     {
         use();
-        if (!*slot) HIPCHECK(hipMalloc(slot, key_elems() * 8));
+        if (!*slot) HIPCHECK(hipMalloc(slot, key_alloc_elems() * 8));
         HIPCHECK(hipMemcpyAsync(*slot, h_key, key_elems() * 8, hipMemcpyHostToDevice, stream_));
         key_finish(*slot);
     }
     void key_synthetic(u64 **slot, u64 seed)
     {
         use();
-        if (!*slot) HIPCHECK(hipMalloc(slot, key_elems() * 8));
+        if (!*slot) HIPCHECK(hipMalloc(slot, key_alloc_elems() * 8));
         PrimeMap pm;
         pm.period = (u32)P.K;
         for (size_t i = 0; i < P.K; ++i) pm.prime_of[i] = (unsigned char)i;
@@ -186,6 +206,17 @@ public:
     void key_finish(u64 *d_key)
     {
         const u64 n_polys = P.Ltop * 2 * P.K, total = n_polys * P.N;
+        const int n_q = (int)n_q_primes();
+        if (n_q) { // before the fp64 conversion below rewrites the other residues; these stay integers
+            PrimeMap qm;
+            qm.period = (u32)n_q;
+            int k = 0;
+            for (size_t i = 0; i < P.K; ++i)
+                if (!env_.prime_f64[i]) qm.prime_of[k++] = (unsigned char)i;
+            const u64 n_dk = P.Ltop * 2, tq = n_dk * n_q * P.N;
+            hipLaunchKernelGGL(k_key_quotients, dim3((unsigned)((tq + 255) / 256)), dim3(256), 0, stream_, d_key, d_key + key_elems(), n_dk, P.logn, d_primes_,
+                               (int)P.K, n_q, qm);
+        }
         hipLaunchKernelGGL(k_key_to_engine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, d_key, n_polys, P.logn, d_primes_, (int)P.K);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipStreamSynchronize(stream_));
@@ -296,11 +327,13 @@ public:
     }
 
     // K2, K3, mod-down; result added into B.c01.  with_tail: also start the rescale (tail of prime L-1)
-    void key_switch_tail(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail)
+    void key_switch_tail(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail,
+                         hipEvent_t after_k2 = nullptr)
     {
         const size_t N = P.N, LN = (size_t)L * N;
         const int SP = (int)P.K - 1;
         launch_k2(env_, L, nc, B);
+        if (after_k2) HIPCHECK(hipEventRecord(after_k2, env_.stream));
         launch_k3(env_, L, nc, B, key);
         launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
         FloorRowsArgs fr;
@@ -343,11 +376,17 @@ public:
         // Alternate chunks between two streams, each with its own scratch arena: the ALU-bound key-product kernel
         // of one chunk overlaps the HBM-bound multiply / digit-lift / floor kernels of the other.
         const bool dual = dual_stream_ && n > chunk_;
+        // The second stream starts half a pipeline late (after the first chunk's K1+K2 on the first stream): from then on
+        // one stream's ALU-bound kernels (K3, floor column pass) run beside the other's HBM-bound ones (K1, K2, floor row pass)
+        // instead of beside their own kind.
+        static const bool stagger = !(getenv("HE355_STAGGER") && getenv("HE355_STAGGER")[0] == '0');
         if (dual) {
             (void)scratch(chunk_, L, 0);
             (void)scratch(chunk_, L, 1);
-            HIPCHECK(hipEventRecord(ev_fork_, stream_));
-            HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+            if (!stagger) {
+                HIPCHECK(hipEventRecord(ev_fork_, stream_));
+                HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+            }
         }
         u64 ci = 0;
         for (u64 off = 0; off < n; off += chunk_, ++ci) {
@@ -359,7 +398,9 @@ public:
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
             launch_k1(env, L, K1_MUL, nc, off, a, b, ix, nullptr, B);
-            key_switch_tail(env, L, nc, S, B, d_relin_, rescale);
+            const bool fork_here = dual && stagger && ci == 0;
+            key_switch_tail(env, L, nc, S, B, d_relin_, rescale, fork_here ? ev_fork_ : nullptr);
+            if (fork_here) HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
             if (rescale) rescale_tail(env, L, 2, nc, S, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N);
         }
         if (dual) {

@@ -30,6 +30,9 @@ namespace {
 #ifndef HE355_K3_U64_SHAPE
 #define HE355_K3_U64_SHAPE 18
 #endif
+#ifndef HE355_K3_STAGE_DEFAULT
+#define HE355_K3_STAGE_DEFAULT 1
+#endif
 constexpr int kBlock = 256;
 #ifndef K2_WAVES
 #define K2_WAVES 2
@@ -134,11 +137,21 @@ __device__ __forceinline__ void lds_rowC(const u64 *lds_row, int lane, u64 v[kRo
 // U rows of the same tile at once (shared twiddles, interleaved butterfly chains); lds_w: U exchange buffers.
 // The twiddles of phase B / C are gathered BEFORE the exchange that precedes the phase and pinned there with a
 // scheduling barrier, so their loads are in flight while the exchange round-trips through LDS.
-template <int U, class Ar, class TW>
-__device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int lane, u64 (*lds_w)[kLdsRow], typename Ar::T (*x)[kRowE])
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `before_c` runs after phase B's math and before the second exchange: a caller uses it to put global loads in flight
+// that it needs right after the transform (they then land during the exchange and phase C).
+// `wa_pre`: phase A's 15 twiddles, already gathered by the caller (they are the same for every lane, so a caller that
+// transforms many rows of one (prime, row) tile keeps them in scalar registers); null: gather them here.
+template <int U, class Ar, class TW, class Hook = NoHook>
+__device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int lane, u64 (*lds_w)[kLdsRow], typename Ar::T (*x)[kRowE],
+                                                Hook before_c = Hook(), const Tw16 *wa_pre = nullptr)
 {
     typedef typename Ar::T T;
-    {
+    if (wa_pre) {
+        row_fwd_A<U>(ar, x, wa_pre);
+    } else {
         Tw16 wa[kTwA];
         gather_A(tw, wa);
         row_fwd_A<U>(ar, x, wa);
@@ -155,6 +168,7 @@ __device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int 
     row_fwd_B<U>(ar, x, wb);
     Tw16 wc[kTwC];
     gather_C(tw, lane, wc);
+    before_c();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u) lds_store_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
@@ -726,6 +740,9 @@ stage_row_twiddles(const PrimeDev &P, const Ar &ar, u32 rowbase, unsigned char *
 
 struct K3Args {
     const u64 *d, *c2n, *key;
+    const u64 *keyq;   // Shoup quotients of the key residues under the u64-engine primes: [L_top][2][n_q][N]
+    int n_q;           // u64-engine primes in the key chain
+    unsigned char q_slot[64]; // tt_list[k] -> its index among them
     u64 *t, *tp;
     u64 n_ops;
     int L, K, logn1, ckks;
@@ -734,7 +751,9 @@ struct K3Args {
     unsigned char tt_list[64];
 };
 
-template <class Ar, int U, int WAVES>
+// STAGE: digit rows reach the wave through an LDS landing buffer filled by LDS-DMA one step ahead (true), or straight
+// into registers by global loads issued one step ahead (false: no LDS traffic for them, 32 more live registers).
+template <class Ar, int U, int WAVES, bool STAGE>
 __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *primes)
 {
     constexpr int kWaves = WAVES, kBlock = WAVES * 64; // this kernel's own block shape (shadows the file-wide one)
@@ -744,7 +763,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
     // One block per CU (one wave per SIMD): the wave gets its latency hiding from the two interleaved digits
     // and from LDS-DMA prefetch, not from co-resident waves.  LDS: 64 KiB exchange + 64 KiB DMA landing + twiddles.
     __shared__ u64 lds[kWaves][U][kLdsRow];
-    __shared__ __attribute__((aligned(16))) u64 stage[kWaves][U][kRowN];
+    __shared__ __attribute__((aligned(16))) u64 stage[STAGE ? kWaves : 1][STAGE ? U : 1][STAGE ? kRowN : 2];
     __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 n1 = 1u << A.logn1;
@@ -761,6 +780,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
     if (tile >= total_tiles) return; // whole block exits together
     const u64 og_first = (s % n_ogb) * A.og_per_block;
     const int tt = A.tt_list[tile >> A.logn1];
+    const int q_slot = A.q_slot[tile >> A.logn1];
     const u32 a_row = (u32)(tile & (n1 - 1));
     const int t = (tt == A.L) ? A.K - 1 : tt;
     const PrimeDev &P = primes[t];
@@ -769,6 +789,18 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
     // this block's forward twiddles of row (t, a_row), staged once in LDS
     const auto twr = stage_row_twiddles<Ar, kBlock>(P, ar, n1 + a_row, twl_raw);
     __syncthreads();
+    // phase A's twiddles are lane-uniform and the same for every digit and op of the tile: fp64 engine keeps them in SGPRs
+    Tw16 wa_s[kTwA];
+    if constexpr (kF64 && !STAGE) {
+        gather_A(twr, wa_s);
+#pragma unroll
+        for (int k = 0; k < kTwA; ++k) {
+            const u32 lo = __builtin_amdgcn_readfirstlane((u32)wa_s[k].a), hi = __builtin_amdgcn_readfirstlane((u32)(wa_s[k].a >> 32));
+            wa_s[k].a = ((u64)hi << 32) | lo;
+            wa_s[k].b = 0;
+        }
+    }
+    const Tw16 *wa_pre = (kF64 && !STAGE) ? wa_s : nullptr;
     for (u32 g = 0; g < A.og_per_block; ++g) {
         const u64 og = og_first + g;
         if (og >= n_og) break; // block-uniform
@@ -779,14 +811,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) { acc0[r] = 0; acc1[r] = 0; }
         auto key_row = [&](int j, int k) -> const u64 * { return A.key + (((u64)j * 2 + k) * A.K + t) * N + rowoff; };
+        auto keyq_row = [&](int j, int k) -> const u64 * { return A.keyq + (((u64)j * 2 + k) * A.n_q + q_slot) * N + rowoff; };
+        auto mac_poly = [&](Acc acc[kRowE], const T x[kRowE], int j, int k) {
+            u64 kv[kRowE], kq[kRowE];
+            load_rowC(key_row(j, k), lane, kv);
+            if constexpr (Ar::kKeyQuotient) load_rowC(keyq_row(j, k), lane, kq);
+#pragma unroll
+            for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc[r], x[r], ar.key_in(kv[r]), Ar::kKeyQuotient ? kq[r] : 0);
+        };
         auto mac_digit = [&](const T x[kRowE], int j) {
-            u64 kv[kRowE], kw[kRowE];
-            load_rowC(key_row(j, 0), lane, kv);
-            load_rowC(key_row(j, 1), lane, kw);
-#pragma unroll
-            for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc0[r], x[r], ar.key_in(kv[r]));
-#pragma unroll
-            for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc1[r], x[r], ar.key_in(kw[r]));
+            mac_poly(acc0, x, j, 0);
+            mac_poly(acc1, x, j, 1);
         };
         // digits that go through the forward row pass: all of them, except (CKKS) the one that lives under this very
         // prime -- that one is the NTT-form target itself and is multiplied in directly
@@ -794,9 +829,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         const int nd = A.L - (has_own ? 1 : 0);
         auto digit = [&](int i) -> int { return (has_own && i >= tt) ? i + 1 : i; };
         auto src_row = [&](int j) -> const u64 * { return A.d + ((op * (A.L + 1) + tt) * A.L + j) * N + rowoff; };
+        if constexpr (STAGE) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u < nd) dma_row_to_lds(src_row(digit(u)), stage[wave][u], lane);
+            for (int u = 0; u < U; ++u)
+                if (u < nd) dma_row_to_lds(src_row(digit(u)), stage[wave][u], lane);
+        }
+        u64 vn[kRowE]; // !STAGE: the next digit's row, in flight or landed
+        if constexpr (!STAGE) {
+            static_assert(STAGE || U == 1, "register prefetch is written for one digit per wave");
+            load_rowA(src_row(digit(0)), lane, vn);
+        }
         if (has_own) {
             T x[kRowE];
             u64 v[kRowE];
@@ -808,25 +850,32 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         for (int i = 0; i < nd; i += U) {
             const int cnt = (nd - i) < U ? (nd - i) : U;
             T x[U][kRowE];
-            u64 v[kRowE];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the rows of this step have landed in the staging buffers
+            if constexpr (STAGE) {
+                u64 v[kRowE];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the rows of this step have landed in the staging buffers
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (u < cnt) {
-                    lds_rowA(stage[wave][u], lane, v);
+                for (int u = 0; u < U; ++u) {
+                    if (u < cnt) {
+                        lds_rowA(stage[wave][u], lane, v);
 #pragma unroll
-                    for (int r = 0; r < kRowE; ++r) x[u][r] = ar.from_raw(v[r]);
+                        for (int r = 0; r < kRowE; ++r) x[u][r] = ar.from_raw(v[r]);
+                    }
                 }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffers drained into registers
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffers drained into registers
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (i + U + u < nd) dma_row_to_lds(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
+                for (int u = 0; u < U; ++u)
+                    if (i + U + u < nd) dma_row_to_lds(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
+            } else {
+                asm volatile("" ::: "memory"); // keeps the LDS twiddle reads inside the loop (hoisted, they would cost 54 registers)
+#pragma unroll
+                for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(vn[r]);
+                if (i + 1 < nd) load_rowA(src_row(digit(i + 1)), lane, vn); // lands behind this step's math
+            }
             if (U == 2 && cnt < U) { // odd digit count: the partner row is zeros (its products add nothing)
 #pragma unroll
                 for (int r = 0; r < kRowE; ++r) x[U - 1][r] = 0;
             }
-            wave_rows_fwd_n<U>(ar, twr, lane, lds[wave], x);
+            wave_rows_fwd_n<U>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (u < cnt) mac_digit(x[u], digit(i + u));
@@ -1357,9 +1406,17 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tp = buf.tp;
         A.n_ops = n_ops; A.L = L; A.K = env.K; A.logn1 = env.logn1; A.ckks = env.scheme == 2;
         A.n_tt = 0;
+        A.n_q = 0;
+        for (int t = 0; t < env.K; ++t) A.n_q += prime_f64[t] == 0;
+        A.keyq = key + (u64)env.Ltop * 2 * env.K * env.N; // the quotient array follows the key in the same allocation
         for (int tt = 0; tt <= L; ++tt) {
             const int t = (tt == L) ? env.K - 1 : tt;
-            if ((prime_f64[t] != 0) == (pass == 0)) A.tt_list[A.n_tt++] = (unsigned char)tt;
+            if ((prime_f64[t] != 0) == (pass == 0)) {
+                int slot = 0;
+                for (int u = 0; u < t; ++u) slot += prime_f64[u] == 0;
+                A.q_slot[A.n_tt] = (unsigned char)slot;
+                A.tt_list[A.n_tt++] = (unsigned char)tt;
+            }
         }
         if (!A.n_tt) continue;
         // block shape per engine: (interleaved digits per wave, waves per block).  HE355_K3_SHAPE=<u><w><u><w> overrides
@@ -1376,16 +1433,24 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.og_per_block = ogpb;
         const u64 n_ogb = (n_og + ogpb - 1) / ogpb;
         const unsigned g = (unsigned)(((tiles + 7) / 8) * 8 * n_ogb);
+        static const int stage_env = getenv("HE355_K3_STAGE") ? atoi(getenv("HE355_K3_STAGE")) : HE355_K3_STAGE_DEFAULT;
+        const bool staged = stage_env != 0 || shape / 10 != 1;
         if (pass == 0) {
             switch (shape) {
-            case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
-            case 18: hipLaunchKernelGGL((k_k3<ArF64, 1, 8>), dim3(g), dim3(512), 0, env.stream, A, env.primes); break;
+            case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
+            case 18:
+                if (staged) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                else hipLaunchKernelGGL((k_k3<ArF64, 1, 8, false>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                break;
             default: throw std::runtime_error("unsupported K3 fp64 shape");
             }
         } else {
             switch (shape) {
-            case 14: hipLaunchKernelGGL((k_k3<ArU64, 1, 4>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
-            case 18: hipLaunchKernelGGL((k_k3<ArU64, 1, 8>), dim3(g), dim3(512), 0, env.stream, A, env.primes); break;
+            case 14: hipLaunchKernelGGL((k_k3<ArU64, 1, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
+            case 18:
+                if (staged) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                else hipLaunchKernelGGL((k_k3<ArU64, 1, 8, false>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                break;
             default: throw std::runtime_error("unsupported K3 u64 shape");
             }
         }

@@ -98,9 +98,17 @@ struct ArU64 {
     HE_HD T dy_add(T x, T y) const { return addmod(x, y, q); }
     HE_HD u64 dy_out(T x) const { return x; }
     HE_HD T key_in(u64 bits) const { return bits; }
-    // acc += x*key, x lazy (< 4q), key canonical
-    HE_HD void acc_mac(Acc &acc, T x, T key) const { acc = addmod(acc, barrett128((u128)x * key, mod()), q); }
-    HE_HD u64 acc_canon(Acc acc) const { return acc; }
+    // acc += x*key, x lazy (< 4q), key canonical, keyq = its Shoup quotient floor(key*2^64/q) or up to 2 below it
+    // (shoup_quotient_est).  The product term lands in [0,3q), the sum stays in [0,4q): 7q < 2^63 for q < 2^60.
+    static constexpr bool kKeyQuotient = true;
+    HE_HD void acc_mac(Acc &acc, T x, T key, u64 keyq) const
+    {
+        const u64 s = acc + (key * x - mulhi64(x, keyq) * q);
+        acc = s >= 2 * two_q ? s - 2 * two_q : s;
+    }
+    HE_HD u64 acc_canon(Acc acc) const { return to_canon(acc); }
+    // floor(w * 2^64 / q) from the Barrett constant floor(2^128/q) = cr1:cr0, at most 2 too small (never too large)
+    HE_HD u64 shoup_quotient_est(u64 w) const { return w * cr1 + mulhi64(w, cr0); }
     // (t - x) * inv (+ addend): t, addend canonical, x lazy < 4q; inv given as Shoup pair
     HE_HD u64 floor_fin(u64 t, T x, u64 inv, u64 inv_shoup, double, double, u64 addend) const
     {
@@ -234,7 +242,8 @@ struct ArF64 {
     HE_HD T dy_add(T x, T y) const { return x + y; }
     HE_HD u64 dy_out(T x) const { return to_canon2(x); }
     HE_HD T key_in(u64 bits) const { return from_raw(bits); }
-    HE_HD void acc_mac(Acc &acc, T x, T key) const { acc += mulmod_vv(x, key); }
+    static constexpr bool kKeyQuotient = false;
+    HE_HD void acc_mac(Acc &acc, T x, T key, u64) const { acc += mulmod_vv(x, key); }
     HE_HD u64 acc_canon(Acc acc) const { return to_canon(acc); }
     HE_HD u64 floor_fin(u64 t, T x, u64, u64, double inv_d, double inv_i, u64 addend) const
     {

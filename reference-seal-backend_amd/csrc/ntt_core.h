@@ -165,7 +165,7 @@ template <class TW> HE_HD void gather_C(const TW &tw, int lane, Tw16 w[kTwC])
 // One radix-2 stage over the 16 registers of U rows: butterflies (r, r | 1<<BIT) with twiddle index widx(r), issued
 // in groups of kBflyGroup independent butterflies (Ar::bfly_fwd_g).
 #ifndef HE355_BFLY_GROUP
-#define HE355_BFLY_GROUP 8
+#define HE355_BFLY_GROUP 2
 #endif
 constexpr int kBflyGroup = HE355_BFLY_GROUP;
 template <int U, int BIT, class Ar, class WIdx> HE_HD void row_fwd_stage(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 *w, WIdx widx)
