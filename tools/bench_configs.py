@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Timings of the other BASELINE.json configurations (configs[0], [1], [3], [4]) on one MI355X, inputs resident in HBM,
+HIP events on the library's stream.  Not the judged bench line (that is bench.py = configs[2]); the output goes to
+profiles/ as evidence for DESIGN.md.  One JSON object per line."""
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+be = importlib.import_module("reference-seal-backend_amd")
+HBM_PEAK = 8.0e12
+
+
+def timed(ctx, fn, reps):
+    fn()
+    ctx.sync()
+    ctx.timer_begin()
+    for _ in range(reps):
+        fn()
+    ms = ctx.timer_end()
+    return ms / reps
+
+
+def cfg1_bfv_add():
+    # configs[0] at the reference's default parameters (N=8192, {60,40,60}), batch scaled up to 4096 results
+    g = be.Context(be.SCHEME_BFV, 8192, bit_sizes=[60, 40, 60], plain_bits=20, device=0)
+    L, N, n = g.L, g.N, 4096
+    a, b, o = g.alloc(n * 2 * L * N), g.alloc(n * 2 * L * N), g.alloc(n * 2 * L * N)
+    g.fill_uniform(a, n * 2 * L, list(range(L)), 1)
+    g.fill_uniform(b, n * 2 * L, list(range(L)), 2)
+    ms = timed(g, lambda: g.add(L, 2, n, a, b, be.Context.pairwise(), o), 20)
+    byts = 3 * 2 * L * N * 8
+    out = dict(config="configs[0] BFV EltwiseAdd N=8192 L=2", results=n, ms=ms, ops_per_s=n / ms * 1e3, algorithmic_bytes_per_op=byts,
+               hbm_GBps=byts * n / ms / 1e6, roofline_frac=byts * n / (ms / 1e3) / HBM_PEAK)
+    g.close()
+    return out
+
+
+def cfg2_ckks_multiply():
+    g = be.Context(be.SCHEME_CKKS, 16384, bit_sizes=be.chain_bits(8, 45), device=0)
+    L, N = g.L, g.N
+    res = []
+    for b0, b1 in ((256, 1), (16, 16)):
+        n = b0 * b1
+        a, b, o = g.alloc(b0 * 2 * L * N), g.alloc(b1 * 2 * L * N), g.alloc(n * 3 * L * N)
+        g.fill_uniform(a, b0 * 2 * L, list(range(L)), 1)
+        g.fill_uniform(b, b1 * 2 * L, list(range(L)), 2)
+        ms = timed(g, lambda: g.multiply(L, n, a, b, be.Context.outer(0, b0, 0, b1), o), 20)
+        byts = 7 * L * N * 8
+        res.append(dict(config=f"configs[1] CKKS EltwiseMult N=2^14 L=8 batch {b0}x{b1}", results=n, ms=ms, ops_per_s=n / ms * 1e3,
+                        algorithmic_bytes_per_op=byts, hbm_GBps=byts * n / ms / 1e6, roofline_frac=byts * n / (ms / 1e3) / HBM_PEAK))
+    g.close()
+    return res
+
+
+def cfg4_dot_product():
+    g = be.Context(be.SCHEME_CKKS, 32768, bit_sizes=be.chain_bits(16, 45), device=0)
+    L, N, n, count = g.L, g.N, 64, 4096
+    a, b, o, t = g.alloc(n * 2 * L * N), g.alloc(2 * L * N), g.alloc(n * 2 * L * N), g.alloc(n * 2 * L * N)
+    g.fill_uniform(a, n * 2 * L, list(range(L)), 1)
+    g.fill_uniform(b, 2 * L, list(range(L)), 2)
+    g.set_relin_key_synthetic(7)
+    for k in range(12):
+        g.set_galois_key_synthetic(g.galois_elt(1 << k), 100 + k)
+
+    def run():
+        g.multiply_relin(L, n, a, b, be.Context.outer(0, n, 0, 1), o)
+        g.accumulate(L, n, o, count, t)
+    ms = timed(g, run, 3)
+    out = dict(config="configs[3] CKKS DotProduct n=4096 N=2^15 L=16 (multiply, relinearize, 12 rotate+add)", results=n, ms=ms, ops_per_s=n / ms * 1e3,
+               key_switches_per_result=13)
+    g.close()
+    return out
+
+
+if __name__ == "__main__":
+    for r in [cfg1_bfv_add()] + cfg2_ckks_multiply() + [cfg4_dot_product()]:
+        print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
