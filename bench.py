@@ -129,6 +129,7 @@ def main():
     for _ in range(args.steps):
         step()
     gpu_ms = ctx.timer_end()  # HIP events on the stream the kernels run on
+    k3_ms, k3_launches, k3_ops = ctx.probe_dominant_kernel()  # HIP events around every k_k3<fp64> launch of the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -165,6 +166,14 @@ def main():
         if os.path.exists(tpath) and n == BATCH:
             traffic = json.load(open(tpath))["hbm_bytes_per_op"] * n
         achieved = bytes_op * n * args.steps / gpu_s / 1e9
+        # dominant kernel: k_k3 for the fp64-engine primes (key products of the key switch).  Algorithmic bytes per op of
+        # that kernel: the lifted digit rows it transforms (n_f * (L-1) + n_f polys), its outputs (2 * n_f polys) and the key
+        # rows of those primes once per launch.
+        n_f = sum(1 for i in list(range(L)) + [K - 1] if ctx.fp64[i])
+        k3_ops_per_launch = k3_ops / max(1, k3_launches)
+        k3_bytes_op = (n_f * L + 2 * n_f) * N * 8 + (L * 2 * n_f * N * 8) / max(1.0, k3_ops_per_launch)
+        k3_avg_ms = k3_ms / max(1, k3_launches)
+        k3_gbps = k3_bytes_op * k3_ops_per_launch / (k3_avg_ms / 1e3) / 1e9 if k3_launches else None
         out = {
             "metric": "ciphertext-ops/sec (CKKS ct x ct mul+relin+rescale, N=2^15, L=16)",
             "value": round(value, 2),
@@ -187,6 +196,14 @@ def main():
                          "traffic_note": "HBM bytes per step (1024 ops) from PMC counters; algorithmic bytes per step = %d" % int(bytes_op * n),
                          "kernel": "mul->relin->rescale kernel sequence (k_k1, k_k2, k_k3 x2, k_floor_cols x2, k_floor_rows x4 per chunk)",
                          "algorithmic_bytes_per_op": bytes_op,
+                         "dominant_kernel": {"name": "k_k3<ArF64> (forward row pass of the lifted digits + key MAC, fp64-engine primes)",
+                                             "launches": k3_launches, "ops_per_launch": k3_ops_per_launch, "avg_launch_ms_hip_events": round(k3_avg_ms, 4),
+                                             "share_of_gpu_time": round(k3_ms / gpu_ms, 3) if gpu_ms else None,
+                                             "algorithmic_bytes_per_launch": round(k3_bytes_op * k3_ops_per_launch),
+                                             "achieved_GBps": round(k3_gbps, 1) if k3_gbps else None,
+                                             "frac_of_hbm_peak": round(k3_gbps * 1e9 / HBM_PEAK, 4) if k3_gbps else None,
+                                             "note": "launch durations overlap the other stream's kernels (two-stream schedule); the rocprofv3 "
+                                                     "kernel-trace of the same command shows the same stretched durations"},
                          "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 3),
                          "note": "expected binding resource is the VALU (64-bit modular butterflies), not HBM: SURVEY.md §0.6"},
             "cpu_baseline": cpu,

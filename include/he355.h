@@ -138,6 +138,9 @@ int he355_ntt_inverse(he355_ctx *ctx, uint64_t *d_polys, uint64_t n_polys, const
 /* ---- timing on the stream the kernels run on (HIP events) ---- */
 int he355_timer_begin(he355_ctx *ctx);
 int he355_timer_end(he355_ctx *ctx, float *elapsed_ms);
+/* HIP events around every launch of the dominant kernel (k_k3, fp64-engine primes: the key-product kernel of the key switch)
+ * between he355_timer_begin and he355_timer_end: summed duration, number of launches and ops they covered */
+int he355_probe_dominant_kernel(he355_ctx *ctx, float *total_ms, uint64_t *launches, uint64_t *ops);
 /* ---- tuning ---- */
 int he355_set_chunk(he355_ctx *ctx, uint64_t ops_per_chunk); /* ops processed per kernel sequence (scratch ~ 117 MiB/op at N=2^15, L=16) */
 

@@ -93,6 +93,7 @@ def lib():
             "he355_ntt_forward": (i32, [vp, vp, u64, u8p, u32]),
             "he355_ntt_inverse": (i32, [vp, vp, u64, u8p, u32]),
             "he355_timer_begin": (i32, [vp]), "he355_timer_end": (i32, [vp, C.POINTER(C.c_float)]),
+            "he355_probe_dominant_kernel": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
             "he355_set_chunk": (i32, [vp, u64]),
         }
         for name, (res, args) in sig.items():
@@ -111,7 +112,7 @@ C_ABI_SYMBOLS = [
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",
     "he355_mod_switch_drop", "he355_sum", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_accumulate",
-    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_set_chunk",
+    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk",
 ]
 
 
@@ -300,6 +301,12 @@ class Context:
     # -- timing on the kernels' stream -----------------------------------------------------------
     def timer_begin(self):
         _check(lib().he355_timer_begin(self.h))
+
+    def probe_dominant_kernel(self):
+        """(total ms, launches, ops) of the k_k3<fp64> launches inside the last timer_begin/timer_end region."""
+        ms, n, ops = C.c_float(), C.c_uint64(), C.c_uint64()
+        _check(lib().he355_probe_dominant_kernel(self.h, C.byref(ms), C.byref(n), C.byref(ops)))
+        return float(ms.value), int(n.value), int(ops.value)
 
     def timer_end(self) -> float:
         ms = C.c_float()

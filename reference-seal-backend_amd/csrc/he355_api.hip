@@ -718,7 +718,29 @@ public:
         else launch_ntt_forward(env_, v, (u32)(n_polys / period));
         HIPCHECK(hipGetLastError());
     }
-    void timer_begin() { use(); HIPCHECK(hipEventRecord(ev0_, stream_)); }
+    void timer_begin()
+    {
+        use();
+        probe_.used = 0;
+        probe_.ops = 0;
+        env_.probe = &probe_; // probed until timer_end
+        HIPCHECK(hipEventRecord(ev0_, stream_));
+    }
+    // dominant-kernel probe of the region closed by the last timer_end: total duration, launches, ops covered
+    void probe_result(float *total_ms, u64 *launches, u64 *ops)
+    {
+        use();
+        float tot = 0;
+        for (int i = 0; i < probe_.used; ++i) {
+            float ms = 0;
+            HIPCHECK(hipEventSynchronize(probe_.stop[i]));
+            HIPCHECK(hipEventElapsedTime(&ms, probe_.start[i], probe_.stop[i]));
+            tot += ms;
+        }
+        if (total_ms) *total_ms = tot;
+        if (launches) *launches = (u64)probe_.used;
+        if (ops) *ops = probe_.ops;
+    }
     float timer_end()
     {
         use();
@@ -726,11 +748,13 @@ public:
         HIPCHECK(hipEventSynchronize(ev1_));
         float ms = 0;
         HIPCHECK(hipEventElapsedTime(&ms, ev0_, ev1_));
+        env_.probe = nullptr;
         return ms;
     }
     void sync() { use(); HIPCHECK(hipStreamSynchronize(stream_)); HIPCHECK(hipStreamSynchronize(stream2_)); }
 
 private:
+    KernelProbe probe_;
     const Params &P;
     int device_;
     hipStream_t stream_ = nullptr;
@@ -997,6 +1021,15 @@ int he355_timer_end(he355_ctx *c, float *ms)
     return guarded([&] {
         const float v = dev(c).timer_end();
         if (ms) *ms = v;
+    });
+}
+int he355_probe_dominant_kernel(he355_ctx *c, float *total_ms, uint64_t *launches, uint64_t *ops)
+{
+    return guarded([&] {
+        u64 l = 0, o = 0;
+        dev(c).probe_result(total_ms, &l, &o);
+        if (launches) *launches = l;
+        if (ops) *ops = o;
     });
 }
 int he355_set_chunk(he355_ctx *c, uint64_t ops)

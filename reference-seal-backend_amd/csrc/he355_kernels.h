@@ -16,7 +16,17 @@ struct FloorConst {
     u64 pad_;
 };
 
+// Optional HIP-event probe around the launches of the dominant kernel (k_k3, fp64 engine): bench.py reports that
+// kernel's average launch duration from inside the timed region (events on the stream the kernel runs on).
+struct KernelProbe {
+    static constexpr int kCap = 2048;
+    hipEvent_t start[kCap], stop[kCap];
+    int created = 0, used = 0;
+    u64 ops = 0; // ops covered by the probed launches
+};
+
 struct KernelEnv {
+    KernelProbe *probe = nullptr; // null: no probing
     const PrimeDev *primes; // device array [K]
     const FloorConst *floor_consts; // device array [K*K], entry [s*K + i]
     int N, logn1, K, Ltop, scheme;

@@ -1435,6 +1435,18 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         const unsigned g = (unsigned)(((tiles + 7) / 8) * 8 * n_ogb);
         static const int stage_env = getenv("HE355_K3_STAGE") ? atoi(getenv("HE355_K3_STAGE")) : HE355_K3_STAGE_DEFAULT;
         const bool staged = stage_env != 0 || shape / 10 != 1;
+        KernelProbe *pr = pass == 0 ? env.probe : nullptr;
+        int slot = -1;
+        if (pr && pr->used < KernelProbe::kCap) {
+            slot = pr->used++;
+            if (slot >= pr->created) {
+                (void)hipEventCreate(&pr->start[slot]);
+                (void)hipEventCreate(&pr->stop[slot]);
+                pr->created = slot + 1;
+            }
+            pr->ops += n_ops;
+            (void)hipEventRecord(pr->start[slot], env.stream);
+        }
         if (pass == 0) {
             switch (shape) {
             case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
@@ -1454,6 +1466,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             default: throw std::runtime_error("unsupported K3 u64 shape");
             }
         }
+        if (slot >= 0) (void)hipEventRecord(pr->stop[slot], env.stream);
     }
     // special-prime sums: start the inverse transform (row pass) for the mod-down
     launch_rows_inv_select(env, env.K - 1, n_ops * 2, buf.tp, (u64)env.N, buf.tpr);
