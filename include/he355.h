@@ -131,6 +131,16 @@ int he355_apply_galois(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, 
 int he355_rotate(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, int step, uint64_t *d_out);
 /* accumulateCKKS: in place log-tree sum of the first `count` slots; d_tmp: scratch slab of the same size */
 int he355_accumulate(he355_ctx *ctx, int L, uint64_t n, uint64_t *d_inout, uint64_t count, uint64_t *d_tmp);
+/* ---- client side on the device: encryptor()->encrypt (ckks eltwise .cpp:242, bfv eltwise .cpp:233) and
+ * SEALContextWrapper::decrypt (src/engine/seal_context.cpp:265-287), batched.  Keys: host arrays in SEAL layout, NTT form:
+ * public key [2][K][N], secret key [K][N].  Randomness of he355_encrypt is counter-based: ciphertext r draws u, e0, e1 from
+ * (seed, index first_index + r) — csrc/client/sampler.h — so the host client with the same seed/index gives the same bits. */
+int he355_set_public_key(he355_ctx *ctx, const uint64_t *h_pk);
+int he355_set_secret_key(he355_ctx *ctx, const uint64_t *h_sk);
+/* d_plain: CKKS [n][L_top][N] NTT-form plaintexts, BFV [n][N] coefficients mod t; d_out: [n][2][L_top][N] */
+int he355_encrypt(he355_ctx *ctx, uint64_t n, const uint64_t *d_plain, uint64_t seed, uint64_t first_index, uint64_t *d_out);
+/* d_ct: [n][size][L][N], size 2 or 3; d_out: CKKS [n][L][N] NTT-form plaintext, BFV [n][N] coefficients mod t */
+int he355_decrypt(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_ct, uint64_t *d_out);
 /* transforms of n_polys residue polynomials, polynomial p under prime prime_of[p % period] (test / client use) */
 int he355_ntt_forward(he355_ctx *ctx, uint64_t *d_polys, uint64_t n_polys, const uint8_t *prime_of, uint32_t period);
 int he355_ntt_inverse(he355_ctx *ctx, uint64_t *d_polys, uint64_t n_polys, const uint8_t *prime_of, uint32_t period);

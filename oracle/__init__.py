@@ -67,6 +67,7 @@ def lib():
             "ho_multiply_ntt": (None, [vp, sz, _u64p, _u64p, _u64p]),
             "ho_switch_key": (None, [vp, sz, _u64p, _u64p, _u64p]),
             "ho_relinearize": (None, [vp, sz, _u64p, _u64p]),
+            "ho_encrypt_explicit": (None, [vp, _u64p, _u64p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u64p]),
             "ho_multiply_plain": (None, [vp, sz, sz, _u64p, _u64p, _u64p]),
             "ho_add_plain": (None, [vp, sz, sz, _u64p, _u64p, _u64p]),
             "ho_mod_switch_drop": (None, [vp, sz, sz, sz, _u64p, _u64p]),
@@ -283,6 +284,14 @@ class Context:
     def encrypt(self, pk, plain, seed):
         out = np.empty((2, self.L, self.N), dtype=np.uint64)
         lib().ho_encrypt(self.h, _p(pk), _p(np.ascontiguousarray(plain, dtype=np.uint64)), seed, _p(out))
+        return out
+
+    def encrypt_explicit(self, pk, plain, u_small, e0_small, e1_small):
+        """ho_encrypt with the three sampled polynomials given (small signed coefficients, int32[N])."""
+        out = np.empty((2, self.L, self.N), dtype=np.uint64)
+        i32p = C.POINTER(C.c_int32)
+        a = [np.ascontiguousarray(x, dtype=np.int32) for x in (u_small, e0_small, e1_small)]
+        lib().ho_encrypt_explicit(self.h, _p(pk), _p(np.ascontiguousarray(plain, dtype=np.uint64)), *[x.ctypes.data_as(i32p) for x in a], _p(out))
         return out
 
     def decrypt_phase(self, ct, sk):

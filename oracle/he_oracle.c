@@ -805,16 +805,47 @@ void ho_keygen_galois(const ho_ctx *c, const u64 *sk, uint32_t elt, u64 seed, u6
 /* encryptor.cpp Encryptor::encrypt_internal (asymmetric): encrypt_zero_asymmetric at the key level
  * (u ternary, e0,e1 CBD), divide-and-round by the special prime, then add the plaintext.
  * Reference: ckks eltwise .cpp:242, bfv eltwise .cpp:233 */
+static void small_to_rns(const ho_ctx *c, size_t nmod, const int32_t *small, u64 *out)
+{
+    for (size_t i = 0; i < nmod; ++i) {
+        const u64 q = c->t[i].m.q;
+        for (size_t n = 0; n < c->N; ++n) out[i * c->N + n] = small[n] >= 0 ? (u64)small[n] : q - (u64)(-small[n]);
+    }
+}
+static void encrypt_core(const ho_ctx *c, const u64 *pk, const u64 *plain, u64 *u, u64 *e01, u64 *out);
 void ho_encrypt(const ho_ctx *c, const u64 *pk, const u64 *plain, u64 seed, u64 *out)
+{
+    const size_t N = c->N, K = c->K;
+    rng_t r; rng_seed(&r, seed);
+    u64 *u = (u64 *)malloc(K * N * 8), *e = (u64 *)malloc(2 * K * N * 8);
+    sample_ternary(&r, c, K, u);
+    sample_cbd(&r, c, K, e);
+    sample_cbd(&r, c, K, e + K * N);
+    encrypt_core(c, pk, plain, u, e, out);
+    free(u); free(e);
+}
+/* the same encryption with the three sampled polynomials given (coefficients in {-1,0,1} / small integers): lets a test
+ * drive it with exactly the randomness another implementation used */
+void ho_encrypt_explicit(const ho_ctx *c, const u64 *pk, const u64 *plain, const int32_t *u_small, const int32_t *e0_small,
+                         const int32_t *e1_small, u64 *out)
+{
+    const size_t N = c->N, K = c->K;
+    u64 *u = (u64 *)malloc(K * N * 8), *e = (u64 *)malloc(2 * K * N * 8);
+    small_to_rns(c, K, u_small, u);
+    small_to_rns(c, K, e0_small, e);
+    small_to_rns(c, K, e1_small, e + K * N);
+    encrypt_core(c, pk, plain, u, e, out);
+    free(u); free(e);
+}
+/* u: [K][N] coefficient form (transformed in place); e01: [2][K][N] coefficient form */
+static void encrypt_core(const ho_ctx *c, const u64 *pk, const u64 *plain, u64 *u, u64 *e01, u64 *out)
 {
     const size_t N = c->N, K = c->K, L = c->Ltop;
     const int ckks = c->scheme == HO_SCHEME_CKKS;
-    rng_t r; rng_seed(&r, seed);
-    u64 *u = (u64 *)malloc(K * N * 8), *e = (u64 *)malloc(K * N * 8), *z = (u64 *)malloc(2 * K * N * 8);
-    sample_ternary(&r, c, K, u);
+    u64 *z = (u64 *)malloc(2 * K * N * 8);
     for (size_t i = 0; i < K; ++i) ntt_forward(&c->t[i], N, u + i * N);
     for (size_t k = 0; k < 2; ++k) {
-        sample_cbd(&r, c, K, e);
+        u64 *e = e01 + k * K * N;
         for (size_t i = 0; i < K; ++i) {
             const ho_mod *m = &c->t[i].m;
             u64 *zi = z + (k * K + i) * N;
@@ -857,7 +888,7 @@ void ho_encrypt(const ho_ctx *c, const u64 *pk, const u64 *plain, u64 seed, u64 
             }
         }
     }
-    free(u); free(e); free(z);
+    free(z);
 }
 
 /* decryptor.cpp dot_product_ct_sk_array: c0 + c1 s + c2 s^2 (+...).  Size-3 inputs must work: the

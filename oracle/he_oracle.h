@@ -125,6 +125,9 @@ void ho_keygen_galois(const ho_ctx *c, const uint64_t *sk, uint32_t elt, uint64_
  * out: [2][L][N] (CKKS NTT form, BFV coefficient form). Follows Encryptor: encrypt zero at key level, then
  * divide-and-round by the special prime. */
 void ho_encrypt(const ho_ctx *c, const uint64_t *pk, const uint64_t *plain, uint64_t seed, uint64_t *out);
+/* same, with the sampled polynomials given as small signed coefficients (u in {-1,0,1}; e0, e1 centred binomial) */
+void ho_encrypt_explicit(const ho_ctx *c, const uint64_t *pk, const uint64_t *plain, const int32_t *u_small, const int32_t *e0_small,
+                         const int32_t *e1_small, uint64_t *out);
 /* phase = c0 + c1 s + c2 s^2 ... : out [L][N]; CKKS: NTT form, BFV: coefficient form */
 void ho_decrypt_phase(const ho_ctx *c, size_t L, size_t size, const uint64_t *ct, const uint64_t *sk, uint64_t *out);
 /* BFV: phase (coefficient form, level L) -> plaintext values mod t, exact round(t*x/q) via CRT */

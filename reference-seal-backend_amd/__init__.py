@@ -81,6 +81,9 @@ def lib():
             "he355_multiply_relin": (i32, [vp, i32, u64, vp, vp, Indexer, i32, vp]),
             "he355_relinearize": (i32, [vp, i32, u64, vp, vp]),
             "he355_relinearize_rescale": (i32, [vp, i32, u64, vp, vp]),
+            "he355_set_public_key": (i32, [vp, vp]), "he355_set_secret_key": (i32, [vp, vp]),
+            "he355_encrypt": (i32, [vp, u64, vp, u64, u64, vp]),
+            "he355_decrypt": (i32, [vp, i32, i32, u64, vp, vp]),
             "he355_multiply_plain": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
             "he355_add_plain": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
             "he355_mod_switch_drop": (i32, [vp, i32, i32, u64, vp, vp]),
@@ -111,7 +114,7 @@ C_ABI_SYMBOLS = [
     "he355_fill_uniform", "he355_set_relin_key", "he355_set_galois_key", "he355_set_relin_key_synthetic",
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",
-    "he355_mod_switch_drop", "he355_sum", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_accumulate",
+    "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_accumulate",
     "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk",
 ]
 
@@ -274,6 +277,20 @@ class Context:
 
     def sum(self, L, size, n, inp, out):
         _check(lib().he355_sum(self.h, L, size, n, inp.ptr, out.ptr))
+
+    def set_public_key(self, pk: np.ndarray):
+        pk = np.ascontiguousarray(pk, dtype=np.uint64)
+        _check(lib().he355_set_public_key(self.h, pk.ctypes.data))
+
+    def set_secret_key(self, sk: np.ndarray):
+        sk = np.ascontiguousarray(sk, dtype=np.uint64)
+        _check(lib().he355_set_secret_key(self.h, sk.ctypes.data))
+
+    def encrypt(self, n, plain, seed, first_index, out):
+        _check(lib().he355_encrypt(self.h, n, plain.ptr, seed, first_index, out.ptr))
+
+    def decrypt(self, L, size, n, ct, out):
+        _check(lib().he355_decrypt(self.h, L, size, n, ct.ptr, out.ptr))
 
     def relinearize_rescale(self, L, n, ct3, out):
         _check(lib().he355_relinearize_rescale(self.h, L, n, ct3.ptr, out.ptr))

@@ -1,5 +1,6 @@
 // he_client.cpp — see he_client.h.  Host-only C++17 (client side of the backend; untimed).
 #include "he_client.h"
+#include "sampler.h"
 
 #include <cmath>
 #include <cstring>
@@ -158,7 +159,7 @@ void host_ntt_inverse(const PrimeTables &pt, size_t N, u64 *x)
     for (size_t j = 0; j < N; ++j) x[j] = mulm(x[j], pt.ninv, pt.mod);
 }
 
-Client::Client(const Params &params, uint64_t seed) : P(params), rng_(seed)
+Client::Client(const Params &params, uint64_t seed) : P(params), rng_(seed), enc_seed_(splitmix64(seed ^ 0x656e6372797074ull))
 {
     const size_t N = P.N, K = P.K;
     // slot -> evaluation-point index: powers of the generator 3 (CKKSEncoder / BatchEncoder matrix_reps_index_map)
@@ -368,11 +369,18 @@ std::vector<u64> Client::encrypt_zero()
     // special prime
     const size_t N = P.N, K = P.K;
     const bool ckks = P.scheme == kSchemeCKKS;
-    std::vector<u64> u, e, z(2 * K * N);
-    sample_ternary(u, K);
+    std::vector<u64> u(K * N), e(K * N), z(2 * K * N);
+    const uint64_t r = enc_index_++;
+    for (size_t n = 0; n < N; ++n) {
+        const int v = sample_ternary_at(enc_seed_, enc_stream(r, 0), n);
+        for (size_t i = 0; i < K; ++i) u[i * N + n] = small_to_residue(v, P.primes[i].q);
+    }
     for (size_t i = 0; i < K; ++i) host_ntt_forward(P.primes[i], N, u.data() + i * N);
     for (size_t k = 0; k < 2; ++k) {
-        sample_cbd(e, K);
+        for (size_t n = 0; n < N; ++n) {
+            const int v = sample_cbd_at(enc_seed_, enc_stream(r, 1 + (int)k), n);
+            for (size_t i = 0; i < K; ++i) e[i * N + n] = small_to_residue(v, P.primes[i].q);
+        }
         for (size_t i = 0; i < K; ++i) {
             const PrimeTables &pt = P.primes[i];
             u64 *zi = z.data() + (k * K + i) * N;

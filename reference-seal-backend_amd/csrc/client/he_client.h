@@ -43,8 +43,14 @@ public:
     void bfv_decode(const u64 *plain, int64_t *out) const;
 
     // ---- encryption at the first data level: ct [2][Ltop][N] (CKKS NTT form, BFV coefficient form) ----
+    // Randomness is counter-based (client/sampler.h): the ciphertext with index r draws its three polynomials from
+    // (encrypt_seed, streams 3r..3r+2); every call uses the next index.  The device encryption (he355_encrypt) given the
+    // same seed and index produces the same bits.
     std::vector<u64> encrypt(const u64 *plain);
     std::vector<u64> encrypt_zero();
+    uint64_t encrypt_seed() const { return enc_seed_; }
+    uint64_t encrypt_index() const { return enc_index_; }               // index the next encryption will use
+    void set_encrypt_index(uint64_t index) { enc_index_ = index; }
     // ---- decryption of a size-`size` ciphertext at level L (size 3 allowed: the reference decrypts
     //      un-relinearized products, ckks eltwise .cpp:342-344). CKKS: [L][N] NTT plaintext; BFV: [N] mod t ----
     std::vector<u64> decrypt(const u64 *ct, size_t size, size_t L) const;
@@ -59,6 +65,7 @@ private:
 
     const Params &P;
     std::mt19937_64 rng_;
+    uint64_t enc_seed_ = 0, enc_index_ = 0;
     std::vector<u64> sk_, pk_;
     std::vector<uint32_t> slot_index_; // encoders' slot -> (bit-reversed) evaluation index map
     PrimeTables plain_tables_;         // BFV: NTT mod t

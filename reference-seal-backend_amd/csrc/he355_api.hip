@@ -17,6 +17,7 @@
 #include "he355_kernels.h"
 #include "he_params.h"
 #include "ntt_core.h"
+#include "client/multiword.h"
 
 namespace he355 {
 
@@ -162,6 +163,7 @@ public:
         (void)hipFree(scratch2_);
         (void)hipFree(rot_tmp_);
         (void)hipFree(bfv_scratch_);
+        (void)hipFree(client_scratch_);
         for (auto &kv : d_gather_) (void)hipFree(kv.second);
         (void)hipEventDestroy(ev_fork_);
         (void)hipEventDestroy(ev_join_);
@@ -703,6 +705,162 @@ public:
         launch_bfv_tail_sp(env_, nc * 2, B.tpr, S.rlr);
         launch_bfv_tail_fin(env_, L, nc, B.t, S.rlr, B.c01, B.c01_item_stride);
     }
+    // ---- client side on the device -----------------------------------------------------
+    void set_public_key(const u64 *h_pk) // [2][K][N], NTT form
+    {
+        use();
+        const size_t bytes = 2 * P.K * P.N * 8;
+        if (!d_pk_) { HIPCHECK(hipMalloc(&d_pk_, bytes)); owned_.push_back(d_pk_); }
+        HIPCHECK(hipMemcpy(d_pk_, h_pk, bytes, hipMemcpyHostToDevice));
+    }
+    void set_secret_key(const u64 *h_sk) // [K][N], NTT form
+    {
+        use();
+        const size_t bytes = P.K * P.N * 8;
+        if (!d_sk_) { HIPCHECK(hipMalloc(&d_sk_, bytes)); owned_.push_back(d_sk_); }
+        HIPCHECK(hipMemcpy(d_sk_, h_sk, bytes, hipMemcpyHostToDevice));
+    }
+    u64 *client_scratch(size_t elems)
+    {
+        if (elems > client_scratch_elems_) {
+            HIPCHECK(hipStreamSynchronize(stream_));
+            if (client_scratch_) HIPCHECK(hipFree(client_scratch_));
+            client_scratch_ = nullptr;
+            HIPCHECK(hipMalloc(&client_scratch_, elems * 8));
+            client_scratch_elems_ = elems;
+        }
+        return client_scratch_;
+    }
+    static PolyView poly_view(u64 *base, int polys_per_item, size_t N, int period)
+    {
+        if (polys_per_item > 64) throw std::invalid_argument("too many polynomials per item");
+        PolyView v;
+        v.base = base; v.item_stride = (u64)polys_per_item * N; v.polys_per_item = polys_per_item; v.pad_ = 0;
+        for (int i = 0; i < polys_per_item; ++i) v.prime_of[i] = (unsigned char)(i % period);
+        return v;
+    }
+    // Encryptor::encrypt (asymmetric) of n plaintexts: CKKS plain [n][Ltop][N] NTT form, BFV plain [n][N] mod t;
+    // out [n][2][Ltop][N].  Ciphertext r uses the counter-based streams of index first_index + r (client/sampler.h).
+    void encrypt(u64 n, const u64 *plain, u64 seed, u64 first_index, u64 *out)
+    {
+        use();
+        if (!d_pk_) throw std::invalid_argument("public key not set");
+        const size_t N = P.N, K = P.K, L = P.Ltop;
+        const bool ckks = P.scheme == kSchemeCKKS;
+        const u64 cmax = 32;
+        // per ciphertext: u K, e 2K, z 2K (BFV), tail 2, cols 2L polys
+        u64 *base = client_scratch(cmax * (K + 2 * K + 2 * K + 2 + 2 * L) * N);
+        u64 *u = base, *e = u + cmax * K * N, *z = e + cmax * 2 * K * N, *tpr = z + cmax * 2 * K * N, *cols = tpr + cmax * 2 * N;
+        u64 qdivt[16] = {0}, q_mod_t = 1;
+        if (!ckks) {
+            const u64 t = P.plain_modulus;
+            for (size_t i = 0; i < L; ++i) q_mod_t = (u64)(((u128)q_mod_t * (P.primes[i].q % t)) % t);
+            for (size_t i = 0; i < L; ++i) {
+                const u64 qi = P.primes[i].q, tinv = Params::invmod(t % qi, qi), neg = (q_mod_t % qi) ? qi - q_mod_t % qi : 0;
+                qdivt[i] = (u64)(((u128)neg * tinv) % qi); // floor(q/t) mod q_i = -(q mod t) * t^-1
+            }
+        }
+        for (u64 off = 0; off < n; off += cmax) {
+            const u64 c = std::min<u64>(cmax, n - off);
+            u64 *o = out + off * 2 * L * N;
+            launch_enc_sample(env_, c, seed, first_index + off, u, e);
+            launch_ntt_forward(env_, poly_view(u, (int)K, N, (int)K), (u32)c);
+            if (ckks) {
+                launch_ntt_forward(env_, poly_view(e, (int)(2 * K), N, (int)K), (u32)c);
+                launch_enc_mul_pk(env_, c, u, d_pk_, e, true); // z := u*pk + NTT(e), in the e buffer
+                if (K > 1) {
+                    const int SP = (int)K - 1;
+                    launch_rows_inv_select(env_, SP, c * 2, e + (size_t)SP * N, (u64)K * N, tpr);
+                    launch_floor_cols(env_, SP, (int)L, c * 2, tpr, cols);
+                    FloorRowsArgs fr;
+                    fr.src_prime = SP; fr.n_tgt = (int)L; fr.n_src = 2;
+                    fr.cols = cols;
+                    fr.tsrc = e; fr.tsrc_op_stride = 2 * K * N; fr.tsrc_poly_stride = K * N;
+                    fr.addend = nullptr; fr.add_op_stride = 0; fr.add_poly_stride = 0;
+                    fr.out = o; fr.out_op_stride = 2 * L * N; fr.out_poly_stride = L * N;
+                    fr.tail_prime = -1; fr.tail = nullptr;
+                    launch_floor_rows(env_, c, fr);
+                } else {
+                    HIPCHECK(hipMemcpyAsync(o, e, c * 2 * N * 8, hipMemcpyDeviceToDevice, stream_));
+                }
+                Indexer pw{};
+                pw.b1 = 1; pw.pairwise = 1;
+                launch_plain_op(env_, (int)L, 2, c, o, plain + off * L * N, pw, o, 1); // c0 += plain
+            } else {
+                launch_enc_mul_pk(env_, c, u, d_pk_, z, false);
+                launch_ntt_inverse(env_, poly_view(z, (int)(2 * K), N, (int)K), (u32)c);
+                Indexer pw{};
+                pw.b1 = 1; pw.pairwise = 1;
+                launch_addsub(env_, (int)K, 2, c, z, e, pw, z, false);
+                if (K > 1) launch_divround_last_coeff(env_, c * 2, z, o);
+                else HIPCHECK(hipMemcpyAsync(o, z, c * 2 * N * 8, hipMemcpyDeviceToDevice, stream_));
+                launch_bfv_add_scaled_plain(env_, (int)L, c, o, plain + off * N, P.plain_modulus, q_mod_t, qdivt);
+            }
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    const CrtTablesDev &crt_tables(int L)
+    {
+        auto it = crt_.find(L);
+        if (it != crt_.end()) return it->second;
+        const int words = L + 2;
+        std::vector<u64> Q(words, 0), halfQ(words, 0), punct((size_t)L * words, 0), inv(L);
+        Q[0] = 1;
+        for (int i = 0; i < L; ++i) client::mw_mul_small(Q.data(), words, P.primes[i].q);
+        for (int i = 0; i < words; ++i) halfQ[i] = (Q[i] >> 1) | (i + 1 < words ? Q[i + 1] << 63 : 0);
+        for (int i = 0; i < L; ++i) {
+            u64 *p = punct.data() + (size_t)i * words;
+            p[0] = 1;
+            u64 pm = 1;
+            const u64 qi = P.primes[i].q;
+            for (int k = 0; k < L; ++k)
+                if (k != i) {
+                    client::mw_mul_small(p, words, P.primes[k].q);
+                    pm = (u64)(((u128)pm * (P.primes[k].q % qi)) % qi);
+                }
+            inv[i] = Params::invmod(pm, qi);
+        }
+        u64 *d = nullptr;
+        const size_t tot = (size_t)words * 2 + (size_t)L * words + L;
+        HIPCHECK(hipMalloc(&d, tot * 8));
+        owned_.push_back(d);
+        HIPCHECK(hipMemcpy(d, Q.data(), words * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(d + words, halfQ.data(), words * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(d + 2 * words, punct.data(), punct.size() * 8, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(d + 2 * words + punct.size(), inv.data(), L * 8, hipMemcpyHostToDevice));
+        CrtTablesDev t;
+        t.L = L; t.words = words; t.Q = d; t.halfQ = d + words; t.punct = d + 2 * words; t.inv = d + 2 * words + punct.size();
+        t.Qd = client::mw_to_double(Q.data(), words); t.t = P.plain_modulus;
+        return crt_[L] = t;
+    }
+    // Decryptor::decrypt of n size-`size` ciphertexts at level L: CKKS -> [n][L][N] NTT-form plaintext (the phase);
+    // BFV -> [n][N] coefficients mod t
+    void decrypt(int L, int size, u64 n, const u64 *ct, u64 *out)
+    {
+        use();
+        check_level(L);
+        if (!d_sk_) throw std::invalid_argument("secret key not set");
+        if (size < 2 || size > 3) throw std::invalid_argument("ciphertext size must be 2 or 3");
+        const size_t N = P.N;
+        if (P.scheme == kSchemeCKKS) {
+            launch_dot_sk(env_, L, size, n, ct, d_sk_, out);
+            HIPCHECK(hipGetLastError());
+            return;
+        }
+        if (L > 16) throw std::invalid_argument("BFV decryption supports up to 16 data primes");
+        const CrtTablesDev &crt = crt_tables(L);
+        const u64 cmax = 64;
+        u64 *tmp = client_scratch(cmax * ((size_t)size * L + L) * N), *phase = tmp + cmax * (size_t)size * L * N;
+        for (u64 off = 0; off < n; off += cmax) {
+            const u64 c = std::min<u64>(cmax, n - off);
+            HIPCHECK(hipMemcpyAsync(tmp, ct + off * size * L * N, c * size * L * N * 8, hipMemcpyDeviceToDevice, stream_));
+            launch_ntt_forward(env_, poly_view(tmp, size * L, N, L), (u32)c);
+            launch_dot_sk(env_, L, size, c, tmp, d_sk_, phase);
+            launch_ntt_inverse(env_, poly_view(phase, L, N, L), (u32)c);
+            launch_bfv_scale_round(env_, c, phase, out + off * N, crt);
+        }
+        HIPCHECK(hipGetLastError());
+    }
     void ntt(u64 *polys, u64 n_polys, const uint8_t *prime_of, u32 period, bool inverse)
     {
         use();
@@ -764,6 +922,10 @@ private:
     FloorConst *d_floor_ = nullptr;
     std::vector<void *> owned_;
     u64 *d_relin_ = nullptr;
+    u64 *d_pk_ = nullptr, *d_sk_ = nullptr;
+    u64 *client_scratch_ = nullptr;
+    size_t client_scratch_elems_ = 0;
+    std::map<int, CrtTablesDev> crt_;
     std::map<uint32_t, u64 *> d_galois_;
     std::map<uint32_t, uint32_t *> d_perm_;
     u64 *scratch_ = nullptr, *scratch2_ = nullptr;
@@ -1022,6 +1184,22 @@ int he355_timer_end(he355_ctx *c, float *ms)
         const float v = dev(c).timer_end();
         if (ms) *ms = v;
     });
+}
+int he355_set_public_key(he355_ctx *c, const uint64_t *h_pk)
+{
+    return guarded([&] { dev(c).set_public_key(h_pk); });
+}
+int he355_set_secret_key(he355_ctx *c, const uint64_t *h_sk)
+{
+    return guarded([&] { dev(c).set_secret_key(h_sk); });
+}
+int he355_encrypt(he355_ctx *c, uint64_t n, const uint64_t *d_plain, uint64_t seed, uint64_t first_index, uint64_t *d_out)
+{
+    return guarded([&] { dev(c).encrypt(n, d_plain, seed, first_index, d_out); });
+}
+int he355_decrypt(he355_ctx *c, int L, int size, uint64_t n, const uint64_t *d_ct, uint64_t *d_out)
+{
+    return guarded([&] { dev(c).decrypt(L, size, n, d_ct, d_out); });
 }
 int he355_probe_dominant_kernel(he355_ctx *c, float *total_ms, uint64_t *launches, uint64_t *ops)
 {

@@ -127,4 +127,21 @@ void launch_bfv_tail_fin(const KernelEnv &env, int L, u64 n_ops, const u64 *t, c
 // inverse row pass of one residue of each poly: src [(op,k)] residue `prime` -> tail [(op,k)][N]
 void launch_rows_inv_select(const KernelEnv &env, int prime, u64 n_polys, const u64 *src, u64 src_poly_stride, u64 *tail);
 
+// ---- client side on the device: encryption / decryption ------------------------------
+// u [n][K][N], e [n][2][K][N]: sampled polynomials of ciphertexts first_index.. (coefficient form, canonical residues)
+void launch_enc_sample(const KernelEnv &env, u64 n_cts, u64 seed, u64 first_index, u64 *u, u64 *e);
+// z[r][k][i] = u[r][i] (.) pk[k][i] (+ z if add_in); NTT form at the key level
+void launch_enc_mul_pk(const KernelEnv &env, u64 n_cts, const u64 *u, const u64 *pk, u64 *z, bool add_in);
+// coefficient-form divide-and-round by the special prime: z [n_polys][K][N] -> out [n_polys][K-1][N]
+void launch_divround_last_coeff(const KernelEnv &env, u64 n_polys, const u64 *z, u64 *out);
+void launch_bfv_add_scaled_plain(const KernelEnv &env, int L, u64 n_cts, u64 *ct, const u64 *plain, u64 t, u64 q_mod_t, const u64 *qdivt);
+void launch_dot_sk(const KernelEnv &env, int L, int size, u64 n_cts, const u64 *ct, const u64 *sk, u64 *out);
+struct CrtTablesDev { // device arrays of the CRT tables of the first L primes (client/multiword.h CrtView)
+    int L, words;
+    const u64 *Q, *halfQ, *punct, *inv;
+    double Qd;
+    u64 t;
+};
+void launch_bfv_scale_round(const KernelEnv &env, u64 n_cts, const u64 *phase, u64 *plain, const CrtTablesDev &c);
+
 } // namespace he355

@@ -20,6 +20,8 @@
 
 #include "he355_kernels.h"
 #include "ntt_core.h"
+#include "client/multiword.h"
+#include "client/sampler.h"
 
 namespace he355 {
 namespace {
@@ -1260,6 +1262,127 @@ __global__ void __launch_bounds__(kBlock) k_bfv_tail_fin(const u64 *t, const u64
     }
 }
 
+// =======================================================================================================
+// Client side on the device: asymmetric encryption and decryption.
+// Reference call sites: encryptor()->encrypt (ckks eltwise .cpp:242, bfv eltwise .cpp:233), SEALContextWrapper::decrypt
+// (seal_context.cpp:265-287).  Same arithmetic as csrc/client/he_client.cpp (host) and oracle ho_encrypt / ho_decrypt_phase.
+// =======================================================================================================
+// u (ternary) and e0, e1 (centred binomial) of ciphertext `first_index + r`, as residues under all K key primes.
+// One thread = one coefficient of one ciphertext: three counter-based draws (client/sampler.h), 3*K stores.
+__global__ void __launch_bounds__(kBlock) k_enc_sample(u64 *u, u64 *e, const PrimeDev *primes, int K, int logN, u64 n_cts, u64 seed, u64 first_index)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 r = gid >> logN, n = gid & (((u64)1 << logN) - 1);
+    if (r >= n_cts) return;
+    const u64 idx = first_index + r;
+    const int vu = client::sample_ternary_at(seed, client::enc_stream(idx, 0), n);
+    const int v0 = client::sample_cbd_at(seed, client::enc_stream(idx, 1), n), v1 = client::sample_cbd_at(seed, client::enc_stream(idx, 2), n);
+    for (int i = 0; i < K; ++i) {
+        const u64 q = primes[i].q;
+        u[((r * K + i) << logN) + n] = client::small_to_residue(vu, q);
+        e[(((r * 2 + 0) * K + i) << logN) + n] = client::small_to_residue(v0, q);
+        e[(((r * 2 + 1) * K + i) << logN) + n] = client::small_to_residue(v1, q);
+    }
+}
+// z[r][k][i] = u[r][i] (.) pk[k][i] (+ z[r][k][i] when add_in: CKKS, where z holds NTT(e_k)); all NTT form, key level.
+__global__ void __launch_bounds__(kBlock) k_enc_mul_pk(const u64 *u, const u64 *pk, u64 *z, const PrimeDev *primes, int K, int logN, u64 n_cts, int add_in)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 pp = gid >> (logN - 1), e2 = gid & (((u64)1 << (logN - 1)) - 1);
+    const u64 r = pp / (2 * K);
+    if (r >= n_cts) return;
+    const int ki = (int)(pp % (2 * K)), i = ki % K;
+    const PrimeDev &P = primes[i];
+    const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(u + ((r * K + i) << logN))[e2];
+    const ulonglong2 y = reinterpret_cast<const ulonglong2 *>(pk + ((u64)ki << logN))[e2];
+    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(z + ((r * 2 * K + ki) << logN)) + e2;
+    const ModU64 m = make_modu(P);
+    ulonglong2 v;
+    v.x = barrett128((u128)x.x * y.x, m); v.y = barrett128((u128)x.y * y.y, m);
+    if (add_in) {
+        const ulonglong2 o = *dst;
+        v.x = addmod(v.x, o.x, P.q); v.y = addmod(v.y, o.y, P.q);
+    }
+    *dst = v;
+}
+// RNSTool::divide_and_round_q_last_inplace on coefficient-form data at the key level (BFV encryption):
+// z [n][2][K][N] -> out [n][2][L][N], L = K-1, dropping the special prime with rounding.
+__global__ void __launch_bounds__(kBlock) k_divround_last_coeff(const u64 *z, u64 *out, const PrimeDev *primes, const FloorConst *fc, int K, int logN,
+                                                                u64 n_polys)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 poly = gid >> logN, n = gid & (((u64)1 << logN) - 1);
+    if (poly >= n_polys) return;
+    const int L = K - 1;
+    const u64 qs = primes[K - 1].q, half = qs >> 1;
+    const u64 r = addmod(z[((poly * K + K - 1) << logN) + n], half, qs);
+    for (int i = 0; i < L; ++i) {
+        const PrimeDev &Pi = primes[i];
+        const FloorConst f = fc[(K - 1) * K + i];
+        const u64 ri = qs > Pi.q ? barrett64(r, make_modu(Pi)) : r;
+        const u64 delta = submod(ri, f.half_mod, Pi.q);
+        out[((poly * L + i) << logN) + n] = mul_shoup(submod(z[((poly * K + i) << logN) + n], delta, Pi.q), f.inv, f.inv_shoup, Pi.q);
+    }
+}
+// BFV: c0 += round(q*m/t) (util/scalingvariant.cpp multiply_add_plain_with_scaling_variant); plain [n][N] mod t.
+struct ScaleVariantConst {
+    u64 t, q_mod_t, thr;
+    u64 qdivt[16]; // floor(q/t) mod q_i
+};
+__global__ void __launch_bounds__(kBlock) k_bfv_add_scaled_plain(u64 *ct, const u64 *plain, const PrimeDev *primes, ScaleVariantConst sv, int L, int logN,
+                                                                 u64 n_cts)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 r = gid >> logN, n = gid & (((u64)1 << logN) - 1);
+    if (r >= n_cts) return;
+    const u64 m = plain[(r << logN) + n];
+    const u64 fix = (u64)(((u128)m * sv.q_mod_t + sv.thr) / sv.t);
+    for (int i = 0; i < L; ++i) {
+        const PrimeDev &Pi = primes[i];
+        const ModU64 mod = make_modu(Pi);
+        const u64 v = addmod(barrett128((u128)m * sv.qdivt[i], mod), barrett64(fix, mod), Pi.q);
+        u64 *c = ct + ((r * 2 * L + i) << logN) + n;
+        *c = addmod(*c, v, Pi.q);
+    }
+}
+// Decryptor dot_product_ct_sk_array: out[r][i] = c0 + c1 s + c2 s^2 ... (Horner in s), NTT form; ct [n][size][L][N], sk [K][N].
+__global__ void __launch_bounds__(kBlock) k_dot_sk(const u64 *ct, const u64 *sk, u64 *out, const PrimeDev *primes, int L, int size, int logN, u64 n_cts)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 pp = gid >> (logN - 1), e2 = gid & (((u64)1 << (logN - 1)) - 1);
+    const u64 r = pp / L;
+    if (r >= n_cts) return;
+    const int i = (int)(pp % L);
+    const PrimeDev &P = primes[i];
+    const ModU64 m = make_modu(P);
+    const ulonglong2 s = reinterpret_cast<const ulonglong2 *>(sk + ((u64)i << logN))[e2];
+    ulonglong2 acc = reinterpret_cast<const ulonglong2 *>(ct + (((r * size + size - 1) * L + i) << logN))[e2];
+    for (int k = size - 2; k >= 0; --k) {
+        const ulonglong2 c = reinterpret_cast<const ulonglong2 *>(ct + (((r * size + k) * L + i) << logN))[e2];
+        acc.x = addmod(barrett128((u128)acc.x * s.x, m), c.x, P.q);
+        acc.y = addmod(barrett128((u128)acc.y * s.y, m), c.y, P.q);
+    }
+    reinterpret_cast<ulonglong2 *>(out + ((r * L + i) << logN))[e2] = acc;
+}
+// BFV Decryptor: plain = round(t * [phase]_Q / Q) mod t per coefficient, exact (CRT composition in multiword arithmetic,
+// client/multiword.h — the same inline code the host client runs).  phase [n][L][N] coefficient form -> plain [n][N].
+struct CrtDev {
+    client::CrtView v;
+    double Qd;
+    u64 t;
+};
+__global__ void __launch_bounds__(kBlock) k_bfv_scale_round(const u64 *phase, u64 *plain, const PrimeDev *primes, CrtDev c, int logN, u64 n_cts)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 r = gid >> logN, n = gid & (((u64)1 << logN) - 1);
+    if (r >= n_cts) return;
+    ModU64 mods[16];
+    for (int i = 0; i < c.v.L; ++i) mods[i] = make_modu(primes[i]);
+    u64 x[client::kMwWords];
+    client::crt_compose(c.v, mods, phase + ((r * c.v.L) << logN) + n, (u64)1 << logN, x);
+    plain[(r << logN) + n] = client::bfv_scale_round(c.v, x, c.t, c.Qd);
+}
+
 inline unsigned grid_for(u64 jobs, u64 per_block) { return (unsigned)((jobs + per_block - 1) / per_block); }
 
 } // namespace
@@ -1585,6 +1708,53 @@ void launch_bfv_tail_fin(const KernelEnv &env, int L, u64 n_ops, const u64 *t, c
     case 4: hipLaunchKernelGGL(k_bfv_tail_fin<4>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
     case 5: hipLaunchKernelGGL(k_bfv_tail_fin<5>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
     }
+}
+
+// ---- client side ----------------------------------------------------------------------------------------
+void launch_enc_sample(const KernelEnv &env, u64 n_cts, u64 seed, u64 first_index, u64 *u, u64 *e)
+{
+    if (!n_cts) return;
+    const int logN = env.logn1 + kRowLog;
+    hipLaunchKernelGGL(k_enc_sample, dim3(grid_for(n_cts << logN, kBlock)), dim3(kBlock), 0, env.stream, u, e, env.primes, env.K, logN, n_cts, seed, first_index);
+}
+void launch_enc_mul_pk(const KernelEnv &env, u64 n_cts, const u64 *u, const u64 *pk, u64 *z, bool add_in)
+{
+    if (!n_cts) return;
+    const int logN = env.logn1 + kRowLog;
+    const u64 threads = (n_cts * 2 * env.K) << (logN - 1);
+    hipLaunchKernelGGL(k_enc_mul_pk, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, u, pk, z, env.primes, env.K, logN, n_cts, add_in ? 1 : 0);
+}
+void launch_divround_last_coeff(const KernelEnv &env, u64 n_polys, const u64 *z, u64 *out)
+{
+    if (!n_polys) return;
+    const int logN = env.logn1 + kRowLog;
+    hipLaunchKernelGGL(k_divround_last_coeff, dim3(grid_for(n_polys << logN, kBlock)), dim3(kBlock), 0, env.stream, z, out, env.primes, env.floor_consts, env.K,
+                       logN, n_polys);
+}
+void launch_bfv_add_scaled_plain(const KernelEnv &env, int L, u64 n_cts, u64 *ct, const u64 *plain, u64 t, u64 q_mod_t, const u64 *qdivt)
+{
+    if (!n_cts) return;
+    const int logN = env.logn1 + kRowLog;
+    ScaleVariantConst sv;
+    sv.t = t; sv.q_mod_t = q_mod_t; sv.thr = (t + 1) >> 1;
+    for (int i = 0; i < 16; ++i) sv.qdivt[i] = i < L ? qdivt[i] : 0;
+    hipLaunchKernelGGL(k_bfv_add_scaled_plain, dim3(grid_for(n_cts << logN, kBlock)), dim3(kBlock), 0, env.stream, ct, plain, env.primes, sv, L, logN, n_cts);
+}
+void launch_dot_sk(const KernelEnv &env, int L, int size, u64 n_cts, const u64 *ct, const u64 *sk, u64 *out)
+{
+    if (!n_cts) return;
+    const int logN = env.logn1 + kRowLog;
+    const u64 threads = (n_cts * L) << (logN - 1);
+    hipLaunchKernelGGL(k_dot_sk, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, ct, sk, out, env.primes, L, size, logN, n_cts);
+}
+void launch_bfv_scale_round(const KernelEnv &env, u64 n_cts, const u64 *phase, u64 *plain, const CrtTablesDev &c)
+{
+    if (!n_cts) return;
+    const int logN = env.logn1 + kRowLog;
+    CrtDev d;
+    d.v.L = c.L; d.v.words = c.words; d.v.Q = c.Q; d.v.halfQ = c.halfQ; d.v.punct = c.punct; d.v.inv = c.inv;
+    d.Qd = c.Qd; d.t = c.t;
+    hipLaunchKernelGGL(k_bfv_scale_round, dim3(grid_for(n_cts << logN, kBlock)), dim3(kBlock), 0, env.stream, phase, plain, env.primes, d, logN, n_cts);
 }
 
 } // namespace he355

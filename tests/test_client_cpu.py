@@ -24,8 +24,14 @@ def sim():
                        "simc_galois_key": [vp, C.c_uint32, u64p], "simc_ckks_encode": [vp, C.POINTER(C.c_double), C.c_size_t, C.c_double, u64p],
                        "simc_ckks_decode": [vp, u64p, C.c_size_t, C.c_double, C.POINTER(C.c_double)],
                        "simc_bfv_encode": [vp, C.POINTER(C.c_int64), C.c_size_t, u64p], "simc_bfv_decode": [vp, u64p, C.POINTER(C.c_int64)],
-                       "simc_encrypt": [vp, u64p, u64p], "simc_decrypt": [vp, u64p, C.c_size_t, C.c_size_t, u64p]}.items():
+                       "simc_encrypt": [vp, u64p, u64p], "simc_decrypt": [vp, u64p, C.c_size_t, C.c_size_t, u64p],
+                       "simc_set_encrypt_index": [vp, C.c_uint64],
+                       "simc_sample": [C.c_uint64, C.c_uint64, C.c_size_t, C.c_int, C.POINTER(C.c_int32)]}.items():
         getattr(L, name).argtypes = args
+    L.simc_encrypt_seed.restype = C.c_uint64
+    L.simc_encrypt_seed.argtypes = [vp]
+    L.simc_encrypt_index.restype = C.c_uint64
+    L.simc_encrypt_index.argtypes = [vp]
     return L
 
 
@@ -112,5 +118,51 @@ def test_bfv_client_interoperates_with_oracle(sim, oracle):
     want = (x * y) % t
     want = np.where(want > t // 2, want - t, want)
     assert np.array_equal(out, want)
+    sim.simc_destroy(c)
+    sim.sim_params_destroy(p)
+
+
+def test_sampler_mirror_matches_shared_header(sim):
+    """tests/sampler_np.py (numpy) == csrc/client/sampler.h (the code the host client and the device kernels run)."""
+    import sampler_np as sn
+    for seed, stream in ((1, 0), (0xDEADBEEFCAFEF00D, 17), (2 ** 64 - 1, 2 ** 40 + 5)):
+        for kind, fn in ((0, sn.sample_ternary), (1, sn.sample_cbd)):
+            got = np.empty(4096, dtype=np.int32)
+            sim.simc_sample(seed, stream, 4096, kind, got.ctypes.data_as(C.POINTER(C.c_int32)))
+            assert np.array_equal(got, fn(seed, stream, 4096)), (seed, stream, kind)
+    t = sn.sample_ternary(5, 9, 1 << 16)
+    assert set(np.unique(t)) == {-1, 0, 1} and abs(t.mean()) < 0.02
+    e = sn.sample_cbd(5, 9, 1 << 16)
+    assert abs(e.mean()) < 0.05 and 3.0 < e.std() < 3.5  # sigma = sqrt(21/2) = 3.24
+
+
+@pytest.mark.parametrize("scheme", ["ckks", "bfv"])
+def test_client_encryption_is_bit_exact_with_oracle(sim, oracle, scheme):
+    """Same public key, same plaintext, same sampled polynomials => the product's host encryption equals the oracle's
+    (ho_encrypt_explicit) bit for bit, including the divide-and-round by the special prime and BFV's scaling variant."""
+    import sampler_np as sn
+    N = 2048
+    if scheme == "ckks":
+        bits, pb = [60, 40, 40, 60], 0
+        p, c = _mk(sim, 2, N, bits)
+        o = oracle.Context(oracle.SCHEME_CKKS, N, bit_sizes=bits, sec128=False)
+    else:
+        bits, pb = [50, 40, 50], 20
+        p, c = _mk(sim, 1, N, bits, pb)
+        o = oracle.Context(oracle.SCHEME_BFV, N, bit_sizes=bits, plain_bits=pb, sec128=False)
+    K, L = o.K, o.L
+    pk = np.empty((2, K, N), dtype=np.uint64)
+    sim.simc_public_key(c, oracle._p(pk))
+    rng = np.random.default_rng(3)
+    seed = sim.simc_encrypt_seed(c)
+    sim.simc_set_encrypt_index(c, 7)
+    for r in range(7, 10):
+        plain = o.random_poly(rng, L, 1)[0] if scheme == "ckks" else rng.integers(0, o.t, N).astype(np.uint64)
+        got = np.empty((2, L, N), dtype=np.uint64)
+        assert sim.simc_encrypt_index(c) == r
+        sim.simc_encrypt(c, oracle._p(np.ascontiguousarray(plain)), oracle._p(got))
+        su, s0, s1 = sn.enc_streams(r)
+        want = o.encrypt_explicit(pk, plain, sn.sample_ternary(seed, su, N), sn.sample_cbd(seed, s0, N), sn.sample_cbd(seed, s1, N))
+        assert np.array_equal(got, want), r
     sim.simc_destroy(c)
     sim.sim_params_destroy(p)

@@ -1,0 +1,121 @@
+"""Client side on the device: he355_encrypt / he355_decrypt against the oracle, bit-exact.
+Encryption randomness is counter-based and shared (csrc/client/sampler.h; numpy mirror tests/sampler_np.py), so the
+oracle is driven with exactly the polynomials the device sampled (ho_encrypt_explicit)."""
+import importlib
+
+import numpy as np
+import pytest
+
+import sampler_np as sn
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (scheme, N, bit sizes, plain bits)
+    "ckks_n2048_mixed": ("ckks", 2048, [60, 40, 40, 60], 0),
+    "ckks_n8192_default": ("ckks", 8192, [60, 45, 60], 0),
+    "ckks_n32768_d4": ("ckks", 32768, [60, 45, 45, 45, 60], 0),
+    "ckks_n4096_single_prime": ("ckks", 4096, [50], 0),
+    "bfv_n2048": ("bfv", 2048, [50, 40, 50], 20),
+    "bfv_n8192_default": ("bfv", 8192, [60, 40, 60], 20),
+    "bfv_n16384_d3": ("bfv", 16384, [60, 40, 40, 60], 20),
+}
+
+
+@pytest.fixture(scope="module")
+def be():
+    mod = importlib.import_module("reference-seal-backend_amd")
+    if mod.device_count() < 1:
+        pytest.fail("no HIP device: the GPU tests must run on the MI355X box")
+    return mod
+
+
+@pytest.fixture(params=list(CASES))
+def case(request, be, oracle):
+    scheme, N, bits, pb = CASES[request.param]
+    sid_g = be.SCHEME_CKKS if scheme == "ckks" else be.SCHEME_BFV
+    sid_o = oracle.SCHEME_CKKS if scheme == "ckks" else oracle.SCHEME_BFV
+    g = be.Context(sid_g, N, bit_sizes=bits, plain_bits=pb, sec128=False, device=0)
+    o = oracle.Context(sid_o, N, bit_sizes=bits, plain_bits=pb, sec128=False)
+    assert g.moduli == o.moduli
+    sk = o.keygen_secret(11)
+    pk = o.keygen_public(sk, 12)
+    g.set_public_key(pk)
+    g.set_secret_key(sk)
+    yield scheme, g, o, sk, pk, np.random.default_rng(len(request.param))
+    g.close()
+
+
+def test_encrypt_matches_oracle(case, be):
+    scheme, g, o, sk, pk, rng = case
+    N, L = g.N, g.L
+    n, seed, first = 35, 0xC0FFEE1234, 1000  # more than one internal chunk (32), ragged
+    if scheme == "ckks":
+        plains = np.stack([o.random_poly(rng, L, 1)[0] for _ in range(n)])  # [n, L, N] NTT-form plaintexts
+    else:
+        plains = rng.integers(0, o.t, (n, N)).astype(np.uint64)
+    dp = g.to_device(plains)
+    out = g.alloc(n * 2 * L * N)
+    g.encrypt(n, dp, seed, first, out)
+    got = out.download((n, 2, L, N))
+    for r in (0, 1, 31, 32, 34):
+        su, s0, s1 = sn.enc_streams(first + r)
+        want = o.encrypt_explicit(pk, plains[r], sn.sample_ternary(seed, su, N), sn.sample_cbd(seed, s0, N), sn.sample_cbd(seed, s1, N))
+        assert np.array_equal(got[r], want), r
+    # and they decrypt: the oracle's phase of a device ciphertext carries the plaintext (plus small noise)
+    ph = o.decrypt_phase(got[3], sk)
+    if scheme == "bfv":
+        assert np.array_equal(o.bfv_decode_phase(ph), plains[3])
+    else:
+        q0 = o.moduli[0]
+        diff = ((ph[0].astype(object) - plains[3][0].astype(object)) % q0).astype(np.uint64)  # e0 + e1*s + u*e under prime 0, NTT form
+        c0 = o.intt(0, diff).astype(object)
+        c0 = np.where(c0 > q0 // 2, c0 - q0, c0)
+        assert max(abs(int(v)) for v in c0) < 2 ** 14  # the encryption noise stays tiny
+
+
+def test_decrypt_matches_oracle(case, be):
+    scheme, g, o, sk, pk, rng = case
+    N = g.N
+    for L in sorted({g.L, max(1, g.L - 1)}):
+        for size in (2, 3):
+            n = 3
+            cts = np.stack([o.random_poly(rng, L, size) for _ in range(n)])  # any residues: the phase is a function of ct and sk
+            d = g.to_device(cts)
+            if scheme == "ckks":
+                out = g.alloc(n * L * N)
+                g.decrypt(L, size, n, d, out)
+                got = out.download((n, L, N))
+                for r in range(n):
+                    assert np.array_equal(got[r], o.decrypt_phase(cts[r], sk)), (L, size, r)
+            else:
+                out = g.alloc(n * N)
+                g.decrypt(L, size, n, d, out)
+                got = out.download((n, N))
+                for r in range(n):
+                    assert np.array_equal(got[r], o.bfv_decode_phase(o.decrypt_phase(cts[r], sk))), (L, size, r)
+
+
+def test_round_trip_through_the_evaluator(case, be):
+    """Enc on the device -> add on the device -> Dec on the device gives the sum of the plaintexts (BFV exactly; CKKS up
+    to the encryption noise, checked in coefficient form)."""
+    scheme, g, o, sk, pk, rng = case
+    N, L = g.N, g.L
+    if scheme == "bfv":
+        a, b = rng.integers(0, o.t, (2, N)).astype(np.uint64)
+        d = g.to_device(np.stack([a, b]))
+        cts, s, out = g.alloc(2 * 2 * L * N), g.alloc(2 * L * N), g.alloc(N)
+        g.encrypt(2, d, 77, 0, cts)
+        g.add(L, 2, 1, cts, cts, be.Context.outer(0, 1, 1, 1), s)
+        g.decrypt(L, 2, 1, s, out)
+        assert np.array_equal(out.download((N,)), (a + b) % np.uint64(o.t))
+    else:
+        scale = 2.0 ** 30
+        x = rng.uniform(-1, 1, N // 2)
+        import oracle as ho
+        plain = ho.ckks_encode(o, x, scale)
+        d = g.to_device(np.ascontiguousarray(plain[None]))
+        ct, out = g.alloc(2 * L * N), g.alloc(L * N)
+        g.encrypt(1, d, 78, 5, ct)
+        g.decrypt(L, 2, 1, ct, out)
+        assert np.allclose(ho.ckks_decode(o, out.download((L, N)), scale).real, x, atol=1e-4)
