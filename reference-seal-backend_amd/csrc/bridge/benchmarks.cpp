@@ -160,10 +160,7 @@ AB::Handle VectorBenchmark::encrypt(AB::Handle encoded_data)
 {
     const std::vector<std::vector<Plain>> &encoded = this->getEngine().retrieveFromHandle<std::vector<std::vector<Plain>>>(encoded_data);
     std::vector<std::vector<Cipher>> encrypted(encoded.size());
-    for (std::size_t param_i = 0; param_i < encoded.size(); ++param_i) {
-        encrypted[param_i].resize(encoded[param_i].size());
-        for (std::size_t s = 0; s < encoded[param_i].size(); ++s) encrypted[param_i][s] = m_p_ctx_wrapper->encrypt(encoded[param_i][s]);
-    }
+    for (std::size_t param_i = 0; param_i < encoded.size(); ++param_i) encrypted[param_i] = m_p_ctx_wrapper->encryptBatch(encoded[param_i]);
     return this->getEngine().createHandle<decltype(encrypted)>(sizeof(encrypted), 0, std::move(encrypted));
 }
 
@@ -172,8 +169,7 @@ AB::Handle VectorBenchmark::decrypt(AB::Handle encrypted_data)
     if ((encrypted_data.tag & hebench::cpp::EngineObject::tag) == 0)
         throw HEBenchError(HEBERROR_MSG_CLASS("Invalid tag detected. Expected EngineObject::tag."), HEBENCH_ECODE_INVALID_ARGS);
     const std::vector<Cipher> &encrypted = this->getEngine().retrieveFromHandle<std::vector<Cipher>>(encrypted_data);
-    std::vector<Plain> plaintext_data(encrypted.size());
-    for (std::size_t i = 0; i < encrypted.size(); ++i) plaintext_data[i] = m_p_ctx_wrapper->decrypt(encrypted[i]); // size-3 results included
+    std::vector<Plain> plaintext_data = m_p_ctx_wrapper->decryptBatch(encrypted); // size-3 results included
     return this->getEngine().createHandle<decltype(plaintext_data)>(sizeof(plaintext_data), 0, std::move(plaintext_data));
 }
 

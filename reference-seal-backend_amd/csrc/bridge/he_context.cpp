@@ -82,8 +82,90 @@ Plain HeContextWrapper::encodeVector(const std::vector<std::int64_t> &values)
     p.L = topLevel();
     return p;
 }
+// Client side: on the MI355X when one is present (he355_encrypt / he355_decrypt: same bits as the host code below for the same
+// randomness counter — tests/test_gpu_client.py), on the host otherwise, as in the reference, whose Encryptor / Decryptor are
+// host code.  This is NOT an evaluator fallback: load() and operate() still need the device.
+bool HeContextWrapper::clientOnDevice()
+{
+    if (m_client_dev < 0) {
+        int n = 0;
+        const char *env = getenv("HE355_DEVICE_CLIENT");
+        m_client_dev = (he355_device_count(&n) == 0 && n > 0 && !(env && env[0] == '0')) ? 1 : 0;
+        if (m_client_dev) {
+            ensureDevice();
+            check(he355_set_public_key(m_ctx, m_client->public_key().data()), "public key upload");
+            check(he355_set_secret_key(m_ctx, m_client->secret_key().data()), "secret key upload");
+        }
+    }
+    return m_client_dev == 1;
+}
+std::vector<Cipher> HeContextWrapper::encryptBatch(const std::vector<Plain> &plains)
+{
+    std::vector<Cipher> out(plains.size());
+    if (plains.empty()) return out;
+    const int L = topLevel();
+    if (!clientOnDevice()) {
+        for (std::size_t i = 0; i < plains.size(); ++i) out[i] = encrypt(plains[i]);
+        return out;
+    }
+    const std::uint64_t N = m_params->N, n = plains.size(), pl = isCKKS() ? (std::uint64_t)L * N : N, cl = 2 * (std::uint64_t)L * N;
+    void *dp = nullptr, *dc = nullptr;
+    check(he355_malloc(m_ctx, n * pl * 8, &dp), "device allocation");
+    check(he355_malloc(m_ctx, n * cl * 8, &dc), "device allocation");
+    for (std::uint64_t i = 0; i < n; ++i) {
+        if (plains[i].data.size() != pl) throw HEBenchError(HEBERROR_MSG_CLASS("plaintext shape"), HEBENCH_ECODE_INVALID_ARGS);
+        check(he355_upload(m_ctx, static_cast<uint64_t *>(dp) + i * pl, plains[i].data.data(), pl * 8), "upload");
+    }
+    const std::uint64_t first = m_client->encrypt_index();
+    check(he355_encrypt(m_ctx, n, static_cast<uint64_t *>(dp), m_client->encrypt_seed(), first, static_cast<uint64_t *>(dc)), "encrypt");
+    m_client->set_encrypt_index(first + n); // the host counter moves on exactly as if it had encrypted them
+    check(he355_sync(m_ctx), "synchronise");
+    for (std::uint64_t i = 0; i < n; ++i) {
+        out[i].data.resize(cl);
+        out[i].size = 2; out[i].L = L; out[i].scale = plains[i].scale;
+        check(he355_download(m_ctx, out[i].data.data(), static_cast<uint64_t *>(dc) + i * cl, cl * 8), "download");
+    }
+    (void)he355_free(m_ctx, dp);
+    (void)he355_free(m_ctx, dc);
+    return out;
+}
+std::vector<Plain> HeContextWrapper::decryptBatch(const std::vector<Cipher> &ciphers)
+{
+    std::vector<Plain> out(ciphers.size());
+    if (ciphers.empty()) return out;
+    bool uniform = true;
+    for (const Cipher &c : ciphers) uniform = uniform && c.size == ciphers[0].size && c.L == ciphers[0].L;
+    if (!clientOnDevice() || !uniform || ciphers[0].size < 2 || ciphers[0].size > 3 || (!isCKKS() && ciphers[0].L > 16)) {
+        for (std::size_t i = 0; i < ciphers.size(); ++i) out[i] = decrypt(ciphers[i]);
+        return out;
+    }
+    try {
+        const int L = ciphers[0].L, size = ciphers[0].size;
+        const std::uint64_t N = m_params->N, n = ciphers.size(), cl = (std::uint64_t)size * L * N, pl = isCKKS() ? (std::uint64_t)L * N : N;
+        void *dp = nullptr, *dc = nullptr;
+        check(he355_malloc(m_ctx, n * pl * 8, &dp), "device allocation");
+        check(he355_malloc(m_ctx, n * cl * 8, &dc), "device allocation");
+        for (std::uint64_t i = 0; i < n; ++i) {
+            if (ciphers[i].data.size() != cl) throw HEBenchError(HEBERROR_MSG_CLASS("ciphertext shape"), HEBENCH_ECODE_INVALID_ARGS);
+            check(he355_upload(m_ctx, static_cast<uint64_t *>(dc) + i * cl, ciphers[i].data.data(), cl * 8), "upload");
+        }
+        check(he355_decrypt(m_ctx, L, size, n, static_cast<uint64_t *>(dc), static_cast<uint64_t *>(dp)), "decrypt");
+        check(he355_sync(m_ctx), "synchronise");
+        for (std::uint64_t i = 0; i < n; ++i) {
+            out[i].data.resize(pl);
+            out[i].L = L; out[i].scale = ciphers[i].scale;
+            check(he355_download(m_ctx, out[i].data.data(), static_cast<uint64_t *>(dp) + i * pl, pl * 8), "download");
+        }
+        (void)he355_free(m_ctx, dp);
+        (void)he355_free(m_ctx, dc);
+        return out;
+    } catch (const std::exception &ex) {
+        throw HEBenchError(ex.what(), HEB355_ECODE_HE_ERROR); // seal_context.cpp:166-169
+    }
+}
 Cipher HeContextWrapper::encrypt(const Plain &plain)
 {
+    if (clientOnDevice()) return encryptBatch(std::vector<Plain>{plain})[0];
     Cipher c;
     c.data = m_client->encrypt(plain.data.data());
     c.size = 2;
@@ -93,6 +175,7 @@ Cipher HeContextWrapper::encrypt(const Plain &plain)
 }
 Plain HeContextWrapper::decrypt(const Cipher &cipher)
 {
+    if (clientOnDevice() && cipher.size >= 2 && cipher.size <= 3 && (isCKKS() || cipher.L <= 16)) return decryptBatch(std::vector<Cipher>{cipher})[0];
     try {
         Plain p;
         p.data = m_client->decrypt(cipher.data.data(), (size_t)cipher.size, (size_t)cipher.L);

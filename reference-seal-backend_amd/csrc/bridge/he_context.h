@@ -65,6 +65,9 @@ public:
     Plain encodeVector(const std::vector<std::int64_t> &values);
     Cipher encrypt(const Plain &plain);
     Plain decrypt(const Cipher &cipher);
+    std::vector<Cipher> encryptBatch(const std::vector<Plain> &plains);   // one device call for the whole operand when a GPU is present
+    std::vector<Plain> decryptBatch(const std::vector<Cipher> &ciphers);
+    bool clientOnDevice(); // true: encrypt/decrypt run on the MI355X (HE355_DEVICE_CLIENT=0 keeps them on the host)
 
     // device side (lazy device init; uploads the keys a workload declared it needs)
     void ensureDevice();
@@ -85,6 +88,7 @@ private:
     std::unique_ptr<he355::client::Client> m_client;
     double m_scale = 1.0;
     bool m_device = false, m_relin = false;
+    int m_client_dev = -1; // -1: not decided yet
     std::map<uint32_t, bool> m_galois;
 };
 

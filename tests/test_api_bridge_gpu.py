@@ -211,3 +211,34 @@ def test_ckks_logreg_horner(backend, category, batch, n):
     assert res.shape == (batch, 1)
     assert np.allclose(res[:, 0], want, atol=1e-3), np.abs(res[:, 0] - want).max()
     backend.destroy(hb)
+
+
+@pytest.mark.parametrize("scheme", [SCHEME_CKKS, SCHEME_BFV])
+def test_client_side_on_device_equals_client_side_on_host(backend, scheme):
+    """encrypt()/decrypt() run on the MI355X by default and on the host with HE355_DEVICE_CLIENT=0: same keys, same
+    randomness counters => the decoded results are identical to the last bit (the ciphertexts are, tests/test_gpu_client.py)."""
+    rng = np.random.default_rng(77)
+    n = 64
+    res = []
+    for flag in ("1", "0"):
+        os.environ["HE355_DEVICE_CLIENT"] = flag
+        try:
+            if scheme == SCHEME_CKKS:
+                if not res:
+                    a, b = rng.uniform(-1, 1, (3, n)), rng.uniform(-1, 1, (2, n))
+                hb = backend.create(backend.find(W_MUL, SCHEME_CKKS, OFFLINE), ckks_params(n), (3, 2))
+                res.append(backend.run(hb, [a, b], n, np.float64))
+            else:
+                if not res:
+                    a, b = rng.integers(-500, 500, (3, n)), rng.integers(-500, 500, (2, n))
+                hb = backend.create(backend.find(W_MUL, SCHEME_BFV, OFFLINE), bfv_params(n), (3, 2))
+                res.append(backend.run(hb, [a.astype(np.int64), b.astype(np.int64)], n, np.int64))
+            backend.destroy(hb)
+        finally:
+            os.environ.pop("HE355_DEVICE_CLIENT", None)
+    assert np.array_equal(res[0], res[1])
+    want = (a[:, None, :] * b[None, :, :]).reshape(6, n)
+    if scheme == SCHEME_CKKS:
+        assert np.allclose(res[0], want, atol=1e-4)
+    else:
+        assert np.array_equal(res[0], _centre(want, 1032193))
