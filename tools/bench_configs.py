@@ -75,6 +75,41 @@ def cfg4_dot_product():
     return out
 
 
+def client_side():
+    """Device-side encryption / decryption rates at the headline parameters (N=2^15, 17 key primes), inputs resident in HBM,
+    with the oracle's single-thread CPU time per ciphertext beside them."""
+    import time
+
+    import numpy as np
+
+    import oracle as ho
+    bits = be.chain_bits(16, 45)
+    g = be.Context(be.SCHEME_CKKS, 32768, bit_sizes=bits, device=0)
+    o = ho.Context(ho.SCHEME_CKKS, 32768, bit_sizes=bits)
+    L, N, n = g.L, g.N, 256
+    sk = o.keygen_secret(1)
+    pk = o.keygen_public(sk, 2)
+    g.set_public_key(pk)
+    g.set_secret_key(sk)
+    plain, ct, ph = g.alloc(n * L * N), g.alloc(n * 2 * L * N), g.alloc(n * L * N)
+    g.fill_uniform(plain, n * L, list(range(L)), 3)
+    ms_e = timed(g, lambda: g.encrypt(n, plain, 5, 0, ct), 3)
+    ms_d = timed(g, lambda: g.decrypt(L, 2, n, ct, ph), 5)
+    rng = np.random.default_rng(0)
+    p1 = o.random_poly(rng, L, 1)[0]
+    t0 = time.perf_counter()
+    c1 = o.encrypt(pk, p1, 9)
+    t_enc = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    o.decrypt_phase(c1, sk)
+    t_dec = time.perf_counter() - t0
+    g.close()
+    return [dict(config="device encrypt (he355_encrypt) CKKS N=2^15 L=16, 256 plaintexts resident", results=n, ms=ms_e, ops_per_s=n / ms_e * 1e3,
+                 cpu_oracle_single_thread_ops_per_s=1 / t_enc),
+            dict(config="device decrypt (he355_decrypt, size 2) CKKS N=2^15 L=16", results=n, ms=ms_d, ops_per_s=n / ms_d * 1e3,
+                 cpu_oracle_single_thread_ops_per_s=1 / t_dec)]
+
+
 if __name__ == "__main__":
-    for r in [cfg1_bfv_add()] + cfg2_ckks_multiply() + [cfg4_dot_product()]:
+    for r in [cfg1_bfv_add()] + cfg2_ckks_multiply() + [cfg4_dot_product()] + client_side():
         print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
