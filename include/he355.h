@@ -141,6 +141,14 @@ int he355_set_secret_key(he355_ctx *ctx, const uint64_t *h_sk);
 int he355_encrypt(he355_ctx *ctx, uint64_t n, const uint64_t *d_plain, uint64_t seed, uint64_t first_index, uint64_t *d_out);
 /* d_ct: [n][size][L][N], size 2 or 3; d_out: CKKS [n][L][N] NTT-form plaintext, BFV [n][N] coefficients mod t */
 int he355_decrypt(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_ct, uint64_t *d_out);
+/* Encoders on the device: CKKSEncoder()->encode / decode and BatchEncoder (src/engine/seal_context.cpp:145-185 and the
+ * benchmarks' encode()/decode(), e.g. src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:163-226).  All pointers are device
+ * pointers.  CKKS: values [n][count] doubles (count <= N/2, missing slots are 0) -> [n][L_top][N] NTT-form plaintexts at `scale`;
+ * decode: [n][L][N] -> [n][N/2] real parts.  BFV: values [n][count] int64 <-> [n][N] coefficients mod t (centred on decode). */
+int he355_ckks_encode(he355_ctx *ctx, uint64_t n, const double *d_values, uint64_t count, double scale, uint64_t *d_plain);
+int he355_ckks_decode(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_plain, double scale, double *d_out);
+int he355_bfv_encode(he355_ctx *ctx, uint64_t n, const int64_t *d_values, uint64_t count, uint64_t *d_plain);
+int he355_bfv_decode(he355_ctx *ctx, uint64_t n, const uint64_t *d_plain, int64_t *d_out);
 /* transforms of n_polys residue polynomials, polynomial p under prime prime_of[p % period] (test / client use) */
 int he355_ntt_forward(he355_ctx *ctx, uint64_t *d_polys, uint64_t n_polys, const uint8_t *prime_of, uint32_t period);
 int he355_ntt_inverse(he355_ctx *ctx, uint64_t *d_polys, uint64_t n_polys, const uint8_t *prime_of, uint32_t period);

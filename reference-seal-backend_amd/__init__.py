@@ -83,6 +83,10 @@ def lib():
             "he355_relinearize_rescale": (i32, [vp, i32, u64, vp, vp]),
             "he355_set_public_key": (i32, [vp, vp]), "he355_set_secret_key": (i32, [vp, vp]),
             "he355_encrypt": (i32, [vp, u64, vp, u64, u64, vp]),
+            "he355_ckks_encode": (i32, [vp, u64, vp, u64, C.c_double, vp]),
+            "he355_ckks_decode": (i32, [vp, i32, u64, vp, C.c_double, vp]),
+            "he355_bfv_encode": (i32, [vp, u64, vp, u64, vp]),
+            "he355_bfv_decode": (i32, [vp, u64, vp, vp]),
             "he355_decrypt": (i32, [vp, i32, i32, u64, vp, vp]),
             "he355_multiply_plain": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
             "he355_add_plain": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
@@ -114,7 +118,8 @@ C_ABI_SYMBOLS = [
     "he355_fill_uniform", "he355_set_relin_key", "he355_set_galois_key", "he355_set_relin_key_synthetic",
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",
-    "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_accumulate",
+    "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_ckks_encode", "he355_ckks_decode",
+    "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_accumulate",
     "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk",
 ]
 
@@ -291,6 +296,18 @@ class Context:
 
     def decrypt(self, L, size, n, ct, out):
         _check(lib().he355_decrypt(self.h, L, size, n, ct.ptr, out.ptr))
+
+    def ckks_encode(self, n, values, count, scale, plain):
+        _check(lib().he355_ckks_encode(self.h, n, values.ptr, count, scale, plain.ptr))
+
+    def ckks_decode(self, L, n, plain, scale, out):
+        _check(lib().he355_ckks_decode(self.h, L, n, plain.ptr, scale, out.ptr))
+
+    def bfv_encode(self, n, values, count, plain):
+        _check(lib().he355_bfv_encode(self.h, n, values.ptr, count, plain.ptr))
+
+    def bfv_decode(self, n, plain, out):
+        _check(lib().he355_bfv_decode(self.h, n, plain.ptr, out.ptr))
 
     def relinearize_rescale(self, L, n, ct3, out):
         _check(lib().he355_relinearize_rescale(self.h, L, n, ct3.ptr, out.ptr))

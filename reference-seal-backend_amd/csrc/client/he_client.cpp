@@ -1,5 +1,7 @@
 // he_client.cpp — see he_client.h.  Host-only C++17 (client side of the backend; untimed).
 #include "he_client.h"
+#include "ckks_codec.h"
+#include "multiword.h"
 #include "sampler.h"
 
 #include <cmath>
@@ -101,27 +103,12 @@ struct Crt {
     }
 };
 
-void fft_inplace(std::vector<std::complex<double>> &a, bool inverse)
+// iterative radix-2 transform on bit-reversed input with the shared butterflies (client/ckks_codec.h)
+void fft_stages(std::vector<Cplx> &z, const std::vector<Cplx> &W, bool inverse)
 {
-    const size_t n = a.size();
-    for (size_t i = 1, j = 0; i < n; ++i) {
-        size_t bit = n >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-        if (i < j) std::swap(a[i], a[j]);
-    }
-    for (size_t len = 2; len <= n; len <<= 1) {
-        const double ang = 2 * M_PI / (double)len * (inverse ? 1 : -1);
-        for (size_t i = 0; i < n; i += len)
-            for (size_t k = 0; k < len / 2; ++k) {
-                const std::complex<double> w(std::cos(ang * (double)k), std::sin(ang * (double)k));
-                const std::complex<double> u = a[i + k], v = a[i + k + len / 2] * w;
-                a[i + k] = u + v;
-                a[i + k + len / 2] = u - v;
-            }
-    }
-    if (inverse)
-        for (auto &x : a) x /= (double)n;
+    const size_t n = z.size();
+    for (size_t len = 2; len <= n; len <<= 1)
+        for (size_t t = 0; t < n / 2; ++t) fft_stage_bfly(z.data(), W.data(), len, t, inverse);
 }
 
 } // namespace
@@ -159,19 +146,43 @@ void host_ntt_inverse(const PrimeTables &pt, size_t N, u64 *x)
     for (size_t j = 0; j < N; ++j) x[j] = mulm(x[j], pt.ninv, pt.mod);
 }
 
+// slot -> evaluation-point index: powers of the generator 3 (CKKSEncoder / BatchEncoder matrix_reps_index_map)
+void build_slot_index(size_t N, std::vector<uint32_t> &slot_index)
+{
+    const size_t half = N / 2, m = 2 * N;
+    slot_index.resize(N);
+    u64 pos = 1;
+    for (size_t i = 0; i < half; ++i) {
+        slot_index[i] = (uint32_t)((pos - 1) >> 1);
+        slot_index[half + i] = (uint32_t)((m - pos - 1) >> 1);
+        pos = (pos * 3) & (m - 1);
+    }
+}
+// cos and sin through separate, non-inlinable calls: an optimiser that fuses the pair into sincos() gets results that can
+// differ from sin()/cos() in the last bit (seen with g++ -O2 against clang), and every build must produce the same tables
+__attribute__((noinline)) static double cos_only(double x) { return std::cos(x); }
+__attribute__((noinline)) static double sin_only(double x) { return std::sin(x); }
+// transform tables of the CKKS encoder (client/ckks_codec.h): W[len/2 + k] = exp(-2 pi i k/len), Z[n] = exp(-i pi n/N)
+void build_ckks_tables(size_t N, std::vector<Cplx> &W, std::vector<Cplx> &Z)
+{
+    W.assign(N, Cplx{1.0, 0.0});
+    for (size_t len = 2; len <= N; len <<= 1) {
+        const double ang = -2 * M_PI / (double)len;
+        for (size_t k = 0; k < len / 2; ++k) W[len / 2 + k] = Cplx{cos_only(ang * (double)k), sin_only(ang * (double)k)};
+    }
+    Z.resize(N);
+    for (size_t n = 0; n < N; ++n) {
+        const double ang = -M_PI * (double)n / (double)N;
+        Z[n] = Cplx{cos_only(ang), sin_only(ang)};
+    }
+}
+
 Client::Client(const Params &params, uint64_t seed) : P(params), rng_(seed), enc_seed_(splitmix64(seed ^ 0x656e6372797074ull))
 {
     const size_t N = P.N, K = P.K;
-    // slot -> evaluation-point index: powers of the generator 3 (CKKSEncoder / BatchEncoder matrix_reps_index_map)
-    const size_t half = N / 2, m = 2 * N;
-    slot_index_.resize(N);
-    u64 pos = 1;
-    for (size_t i = 0; i < half; ++i) {
-        slot_index_[i] = (uint32_t)((pos - 1) >> 1);
-        slot_index_[half + i] = (uint32_t)((m - pos - 1) >> 1);
-        pos = (pos * 3) & (m - 1);
-    }
+    build_slot_index(N, slot_index_);
     if (P.scheme == kSchemeBFV) plain_tables_ = Params::make_prime_tables(P.plain_modulus, N, P.logn, false);
+    if (P.scheme == kSchemeCKKS) build_ckks_tables(N, fft_w_, zeta_);
     // secret key: ternary, NTT form at the key level
     sample_ternary(sk_, K);
     for (size_t i = 0; i < K; ++i) host_ntt_forward(P.primes[i], N, sk_.data() + i * N);
@@ -264,20 +275,17 @@ std::vector<u64> Client::ckks_encode(const double *values, size_t count, double 
 {
     const size_t N = P.N, half = N / 2;
     if (count > half) throw std::invalid_argument("Not enough slots available to create packed plaintext");
-    std::vector<std::complex<double>> z(N);
-    for (size_t i = 0; i < half; ++i) {
-        const double v = i < count ? values[i] : 0.0;
-        z[slot_index_[i]] = v;
-        z[slot_index_[half + i]] = v; // conjugate of a real value
-    }
     // z[j] = p(zeta^(2j+1)) = sum_n (c_n zeta^n) e^{2 pi i jn/N}  =>  c_n = zeta^{-n} * DFT(z)[n] / N
-    fft_inplace(z, false);
+    std::vector<Cplx> z(N, Cplx{0.0, 0.0});
+    for (size_t i = 0; i < count; ++i) { // values land bit-reversed: the transform below runs on bit-reversed input
+        z[bitrev_u32(slot_index_[i], P.logn)].re = values[i];
+        z[bitrev_u32(slot_index_[half + i], P.logn)].re = values[i]; // conjugate of a real value
+    }
+    fft_stages(z, fft_w_, false);
     std::vector<u64> out(P.Ltop * N);
     for (size_t n = 0; n < N; ++n) {
-        const double ang = -M_PI * (double)n / (double)N;
-        const double c = (z[n] * std::complex<double>(std::cos(ang), std::sin(ang))).real() / (double)N * scale;
-        const double r = std::nearbyint(c);
-        if (std::fabs(r) >= 9.2e18) throw std::invalid_argument("encoded values are too large");
+        const double r = ckks_encode_coeff(z[n], zeta_[n], (double)N, scale);
+        if (!(std::fabs(r) < 9.2e18)) throw std::invalid_argument("encoded values are too large");
         const long long iv = (long long)r;
         for (size_t i = 0; i < P.Ltop; ++i) {
             const u64 q = P.primes[i].q;
@@ -295,22 +303,21 @@ void Client::ckks_decode(const u64 *plain_ntt, size_t L, double scale, double *o
     for (size_t i = 0; i < L; ++i) host_ntt_inverse(P.primes[i], N, coeff.data() + i * N);
     const Crt crt(P, L);
     Wide x(crt.words), y(crt.words);
-    std::vector<std::complex<double>> z(N);
+    std::vector<Cplx> z(N);
     for (size_t n = 0; n < N; ++n) {
         crt.compose(P, coeff.data() + n, N, x);
         double v;
         if (x.cmp(crt.halfQ) > 0) {
             y = crt.Q;
             y.sub(x);
-            v = -y.to_double();
+            v = -mw_to_double(y.w.data(), (int)crt.words);
         } else {
-            v = x.to_double();
+            v = mw_to_double(x.w.data(), (int)crt.words);
         }
-        const double ang = M_PI * (double)n / (double)N;
-        z[n] = std::complex<double>(std::cos(ang), std::sin(ang)) * (v / scale);
+        z[bitrev_u32((u32)n, P.logn)] = ckks_decode_coeff(v, zeta_[n], scale);
     }
-    fft_inplace(z, true); // z[j] = (1/N) sum_n ...; evaluation needs N * ifft
-    for (size_t i = 0; i < half; ++i) out[i] = z[slot_index_[i]].real() * (double)N;
+    fft_stages(z, fft_w_, true); // unnormalised inverse transform = evaluation at the slots' points
+    for (size_t i = 0; i < half; ++i) out[i] = z[slot_index_[i]].re;
 }
 
 std::vector<u64> Client::bfv_encode(const int64_t *values, size_t count) const

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../he_params.h"
+#include "ckks_codec.h"
 
 namespace he355 {
 namespace client {
@@ -19,6 +20,10 @@ namespace client {
 // scalar host transforms over one residue (same ordering as the device: natural <-> bit-reversed)
 void host_ntt_forward(const PrimeTables &pt, size_t N, u64 *poly);
 void host_ntt_inverse(const PrimeTables &pt, size_t N, u64 *poly);
+
+// encoder tables (also built by the device context, so that both sides use the very same values)
+void build_slot_index(size_t N, std::vector<uint32_t> &slot_index);
+void build_ckks_tables(size_t N, std::vector<Cplx> &W, std::vector<Cplx> &Z);
 
 class Client {
 public:
@@ -30,6 +35,10 @@ public:
     // ---- keys (SEAL layouts, NTT form) ----
     const std::vector<u64> &secret_key() const { return sk_; } // [K][N]
     const std::vector<u64> &public_key() const { return pk_; } // [2][K][N]
+    // encoder tables, for the device-side encoders: slot -> evaluation-point index (N entries), transform and twist tables
+    const std::vector<uint32_t> &slot_index() const { return slot_index_; }
+    const std::vector<Cplx> &fft_table() const { return fft_w_; }
+    const std::vector<Cplx> &twist_table() const { return zeta_; }
     std::vector<u64> make_relin_key();                         // [Ltop][2][K][N]
     std::vector<u64> make_galois_key(uint32_t galois_elt);     // [Ltop][2][K][N]
 
@@ -68,6 +77,7 @@ private:
     uint64_t enc_seed_ = 0, enc_index_ = 0;
     std::vector<u64> sk_, pk_;
     std::vector<uint32_t> slot_index_; // encoders' slot -> (bit-reversed) evaluation index map
+    std::vector<Cplx> fft_w_, zeta_;   // CKKS encoder transform tables (client/ckks_codec.h); the device gets copies
     PrimeTables plain_tables_;         // BFV: NTT mod t
 };
 

@@ -60,6 +60,9 @@ HE_HD void mw_add(u64 *x, const u64 *o, int w)
 }
 HE_HD double mw_to_double(const u64 *x, int w)
 {
+#if defined(__clang__)
+    _Pragma("clang fp contract(off)") // same roundings on host and device
+#endif
     double r = 0;
     for (int i = w; i-- > 0;) r = r * 18446744073709551616.0 + (double)x[i];
     return r;

@@ -17,6 +17,7 @@
 #include "he355_kernels.h"
 #include "he_params.h"
 #include "ntt_core.h"
+#include "client/he_client.h"
 #include "client/multiword.h"
 
 namespace he355 {
@@ -100,10 +101,14 @@ public:
         HIPCHECK(hipEventCreate(&ev0_));
         HIPCHECK(hipEventCreate(&ev1_));
         const size_t N = P.N, K = P.K;
-        const size_t n_all = K + P.aux.size(); // BFV: the BEHZ auxiliary primes follow the key chain
+        // BFV: the BEHZ auxiliary primes follow the key chain, then the plain modulus t (BatchEncoder's NTT mod t)
+        const bool with_t = P.scheme == kSchemeBFV && P.plain_modulus > 2 && (P.plain_modulus - 1) % (2 * N) == 0;
+        if (with_t) plain_tables_ = Params::make_prime_tables(P.plain_modulus, N, P.logn, false);
+        t_index_ = with_t ? (int)(K + P.aux.size()) : -1;
+        const size_t n_all = K + P.aux.size() + (with_t ? 1 : 0);
         std::vector<PrimeDev> pd(n_all);
         for (size_t i = 0; i < n_all; ++i) {
-            const PrimeTables &pt = i < K ? P.primes[i] : P.aux[i - K];
+            const PrimeTables &pt = i < K ? P.primes[i] : i < K + P.aux.size() ? P.aux[i - K] : plain_tables_;
             Tw16 *dfwd = nullptr, *dinv = nullptr;
             HIPCHECK(hipMalloc(&dfwd, N * sizeof(Tw16)));
             owned_.push_back(dfwd);
@@ -861,6 +866,102 @@ public:
         }
         HIPCHECK(hipGetLastError());
     }
+    // ---- encoders (CKKSEncoder / BatchEncoder) -------------------------------------------------------------------
+    const EncTablesDev &enc_tables()
+    {
+        if (enc_.slot_index) return enc_;
+        std::vector<uint32_t> si;
+        client::build_slot_index(P.N, si);
+        uint32_t *dsi = nullptr;
+        HIPCHECK(hipMalloc(&dsi, P.N * 4));
+        owned_.push_back(dsi);
+        HIPCHECK(hipMemcpy(dsi, si.data(), P.N * 4, hipMemcpyHostToDevice));
+        enc_.slot_index = dsi;
+        if (P.scheme == kSchemeCKKS) {
+            std::vector<client::Cplx> W, Z;
+            client::build_ckks_tables(P.N, W, Z);
+            client::Cplx *dw = nullptr;
+            HIPCHECK(hipMalloc(&dw, 2 * P.N * sizeof(client::Cplx)));
+            owned_.push_back(dw);
+            HIPCHECK(hipMemcpy(dw, W.data(), P.N * sizeof(client::Cplx), hipMemcpyHostToDevice));
+            HIPCHECK(hipMemcpy(dw + P.N, Z.data(), P.N * sizeof(client::Cplx), hipMemcpyHostToDevice));
+            enc_.W = dw; enc_.Z = dw + P.N;
+        }
+        if (!d_err_) { HIPCHECK(hipMalloc(&d_err_, sizeof(int))); owned_.push_back(d_err_); }
+        return enc_;
+    }
+    // CKKSEncoder::encode: values [n][count] (count <= N/2) at `scale` -> [n][Ltop][N] NTT-form plaintexts
+    void ckks_encode(u64 n, const double *values, u64 count, double scale, u64 *plain)
+    {
+        use();
+        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_ckks_encode needs a CKKS context");
+        if (count > P.N / 2) throw std::invalid_argument("Not enough slots available to create packed plaintext");
+        const EncTablesDev &T = enc_tables();
+        const size_t N = P.N, L = P.Ltop;
+        const u64 cmax = 256;
+        u64 *zbuf = client_scratch(cmax * 2 * N);
+        HIPCHECK(hipMemsetAsync(d_err_, 0, sizeof(int), stream_));
+        for (u64 off = 0; off < n; off += cmax) {
+            const u64 c = std::min<u64>(cmax, n - off);
+            launch_ckks_encode(env_, c, values + off * count, count, scale, zbuf, plain + off * L * N, T, d_err_);
+            launch_ntt_forward(env_, poly_view(plain + off * L * N, (int)L, N, (int)L), (u32)c);
+        }
+        int err = 0;
+        HIPCHECK(hipMemcpyAsync(&err, d_err_, sizeof(int), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+        if (err) throw std::invalid_argument("encoded values are too large");
+    }
+    // CKKSEncoder::decode: [n][L][N] NTT-form plaintexts -> [n][N/2] real slot values
+    void ckks_decode(int L, u64 n, const u64 *plain, double scale, double *out)
+    {
+        use();
+        check_level(L);
+        if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_ckks_decode needs a CKKS context");
+        if (L > 16) throw std::invalid_argument("decoding supports up to 16 data primes");
+        const EncTablesDev &T = enc_tables();
+        const CrtTablesDev &crt = crt_tables(L);
+        const size_t N = P.N;
+        const u64 cmax = 128;
+        u64 *coeff = client_scratch(cmax * ((size_t)L * N + 2 * N)), *zbuf = coeff + cmax * (size_t)L * N;
+        for (u64 off = 0; off < n; off += cmax) {
+            const u64 c = std::min<u64>(cmax, n - off);
+            HIPCHECK(hipMemcpyAsync(coeff, plain + off * L * N, c * L * N * 8, hipMemcpyDeviceToDevice, stream_));
+            launch_ntt_inverse(env_, poly_view(coeff, L, N, L), (u32)c);
+            launch_ckks_decode(env_, c, coeff, scale, zbuf, out + off * (N / 2), T, crt);
+        }
+        HIPCHECK(hipGetLastError());
+    }
+    // BatchEncoder::encode / decode: [n][count] int64 <-> [n][N] coefficients mod t
+    void bfv_encode(u64 n, const long long *values, u64 count, u64 *plain)
+    {
+        use();
+        if (t_index_ < 0) throw std::invalid_argument("he355_bfv_encode needs a BFV context with a batching plain modulus");
+        if (count > P.N) throw std::invalid_argument("Not enough slots available to create packed plaintext");
+        const EncTablesDev &T = enc_tables();
+        HIPCHECK(hipMemsetAsync(plain, 0, n * P.N * 8, stream_));
+        launch_bfv_encode_scatter(env_, n, values, count, plain, T.slot_index, P.plain_modulus);
+        PolyView v = poly_view(plain, 1, P.N, 1);
+        v.prime_of[0] = (unsigned char)t_index_;
+        launch_ntt_inverse(env_, v, (u32)n);
+        HIPCHECK(hipGetLastError());
+    }
+    void bfv_decode(u64 n, const u64 *plain, long long *out)
+    {
+        use();
+        if (t_index_ < 0) throw std::invalid_argument("he355_bfv_decode needs a BFV context with a batching plain modulus");
+        const EncTablesDev &T = enc_tables();
+        const u64 cmax = 1024;
+        u64 *ev = client_scratch(cmax * P.N);
+        for (u64 off = 0; off < n; off += cmax) {
+            const u64 c = std::min<u64>(cmax, n - off);
+            HIPCHECK(hipMemcpyAsync(ev, plain + off * P.N, c * P.N * 8, hipMemcpyDeviceToDevice, stream_));
+            PolyView v = poly_view(ev, 1, P.N, 1);
+            v.prime_of[0] = (unsigned char)t_index_;
+            launch_ntt_forward(env_, v, (u32)c);
+            launch_bfv_decode_gather(env_, c, ev, out + off * P.N, T.slot_index, P.plain_modulus);
+        }
+        HIPCHECK(hipGetLastError());
+    }
     void ntt(u64 *polys, u64 n_polys, const uint8_t *prime_of, u32 period, bool inverse)
     {
         use();
@@ -922,6 +1023,10 @@ private:
     FloorConst *d_floor_ = nullptr;
     std::vector<void *> owned_;
     u64 *d_relin_ = nullptr;
+    PrimeTables plain_tables_; // BFV: NTT tables mod t
+    int t_index_ = -1;         // index of t in the device prime array (-1: none)
+    EncTablesDev enc_{nullptr, nullptr, nullptr};
+    int *d_err_ = nullptr;
     u64 *d_pk_ = nullptr, *d_sk_ = nullptr;
     u64 *client_scratch_ = nullptr;
     size_t client_scratch_elems_ = 0;
@@ -1200,6 +1305,22 @@ int he355_encrypt(he355_ctx *c, uint64_t n, const uint64_t *d_plain, uint64_t se
 int he355_decrypt(he355_ctx *c, int L, int size, uint64_t n, const uint64_t *d_ct, uint64_t *d_out)
 {
     return guarded([&] { dev(c).decrypt(L, size, n, d_ct, d_out); });
+}
+int he355_ckks_encode(he355_ctx *c, uint64_t n, const double *d_values, uint64_t count, double scale, uint64_t *d_plain)
+{
+    return guarded([&] { dev(c).ckks_encode(n, d_values, count, scale, d_plain); });
+}
+int he355_ckks_decode(he355_ctx *c, int L, uint64_t n, const uint64_t *d_plain, double scale, double *d_out)
+{
+    return guarded([&] { dev(c).ckks_decode(L, n, d_plain, scale, d_out); });
+}
+int he355_bfv_encode(he355_ctx *c, uint64_t n, const int64_t *d_values, uint64_t count, uint64_t *d_plain)
+{
+    return guarded([&] { dev(c).bfv_encode(n, reinterpret_cast<const long long *>(d_values), count, d_plain); });
+}
+int he355_bfv_decode(he355_ctx *c, uint64_t n, const uint64_t *d_plain, int64_t *d_out)
+{
+    return guarded([&] { dev(c).bfv_decode(n, d_plain, reinterpret_cast<long long *>(d_out)); });
 }
 int he355_probe_dominant_kernel(he355_ctx *c, float *total_ms, uint64_t *launches, uint64_t *ops)
 {

@@ -144,4 +144,16 @@ struct CrtTablesDev { // device arrays of the CRT tables of the first L primes (
 };
 void launch_bfv_scale_round(const KernelEnv &env, u64 n_cts, const u64 *phase, u64 *plain, const CrtTablesDev &c);
 
+// ---- encoders on the device ---------------------------------------------------------------------------------
+struct EncTablesDev { // device copies of the host client's encoder tables (client/ckks_codec.h); W, Z: [N] {re, im} doubles
+    const uint32_t *slot_index;
+    const void *W, *Z;
+};
+// values [n][count] -> plain [n][Ltop][N] coefficient form (zbuf: [n][N] complex scratch; *err |= 1 if a coefficient overflows)
+void launch_ckks_encode(const KernelEnv &env, u64 n_vec, const double *values, u64 count, double scale, void *zbuf, u64 *plain, const EncTablesDev &t, int *err);
+// coeff [n][L][N] coefficient form -> out [n][N/2]
+void launch_ckks_decode(const KernelEnv &env, u64 n_vec, const u64 *coeff, double scale, void *zbuf, double *out, const EncTablesDev &t, const CrtTablesDev &c);
+void launch_bfv_encode_scatter(const KernelEnv &env, u64 n_vec, const long long *values, u64 count, u64 *ev, const uint32_t *slot_index, u64 t);
+void launch_bfv_decode_gather(const KernelEnv &env, u64 n_vec, const u64 *ev, long long *out, const uint32_t *slot_index, u64 t);
+
 } // namespace he355

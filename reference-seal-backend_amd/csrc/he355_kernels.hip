@@ -20,6 +20,7 @@
 
 #include "he355_kernels.h"
 #include "ntt_core.h"
+#include "client/ckks_codec.h"
 #include "client/multiword.h"
 #include "client/sampler.h"
 
@@ -1383,6 +1384,96 @@ __global__ void __launch_bounds__(kBlock) k_bfv_scale_round(const u64 *phase, u6
     plain[(r << logN) + n] = client::bfv_scale_round(c.v, x, c.t, c.Qd);
 }
 
+// ---- encoders on the device: CKKSEncoder / BatchEncoder encode and decode (seal_context.cpp:145-185 call sites) ------------
+// The floating-point work is the shared inline code of client/ckks_codec.h (same IEEE operations, same tables as the host
+// client).  One 1024-thread workgroup owns one vector; the N-point transform runs stage by stage on a per-vector buffer in
+// global memory (L2-resident: 16 B x N), workgroup barriers between stages.
+constexpr int kEncBlock = 1024;
+struct EncTables {
+    const uint32_t *slot_index; // [N] slot -> evaluation-point index
+    const client::Cplx *W, *Z;  // transform and twist tables
+};
+__device__ __forceinline__ void fft_stages_block(client::Cplx *z, const client::Cplx *W, u32 N, bool inverse)
+{
+    for (u32 len = 2; len <= N; len <<= 1) {
+        for (u32 t = threadIdx.x; t < N / 2; t += kEncBlock) client::fft_stage_bfly(z, W, len, t, inverse);
+        __syncthreads();
+    }
+}
+// values [n][count] doubles -> plain [n][Ltop][N] integer coefficients as residues (coefficient form; the caller transforms them)
+__global__ void __launch_bounds__(kEncBlock) k_ckks_encode(const double *values, u64 count, double scale, client::Cplx *zbuf, u64 *plain, EncTables T,
+                                                           const PrimeDev *primes, int Ltop, int logN, int *err)
+{
+    const u32 N = 1u << logN, half = N >> 1;
+    const u64 r = blockIdx.x;
+    client::Cplx *z = zbuf + r * N;
+    for (u32 n = threadIdx.x; n < N; n += kEncBlock) z[n] = client::Cplx{0.0, 0.0};
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < count; i += kEncBlock) {
+        const double v = values[r * count + i];
+        z[client::bitrev_u32(T.slot_index[i], logN)].re = v;
+        z[client::bitrev_u32(T.slot_index[half + i], logN)].re = v;
+    }
+    __syncthreads();
+    fft_stages_block(z, T.W, N, false);
+    for (u32 n = threadIdx.x; n < N; n += kEncBlock) {
+        const double rv = client::ckks_encode_coeff(z[n], T.Z[n], (double)N, scale);
+        long long iv = 0;
+        if (!(fabs(rv) < 9.2e18)) atomicOr(err, 1);
+        else iv = (long long)rv;
+        for (int i = 0; i < Ltop; ++i) {
+            const u64 q = primes[i].q;
+            const u64 m = iv >= 0 ? (u64)iv % q : (u64)(-iv) % q;
+            plain[((r * Ltop + i) << logN) + n] = (iv >= 0 || m == 0) ? m : q - m;
+        }
+    }
+}
+// coeff [n][L][N] coefficient-form plaintext -> out [n][N/2] slot values (real parts)
+__global__ void __launch_bounds__(kEncBlock) k_ckks_decode(const u64 *coeff, double scale, client::Cplx *zbuf, double *out, EncTables T, const PrimeDev *primes,
+                                                           CrtDev c, int logN)
+{
+    const u32 N = 1u << logN, half = N >> 1;
+    const u64 r = blockIdx.x;
+    client::Cplx *z = zbuf + r * N;
+    ModU64 mods[16];
+    for (int i = 0; i < c.v.L; ++i) mods[i] = make_modu(primes[i]);
+    for (u32 n = threadIdx.x; n < N; n += kEncBlock) {
+        u64 x[client::kMwWords], y[client::kMwWords];
+        client::crt_compose(c.v, mods, coeff + ((r * c.v.L) << logN) + n, (u64)1 << logN, x);
+        double v;
+        if (client::mw_cmp(x, c.v.halfQ, c.v.words) > 0) {
+            client::mw_copy(y, c.v.Q, c.v.words);
+            client::mw_sub(y, x, c.v.words);
+            v = -client::mw_to_double(y, c.v.words);
+        } else {
+            v = client::mw_to_double(x, c.v.words);
+        }
+        z[client::bitrev_u32(n, logN)] = client::ckks_decode_coeff(v, T.Z[n], scale);
+    }
+    __syncthreads();
+    fft_stages_block(z, T.W, N, true);
+    for (u32 i = threadIdx.x; i < half; i += kEncBlock) out[r * half + i] = z[T.slot_index[i]].re;
+}
+// BatchEncoder::encode: values [n][count] int64 -> evaluations mod t at the bit-reversed slot positions (the caller applies the
+// inverse NTT mod t); BatchEncoder::decode: evaluations -> centred int64 slots
+__global__ void __launch_bounds__(kBlock) k_bfv_encode_scatter(const long long *values, u64 count, u64 *ev, const uint32_t *slot_index, u64 t, int logN, u64 n_vec)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 r = gid >> logN, i = gid & (((u64)1 << logN) - 1);
+    if (r >= n_vec || i >= count) return;
+    const long long v = values[r * count + i];
+    const u64 m = v >= 0 ? (u64)v % t : (u64)(-v) % t;
+    ev[(r << logN) + client::bitrev_u32(slot_index[i], logN)] = (v >= 0 || m == 0) ? m : t - m;
+}
+__global__ void __launch_bounds__(kBlock) k_bfv_decode_gather(const u64 *ev, long long *out, const uint32_t *slot_index, u64 t, int logN, u64 n_vec)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 r = gid >> logN, i = gid & (((u64)1 << logN) - 1);
+    if (r >= n_vec) return;
+    const u64 v = ev[(r << logN) + client::bitrev_u32(slot_index[i], logN)];
+    out[(r << logN) + i] = v > t / 2 ? (long long)v - (long long)t : (long long)v;
+}
+
 inline unsigned grid_for(u64 jobs, u64 per_block) { return (unsigned)((jobs + per_block - 1) / per_block); }
 
 } // namespace
@@ -1755,6 +1846,38 @@ void launch_bfv_scale_round(const KernelEnv &env, u64 n_cts, const u64 *phase, u
     d.v.L = c.L; d.v.words = c.words; d.v.Q = c.Q; d.v.halfQ = c.halfQ; d.v.punct = c.punct; d.v.inv = c.inv;
     d.Qd = c.Qd; d.t = c.t;
     hipLaunchKernelGGL(k_bfv_scale_round, dim3(grid_for(n_cts << logN, kBlock)), dim3(kBlock), 0, env.stream, phase, plain, env.primes, d, logN, n_cts);
+}
+
+void launch_ckks_encode(const KernelEnv &env, u64 n_vec, const double *values, u64 count, double scale, void *zbuf, u64 *plain, const EncTablesDev &t, int *err)
+{
+    if (!n_vec) return;
+    EncTables T;
+    T.slot_index = t.slot_index; T.W = static_cast<const client::Cplx *>(t.W); T.Z = static_cast<const client::Cplx *>(t.Z);
+    hipLaunchKernelGGL(k_ckks_encode, dim3((unsigned)n_vec), dim3(kEncBlock), 0, env.stream, values, count, scale, static_cast<client::Cplx *>(zbuf), plain, T,
+                       env.primes, env.Ltop, env.logn1 + kRowLog, err);
+}
+void launch_ckks_decode(const KernelEnv &env, u64 n_vec, const u64 *coeff, double scale, void *zbuf, double *out, const EncTablesDev &t, const CrtTablesDev &c)
+{
+    if (!n_vec) return;
+    EncTables T;
+    T.slot_index = t.slot_index; T.W = static_cast<const client::Cplx *>(t.W); T.Z = static_cast<const client::Cplx *>(t.Z);
+    CrtDev d;
+    d.v.L = c.L; d.v.words = c.words; d.v.Q = c.Q; d.v.halfQ = c.halfQ; d.v.punct = c.punct; d.v.inv = c.inv;
+    d.Qd = c.Qd; d.t = c.t;
+    hipLaunchKernelGGL(k_ckks_decode, dim3((unsigned)n_vec), dim3(kEncBlock), 0, env.stream, coeff, scale, static_cast<client::Cplx *>(zbuf), out, T, env.primes, d,
+                       env.logn1 + kRowLog);
+}
+void launch_bfv_encode_scatter(const KernelEnv &env, u64 n_vec, const long long *values, u64 count, u64 *ev, const uint32_t *slot_index, u64 t)
+{
+    if (!n_vec) return;
+    const int logN = env.logn1 + kRowLog;
+    hipLaunchKernelGGL(k_bfv_encode_scatter, dim3(grid_for(n_vec << logN, kBlock)), dim3(kBlock), 0, env.stream, values, count, ev, slot_index, t, logN, n_vec);
+}
+void launch_bfv_decode_gather(const KernelEnv &env, u64 n_vec, const u64 *ev, long long *out, const uint32_t *slot_index, u64 t)
+{
+    if (!n_vec) return;
+    const int logN = env.logn1 + kRowLog;
+    hipLaunchKernelGGL(k_bfv_decode_gather, dim3(grid_for(n_vec << logN, kBlock)), dim3(kBlock), 0, env.stream, ev, out, slot_index, t, logN, n_vec);
 }
 
 } // namespace he355

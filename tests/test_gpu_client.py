@@ -119,3 +119,96 @@ def test_round_trip_through_the_evaluator(case, be):
         g.encrypt(1, d, 78, 5, ct)
         g.decrypt(L, 2, 1, ct, out)
         assert np.allclose(ho.ckks_decode(o, out.download((L, N)), scale).real, x, atol=1e-4)
+
+
+# ---- encoders on the device ---------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sim():
+    import ctypes as C
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.run(["make", "-C", os.path.join(here, "csim"), "-s"], check=True)
+    L = C.CDLL(os.path.join(here, "csim", "_build", "libcsim.so"))
+    vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+    L.sim_params_create.restype = vp
+    L.sim_params_create.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_int), C.c_size_t, C.c_int, C.c_int]
+    L.sim_params_destroy.argtypes = [vp]
+    L.simc_create.restype = vp
+    L.simc_create.argtypes = [vp, C.c_uint64]
+    L.simc_destroy.argtypes = [vp]
+    L.simc_ckks_encode.argtypes = [vp, C.POINTER(C.c_double), C.c_size_t, C.c_double, u64p]
+    L.simc_ckks_decode.argtypes = [vp, u64p, C.c_size_t, C.c_double, C.POINTER(C.c_double)]
+    L.simc_bfv_encode.argtypes = [vp, C.POINTER(C.c_int64), C.c_size_t, u64p]
+    L.simc_bfv_decode.argtypes = [vp, u64p, C.POINTER(C.c_int64)]
+    return L
+
+
+def _host_client(sim, scheme, N, bits, pb):
+    import ctypes as C
+    arr = (C.c_int * len(bits))(*bits)
+    p = sim.sim_params_create(2 if scheme == "ckks" else 1, N, arr, len(bits), pb, 0)
+    return p, sim.simc_create(p, 42)
+
+
+def test_encoders_match_host_client_and_oracle(request, case, be, sim, oracle):
+    """he355_ckks_encode / _decode and he355_bfv_encode / _decode: bit-identical to the product's host encoders (same inline
+    floating-point code and tables: csrc/client/ckks_codec.h) and consistent with the oracle's numpy restatement (CKKS: the
+    encoders are floating point; the coefficient rounding alone leaves ~sqrt(N)/2/scale per slot, 8e-8 at N=2^15 and scale 2^30:
+    tolerance 1e-6; BFV: exact)."""
+    import ctypes as C
+    import oracle as ho
+    scheme, g, o, sk, pk, rng = case
+    N, L = g.N, g.L
+    name = request.node.callspec.params["case"]
+    _, _, bits, pb = CASES[name]
+    p, c = _host_client(sim, scheme, N, bits, pb)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    if scheme == "ckks":
+        scale, n = 2.0 ** 30, 3
+        for count in (N // 2, 5):
+            x = rng.uniform(-1, 1, (n, count))
+            dv = g.to_device(x.view(np.uint64))
+            plain = g.alloc(n * L * N)
+            g.ckks_encode(n, dv, count, scale, plain)
+            got = plain.download((n, L, N))
+            for r in range(n):
+                want = np.empty((L, N), dtype=np.uint64)
+                row = np.ascontiguousarray(x[r])
+                sim.simc_ckks_encode(c, row.ctypes.data_as(dp), count, scale, oracle._p(want))
+                assert np.array_equal(got[r], want), (count, r)
+                assert np.allclose(ho.ckks_decode(o, got[r], scale).real[:count], x[r], atol=1e-6)
+            # decode on the device: bit-identical to the host decoder, and the values come back
+            for Ld in sorted({L, max(1, L - 1)}):
+                sub = np.ascontiguousarray(got[:, :Ld])
+                dpl = g.to_device(sub)
+                out = g.alloc(n * (N // 2))
+                g.ckks_decode(Ld, n, dpl, scale, out)
+                vals = out.download().view(np.float64).reshape(n, N // 2)
+                for r in range(n):
+                    want = np.empty(N // 2)
+                    sim.simc_ckks_decode(c, oracle._p(np.ascontiguousarray(sub[r])), Ld, scale, want.ctypes.data_as(dp))
+                    assert np.array_equal(vals[r], want), (count, Ld, r)
+                    assert np.allclose(vals[r, :count], x[r], atol=1e-6) and np.allclose(vals[r, count:], 0, atol=1e-6)
+    else:
+        n = 3
+        codec = ho.BatchCodec(N, o.t)
+        for count in (N, 7):
+            x = rng.integers(-(o.t // 2), o.t // 2, (n, count)).astype(np.int64)
+            dv = g.to_device(x.view(np.uint64))
+            plain = g.alloc(n * N)
+            g.bfv_encode(n, dv, count, plain)
+            got = plain.download((n, N))
+            for r in range(n):
+                full = np.zeros(N, dtype=np.int64)
+                full[:count] = x[r]
+                assert np.array_equal(got[r], codec.encode(full)), (count, r)
+                want = np.empty(N, dtype=np.uint64)
+                sim.simc_bfv_encode(c, np.ascontiguousarray(x[r]).ctypes.data_as(ip), count, oracle._p(want))
+                assert np.array_equal(got[r], want)
+            out = g.alloc(n * N)
+            g.bfv_decode(n, plain, out)
+            vals = out.download().view(np.int64).reshape(n, N)
+            assert np.array_equal(vals[:, :count], x) and not vals[:, count:].any()
+    sim.simc_destroy(c)
+    sim.sim_params_destroy(p)
