@@ -116,19 +116,21 @@ AB::Handle VectorBenchmark::encode(const AB::DataPackCollection *p_parameters)
     std::vector<std::vector<Plain>> params(p_parameters->pack_count);
     for (std::size_t x = 0; x < params.size(); ++x) {
         const AB::DataPack &parameter = p_parameters->p_data_packs[x];
-        params[x].resize(parameter.buffer_count);
-        for (std::size_t y = 0; y < params[x].size(); ++y) {
+        std::vector<std::vector<double>> rows_d;
+        std::vector<std::vector<std::int64_t>> rows_i;
+        for (std::size_t y = 0; y < parameter.buffer_count; ++y) {
             const AB::NativeDataBuffer &sample = parameter.p_buffers[y];
             if (!sample.p || sample.size < m_w_params.n() * 8)
                 throw HEBenchError(HEBERROR_MSG_CLASS("Invalid sample buffer."), HEBENCH_ECODE_INVALID_ARGS);
             if (m_scheme == Scheme::CKKS) {
                 const double *p_row = reinterpret_cast<const double *>(sample.p);
-                params[x][y] = m_p_ctx_wrapper->encodeVector(std::vector<double>(p_row, p_row + m_w_params.n()));
+                rows_d.emplace_back(p_row, p_row + m_w_params.n());
             } else {
                 const std::int64_t *p_row = reinterpret_cast<const std::int64_t *>(sample.p);
-                params[x][y] = m_p_ctx_wrapper->encodeVector(std::vector<std::int64_t>(p_row, p_row + m_w_params.n()));
+                rows_i.emplace_back(p_row, p_row + m_w_params.n());
             }
         }
+        params[x] = m_scheme == Scheme::CKKS ? m_p_ctx_wrapper->encodeBatch(rows_d) : m_p_ctx_wrapper->encodeBatch(rows_i); // one plaintext per sample
     }
     return this->getEngine().createHandle<decltype(params)>(sizeof(params), 0, std::move(params));
 }
@@ -139,19 +141,20 @@ void VectorBenchmark::decode(AB::Handle encoded_data, AB::DataPackCollection *p_
     if (p_native->pack_count < 1) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid output data pack."), HEBENCH_ECODE_INVALID_ARGS);
     const bool dot = this->getDescriptor().workload == AB::Workload::DotProduct;
     const std::size_t out_n = dot ? 1 : m_w_params.n();
-    for (std::size_t result_i = 0; result_i < params.size() && result_i < p_native->p_data_packs[0].buffer_count; ++result_i) {
-        void *loc = p_native->p_data_packs[0].p_buffers[result_i].p;
-        if (m_scheme == Scheme::CKKS) {
-            double *output_location = reinterpret_cast<double *>(loc);
-            std::vector<double> result_vec(m_p_ctx_wrapper->slot_count());
-            m_p_ctx_wrapper->client().ckks_decode(params[result_i].data.data(), (size_t)params[result_i].L, params[result_i].scale, result_vec.data());
+    const std::size_t n_res = std::min<std::size_t>(params.size(), p_native->p_data_packs[0].buffer_count);
+    const std::vector<Plain> wanted(params.begin(), params.begin() + n_res);
+    if (m_scheme == Scheme::CKKS) {
+        const std::vector<std::vector<double>> vals = m_p_ctx_wrapper->decodeBatchCKKS(wanted);
+        for (std::size_t result_i = 0; result_i < n_res; ++result_i) {
+            double *output_location = reinterpret_cast<double *>(p_native->p_data_packs[0].p_buffers[result_i].p);
             for (std::size_t x = 0; x < out_n; ++x) // same clamp as ckks eltwise .cpp:222-225
-                output_location[x] = std::abs(result_vec[x]) < 0.00005 ? 0 : result_vec[x];
-        } else {
-            std::int64_t *output_location = reinterpret_cast<std::int64_t *>(loc);
-            std::vector<std::int64_t> result_vec(m_p_ctx_wrapper->slot_count());
-            m_p_ctx_wrapper->client().bfv_decode(params[result_i].data.data(), result_vec.data());
-            for (std::size_t x = 0; x < out_n; ++x) output_location[x] = result_vec[x];
+                output_location[x] = std::abs(vals[result_i][x]) < 0.00005 ? 0 : vals[result_i][x];
+        }
+    } else {
+        const std::vector<std::vector<std::int64_t>> vals = m_p_ctx_wrapper->decodeBatchBFV(wanted);
+        for (std::size_t result_i = 0; result_i < n_res; ++result_i) {
+            std::int64_t *output_location = reinterpret_cast<std::int64_t *>(p_native->p_data_packs[0].p_buffers[result_i].p);
+            for (std::size_t x = 0; x < out_n; ++x) output_location[x] = vals[result_i][x];
         }
     }
 }

@@ -1,6 +1,8 @@
 // he_context.cpp — see he_context.h
 #include "he_context.h"
 
+#include <algorithm>
+
 #include <cmath>
 
 #include "../he355_internal.h"
@@ -81,6 +83,114 @@ Plain HeContextWrapper::encodeVector(const std::vector<std::int64_t> &values)
     p.data = m_client->bfv_encode(values.data(), values.size());
     p.L = topLevel();
     return p;
+}
+// Batched encoders: on the device when present (bit-identical to the host encoders: tests/test_gpu_client.py)
+template <class V> static std::uint64_t max_len(const std::vector<std::vector<V>> &rows)
+{
+    std::uint64_t m = 0;
+    for (const auto &r : rows) m = std::max<std::uint64_t>(m, r.size());
+    return m;
+}
+std::vector<Plain> HeContextWrapper::encodeBatch(const std::vector<std::vector<double>> &rows)
+{
+    std::vector<Plain> out(rows.size());
+    const std::uint64_t n = rows.size(), count = max_len(rows);
+    if (count > slot_count())
+        throw HEBenchError(HEBERROR_MSG_CLASS("Not enough slots available to create packed plaintext"), HEBENCH_ECODE_INVALID_ARGS);
+    if (n == 0) return out;
+    if (!clientOnDevice() || count == 0) {
+        for (std::uint64_t i = 0; i < n; ++i) out[i] = encodeVector(rows[i]);
+        return out;
+    }
+    const std::uint64_t N = m_params->N, pl = (std::uint64_t)topLevel() * N;
+    std::vector<double> flat(n * count, 0.0); // missing trailing slots are zeros, as in CKKSEncoder::encode
+    for (std::uint64_t i = 0; i < n; ++i) std::copy(rows[i].begin(), rows[i].end(), flat.begin() + i * count);
+    void *dv = nullptr, *dp = nullptr;
+    check(he355_malloc(m_ctx, flat.size() * 8, &dv), "device allocation");
+    check(he355_malloc(m_ctx, n * pl * 8, &dp), "device allocation");
+    check(he355_upload(m_ctx, dv, flat.data(), flat.size() * 8), "upload");
+    check(he355_ckks_encode(m_ctx, n, static_cast<double *>(dv), count, m_scale, static_cast<uint64_t *>(dp)), "encode");
+    for (std::uint64_t i = 0; i < n; ++i) {
+        out[i].data.resize(pl);
+        out[i].L = topLevel(); out[i].scale = m_scale;
+        check(he355_download(m_ctx, out[i].data.data(), static_cast<uint64_t *>(dp) + i * pl, pl * 8), "download");
+    }
+    (void)he355_free(m_ctx, dv);
+    (void)he355_free(m_ctx, dp);
+    return out;
+}
+std::vector<Plain> HeContextWrapper::encodeBatch(const std::vector<std::vector<std::int64_t>> &rows)
+{
+    std::vector<Plain> out(rows.size());
+    const std::uint64_t n = rows.size(), count = max_len(rows);
+    if (count > slot_count())
+        throw HEBenchError(HEBERROR_MSG_CLASS("Not enough slots available to create packed plaintext"), HEBENCH_ECODE_INVALID_ARGS);
+    if (n == 0) return out;
+    if (!clientOnDevice() || count == 0) {
+        for (std::uint64_t i = 0; i < n; ++i) out[i] = encodeVector(rows[i]);
+        return out;
+    }
+    const std::uint64_t N = m_params->N;
+    std::vector<std::int64_t> flat(n * count, 0);
+    for (std::uint64_t i = 0; i < n; ++i) std::copy(rows[i].begin(), rows[i].end(), flat.begin() + i * count);
+    void *dv = nullptr, *dp = nullptr;
+    check(he355_malloc(m_ctx, flat.size() * 8, &dv), "device allocation");
+    check(he355_malloc(m_ctx, n * N * 8, &dp), "device allocation");
+    check(he355_upload(m_ctx, dv, flat.data(), flat.size() * 8), "upload");
+    check(he355_bfv_encode(m_ctx, n, static_cast<std::int64_t *>(dv), count, static_cast<uint64_t *>(dp)), "encode");
+    check(he355_sync(m_ctx), "synchronise");
+    for (std::uint64_t i = 0; i < n; ++i) {
+        out[i].data.resize(N);
+        out[i].L = topLevel();
+        check(he355_download(m_ctx, out[i].data.data(), static_cast<uint64_t *>(dp) + i * N, N * 8), "download");
+    }
+    (void)he355_free(m_ctx, dv);
+    (void)he355_free(m_ctx, dp);
+    return out;
+}
+// decode: slot values of each plaintext (CKKS: N/2 doubles; BFV: N int64)
+std::vector<std::vector<double>> HeContextWrapper::decodeBatchCKKS(const std::vector<Plain> &plains)
+{
+    std::vector<std::vector<double>> out(plains.size(), std::vector<double>(slot_count()));
+    if (plains.empty()) return out;
+    bool uniform = true;
+    for (const Plain &p : plains) uniform = uniform && p.L == plains[0].L && p.scale == plains[0].scale;
+    if (!clientOnDevice() || !uniform || plains[0].L > 16) {
+        for (std::size_t i = 0; i < plains.size(); ++i) m_client->ckks_decode(plains[i].data.data(), (size_t)plains[i].L, plains[i].scale, out[i].data());
+        return out;
+    }
+    const int L = plains[0].L;
+    const std::uint64_t N = m_params->N, n = plains.size(), pl = (std::uint64_t)L * N, half = N / 2;
+    void *dv = nullptr, *dp = nullptr;
+    check(he355_malloc(m_ctx, n * half * 8, &dv), "device allocation");
+    check(he355_malloc(m_ctx, n * pl * 8, &dp), "device allocation");
+    for (std::uint64_t i = 0; i < n; ++i) check(he355_upload(m_ctx, static_cast<uint64_t *>(dp) + i * pl, plains[i].data.data(), pl * 8), "upload");
+    check(he355_ckks_decode(m_ctx, L, n, static_cast<uint64_t *>(dp), plains[0].scale, static_cast<double *>(dv)), "decode");
+    check(he355_sync(m_ctx), "synchronise");
+    for (std::uint64_t i = 0; i < n; ++i) check(he355_download(m_ctx, out[i].data(), static_cast<double *>(dv) + i * half, half * 8), "download");
+    (void)he355_free(m_ctx, dv);
+    (void)he355_free(m_ctx, dp);
+    return out;
+}
+std::vector<std::vector<std::int64_t>> HeContextWrapper::decodeBatchBFV(const std::vector<Plain> &plains)
+{
+    std::vector<std::vector<std::int64_t>> out(plains.size(), std::vector<std::int64_t>(slot_count()));
+    if (plains.empty()) return out;
+    if (!clientOnDevice()) {
+        for (std::size_t i = 0; i < plains.size(); ++i) m_client->bfv_decode(plains[i].data.data(), out[i].data());
+        return out;
+    }
+    const std::uint64_t N = m_params->N, n = plains.size();
+    void *dv = nullptr, *dp = nullptr;
+    check(he355_malloc(m_ctx, n * N * 8, &dv), "device allocation");
+    check(he355_malloc(m_ctx, n * N * 8, &dp), "device allocation");
+    for (std::uint64_t i = 0; i < n; ++i) check(he355_upload(m_ctx, static_cast<uint64_t *>(dp) + i * N, plains[i].data.data(), N * 8), "upload");
+    check(he355_bfv_decode(m_ctx, n, static_cast<uint64_t *>(dp), static_cast<std::int64_t *>(dv)), "decode");
+    check(he355_sync(m_ctx), "synchronise");
+    for (std::uint64_t i = 0; i < n; ++i) check(he355_download(m_ctx, out[i].data(), static_cast<std::int64_t *>(dv) + i * N, N * 8), "download");
+    (void)he355_free(m_ctx, dv);
+    (void)he355_free(m_ctx, dp);
+    return out;
 }
 // Client side: on the MI355X when one is present (he355_encrypt / he355_decrypt: same bits as the host code below for the same
 // randomness counter — tests/test_gpu_client.py), on the host otherwise, as in the reference, whose Encryptor / Decryptor are

@@ -63,6 +63,11 @@ public:
     // host side
     Plain encodeVector(const std::vector<double> &values);
     Plain encodeVector(const std::vector<std::int64_t> &values);
+    // batched encoders / decoders: one device call per operand when a GPU is present (same bits as the host encoders)
+    std::vector<Plain> encodeBatch(const std::vector<std::vector<double>> &rows);
+    std::vector<Plain> encodeBatch(const std::vector<std::vector<std::int64_t>> &rows);
+    std::vector<std::vector<double>> decodeBatchCKKS(const std::vector<Plain> &plains);
+    std::vector<std::vector<std::int64_t>> decodeBatchBFV(const std::vector<Plain> &plains);
     Cipher encrypt(const Plain &plain);
     Plain decrypt(const Cipher &cipher);
     std::vector<Cipher> encryptBatch(const std::vector<Plain> &plains);   // one device call for the whole operand when a GPU is present
