@@ -92,6 +92,11 @@ int he355_fill_uniform(he355_ctx *ctx, uint64_t *d_dst, uint64_t n_polys, const 
 /* ---- evaluation keys: host arrays [L_top digits][2][K][N], NTT form (SEAL KSwitchKeys layout) ---- */
 int he355_set_relin_key(he355_ctx *ctx, const uint64_t *h_key);
 int he355_set_galois_key(he355_ctx *ctx, uint32_t galois_elt, const uint64_t *h_key);
+/* KeyGenerator on the device (create_relin_keys / create_galois_keys, src/engine/seal_context.cpp:53,69) from the secret key given
+ * to he355_set_secret_key; randomness: counter-based streams of `seed` (csrc/client/sampler.h keygen_stream) — the host client's
+ * make_relin_key / make_galois_key with the same seed give the same bits */
+int he355_keygen_relin(he355_ctx *ctx, uint64_t seed);
+int he355_keygen_galois(he355_ctx *ctx, uint32_t galois_elt, uint64_t seed);
 int he355_set_relin_key_synthetic(he355_ctx *ctx, uint64_t seed);                       /* uniform residues, generated in HBM */
 int he355_set_galois_key_synthetic(he355_ctx *ctx, uint32_t galois_elt, uint64_t seed);
 

@@ -83,6 +83,7 @@ def lib():
             "he355_relinearize_rescale": (i32, [vp, i32, u64, vp, vp]),
             "he355_set_public_key": (i32, [vp, vp]), "he355_set_secret_key": (i32, [vp, vp]),
             "he355_encrypt": (i32, [vp, u64, vp, u64, u64, vp]),
+            "he355_keygen_relin": (i32, [vp, u64]), "he355_keygen_galois": (i32, [vp, C.c_uint32, u64]),
             "he355_ckks_encode": (i32, [vp, u64, vp, u64, C.c_double, vp]),
             "he355_ckks_decode": (i32, [vp, i32, u64, vp, C.c_double, vp]),
             "he355_bfv_encode": (i32, [vp, u64, vp, u64, vp]),
@@ -118,7 +119,7 @@ C_ABI_SYMBOLS = [
     "he355_fill_uniform", "he355_set_relin_key", "he355_set_galois_key", "he355_set_relin_key_synthetic",
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",
-    "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_ckks_encode", "he355_ckks_decode",
+    "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_keygen_relin", "he355_keygen_galois", "he355_ckks_encode", "he355_ckks_decode",
     "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_accumulate",
     "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk",
 ]
@@ -230,6 +231,12 @@ class Context:
         k = np.ascontiguousarray(key, dtype=np.uint64)
         assert k.size == self.L * 2 * self.K * self.N
         _check(lib().he355_set_galois_key(self.h, elt, k.ctypes.data_as(_u64p)))
+
+    def keygen_relin(self, seed: int):
+        _check(lib().he355_keygen_relin(self.h, seed))
+
+    def keygen_galois(self, elt: int, seed: int):
+        _check(lib().he355_keygen_galois(self.h, elt, seed))
 
     def set_relin_key_synthetic(self, seed: int):
         _check(lib().he355_set_relin_key_synthetic(self.h, seed))

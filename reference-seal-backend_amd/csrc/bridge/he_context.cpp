@@ -307,8 +307,12 @@ void HeContextWrapper::needRelinKey()
 {
     ensureDevice();
     if (m_relin) return;
-    const std::vector<uint64_t> k = m_client->make_relin_key();
-    check(he355_set_relin_key(m_ctx, k.data()), "relinearization key upload");
+    if (clientOnDevice()) { // KeyGenerator on the device: same key as make_relin_key() (tests/test_gpu_client.py)
+        check(he355_keygen_relin(m_ctx, m_client->keygen_seed()), "relinearization key generation");
+    } else {
+        const std::vector<uint64_t> k = m_client->make_relin_key();
+        check(he355_set_relin_key(m_ctx, k.data()), "relinearization key upload");
+    }
     m_relin = true;
 }
 void HeContextWrapper::needRotationKey(int step)
@@ -321,8 +325,12 @@ void HeContextWrapper::needGaloisKey(uint32_t elt)
 {
     ensureDevice();
     if (m_galois.count(elt)) return;
-    const std::vector<uint64_t> k = m_client->make_galois_key(elt);
-    check(he355_set_galois_key(m_ctx, elt, k.data()), "Galois key upload");
+    if (clientOnDevice()) {
+        check(he355_keygen_galois(m_ctx, elt, m_client->keygen_seed()), "Galois key generation");
+    } else {
+        const std::vector<uint64_t> k = m_client->make_galois_key(elt);
+        check(he355_set_galois_key(m_ctx, elt, k.data()), "Galois key upload");
+    }
     m_galois[elt] = true;
 }
 void HeContextWrapper::needDefaultGaloisKeys()

@@ -177,7 +177,7 @@ void build_ckks_tables(size_t N, std::vector<Cplx> &W, std::vector<Cplx> &Z)
     }
 }
 
-Client::Client(const Params &params, uint64_t seed) : P(params), rng_(seed), enc_seed_(splitmix64(seed ^ 0x656e6372797074ull))
+Client::Client(const Params &params, uint64_t seed) : P(params), rng_(seed), enc_seed_(splitmix64(seed ^ 0x656e6372797074ull)), key_seed_(splitmix64(seed ^ 0x6b657967656eull))
 {
     const size_t N = P.N, K = P.K;
     build_slot_index(N, slot_index_);
@@ -187,7 +187,7 @@ Client::Client(const Params &params, uint64_t seed) : P(params), rng_(seed), enc
     sample_ternary(sk_, K);
     for (size_t i = 0; i < K; ++i) host_ntt_forward(P.primes[i], N, sk_.data() + i * N);
     pk_.resize(2 * K * N);
-    enc_zero_symmetric(pk_.data());
+    enc_zero_symmetric(pk_.data(), 0, 0);
 }
 
 void Client::sample_ternary(std::vector<u64> &out, size_t nmod)
@@ -221,26 +221,30 @@ void Client::sample_uniform(std::vector<u64> &out, size_t nmod)
     }
 }
 
-// (b, a) with b = -(a*s + e), NTT form, key level
-void Client::enc_zero_symmetric(u64 *out)
+// (b, a) with b = -(a*s + e), NTT form, key level.  Randomness: counter-based streams of (key_id, digit) (client/sampler.h),
+// so the device key generator (he355_keygen_*) produces the same key from the same seed.
+void Client::enc_zero_symmetric(u64 *out, u64 key_id, u64 digit)
 {
     const size_t N = P.N, K = P.K;
-    std::vector<u64> a, e;
-    sample_uniform(a, K);
-    sample_cbd(e, K);
+    std::vector<u64> e(K * N);
+    for (size_t n = 0; n < N; ++n) {
+        const int v = sample_cbd_at(key_seed_, keygen_stream(key_id, digit, K, K), n);
+        for (size_t i = 0; i < K; ++i) e[i * N + n] = small_to_residue(v, P.primes[i].q);
+    }
     for (size_t i = 0; i < K; ++i) {
         const PrimeTables &pt = P.primes[i];
         host_ntt_forward(pt, N, e.data() + i * N);
         for (size_t n = 0; n < N; ++n) {
-            const u64 v = addmod(mulm(a[i * N + n], sk_[i * N + n], pt.mod), e[i * N + n], pt.q);
+            const u64 a = sample_uniform_at(key_seed_, keygen_stream(key_id, digit, K, i), n, pt.q);
+            const u64 v = addmod(mulm(a, sk_[i * N + n], pt.mod), e[i * N + n], pt.q);
             out[i * N + n] = negm(v, pt.q);
-            out[(K + i) * N + n] = a[i * N + n];
+            out[(K + i) * N + n] = a;
         }
     }
 }
 
 // KeyGenerator::generate_one_kswitch_key: digit j = Enc(0) + (P mod q_j) * new_key on residue j of the first poly
-std::vector<u64> Client::make_kswitch_key(const std::vector<u64> &new_key)
+std::vector<u64> Client::make_kswitch_key(const std::vector<u64> &new_key, u64 key_id)
 {
     const size_t N = P.N, K = P.K, Ld = P.Ltop;
     if (K < 2) throw std::invalid_argument("encryption parameters do not support key switching");
@@ -248,7 +252,7 @@ std::vector<u64> Client::make_kswitch_key(const std::vector<u64> &new_key)
     const u64 special = P.primes[K - 1].q;
     for (size_t j = 0; j < Ld; ++j) {
         u64 *dig = out.data() + j * 2 * K * N;
-        enc_zero_symmetric(dig);
+        enc_zero_symmetric(dig, key_id, j);
         const PrimeTables &pt = P.primes[j];
         const u64 f = special % pt.q;
         for (size_t n = 0; n < N; ++n) dig[j * N + n] = addmod(dig[j * N + n], mulm(new_key[j * N + n], f, pt.mod), pt.q);
@@ -260,7 +264,7 @@ std::vector<u64> Client::make_relin_key()
     std::vector<u64> s2(P.K * P.N);
     for (size_t i = 0; i < P.K; ++i)
         for (size_t n = 0; n < P.N; ++n) s2[i * P.N + n] = mulm(sk_[i * P.N + n], sk_[i * P.N + n], P.primes[i].mod);
-    return make_kswitch_key(s2);
+    return make_kswitch_key(s2, 1);
 }
 std::vector<u64> Client::make_galois_key(uint32_t elt)
 {
@@ -268,7 +272,7 @@ std::vector<u64> Client::make_galois_key(uint32_t elt)
     std::vector<u64> rs(P.K * P.N);
     for (size_t i = 0; i < P.K; ++i)
         for (size_t n = 0; n < P.N; ++n) rs[i * P.N + n] = sk_[i * P.N + perm[n]];
-    return make_kswitch_key(rs);
+    return make_kswitch_key(rs, 2 + (u64)elt);
 }
 
 std::vector<u64> Client::ckks_encode(const double *values, size_t count, double scale) const

@@ -58,6 +58,7 @@ public:
     std::vector<u64> encrypt(const u64 *plain);
     std::vector<u64> encrypt_zero();
     uint64_t encrypt_seed() const { return enc_seed_; }
+    uint64_t keygen_seed() const { return key_seed_; } // evaluation keys: streams keygen_stream(key id, digit, ...) of this seed
     uint64_t encrypt_index() const { return enc_index_; }               // index the next encryption will use
     void set_encrypt_index(uint64_t index) { enc_index_ = index; }
     // ---- decryption of a size-`size` ciphertext at level L (size 3 allowed: the reference decrypts
@@ -68,13 +69,14 @@ private:
     void sample_ternary(std::vector<u64> &out, size_t nmod);
     void sample_cbd(std::vector<u64> &out, size_t nmod);
     void sample_uniform(std::vector<u64> &out, size_t nmod);
-    void enc_zero_symmetric(u64 *out /*[2][K][N]*/);
-    std::vector<u64> make_kswitch_key(const std::vector<u64> &new_key);
+    void enc_zero_symmetric(u64 *out /*[2][K][N]*/, u64 key_id, u64 digit);
+    std::vector<u64> make_kswitch_key(const std::vector<u64> &new_key, u64 key_id);
     void divide_round_last(const std::vector<u64> &in, size_t size, std::vector<u64> &out) const; // key level -> data level
 
     const Params &P;
     std::mt19937_64 rng_;
     uint64_t enc_seed_ = 0, enc_index_ = 0;
+    uint64_t key_seed_ = 0;
     std::vector<u64> sk_, pk_;
     std::vector<uint32_t> slot_index_; // encoders' slot -> (bit-reversed) evaluation index map
     std::vector<Cplx> fft_w_, zeta_;   // CKKS encoder transform tables (client/ckks_codec.h); the device gets copies

@@ -47,6 +47,25 @@ HE_HD int sample_cbd_at(u64 seed, u64 stream, u64 n)
 // small signed value -> residue mod q
 HE_HD u64 small_to_residue(int e, u64 q) { return e >= 0 ? (u64)e : q - (u64)(-e); }
 
+// uniform in [0, q): rejection sampling below the largest multiple of q (SEAL sample_poly_uniform), at most 8 draws per
+// coefficient from the sub-counter 8n..8n+7; all eight rejected (probability < 2^-32 for q < 2^60) falls back to the last
+// draw reduced mod q
+HE_HD u64 sample_uniform_at(u64 seed, u64 stream, u64 n, u64 q)
+{
+    const u64 lim = ~(u64)0 - (~(u64)0 % q) - 1; // accept v <= lim
+    u64 v = 0;
+    for (int k = 0; k < 8; ++k) {
+        v = sample_word(seed, stream, 8 * n + (u64)k);
+        if (v <= lim) break;
+    }
+    return v % q;
+}
+// streams of key generation: key `key_id` (0: public key, 1: relinearization key, 2 + galois_elt: Galois keys), digit j, then
+// K streams for the uniform polynomial (one per prime) and one for the error polynomial
+HE_HD u64 keygen_stream(u64 key_id, u64 digit, u64 K, u64 which /* prime index, or K for the error */)
+{
+    return ((u64)1 << 40) + (key_id * 64 + digit) * (K + 1) + which;
+}
 // streams of one asymmetric encryption, ciphertext index r: u, e0, e1
 HE_HD u64 enc_stream(u64 r, int which) { return 3 * r + (u64)which; }
 

@@ -210,6 +210,19 @@ public:
         hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, *slot, n_polys, P.logn, d_primes_, pm, seed);
         key_finish(*slot);
     }
+    // KeyGenerator on the device: the key for key_id 1 (relinearization) or 2 + galois_elt, from the secret key set with
+    // he355_set_secret_key; same bits as the host client's make_relin_key / make_galois_key for the same seed
+    void key_generate(u64 **slot, u64 seed, uint32_t galois_elt /* 0: relinearization key */)
+    {
+        use();
+        require_keyswitch();
+        if (!d_sk_) throw std::invalid_argument("secret key not set");
+        if (!*slot) HIPCHECK(hipMalloc(slot, key_alloc_elems() * 8));
+        const uint32_t *perm_tab = galois_elt ? perm(galois_elt) : nullptr;
+        u64 *scr = client_scratch((P.Ltop * P.K + P.K) * P.N);
+        launch_keygen_kswitch(env_, *slot, scr, scr + P.Ltop * P.K * P.N, d_sk_, perm_tab, seed, galois_elt ? 2 + (u64)galois_elt : 1);
+        key_finish(*slot);
+    }
     void key_finish(u64 *d_key)
     {
         const u64 n_polys = P.Ltop * 2 * P.K, total = n_polys * P.N;
@@ -1200,6 +1213,17 @@ int he355_set_relin_key(he355_ctx *c, const uint64_t *h_key)
 int he355_set_galois_key(he355_ctx *c, uint32_t elt, const uint64_t *h_key)
 {
     return guarded([&] { dev(c).key_from_host(dev(c).galois_slot(elt), h_key); });
+}
+int he355_keygen_relin(he355_ctx *c, uint64_t seed)
+{
+    return guarded([&] { dev(c).key_generate(dev(c).relin_slot(), seed, 0); });
+}
+int he355_keygen_galois(he355_ctx *c, uint32_t galois_elt, uint64_t seed)
+{
+    return guarded([&] {
+        if (!(galois_elt & 1) || galois_elt >= 2 * he355_poly_degree(c) || galois_elt < 3) throw std::invalid_argument("Galois element is not valid");
+        dev(c).key_generate(dev(c).galois_slot(galois_elt), seed, galois_elt);
+    });
 }
 int he355_set_relin_key_synthetic(he355_ctx *c, uint64_t seed)
 {

@@ -156,4 +156,9 @@ void launch_ckks_decode(const KernelEnv &env, u64 n_vec, const u64 *coeff, doubl
 void launch_bfv_encode_scatter(const KernelEnv &env, u64 n_vec, const long long *values, u64 count, u64 *ev, const uint32_t *slot_index, u64 t);
 void launch_bfv_decode_gather(const KernelEnv &env, u64 n_vec, const u64 *ev, long long *out, const uint32_t *slot_index, u64 t);
 
+// ---- key generation on the device --------------------------------------------------------------------------------
+// key [Ltop][2][K][N] <- key-switching key for new_key = s^2 (perm == null) or s permuted by `perm` (Galois key);
+// e_scratch [Ltop][K][N], target_scratch [K][N]; randomness: keygen_stream(key_id, digit, ...) of `seed` (client/sampler.h)
+void launch_keygen_kswitch(const KernelEnv &env, u64 *key, u64 *e_scratch, u64 *target_scratch, const u64 *sk, const uint32_t *perm, u64 seed, u64 key_id);
+
 } // namespace he355

