@@ -126,15 +126,6 @@ __device__ __forceinline__ void lds_rowA(const u64 *lds_row, int lane, u64 v[kRo
 #pragma unroll
     for (int r = 0; r < kRowE; ++r) v[r] = lds_row[(r << 6) | lane];
 }
-__device__ __forceinline__ void lds_rowC(const u64 *lds_row, int lane, u64 v[kRowE])
-{
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(lds_row + (c << 8) + (lane << 2));
-        const ulonglong2 lo = p[0], hi = p[1];
-        v[4 * c + 0] = lo.x; v[4 * c + 1] = lo.y; v[4 * c + 2] = hi.x; v[4 * c + 3] = hi.y;
-    }
-}
 
 // ---- wave-level row transforms (x in: layout A for forward, layout C for inverse) ---------------------
 // U rows of the same tile at once (shared twiddles, interleaved butterfly chains); lds_w: U exchange buffers.
@@ -720,22 +711,25 @@ stage_row_twiddles(const PrimeDev &P, const Ar &ar, u32 rowbase, unsigned char *
     constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
     typename std::conditional<kF64, TwRowF64, TwRow>::type twr;
     const gtw_t gf = gtw(P.fwd);
-    Tw16 tmp[kRowTw / BLOCK];
+    constexpr int kIter = (kRowTw + BLOCK - 1) / BLOCK;
+    Tw16 tmp[kIter];
 #pragma unroll
-    for (int k = 0; k < kRowTw / BLOCK; ++k) { // all loads in flight together
+    for (int k = 0; k < kIter; ++k) { // all loads in flight together
         const u32 i = threadIdx.x + k * BLOCK;
         tmp[k] = tw_load(gf, tw_row_source(rowbase, i + 1 < (u32)kRowTw ? i : 0));
     }
     if constexpr (kF64) {
         double *twl = reinterpret_cast<double *>(twl_raw);
 #pragma unroll
-        for (int k = 0; k < kRowTw / BLOCK; ++k) twl[threadIdx.x + k * BLOCK] = ArF64::tw_w(tmp[k]);
+        for (int k = 0; k < kIter; ++k)
+            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[threadIdx.x + k * BLOCK] = ArF64::tw_w(tmp[k]);
         twr.t = twl;
         twr.qinv = ar.qinv;
     } else {
         Tw16 *twl = reinterpret_cast<Tw16 *>(twl_raw);
 #pragma unroll
-        for (int k = 0; k < kRowTw / BLOCK; ++k) twl[threadIdx.x + k * BLOCK] = tmp[k];
+        for (int k = 0; k < kIter; ++k)
+            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[threadIdx.x + k * BLOCK] = tmp[k];
         twr.t = twl;
     }
     return twr;

@@ -409,3 +409,35 @@ def test_cfg4_full_size_dot_product(be, oracle):
             t = o.add(t, o.apply_galois(t, e, gks[e]))
         assert np.array_equal(got[r], t), r
     g.close()
+
+
+def test_empty_batches_and_argument_errors(be, oracle):
+    """n = 0 is a no-op for every batched entry point; bad levels / sizes / missing keys are reported as HE355_E_INVALID_ARGS
+    (the bridge maps them to the reference's error codes), never executed."""
+    g = be.Context(be.SCHEME_CKKS, 2048, bit_sizes=[60, 40, 40, 60], sec128=False, device=0)
+    L, N = g.L, g.N
+    buf = g.alloc(4 * 3 * L * N)
+    ix = be.Context.pairwise()
+    g.add(L, 2, 0, buf, buf, ix, buf)
+    g.multiply(L, 0, buf, buf, ix, buf)
+    g.rescale(L, 2, 0, buf, buf)
+    g.mod_switch_drop(L, L - 1, 0, buf, buf)
+    g.multiply_plain(L, 2, 0, buf, buf, ix, buf)
+    g.set_relin_key_synthetic(1)
+    g.multiply_relin(L, 0, buf, buf, ix, buf, rescale=True)
+    g.relinearize(L, 0, buf, buf)
+    g.sync()
+    for bad in (lambda: g.add(L + 1, 2, 1, buf, buf, ix, buf),            # level above the top
+                lambda: g.add(0, 2, 1, buf, buf, ix, buf),                # level 0
+                lambda: g.rescale(1, 2, 1, buf, buf),                     # nothing left to drop
+                lambda: g.rescale(L, 4, 1, buf, buf),                     # size out of range
+                lambda: g.mod_switch_drop(L, L + 1, 1, buf, buf),         # cannot switch upwards
+                lambda: g.apply_galois(L, 1, buf, 4, buf),                # even Galois element
+                lambda: g.rotate(L, 1, buf, 1, buf),                      # Galois key for step 1 not set
+                lambda: g.sum(L, 2, 0, buf, buf),                         # nothing to sum
+                lambda: g.decrypt(L, 2, 1, buf, buf),                     # secret key not set
+                lambda: g.bfv_multiply(L, 1, buf, buf, ix, buf)):         # BFV op on a CKKS context
+        with pytest.raises(be.HE355Error) as ei:
+            bad()
+        assert ei.value.code == 1, ei.value
+    g.close()
