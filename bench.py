@@ -171,7 +171,11 @@ def main():
         # rows of those primes once per launch.
         n_f = sum(1 for i in list(range(L)) + [K - 1] if ctx.fp64[i])
         k3_ops_per_launch = k3_ops / max(1, k3_launches)
-        k3_bytes_op = (n_f * L + 2 * n_f) * N * 8 + (L * 2 * n_f * N * 8) / max(1.0, k3_ops_per_launch)
+        # with the mod-down fused into it (default): + the correction rows and the c01 rows it reads, and the c01 rows it writes
+        # replace the sums slab: n_f * L digit rows + 2 n_f (corrections) + 2 n_f (c01 in) + 2 n_f (c01 out)
+        fused = os.environ.get("HE355_K3_FUSE", "1") != "0"
+        k3_polys = n_f * L + (6 * n_f if fused else 2 * n_f)
+        k3_bytes_op = k3_polys * N * 8 + (L * 2 * n_f * N * 8) / max(1.0, k3_ops_per_launch)
         k3_avg_ms = k3_ms / max(1, k3_launches)
         k3_gbps = k3_bytes_op * k3_ops_per_launch / (k3_avg_ms / 1e3) / 1e9 if k3_launches else None
         out = {
@@ -194,9 +198,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": traffic,
                          "traffic_note": "HBM bytes per step (1024 ops) from PMC counters; algorithmic bytes per step = %d" % int(bytes_op * n),
-                         "kernel": "mul->relin->rescale kernel sequence (k_k1, k_k2, k_k3 x2, k_floor_cols x2, k_floor_rows x4 per chunk)",
+                         "kernel": "mul->relin->rescale kernel sequence per chunk (k_k1, k_k2, k_k3 special prime, k_floor_cols, k_k3 data primes with fused mod-down, k_floor_cols, k_floor_rows)",
                          "algorithmic_bytes_per_op": bytes_op,
-                         "dominant_kernel": {"name": "k_k3<ArF64> (forward row pass of the lifted digits + key MAC, fp64-engine primes)",
+                         "dominant_kernel": {"name": "k_k3<ArF64> (forward row pass of the lifted digits + key MAC + fused mod-down, fp64-engine primes)",
                                              "launches": k3_launches, "ops_per_launch": k3_ops_per_launch, "avg_launch_ms_hip_events": round(k3_avg_ms, 4),
                                              "share_of_gpu_time": round(k3_ms / gpu_ms, 3) if gpu_ms else None,
                                              "algorithmic_bytes_per_launch": round(k3_bytes_op * k3_ops_per_launch),

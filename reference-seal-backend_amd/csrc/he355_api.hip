@@ -354,6 +354,16 @@ public:
         const int SP = (int)P.K - 1;
         launch_k2(env_, L, nc, B);
         if (after_k2) HIPCHECK(hipEventRecord(after_k2, env_.stream));
+        if (k3_can_fuse(env_) && B.c01_item_stride == 2 * LN) {
+            // special prime first, its correction through the column pass, then the data primes with the mod-down finished
+            // inside K3 (the sums never go to HBM); the rescale prime's inverse row pass is a small launch of its own
+            launch_k3(env_, L, nc, B, key, K3_SPECIAL_ONLY);
+            launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
+            K3Fuse fuse{B.e, B.c01, B.c01_item_stride};
+            launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &fuse);
+            if (with_tail) launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
+            return;
+        }
         launch_k3(env_, L, nc, B, key);
         launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
         FloorRowsArgs fr;

@@ -73,7 +73,16 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
 void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *src = nullptr, u64 src_op_stride = 0);
 // K3: forward row pass of every (tt, j) + multiply-accumulate with the key -> t (data primes) / tpr (special)
 // BFV (env.scheme == 1): the products of ALL primes continue into the inverse row pass (t then holds raw rows)
-void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key);
+// `part`: all tiles, only the special prime's, or only the data primes'.  With `fuse` (data-prime tiles, CKKS, default block
+// shapes: k3_can_fuse) the mod-down is finished inside the kernel: c01 += (sums - NTT(cols)) * P^-1, no t slab, no k_floor_rows.
+enum K3Part { K3_ALL = 0, K3_SPECIAL_ONLY = 1, K3_DATA_ONLY = 2 };
+struct K3Fuse {
+    const u64 *cols;     // [n_ops*2][L][N] output of launch_floor_cols(special prime -> L targets)
+    u64 *c01;
+    u64 c01_item_stride;
+};
+bool k3_can_fuse(const KernelEnv &env);
+void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part = K3_ALL, const K3Fuse *fuse = nullptr);
 // floor step, column half: src [n_ops*n_src][N] raw of prime s -> r = (x + floor(s/2)) mod s ->
 // (r mod q_i - floor(s/2) mod q_i) for i < n_tgt -> forward column pass -> dst [n_ops*n_src][n_tgt][N]
 void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst);

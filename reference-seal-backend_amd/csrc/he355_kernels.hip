@@ -737,6 +737,9 @@ stage_row_twiddles(const PrimeDev &P, const Ar &ar, u32 rowbase, unsigned char *
 
 struct K3Args {
     const u64 *d, *c2n, *key;
+    const u64 *cols;   // FUSE: mod-down corrections after the forward column pass [n_ops*2][L][N] (raw of prime tt)
+    u64 *c01; u64 c01_item_stride; // FUSE: polys that receive (T - NTT(cols)) * P^-1
+    const FloorConst *fc;          // FUSE: floor constants [K][K]
     const u64 *keyq;   // Shoup quotients of the key residues under the u64-engine primes: [L_top][2][n_q][N]
     int n_q;           // u64-engine primes in the key chain
     unsigned char q_slot[64]; // tt_list[k] -> its index among them
@@ -750,7 +753,11 @@ struct K3Args {
 
 // STAGE: digit rows reach the wave through an LDS landing buffer filled by LDS-DMA one step ahead (true), or straight
 // into registers by global loads issued one step ahead (false: no LDS traffic for them, 32 more live registers).
-template <class Ar, int U, int WAVES, bool STAGE>
+// FUSE: the mod-down of the key switch is finished here instead of in k_floor_rows: the tile's sums never leave the
+// registers — the wave transforms the matching rows of the special-prime correction (forward row pass, same tile twiddles)
+// and writes (T - NTT(delta)) * P^-1 + c01 straight into c01.  Needs the special prime's sums first: the caller launches the
+// special-prime tiles, the inverse transform and k_floor_cols before the data-prime tiles.
+template <class Ar, int U, int WAVES, bool STAGE, bool FUSE = false>
 __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *primes)
 {
     constexpr int kWaves = WAVES, kBlock = WAVES * 64; // this kernel's own block shape (shadows the file-wide one)
@@ -877,18 +884,39 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             for (int u = 0; u < U; ++u)
                 if (u < cnt) mac_digit(x[u], digit(i + u));
         }
-        // Epilogue: canonical sums, NTT form, layout C.  Data primes -> t; special prime -> tp.  The inverse row passes
-        // that follow (special prime always, every prime for BFV) are separate small launches: keeping them out of this
-        // kernel keeps its loop inside the instruction cache.
-        u64 v[kRowE];
-        u64 *dst0 = tt < A.L ? A.t + ((op * 2 + 0) * A.L + tt) * N + rowoff : A.tp + (op * 2 + 0) * N + rowoff;
-        u64 *dst1 = tt < A.L ? A.t + ((op * 2 + 1) * A.L + tt) * N + rowoff : A.tp + (op * 2 + 1) * N + rowoff;
+        if constexpr (FUSE) {
+            static_assert(!FUSE || U == 1, "the fused mod-down is written for one digit per wave");
+            const FloorConst fc = A.fc[(A.K - 1) * A.K + t];
+            const u64 LN = (u64)A.L * N;
+#pragma unroll 1
+            for (int k = 0; k < 2; ++k) {
+                T x[1][kRowE];
+                u64 v[kRowE], av[kRowE];
+                load_rowA(A.cols + ((op * 2 + k) * A.L + tt) * N + rowoff, lane, v);
 #pragma unroll
-        for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc0[r]);
-        if (valid) store_rowC(dst0, lane, v);
+                for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
+                wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x);
+                u64 *row = A.c01 + op * A.c01_item_stride + k * LN + (u64)tt * N + rowoff;
+                load_rowC(row, lane, av);
 #pragma unroll
-        for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc1[r]);
-        if (valid) store_rowC(dst1, lane, v);
+                for (int r = 0; r < kRowE; ++r)
+                    v[r] = ar.floor_fin(ar.acc_canon(k == 0 ? acc0[r] : acc1[r]), x[0][r], fc.inv, fc.inv_shoup, fc.inv_d, fc.inv_i, av[r]);
+                if (valid) store_rowC(row, lane, v);
+            }
+        } else {
+            // Epilogue: canonical sums, NTT form, layout C.  Data primes -> t; special prime -> tp.  The inverse row passes
+            // that follow (special prime always, every prime for BFV) are separate small launches: keeping them out of this
+            // kernel keeps its loop inside the instruction cache.
+            u64 v[kRowE];
+            u64 *dst0 = tt < A.L ? A.t + ((op * 2 + 0) * A.L + tt) * N + rowoff : A.tp + (op * 2 + 0) * N + rowoff;
+            u64 *dst1 = tt < A.L ? A.t + ((op * 2 + 1) * A.L + tt) * N + rowoff : A.tp + (op * 2 + 1) * N + rowoff;
+#pragma unroll
+            for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc0[r]);
+            if (valid) store_rowC(dst0, lane, v);
+#pragma unroll
+            for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc1[r]);
+            if (valid) store_rowC(dst1, lane, v);
+        }
     }
 }
 
@@ -1652,19 +1680,32 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     }
 }
 
-void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key)
+bool k3_can_fuse(const KernelEnv &env)
+{
+    static const bool off = getenv("HE355_K3_FUSE") && getenv("HE355_K3_FUSE")[0] == '0';
+    static const int shape_env = getenv("HE355_K3_SHAPE") ? atoi(getenv("HE355_K3_SHAPE")) : 0;
+    static const int stage_env = getenv("HE355_K3_STAGE") ? atoi(getenv("HE355_K3_STAGE")) : HE355_K3_STAGE_DEFAULT;
+    const int sf = shape_env ? shape_env / 100 : HE355_K3_F64_SHAPE, su = shape_env ? shape_env % 100 : HE355_K3_U64_SHAPE;
+    return !off && env.scheme == 2 && env.K >= 2 && sf == 18 && su == 18 && stage_env != 0; // the fused instantiations exist for the default shapes
+}
+
+void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part, const K3Fuse *fuse)
 {
     const unsigned char *prime_f64 = env.prime_f64;
     if (!n_ops) return;
+    if (fuse && (part != K3_DATA_ONLY || !k3_can_fuse(env))) throw std::runtime_error("fused mod-down: data-prime tiles of the default shapes only");
     for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine primes, pass 1: u64-engine primes
         K3Args A;
         A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tp = buf.tp;
         A.n_ops = n_ops; A.L = L; A.K = env.K; A.logn1 = env.logn1; A.ckks = env.scheme == 2;
+        A.cols = fuse ? fuse->cols : nullptr; A.c01 = fuse ? fuse->c01 : nullptr; A.c01_item_stride = fuse ? fuse->c01_item_stride : 0;
+        A.fc = env.floor_consts;
         A.n_tt = 0;
         A.n_q = 0;
         for (int t = 0; t < env.K; ++t) A.n_q += prime_f64[t] == 0;
         A.keyq = key + (u64)env.Ltop * 2 * env.K * env.N; // the quotient array follows the key in the same allocation
         for (int tt = 0; tt <= L; ++tt) {
+            if ((part == K3_SPECIAL_ONLY && tt != L) || (part == K3_DATA_ONLY && tt == L)) continue;
             const int t = (tt == L) ? env.K - 1 : tt;
             if ((prime_f64[t] != 0) == (pass == 0)) {
                 int slot = 0;
@@ -1688,8 +1729,6 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.og_per_block = ogpb;
         const u64 n_ogb = (n_og + ogpb - 1) / ogpb;
         const unsigned g = (unsigned)(((tiles + 7) / 8) * 8 * n_ogb);
-        static const int stage_env = getenv("HE355_K3_STAGE") ? atoi(getenv("HE355_K3_STAGE")) : HE355_K3_STAGE_DEFAULT;
-        const bool staged = stage_env != 0 || shape / 10 != 1;
         KernelProbe *pr = pass == 0 ? env.probe : nullptr;
         int slot = -1;
         if (pr && pr->used < KernelProbe::kCap) {
@@ -1702,11 +1741,14 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             pr->ops += n_ops;
             (void)hipEventRecord(pr->start[slot], env.stream);
         }
+        static const int stage_env = getenv("HE355_K3_STAGE") ? atoi(getenv("HE355_K3_STAGE")) : HE355_K3_STAGE_DEFAULT;
+        const bool staged = stage_env != 0 || shape / 10 != 1;
         if (pass == 0) {
             switch (shape) {
             case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
             case 18:
-                if (staged) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                if (fuse) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                else if (staged) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 else hipLaunchKernelGGL((k_k3<ArF64, 1, 8, false>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 break;
             default: throw std::runtime_error("unsupported K3 fp64 shape");
@@ -1715,7 +1757,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             switch (shape) {
             case 14: hipLaunchKernelGGL((k_k3<ArU64, 1, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
             case 18:
-                if (staged) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                else if (staged) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 else hipLaunchKernelGGL((k_k3<ArU64, 1, 8, false>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 break;
             default: throw std::runtime_error("unsupported K3 u64 shape");
@@ -1723,6 +1766,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         }
         if (slot >= 0) (void)hipEventRecord(pr->stop[slot], env.stream);
     }
+    if (part == K3_DATA_ONLY) return;
     // special-prime sums: start the inverse transform (row pass) for the mod-down
     launch_rows_inv_select(env, env.K - 1, n_ops * 2, buf.tp, (u64)env.N, buf.tpr);
     if (env.scheme != 2) { // BFV: every data prime's sums go back to coefficient form as well
