@@ -617,6 +617,13 @@ struct K2Args {
     int L, K, ckks, src_is_coeff;
 };
 
+// The digit slab is written once and read once, much later and by other CUs (a chunk of it is gigabytes): HE355_K2_NT=1
+// builds the stores as non-temporal.
+#if defined(HE355_K2_NT) && HE355_K2_NT
+#define K2_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define K2_STORE(p, v) (*(p) = (v))
+#endif
 // lift canonical c (mod q_j) to a value usable as forward-transform input under prime t
 template <int LOGN1>
 __device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt, const u64 c[1 << LOGN1], u64 *dst, int col)
@@ -638,7 +645,7 @@ __device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt
         }
         col_fwd<ArF64, LOGN1>(ar, x, gtw(Pt.fwd));
 #pragma unroll
-        for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = ar.to_raw(x[a]);
+        for (int a = 0; a < N1; ++a) K2_STORE(&dst[(a << kRowLog) + col], ar.to_raw(x[a]));
     } else {
         const ArU64 ar = make_ar(Pt, (ArU64 *)nullptr);
         u64 x[N1];
@@ -652,7 +659,7 @@ __device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt
         }
         col_fwd<ArU64, LOGN1>(ar, x, gtw(Pt.fwd));
 #pragma unroll
-        for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = x[a];
+        for (int a = 0; a < N1; ++a) K2_STORE(&dst[(a << kRowLog) + col], x[a]);
     }
 }
 
