@@ -441,3 +441,58 @@ def test_empty_batches_and_argument_errors(be, oracle):
             bad()
         assert ei.value.code == 1, ei.value
     g.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_parameter_chains(be, oracle, seed):
+    """Randomly drawn chains (ring size, number of primes, bit sizes 30..60 in any position, so both arithmetic engines end up
+    anywhere in the chain, including an fp64-engine special prime): the fused multiply -> relinearize -> rescale pipeline, the
+    unfused building blocks and a rotation, all bit-exact against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([1024, 2048, 4096, 8192]))
+    K = int(rng.integers(2, 7))
+    bits = [int(b) for b in rng.integers(30, 61, K)]
+    g = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, sec128=False, device=0)
+    o = oracle.Context(oracle.SCHEME_CKKS, N, bit_sizes=bits, sec128=False)
+    assert g.moduli == o.moduli
+    L = g.L
+    rk = o.random_kswitch_key(rng)
+    g.set_relin_key(rk)
+    n = int(rng.integers(1, 12))
+    a, b = rand_cts(o, rng, n, L), rand_cts(o, rng, n, L)
+    da, db = g.to_device(a), g.to_device(b)
+    g.set_chunk(int(rng.integers(1, 9)))
+    want = [o.relinearize(o.multiply_ntt(a[r], b[r]), rk) for r in range(n)]
+    out = g.alloc(n * 2 * L * N)
+    g.multiply_relin(L, n, da, db, be.Context.pairwise(), out)
+    got = out.download((n, 2, L, N))
+    for r in range(n):
+        assert np.array_equal(got[r], want[r]), (bits, N, r)
+    if L >= 2:
+        out2 = g.alloc(n * 2 * (L - 1) * N)
+        g.multiply_relin(L, n, da, db, be.Context.pairwise(), out2, rescale=True)
+        got2 = out2.download((n, 2, L - 1, N))
+        for r in range(n):
+            assert np.array_equal(got2[r], o.rescale(want[r])), (bits, N, r)
+    step = int(rng.integers(1, N // 2))
+    # SEAL's NAF terms of the step, least significant first (Evaluator::rotate_internal); a term of N/2 is no rotation
+    elt_list, x, i = [], step, 0
+    while x:
+        z = 2 - (x & 3) if x & 1 else 0
+        x = (x - z) >> 1
+        if z and (1 << i) != N // 2:
+            elt_list.append(g.galois_elt(z * (1 << i)))
+        i += 1
+    keys = {}
+    for e in set(elt_list):
+        keys[e] = o.random_kswitch_key(rng)
+        g.set_galois_key(e, keys[e])
+    rot = g.alloc(n * 2 * L * N)
+    g.rotate(L, n, da, step, rot)
+    gotr = rot.download((n, 2, L, N))
+    for r in range(min(n, 2)):
+        w = a[r]
+        for e in elt_list:
+            w = o.apply_galois(w, e, keys[e])
+        assert np.array_equal(gotr[r], w), (bits, N, step, r)
+    g.close()

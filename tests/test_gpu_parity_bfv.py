@@ -124,3 +124,42 @@ def test_bfv_semantic_end_to_end(be, oracle):
     want = np.where(want > t // 2, want - t, want)
     assert np.array_equal(v, want)
     g.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bfv_random_parameter_chains(be, oracle, seed):
+    """Randomly drawn BFV chains (ring size, 2..5 key primes of 35..60 bits in any order, plain modulus 16..22 bits): BEHZ
+    multiply, relinearize and a row rotation, bit-exact against the oracle — both arithmetic engines in every role."""
+    rng = np.random.default_rng(5000 + seed)
+    N = int(rng.choice([1024, 2048, 4096]))
+    K = int(rng.integers(2, 6))
+    bits = [int(b) for b in rng.integers(35, 61, K)]
+    pb = int(rng.integers(16, 23))
+    g = be.Context(be.SCHEME_BFV, N, bit_sizes=bits, plain_bits=pb, sec128=False, device=0)
+    o = oracle.Context(oracle.SCHEME_BFV, N, bit_sizes=bits, plain_bits=pb, sec128=False)
+    assert g.moduli == o.moduli and g.t == o.t
+    L = g.L
+    n = int(rng.integers(1, 6))
+    a, b = rand_cts(o, rng, n, L), rand_cts(o, rng, n, L)
+    da, db = g.to_device(a), g.to_device(b)
+    c3 = g.alloc(n * 3 * L * N)
+    g.bfv_multiply(L, n, da, db, be.Context.pairwise(), c3)
+    got3 = c3.download((n, 3, L, N))
+    for r in range(n):
+        assert np.array_equal(got3[r], o.bfv_multiply(a[r], b[r])), (bits, pb, N, r)
+    rk = o.random_kswitch_key(rng)
+    g.set_relin_key(rk)
+    out = g.alloc(n * 2 * L * N)
+    g.relinearize(L, n, c3, out)
+    got = out.download((n, 2, L, N))
+    for r in range(n):
+        assert np.array_equal(got[r], o.relinearize(got3[r], rk)), (bits, pb, N, r)
+    elt = g.galois_elt(int(rng.choice([1, 2, -1])))
+    gk = o.random_kswitch_key(rng)
+    g.set_galois_key(elt, gk)
+    rot = g.alloc(n * 2 * L * N)
+    g.apply_galois(L, n, da, elt, rot)
+    gotr = rot.download((n, 2, L, N))
+    for r in range(n):
+        assert np.array_equal(gotr[r], o.apply_galois(a[r], elt, gk)), (bits, pb, N, r)
+    g.close()
