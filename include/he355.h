@@ -165,7 +165,7 @@ int he355_timer_end(he355_ctx *ctx, float *elapsed_ms);
  * between he355_timer_begin and he355_timer_end: summed duration, number of launches and ops they covered */
 int he355_probe_dominant_kernel(he355_ctx *ctx, float *total_ms, uint64_t *launches, uint64_t *ops);
 /* ---- tuning ---- */
-int he355_set_chunk(he355_ctx *ctx, uint64_t ops_per_chunk); /* ops processed per kernel sequence (scratch ~ 117 MiB/op at N=2^15, L=16) */
+int he355_set_chunk(he355_ctx *ctx, uint64_t ops_per_chunk); /* ops processed per kernel sequence, default 256 (scratch ~ 117 MiB/op at N=2^15, L=16) */
 
 #ifdef __cplusplus
 }

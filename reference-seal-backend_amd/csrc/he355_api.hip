@@ -411,8 +411,8 @@ public:
         // instead of beside their own kind.
         static const bool stagger = !(getenv("HE355_STAGGER") && getenv("HE355_STAGGER")[0] == '0');
         if (dual) {
-            (void)scratch(chunk_, L, 0);
-            (void)scratch(chunk_, L, 1);
+            (void)scratch(std::min<u64>(chunk_, n), L, 0);
+            (void)scratch(std::min<u64>(chunk_, n), L, 1);
             if (!stagger) {
                 HIPCHECK(hipEventRecord(ev_fork_, stream_));
                 HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
@@ -424,7 +424,7 @@ public:
             const int which = dual ? (int)(ci & 1) : 0;
             KernelEnv env = env_;
             env.stream = which ? stream2_ : stream_;
-            Scratch S = scratch(chunk_, L, which);
+            Scratch S = scratch(std::min<u64>(chunk_, n), L, which);
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
             launch_k1(env, L, K1_MUL, nc, off, a, b, ix, nullptr, B);
@@ -450,7 +450,7 @@ public:
             if (rescale) throw std::invalid_argument("rescale is a CKKS operation");
             for (u64 off = 0; off < n; off += chunk_) {
                 const u64 nc = std::min<u64>(chunk_, n - off);
-                Scratch S = scratch(chunk_, L);
+                Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
                 KsBuffers B = S.ks;
                 B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
                 const u64 *src = ct3 + off * 3 * LN;
@@ -465,7 +465,7 @@ public:
         Indexer ix{};
         for (u64 off = 0; off < n; off += chunk_) {
             const u64 nc = std::min<u64>(chunk_, n - off);
-            Scratch S = scratch(chunk_, L);
+            Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
             launch_k1(env_, L, K1_CT3, nc, off, ct3, nullptr, ix, nullptr, B);
@@ -522,7 +522,7 @@ public:
         const size_t N = P.N, LN = (size_t)L * N;
         for (u64 off = 0; off < n; off += chunk_) {
             const u64 nc = std::min<u64>(chunk_, n - off);
-            Scratch S = scratch(chunk_, L);
+            Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
             const u64 *src = in + off * size * LN;
             launch_rows_inv_select(env_, L - 1, nc * size, src + (size_t)(L - 1) * N, LN, S.rlr);
             rescale_tail(env_, L, size, nc, S, src, (u64)size * LN, out + off * size * (size_t)(L - 1) * N);
@@ -543,7 +543,7 @@ public:
             const size_t LN = (size_t)L * P.N;
             for (u64 off = 0; off < n; off += chunk_) {
                 const u64 nc = std::min<u64>(chunk_, n - off);
-                Scratch S = scratch(chunk_, L);
+                Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
                 KsBuffers B = S.ks;
                 B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
                 launch_bfv_galois(env_, L, nc, in + off * 2 * LN, gt, B.c01, B.c01_item_stride, B.c2n);
@@ -557,7 +557,7 @@ public:
         Indexer ix{};
         for (u64 off = 0; off < n; off += chunk_) {
             const u64 nc = std::min<u64>(chunk_, n - off);
-            Scratch S = scratch(chunk_, L);
+            Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
             KsBuffers B = S.ks;
             B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
             launch_k1(env_, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B);
@@ -1067,7 +1067,7 @@ private:
     size_t bfv_bytes_ = 0;
     std::map<int, BehzDev> behz_;
     std::map<uint32_t, uint32_t *> d_gather_;
-    size_t chunk_ = 128;
+    size_t chunk_ = 256;
 };
 
 } // namespace he355
