@@ -166,18 +166,17 @@ def main():
         if os.path.exists(tpath) and n == BATCH:
             traffic = json.load(open(tpath))["hbm_bytes_per_op"] * n
         achieved = bytes_op * n * args.steps / gpu_s / 1e9
-        # dominant kernel: k_k3 for the fp64-engine primes (key products of the key switch).  Algorithmic bytes per op of
-        # that kernel: the lifted digit rows it transforms (n_f * (L-1) + n_f polys), its outputs (2 * n_f polys) and the key
-        # rows of those primes once per launch.
+        # dominant kernel: k_k3 for the fp64-engine primes (key products of the key switch, with both floor steps finished in
+        # its epilogue by default).  Algorithmic bytes per op of that kernel, in residue polynomials:
+        # n_f * L lifted-digit / own-digit rows in; fused: + 2 n_f mod-down corrections + 2 n_f c01 rows in
+        # + 2 (n_f - 1) rescale corrections + 2 (n_f - 1) result rows out + 2 c01 rows out (the prime divided out);
+        # unfused: 2 n_f sums out.  Plus the key rows of those primes once per launch.
         n_f = sum(1 for i in list(range(L)) + [K - 1] if ctx.fp64[i])
-        k3_ops_per_launch = k3_ops / max(1, k3_launches)
-        # with the mod-down fused into it (default): + the correction rows and the c01 rows it reads, and the c01 rows it writes
-        # replace the sums slab: n_f * L digit rows + 2 n_f (corrections) + 2 n_f (c01 in) + 2 n_f (c01 out)
         fused = os.environ.get("HE355_K3_FUSE", "1") != "0"
-        k3_polys = n_f * L + (6 * n_f if fused else 2 * n_f)
-        k3_bytes_op = k3_polys * N * 8 + (L * 2 * n_f * N * 8) / max(1.0, k3_ops_per_launch)
-        k3_avg_ms = k3_ms / max(1, k3_launches)
-        k3_gbps = k3_bytes_op * k3_ops_per_launch / (k3_avg_ms / 1e3) / 1e9 if k3_launches else None
+        k3_polys = n_f * (L + 8) - 2 if fused else n_f * (L + 2)
+        k3_key_bytes = L * 2 * n_f * N * 8 * (n * args.steps / float(args.chunk or 256))  # once per chunk of ops
+        k3_bytes_total = k3_polys * N * 8 * n * args.steps + k3_key_bytes
+        k3_gbps = k3_bytes_total / (k3_ms / 1e3) / 1e9 if k3_ms > 0 else None
         out = {
             "metric": "ciphertext-ops/sec (CKKS ct x ct mul+relin+rescale, N=2^15, L=16)",
             "value": round(value, 2),
@@ -200,14 +199,16 @@ def main():
                          "traffic_note": "HBM bytes per step (1024 ops) from PMC counters; algorithmic bytes per step = %d" % int(bytes_op * n),
                          "kernel": "mul->relin->rescale kernel sequence per chunk (k_k1, k_k2, k_k3 special prime, k_floor_cols, k_k3 data primes with fused mod-down, k_floor_cols, k_floor_rows)",
                          "algorithmic_bytes_per_op": bytes_op,
-                         "dominant_kernel": {"name": "k_k3<ArF64> (forward row pass of the lifted digits + key MAC + fused mod-down, fp64-engine primes)",
-                                             "launches": k3_launches, "ops_per_launch": k3_ops_per_launch, "avg_launch_ms_hip_events": round(k3_avg_ms, 4),
+                         "dominant_kernel": {"name": "k_k3<ArF64> (forward row pass of the lifted digits + key MAC + fused floor steps, fp64-engine primes)",
+                                             "launches": k3_launches, "total_ms_hip_events": round(k3_ms, 3),
+                                             "avg_launch_ms_hip_events": round(k3_ms / max(1, k3_launches), 4),
+                                             "ms_per_step": round(k3_ms / args.steps, 3),
                                              "share_of_gpu_time": round(k3_ms / gpu_ms, 3) if gpu_ms else None,
-                                             "algorithmic_bytes_per_launch": round(k3_bytes_op * k3_ops_per_launch),
+                                             "algorithmic_bytes_per_op": k3_polys * N * 8,
                                              "achieved_GBps": round(k3_gbps, 1) if k3_gbps else None,
                                              "frac_of_hbm_peak": round(k3_gbps * 1e9 / HBM_PEAK, 4) if k3_gbps else None,
-                                             "note": "launch durations overlap the other stream's kernels (two-stream schedule); the rocprofv3 "
-                                                     "kernel-trace of the same command shows the same stretched durations"},
+                                             "note": "two launches per chunk (the tiles of the prime the rescale divides out, then the rest); durations "
+                                                     "overlap the other stream's kernels (two-stream schedule), as in the rocprofv3 kernel trace of the same command"},
                          "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 3),
                          "note": "expected binding resource is the VALU (64-bit modular butterflies), not HBM: SURVEY.md §0.6"},
             "cpu_baseline": cpu,

@@ -347,8 +347,10 @@ public:
     }
 
     // K2, K3, mod-down; result added into B.c01.  with_tail: also start the rescale (tail of prime L-1)
-    void key_switch_tail(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail,
-                         hipEvent_t after_k2 = nullptr)
+    // rescale_out != null (size-2 result wanted at level L-1): when the fused path applies, the rescale is finished here too
+    // and the function returns true (the caller skips rescale_tail).
+    bool key_switch_tail(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail,
+                         hipEvent_t after_k2 = nullptr, u64 *rescale_out = nullptr)
     {
         const size_t N = P.N, LN = (size_t)L * N;
         const int SP = (int)P.K - 1;
@@ -356,13 +358,24 @@ public:
         if (after_k2) HIPCHECK(hipEventRecord(after_k2, env_.stream));
         if (k3_can_fuse(env_) && B.c01_item_stride == 2 * LN) {
             // special prime first, its correction through the column pass, then the data primes with the mod-down finished
-            // inside K3 (the sums never go to HBM); the rescale prime's inverse row pass is a small launch of its own
+            // inside K3 (the sums never go to HBM)
             launch_k3(env_, L, nc, B, key, K3_SPECIAL_ONLY);
             launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
-            K3Fuse fuse{B.e, B.c01, B.c01_item_stride};
+            if (rescale_out && L >= 2) {
+                // ... and the rescale too: the last data prime's tiles first (mod-down only), their inverse transform and the
+                // second correction slab, then all other primes with BOTH floor steps finished in the epilogue -> rescale_out
+                K3Fuse last{B.e, B.c01, B.c01_item_stride, L - 1, L, nullptr, nullptr};
+                launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &last);
+                launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
+                launch_floor_cols(env_, L - 1, L - 1, nc * 2, S.rlr, S.f);
+                K3Fuse rest{B.e, B.c01, B.c01_item_stride, 0, L - 1, S.f, rescale_out};
+                launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &rest);
+                return true;
+            }
+            K3Fuse fuse{B.e, B.c01, B.c01_item_stride, 0, L, nullptr, nullptr};
             launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &fuse);
             if (with_tail) launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
-            return;
+            return false;
         }
         launch_k3(env_, L, nc, B, key);
         launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
@@ -375,6 +388,7 @@ public:
         fr.tail_prime = with_tail ? L - 1 : -1;
         fr.tail = S.rlr;
         launch_floor_rows(env_, nc, fr);
+        return false;
     }
     void rescale_tail(const KernelEnv &env_, int L, int size, u64 nc, const Scratch &S, const u64 *src, u64 src_op_stride, u64 *out)
     {
@@ -429,9 +443,10 @@ public:
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
             launch_k1(env, L, K1_MUL, nc, off, a, b, ix, nullptr, B);
             const bool fork_here = dual && stagger && ci == 0;
-            key_switch_tail(env, L, nc, S, B, d_relin_, rescale, fork_here ? ev_fork_ : nullptr);
+            u64 *ro = rescale ? out + off * 2 * (size_t)(L - 1) * N : nullptr;
+            const bool done = key_switch_tail(env, L, nc, S, B, d_relin_, rescale, fork_here ? ev_fork_ : nullptr, ro);
             if (fork_here) HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
-            if (rescale) rescale_tail(env, L, 2, nc, S, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N);
+            if (rescale && !done) rescale_tail(env, L, 2, nc, S, B.c01, 2 * LN, ro);
         }
         if (dual) {
             HIPCHECK(hipEventRecord(ev_join_, stream2_));
@@ -469,8 +484,9 @@ public:
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
             launch_k1(env_, L, K1_CT3, nc, off, ct3, nullptr, ix, nullptr, B);
-            key_switch_tail(env_, L, nc, S, B, d_relin_, rescale);
-            if (rescale) rescale_tail(env_, L, 2, nc, S, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N);
+            u64 *ro = rescale ? out + off * 2 * (size_t)(L - 1) * N : nullptr;
+            const bool done = key_switch_tail(env_, L, nc, S, B, d_relin_, rescale, nullptr, ro);
+            if (rescale && !done) rescale_tail(env_, L, 2, nc, S, B.c01, 2 * LN, ro);
         }
         HIPCHECK(hipGetLastError());
     }

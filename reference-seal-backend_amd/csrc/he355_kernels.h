@@ -80,6 +80,12 @@ struct K3Fuse {
     const u64 *cols;     // [n_ops*2][L][N] output of launch_floor_cols(special prime -> L targets)
     u64 *c01;
     u64 c01_item_stride;
+    // data-prime range of this launch [tt_lo, tt_hi) (K3_DATA_ONLY)
+    int tt_lo, tt_hi;
+    // second floor step (CKKS rescale by prime L-1) finished in the same epilogue, for primes < L-1: cols2 is the output of
+    // launch_floor_cols(prime L-1 -> L-1 targets) [n_ops*2][L-1][N]; out [n_ops][2][L-1][N].  Null: mod-down only.
+    const u64 *cols2;
+    u64 *out;
 };
 bool k3_can_fuse(const KernelEnv &env);
 void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part = K3_ALL, const K3Fuse *fuse = nullptr);

@@ -747,6 +747,7 @@ struct K3Args {
     const u64 *cols;   // FUSE: mod-down corrections after the forward column pass [n_ops*2][L][N] (raw of prime tt)
     u64 *c01; u64 c01_item_stride; // FUSE: polys that receive (T - NTT(cols)) * P^-1
     const FloorConst *fc;          // FUSE: floor constants [K][K]
+    const u64 *cols2; u64 *out2;   // FUSE + rescale: second correction slab [n_ops*2][L-1][N] and the final output [n_ops][2][L-1][N]
     const u64 *keyq;   // Shoup quotients of the key residues under the u64-engine primes: [L_top][2][n_q][N]
     int n_q;           // u64-engine primes in the key chain
     unsigned char q_slot[64]; // tt_list[k] -> its index among them
@@ -858,59 +859,97 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
             mac_digit(x, tt);
         }
-        for (int i = 0; i < nd; i += U) {
-            const int cnt = (nd - i) < U ? (nd - i) : U;
-            T x[U][kRowE];
-            if constexpr (STAGE) {
-                u64 v[kRowE];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the rows of this step have landed in the staging buffers
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (u < cnt) {
-                        lds_rowA(stage[wave][u], lane, v);
-#pragma unroll
-                        for (int r = 0; r < kRowE; ++r) x[u][r] = ar.from_raw(v[r]);
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffers drained into registers
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (i + U + u < nd) dma_row_to_lds(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
-            } else {
-                asm volatile("" ::: "memory"); // keeps the LDS twiddle reads inside the loop (hoisted, they would cost 54 registers)
-#pragma unroll
-                for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(vn[r]);
-                if (i + 1 < nd) load_rowA(src_row(digit(i + 1)), lane, vn); // lands behind this step's math
-            }
-            if (U == 2 && cnt < U) { // odd digit count: the partner row is zeros (its products add nothing)
-#pragma unroll
-                for (int r = 0; r < kRowE; ++r) x[U - 1][r] = 0;
-            }
-            wave_rows_fwd_n<U>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (u < cnt) mac_digit(x[u], digit(i + u));
-        }
         if constexpr (FUSE) {
-            static_assert(!FUSE || U == 1, "the fused mod-down is written for one digit per wave");
+            // One digit per wave, mod-down (and rescale) finished here.  The correction rows ride the same pipeline as the digit
+            // rows: rows [0, nd) are digits (transform + key MAC), rows nd, nd+1 the special-prime correction of polynomial
+            // 0 / 1 (transform, then (sums - x) * P^-1 + c01), rows nd+2, nd+3 the rescale correction (transform, then
+            // (result - x) * q_last^-1).  Every row is prefetched into the LDS landing buffer behind the previous row's math.
+            static_assert(!FUSE || (U == 1 && STAGE), "the fused floor steps are written for one staged digit per wave");
+            const bool resc = A.cols2 != nullptr;
+            const int n_rows = nd + 2 + (resc ? 2 : 0);
+            const u64 LN = (u64)A.L * N, L1N = (u64)(A.L - 1) * N;
+            auto row_ptr = [&](int i) -> const u64 * {
+                if (i < nd) return src_row(digit(i));
+                if (i < nd + 2) return A.cols + ((op * 2 + (i - nd)) * A.L + tt) * N + rowoff;
+                return A.cols2 + ((op * 2 + (i - nd - 2)) * (A.L - 1) + tt) * N + rowoff;
+            };
             const FloorConst fc = A.fc[(A.K - 1) * A.K + t];
-            const u64 LN = (u64)A.L * N;
-#pragma unroll 1
-            for (int k = 0; k < 2; ++k) {
+            const FloorConst fc2 = A.fc[(resc ? A.L - 1 : 0) * A.K + t];
+            if (nd == 0) dma_row_to_lds(row_ptr(0), stage[wave][0], lane); // no digit row was primed above
+            // digit rows: transform + key MAC (the last one prefetches the first correction row)
+            for (int i = 0; i < nd; ++i) {
                 T x[1][kRowE];
-                u64 v[kRowE], av[kRowE];
-                load_rowA(A.cols + ((op * 2 + k) * A.L + tt) * N + rowoff, lane, v);
+                u64 v[kRowE];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's row has landed in the staging buffer
+                lds_rowA(stage[wave][0], lane, v);
 #pragma unroll
                 for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
-                wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x);
-                u64 *row = A.c01 + op * A.c01_item_stride + k * LN + (u64)tt * N + rowoff;
-                load_rowC(row, lane, av);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffer drained into registers
+                dma_row_to_lds(row_ptr(i + 1), stage[wave][0], lane); // next row (digit or correction), behind this step's math
+                wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
+                mac_digit(x[0], digit(i));
+            }
+            // correction rows: transform + floor step
+#pragma unroll 1
+            for (int i = nd; i < n_rows; ++i) {
+                T x[1][kRowE];
+                u64 v[kRowE], av[kRowE];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_rowA(stage[wave][0], lane, v);
 #pragma unroll
-                for (int r = 0; r < kRowE; ++r)
-                    v[r] = ar.floor_fin(ar.acc_canon(k == 0 ? acc0[r] : acc1[r]), x[0][r], fc.inv, fc.inv_shoup, fc.inv_d, fc.inv_i, av[r]);
-                if (valid) store_rowC(row, lane, v);
+                for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (i + 1 < n_rows) dma_row_to_lds(row_ptr(i + 1), stage[wave][0], lane);
+                const int k = (i - nd) & 1;
+                const bool md = i < nd + 2;
+                u64 *c01_row = A.c01 + op * A.c01_item_stride + k * LN + (u64)tt * N + rowoff;
+                if (md) load_rowC(c01_row, lane, av); // the addend of the mod-down, in flight during the transform
+                wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
+                Acc *acc = k == 0 ? acc0 : acc1;
+                const FloorConst f = md ? fc : fc2;
+#pragma unroll
+                for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin(ar.acc_canon(acc[r]), x[0][r], f.inv, f.inv_shoup, f.inv_d, f.inv_i, md ? av[r] : 0);
+                if (md && resc) { // the key-switched row stays in registers (in the sums' place) for the rescale step
+#pragma unroll
+                    for (int r = 0; r < kRowE; ++r) acc[r] = ar.acc_from_canon(v[r]);
+                } else if (valid) {
+                    store_rowC(md ? c01_row : A.out2 + (op * 2 + k) * L1N + (u64)tt * N + rowoff, lane, v);
+                }
             }
         } else {
+            for (int i = 0; i < nd; i += U) {
+                const int cnt = (nd - i) < U ? (nd - i) : U;
+                T x[U][kRowE];
+                if constexpr (STAGE) {
+                    u64 v[kRowE];
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the rows of this step have landed in the staging buffers
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (u < cnt) {
+                            lds_rowA(stage[wave][u], lane, v);
+#pragma unroll
+                            for (int r = 0; r < kRowE; ++r) x[u][r] = ar.from_raw(v[r]);
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffers drained into registers
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (i + U + u < nd) dma_row_to_lds(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
+                } else {
+                    asm volatile("" ::: "memory"); // keeps the LDS twiddle reads inside the loop (hoisted, they would cost 54 registers)
+#pragma unroll
+                    for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(vn[r]);
+                    if (i + 1 < nd) load_rowA(src_row(digit(i + 1)), lane, vn); // lands behind this step's math
+                }
+                if (U == 2 && cnt < U) { // odd digit count: the partner row is zeros (its products add nothing)
+#pragma unroll
+                    for (int r = 0; r < kRowE; ++r) x[U - 1][r] = 0;
+                }
+                wave_rows_fwd_n<U>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (u < cnt) mac_digit(x[u], digit(i + u));
+            }
             // Epilogue: canonical sums, NTT form, layout C.  Data primes -> t; special prime -> tp.  The inverse row passes
             // that follow (special prime always, every prime for BFV) are separate small launches: keeping them out of this
             // kernel keeps its loop inside the instruction cache.
@@ -1706,6 +1745,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tp = buf.tp;
         A.n_ops = n_ops; A.L = L; A.K = env.K; A.logn1 = env.logn1; A.ckks = env.scheme == 2;
         A.cols = fuse ? fuse->cols : nullptr; A.c01 = fuse ? fuse->c01 : nullptr; A.c01_item_stride = fuse ? fuse->c01_item_stride : 0;
+        A.cols2 = fuse ? fuse->cols2 : nullptr; A.out2 = fuse ? fuse->out : nullptr;
+        if (fuse && fuse->cols2 && fuse->tt_hi > L - 1) throw std::runtime_error("fused rescale: only primes below the one divided out");
         A.fc = env.floor_consts;
         A.n_tt = 0;
         A.n_q = 0;
@@ -1713,6 +1754,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.keyq = key + (u64)env.Ltop * 2 * env.K * env.N; // the quotient array follows the key in the same allocation
         for (int tt = 0; tt <= L; ++tt) {
             if ((part == K3_SPECIAL_ONLY && tt != L) || (part == K3_DATA_ONLY && tt == L)) continue;
+            if (fuse && (tt < fuse->tt_lo || tt >= fuse->tt_hi)) continue;
             const int t = (tt == L) ? env.K - 1 : tt;
             if ((prime_f64[t] != 0) == (pass == 0)) {
                 int slot = 0;

@@ -107,6 +107,7 @@ struct ArU64 {
         acc = s >= 2 * two_q ? s - 2 * two_q : s;
     }
     HE_HD u64 acc_canon(Acc acc) const { return to_canon(acc); }
+    HE_HD Acc acc_from_canon(u64 v) const { return v; }
     // floor(w * 2^64 / q) from the Barrett constant floor(2^128/q) = cr1:cr0, at most 2 too small (never too large)
     HE_HD u64 shoup_quotient_est(u64 w) const { return w * cr1 + mulhi64(w, cr0); }
     // (t - x) * inv (+ addend): t, addend canonical, x lazy < 4q; inv given as Shoup pair
@@ -245,6 +246,7 @@ struct ArF64 {
     static constexpr bool kKeyQuotient = false;
     HE_HD void acc_mac(Acc &acc, T x, T key, u64) const { acc += mulmod_vv(x, key); }
     HE_HD u64 acc_canon(Acc acc) const { return to_canon(acc); }
+    HE_HD Acc acc_from_canon(u64 v) const { return u52_to_f64(v); }
     HE_HD u64 floor_fin(u64 t, T x, u64, u64, double inv_d, double inv_i, u64 addend) const
     {
         double m = mulmod_c(u52_to_f64(t) - x, inv_d, inv_i);
