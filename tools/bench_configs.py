@@ -75,6 +75,38 @@ def cfg4_dot_product():
     return out
 
 
+def cfg5_bfv_matmul():
+    """configs[4]: BFV MatMul 128x128x128 at N=2^15, depth 3 ({60,40,40,60}): 64 row-pair ciphertexts x (BEHZ multiply + relinearize +
+    127 rotate_rows(j*128) + add), rotations by non-power-of-two steps through SEAL's NAF terms (355 key switches per ciphertext)."""
+    g = be.Context(be.SCHEME_BFV, 32768, bit_sizes=[60, 40, 40, 60], plain_bits=20, device=0)
+    L, N, n = g.L, g.N, 64
+    a, b = g.alloc(n * 2 * L * N), g.alloc(2 * L * N)
+    c3, base, rot, acc = g.alloc(n * 3 * L * N), g.alloc(n * 2 * L * N), g.alloc(n * 2 * L * N), g.alloc(n * 2 * L * N)
+    g.fill_uniform(a, n * 2 * L, list(range(L)), 1)
+    g.fill_uniform(b, 2 * L, list(range(L)), 2)
+    g.set_relin_key_synthetic(7)
+    k = 0
+    while (1 << k) < N // 2:  # the default Galois key set: +-2^k row rotations
+        g.set_galois_key_synthetic(g.galois_elt(1 << k), 100 + k)
+        g.set_galois_key_synthetic(g.galois_elt(-(1 << k)), 200 + k)
+        k += 1
+    spacers = (N // 2) // 128
+    pw = be.Context.pairwise()
+
+    def run():
+        g.bfv_multiply(L, n, a, b, be.Context.outer(0, n, 0, 1), c3)
+        g.relinearize(L, n, c3, base)
+        g.rotate(L, n, base, 0, acc)
+        for j in range(1, 128):
+            g.rotate(L, n, base, j * spacers, rot)
+            g.add(L, 2, n, acc, rot, pw, acc)
+    ms = timed(g, run, 2)
+    out = dict(config="configs[4] BFV MatMul 128x128x128 N=2^15 L=3: 64 row-pair cts x (multiply, relinearize, 127 rotate_rows + add)", results=n, ms=ms,
+               latency_ms_per_matrix_product=ms, key_switches_total=64 * 356)
+    g.close()
+    return out
+
+
 def client_side():
     """Device-side encryption / decryption rates at the headline parameters (N=2^15, 17 key primes), inputs resident in HBM,
     with the oracle's single-thread CPU time per ciphertext beside them."""
@@ -111,5 +143,5 @@ def client_side():
 
 
 if __name__ == "__main__":
-    for r in [cfg1_bfv_add()] + cfg2_ckks_multiply() + [cfg4_dot_product()] + client_side():
+    for r in [cfg1_bfv_add()] + cfg2_ckks_multiply() + [cfg4_dot_product(), cfg5_bfv_matmul()] + client_side():
         print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
