@@ -142,7 +142,7 @@ def main():
 
     cpu = None
     parity = None
-    if rank == 0 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0:  # the CPU baseline is a single-GPU-run item (rank 0 at N=1 only)
         cb = cpu_baseline(be, args.cpu_sample, bits)
         # push the identical sample through the GPU path: the measured path is the checked path
         s = args.cpu_sample
