@@ -772,8 +772,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
     typedef typename Ar::T T;
     typedef typename Ar::Acc Acc;
     constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
-    // One block per CU (one wave per SIMD): the wave gets its latency hiding from the two interleaved digits
-    // and from LDS-DMA prefetch, not from co-resident waves.  LDS: 64 KiB exchange + 64 KiB DMA landing + twiddles.
+    // One block per CU.  Default shape (U = 1, 8 waves): two waves per SIMD, each on its own op, LDS-DMA prefetch of the next
+    // row; LDS: 8 x 8.5 KiB exchange + 8 x 8 KiB DMA landing + the tile's twiddles.  (U = 2, 4 waves: one wave per SIMD with two
+    // interleaved digits -- the earlier shape, kept selectable.)
     __shared__ u64 lds[kWaves][U][kLdsRow];
     __shared__ __attribute__((aligned(16))) u64 stage[STAGE ? kWaves : 1][STAGE ? U : 1][STAGE ? kRowN : 2];
     __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
