@@ -716,7 +716,7 @@ public:
         vb.polys_per_item = (int)S; vb.item_stride = (u64)S * N;
         for (u64 off = 0; off < n; off += c) {
             const u64 nc = std::min<u64>(c, n - off);
-            launch_behz_extend_off(nc, off, a, b, ix, Z, xq, xb);
+            launch_behz_extend(env_, Z, nc, off, a, b, ix, xq, xb);
             vq.base = xq; launch_ntt_forward(env_, vq, (u32)(nc * 4));
             vb.base = xb; launch_ntt_forward(env_, vb, (u32)(nc * 4));
             launch_tensor4(env_, L, pq, nc, xq, dq);
@@ -726,20 +726,6 @@ public:
             launch_behz_floor_sk(env_, Z, nc, dq, ds, out + off * 3 * (size_t)L * N);
         }
         HIPCHECK(hipGetLastError());
-    }
-    void launch_behz_extend_off(u64 nc, u64 off, const u64 *a, const u64 *b, Indexer ix, const BehzDev &Z, u64 *xq, u64 *xb)
-    {
-        // results off..off+nc-1: shift the indexer (outer product: r -> r + off needs the generic form, so pass the
-        // offset through a_base/b_base only when it stays exact; otherwise fold it by calling with a shifted view)
-        if (ix.pairwise) {
-            ix.a_base += off; ix.b_base += off;
-            launch_behz_extend(env_, Z, nc, a, b, ix, xq, xb);
-        } else if (off % ix.b1 == 0) {
-            ix.a_base += off / ix.b1;
-            launch_behz_extend(env_, Z, nc, a, b, ix, xq, xb);
-        } else {
-            throw std::invalid_argument("BFV multiply: chunk size must be a multiple of the operand-1 batch size");
-        }
     }
     // key switching for BFV: the target is in coefficient form; result added into c01 (coefficient form)
     void bfv_key_switch(int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, const u64 *target, u64 target_op_stride)

@@ -1110,7 +1110,7 @@ __global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const Pri
 __device__ __forceinline__ ModU64 mod_of(const PrimeDev *primes, int idx) { return make_modu(primes[idx]); }
 
 __global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDev *primes, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk,
-                                                        u64 n_ops, int logN)
+                                                        u64 n_ops, int logN, u64 op_offset)
 {
     const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
     const u64 n = gid & (((u64)1 << logN) - 1);
@@ -1120,7 +1120,8 @@ __global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDe
     const int c = (int)((pid >> 1) & 1), k = (int)(pid & 1);
     const int L = Z.L, S = L + 1;
     const u64 N = (u64)1 << logN, P1 = (u64)L * N;
-    const u64 *src = (c ? b + idx_b(ix, r) * 2 * P1 : a + idx_a(ix, r) * 2 * P1) + (u64)k * P1 + n;
+    const u64 rg = op_offset + r; // result index in the whole batch: picks the operands (outer product or pairwise)
+    const u64 *src = (c ? b + idx_b(ix, rg) * 2 * P1 : a + idx_a(ix, rg) * 2 * P1) + (u64)k * P1 + n;
     u64 tmp[kBehzMaxL];
     u64 mt_acc = 0;
 #pragma unroll
@@ -1877,12 +1878,12 @@ void launch_rows_inv_select(const KernelEnv &env, int prime, u64 n_polys, const 
                        env.logn1);
 }
 
-void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk)
+void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk)
 {
     if (!n_ops) return;
     const int logN = env.logn1 + kRowLog;
     const u64 threads = (n_ops * 4) << logN;
-    hipLaunchKernelGGL(k_behz_extend, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, a, b, ix, xq, xbsk, n_ops, logN);
+    hipLaunchKernelGGL(k_behz_extend, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, a, b, ix, xq, xbsk, n_ops, logN, op_offset);
 }
 void launch_tensor4(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d)
 {

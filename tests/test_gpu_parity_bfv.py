@@ -50,6 +50,23 @@ def test_bfv_multiply_behz(pair, be):
             assert np.array_equal(got[i * 2 + x], o.bfv_multiply(a[i], b[x])), (i, x)
 
 
+def test_bfv_multiply_chunks_cut_across_outer_product_rows(pair, be):
+    """A chunk size that does not divide the operand-1 batch (chunks then start in the middle of an outer-product row)."""
+    g, o, rng = pair
+    L, N = g.L, g.N
+    a, b = rand_cts(o, rng, 3, L), rand_cts(o, rng, 2, L)
+    out = g.alloc(6 * 3 * L * N)
+    g.set_chunk(3)
+    try:
+        g.bfv_multiply(L, 6, g.to_device(a), g.to_device(b), be.Context.outer(0, 3, 0, 2), out)
+    finally:
+        g.set_chunk(256)
+    got = out.download((6, 3, L, N))
+    for i in range(3):
+        for x in range(2):
+            assert np.array_equal(got[i * 2 + x], o.bfv_multiply(a[i], b[x])), (i, x)
+
+
 def test_bfv_relinearize(pair, be):
     g, o, rng = pair
     L, N = g.L, g.N
