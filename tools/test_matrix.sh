@@ -1,0 +1,12 @@
+#!/bin/bash
+# Runs the GPU test-suite under every selectable code path (usage on the GPU box: tools/test_matrix.sh).
+# Default settings first, then: unfused floor steps, the one-wave-per-SIMD K3 shape, register-prefetch K3, host-side client,
+# single stream with a chunk size that divides nothing.
+set -o pipefail
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+rc=0
+for cfg in "HE355_NONE=1" "HE355_K3_FUSE=0" "HE355_K3_SHAPE=2414" "HE355_K3_STAGE=0" "HE355_DEVICE_CLIENT=0" "HE355_DUAL_STREAM=0 HE355_CHUNK=3"; do
+  echo "== $cfg"
+  env $cfg timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -1 || rc=1
+done
+exit $rc
