@@ -2,6 +2,7 @@
 #include "he_context.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include <cmath>
 
@@ -300,7 +301,13 @@ Plain HeContextWrapper::decrypt(const Cipher &cipher)
 void HeContextWrapper::ensureDevice()
 {
     if (m_device) return;
-    check(he355_device_init(m_ctx, 0), "device initialisation");
+    // one harness process per GPU: HE355_DEVICE selects the ordinal, otherwise LOCAL_RANK (torchrun / mpirun conventions) modulo
+    // the number of devices, otherwise device 0
+    int ordinal = 0, count = 0;
+    const char *dev = getenv("HE355_DEVICE"), *lr = getenv("LOCAL_RANK");
+    if (dev && *dev) ordinal = std::atoi(dev);
+    else if (lr && *lr && he355_device_count(&count) == 0 && count > 0) ordinal = std::atoi(lr) % count;
+    check(he355_device_init(m_ctx, ordinal), "device initialisation");
     m_device = true;
 }
 void HeContextWrapper::needRelinKey()
