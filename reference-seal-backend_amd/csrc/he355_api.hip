@@ -367,7 +367,7 @@ public:
                 K3Fuse last{B.e, B.c01, B.c01_item_stride, L - 1, L, nullptr, nullptr};
                 launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &last);
                 launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
-                launch_floor_cols(env_, L - 1, L - 1, nc * 2, S.rlr, S.f);
+                launch_floor_cols(env_, L - 1, L - 1, nc * 2, S.rlr, S.f, B.e, SP, L); // combined correction: delta2 + P^-1 * delta1
                 K3Fuse rest{B.e, B.c01, B.c01_item_stride, 0, L - 1, S.f, rescale_out};
                 launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &rest);
                 return true;

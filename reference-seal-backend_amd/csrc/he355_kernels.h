@@ -83,7 +83,8 @@ struct K3Fuse {
     // data-prime range of this launch [tt_lo, tt_hi) (K3_DATA_ONLY)
     int tt_lo, tt_hi;
     // second floor step (CKKS rescale by prime L-1) finished in the same epilogue, for primes < L-1: cols2 is the output of
-    // launch_floor_cols(prime L-1 -> L-1 targets) [n_ops*2][L-1][N]; out [n_ops][2][L-1][N].  Null: mod-down only.
+    // launch_floor_cols(prime L-1 -> L-1 targets, addin = cols) [n_ops*2][L-1][N], i.e. the COMBINED correction
+    // delta2 + P^-1 * delta1; out [n_ops][2][L-1][N].  Null: mod-down only (correction from cols).
     const u64 *cols2;
     u64 *out;
 };
@@ -91,7 +92,10 @@ bool k3_can_fuse(const KernelEnv &env);
 void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part = K3_ALL, const K3Fuse *fuse = nullptr);
 // floor step, column half: src [n_ops*n_src][N] raw of prime s -> r = (x + floor(s/2)) mod s ->
 // (r mod q_i - floor(s/2) mod q_i) for i < n_tgt -> forward column pass -> dst [n_ops*n_src][n_tgt][N]
-void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst);
+// addin (optional): the column-passed correction of an earlier floor step [n_polys][addin_ntgt][N], folded in scaled by
+// addin_src^-1 mod q_i (mod-down + rescale then share one row transform per residue)
+void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst, const u64 *addin = nullptr,
+                       int addin_src = 0, int addin_ntgt = 0);
 // floor step, row half: out[(op,k,i)] = (tsrc[(op,k,i)] - NTT(dst_cols[(op,k,i)])) * s^-1 (+ addend) mod q_i.
 // Strides are in u64 elements.  If tail_prime >= 0 the rows of that prime additionally go through the
 // inverse row pass into tail[(op,k)] (next floor step's source).

@@ -866,13 +866,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             // 0 / 1 (transform, then (sums - x) * P^-1 + c01), rows nd+2, nd+3 the rescale correction (transform, then
             // (result - x) * q_last^-1).  Every row is prefetched into the LDS landing buffer behind the previous row's math.
             static_assert(!FUSE || (U == 1 && STAGE), "the fused floor steps are written for one staged digit per wave");
+            // resc: the rescale is finished here too.  Its correction slab already holds delta2 + P^-1 * delta1 (k_floor_cols folded
+            // the mod-down correction in), so there are two correction rows per tile either way:
+            //   mod-down only: rows nd, nd+1 from cols:   c01 <- (sums - x) * P^-1 + c01
+            //   with rescale : rows nd, nd+1 from cols2:  out <- ((sums * P^-1 + c01) - x) * q_last^-1
             const bool resc = A.cols2 != nullptr;
-            const int n_rows = nd + 2 + (resc ? 2 : 0);
+            const int n_rows = nd + 2;
             const u64 LN = (u64)A.L * N, L1N = (u64)(A.L - 1) * N;
             auto row_ptr = [&](int i) -> const u64 * {
                 if (i < nd) return src_row(digit(i));
-                if (i < nd + 2) return A.cols + ((op * 2 + (i - nd)) * A.L + tt) * N + rowoff;
-                return A.cols2 + ((op * 2 + (i - nd - 2)) * (A.L - 1) + tt) * N + rowoff;
+                if (!resc) return A.cols + ((op * 2 + (i - nd)) * A.L + tt) * N + rowoff;
+                return A.cols2 + ((op * 2 + (i - nd)) * (A.L - 1) + tt) * N + rowoff;
             };
             const FloorConst fc = A.fc[(A.K - 1) * A.K + t];
             const FloorConst fc2 = A.fc[(resc ? A.L - 1 : 0) * A.K + t];
@@ -890,7 +894,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
                 mac_digit(x[0], digit(i));
             }
-            // correction rows: transform + floor step
+            // correction rows: transform + floor step(s)
 #pragma unroll 1
             for (int i = nd; i < n_rows; ++i) {
                 T x[1][kRowE];
@@ -901,20 +905,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (i + 1 < n_rows) dma_row_to_lds(row_ptr(i + 1), stage[wave][0], lane);
-                const int k = (i - nd) & 1;
-                const bool md = i < nd + 2;
+                const int k = i - nd;
                 u64 *c01_row = A.c01 + op * A.c01_item_stride + k * LN + (u64)tt * N + rowoff;
-                if (md) load_rowC(c01_row, lane, av); // the addend of the mod-down, in flight during the transform
+                load_rowC(c01_row, lane, av); // the addend, in flight during the transform
                 wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
-                Acc *acc = k == 0 ? acc0 : acc1;
-                const FloorConst f = md ? fc : fc2;
+                const Acc *acc = k == 0 ? acc0 : acc1;
+                if (!resc) {
 #pragma unroll
-                for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin(ar.acc_canon(acc[r]), x[0][r], f.inv, f.inv_shoup, f.inv_d, f.inv_i, md ? av[r] : 0);
-                if (md && resc) { // the key-switched row stays in registers (in the sums' place) for the rescale step
+                    for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin(ar.acc_canon(acc[r]), x[0][r], fc.inv, fc.inv_shoup, fc.inv_d, fc.inv_i, av[r]);
+                    if (valid) store_rowC(c01_row, lane, v);
+                } else {
 #pragma unroll
-                    for (int r = 0; r < kRowE; ++r) acc[r] = ar.acc_from_canon(v[r]);
-                } else if (valid) {
-                    store_rowC(md ? c01_row : A.out2 + (op * 2 + k) * L1N + (u64)tt * N + rowoff, lane, v);
+                    for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin2(ar.acc_canon(acc[r]), x[0][r], fc, fc2, av[r]);
+                    if (valid) store_rowC(A.out2 + (op * 2 + k) * L1N + (u64)tt * N + rowoff, lane, v);
                 }
             }
         } else {
@@ -976,6 +979,10 @@ struct FloorColsArgs {
     u64 *dst;
     int src_prime, n_tgt, K;
     const FloorConst *fc;
+    // optional: an earlier floor step's column-passed correction [n_polys][addin_ntgt][N] (raw of the target prime) is folded in,
+    // scaled by addin_src^-1 mod q_i: the two corrections of mod-down + rescale then need ONE row transform (both passes are linear)
+    const u64 *addin;
+    int addin_src, addin_ntgt;
 };
 
 template <int LOGN1>
@@ -1025,11 +1032,26 @@ __global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const Pr
 #pragma unroll
             for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(dl[a]);
             col_fwd<ArF64, LOGN1>(ar, x, gtw(Pi.fwd));
+            if (A.addin) {
+                const FloorConst fa = A.fc[A.addin_src * A.K + i];
+                const u64 *ad = A.addin + (poly * A.addin_ntgt + i) * N;
+#pragma unroll
+                for (int a = 0; a < N1; ++a) x[a] += ar.mulmod_c(ar.from_raw(ad[(a << kRowLog) + col]), fa.inv_d, fa.inv_i);
+            }
 #pragma unroll
             for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = ar.to_raw(x[a]);
         } else {
             const ArU64 ar = make_ar(Pi, (ArU64 *)nullptr);
             col_fwd<ArU64, LOGN1>(ar, dl, gtw(Pi.fwd));
+            if (A.addin) {
+                const FloorConst fa = A.fc[A.addin_src * A.K + i];
+                const u64 *ad = A.addin + (poly * A.addin_ntgt + i) * N;
+#pragma unroll
+                for (int a = 0; a < N1; ++a) { // lazy values: [0,4q) + [0,2q), brought back under 4q
+                    const u64 sum = dl[a] + mul_shoup_lazy(ad[(a << kRowLog) + col], fa.inv, fa.inv_shoup, qi);
+                    dl[a] = sum >= 2 * ar.two_q ? sum - 2 * ar.two_q : sum;
+                }
+            }
 #pragma unroll
             for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = dl[a];
         }
@@ -1829,11 +1851,13 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     }
 }
 
-void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst)
+void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst, const u64 *addin, int addin_src,
+                       int addin_ntgt)
 {
     if (!n_polys) return;
     FloorColsArgs A;
     A.src = src; A.dst = dst; A.src_prime = src_prime; A.n_tgt = n_tgt; A.K = env.K; A.fc = env.floor_consts;
+    A.addin = addin; A.addin_src = addin_src; A.addin_ntgt = addin_ntgt;
     const unsigned g = (unsigned)(n_polys * 4);
     switch (env.logn1) {
     case 0: hipLaunchKernelGGL(k_floor_cols<0>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;

@@ -117,6 +117,12 @@ struct ArU64 {
         return addmod(r, addend, q);
     }
 
+    // two floor steps with one combined correction x: ((t * inv1 + addend) - x) * inv2; t, addend canonical, x lazy < 4q
+    template <class FC> HE_HD u64 floor_fin2(u64 t, T x, const FC &f1, const FC &f2, u64 addend) const
+    {
+        const u64 r1 = mul_shoup(t, f1.inv, f1.inv_shoup, q);
+        return mul_shoup(r1 + addend + 2 * two_q - x, f2.inv, f2.inv_shoup, q);
+    }
     HE_HD T from_canon(u64 x) const { return x; }
     HE_HD T from_raw(u64 bits) const { return bits; }
     HE_HD u64 to_raw(T x) const { return x; }
@@ -251,6 +257,12 @@ struct ArF64 {
     {
         double m = mulmod_c(u52_to_f64(t) - x, inv_d, inv_i);
         return to_canon2(m + u52_to_f64(addend));
+    }
+    // two floor steps with one combined correction x: ((t * inv1 + addend) - x) * inv2
+    template <class FC> HE_HD u64 floor_fin2(u64 t, T x, const FC &f1, const FC &f2, u64 addend) const
+    {
+        const double m1 = mulmod_c(u52_to_f64(t), f1.inv_d, f1.inv_i);
+        return to_canon2(mulmod_c(m1 + u52_to_f64(addend) - x, f2.inv_d, f2.inv_i));
     }
     HE_HD static double tw_w(const Tw16 &t)
     {
