@@ -171,12 +171,12 @@ def main():
         achieved = bytes_op * n * args.steps / gpu_s / 1e9
         # dominant kernel: k_k3 for the fp64-engine primes (key products of the key switch, with both floor steps finished in
         # its epilogue by default).  Algorithmic bytes per op of that kernel, in residue polynomials:
-        # n_f * L lifted-digit / own-digit rows in; fused: + 2 n_f mod-down corrections + 2 n_f c01 rows in
-        # + 2 (n_f - 1) rescale corrections + 2 (n_f - 1) result rows out + 2 c01 rows out (the prime divided out);
-        # unfused: 2 n_f sums out.  Plus the key rows of those primes once per launch.
+        # n_f * L lifted-digit / own-digit rows in; fused: + 2 n_f correction rows (one combined correction per residue; the
+        # prime divided out has its mod-down correction) + 2 n_f c01 rows in + 2 (n_f - 1) result rows + 2 c01 rows out;
+        # unfused: 2 n_f sums out.  Plus the key rows of those primes once per chunk.
         n_f = sum(1 for i in list(range(L)) + [K - 1] if ctx.fp64[i])
         fused = os.environ.get("HE355_K3_FUSE", "1") != "0"
-        k3_polys = n_f * (L + 8) - 2 if fused else n_f * (L + 2)
+        k3_polys = n_f * (L + 6) if fused else n_f * (L + 2)
         k3_key_bytes = L * 2 * n_f * N * 8 * (n * args.steps / float(args.chunk or 256))  # once per chunk of ops
         k3_bytes_total = k3_polys * N * 8 * n * args.steps + k3_key_bytes
         k3_gbps = k3_bytes_total / (k3_ms / 1e3) / 1e9 if k3_ms > 0 else None
