@@ -751,7 +751,7 @@ struct K3Args {
     const u64 *keyq;   // Shoup quotients of the key residues under the u64-engine primes: [L_top][2][n_q][N]
     int n_q;           // u64-engine primes in the key chain
     unsigned char q_slot[64]; // tt_list[k] -> its index among them
-    u64 *t, *tp;
+    u64 *t, *tp, *tpr; // sums of the data primes; of the special prime (unused: its rows leave through tpr, inverse row pass done)
     u64 n_ops;
     int L, K, logn1, ckks;
     int n_tt;
@@ -954,18 +954,30 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 for (int u = 0; u < U; ++u)
                     if (u < cnt) mac_digit(x[u], digit(i + u));
             }
-            // Epilogue: canonical sums, NTT form, layout C.  Data primes -> t; special prime -> tp.  The inverse row passes
-            // that follow (special prime always, every prime for BFV) are separate small launches: keeping them out of this
-            // kernel keeps its loop inside the instruction cache.
-            u64 v[kRowE];
-            u64 *dst0 = tt < A.L ? A.t + ((op * 2 + 0) * A.L + tt) * N + rowoff : A.tp + (op * 2 + 0) * N + rowoff;
-            u64 *dst1 = tt < A.L ? A.t + ((op * 2 + 1) * A.L + tt) * N + rowoff : A.tp + (op * 2 + 1) * N + rowoff;
+            // Epilogue: canonical sums, NTT form, layout C.  Data primes -> t; special prime -> tp.  Where the next step is the
+            // inverse transform of these very rows (the special prime always; every prime for BFV, whose key switch returns to
+            // coefficient form) the wave runs the inverse row pass right here and writes the raw rows (special prime -> tpr).
+            const bool inv_here = tt == A.L || !A.ckks;
+            const bool last = A.logn1 == 0;
+#pragma unroll 1
+            for (int k = 0; k < 2; ++k) {
+                u64 v[kRowE];
+                const Acc *acc = k == 0 ? acc0 : acc1;
 #pragma unroll
-            for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc0[r]);
-            if (valid) store_rowC(dst0, lane, v);
+                for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc[r]);
+                if (!inv_here) {
+                    if (valid) store_rowC(A.t + ((op * 2 + k) * A.L + tt) * N + rowoff, lane, v);
+                    continue;
+                }
+                T x[kRowE];
 #pragma unroll
-            for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc1[r]);
-            if (valid) store_rowC(dst1, lane, v);
+                for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
+                wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave][0], x);
+#pragma unroll
+                for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
+                u64 *dst = tt < A.L ? A.t + ((op * 2 + k) * A.L + tt) * N + rowoff : A.tpr + (op * 2 + k) * N + rowoff;
+                if (valid) store_rowA(dst, lane, v);
+            }
         }
     }
 }
@@ -1766,7 +1778,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     if (fuse && (part != K3_DATA_ONLY || !k3_can_fuse(env))) throw std::runtime_error("fused mod-down: data-prime tiles of the default shapes only");
     for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine primes, pass 1: u64-engine primes
         K3Args A;
-        A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tp = buf.tp;
+        A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tp = buf.tp; A.tpr = buf.tpr;
         A.n_ops = n_ops; A.L = L; A.K = env.K; A.logn1 = env.logn1; A.ckks = env.scheme == 2;
         A.cols = fuse ? fuse->cols : nullptr; A.c01 = fuse ? fuse->c01 : nullptr; A.c01_item_stride = fuse ? fuse->c01_item_stride : 0;
         A.cols2 = fuse ? fuse->cols2 : nullptr; A.out2 = fuse ? fuse->out : nullptr;
@@ -1839,16 +1851,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         }
         if (slot >= 0) (void)hipEventRecord(pr->stop[slot], env.stream);
     }
-    if (part == K3_DATA_ONLY) return;
-    // special-prime sums: start the inverse transform (row pass) for the mod-down
-    launch_rows_inv_select(env, env.K - 1, n_ops * 2, buf.tp, (u64)env.N, buf.tpr);
-    if (env.scheme != 2) { // BFV: every data prime's sums go back to coefficient form as well
-        PolyView v;
-        v.base = buf.t; v.item_stride = (u64)L * env.N; v.polys_per_item = L; v.pad_ = 0;
-        for (int i = 0; i < L; ++i) v.prime_of[i] = (unsigned char)i;
-        const u64 jobs = (n_ops * 2 * L) << env.logn1;
-        hipLaunchKernelGGL(k_rows_inv, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, v, env.primes, jobs, env.logn1);
-    }
+    // (the inverse row pass of the special-prime sums, and of every prime's sums for BFV, happened in the kernel's epilogue)
 }
 
 void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst, const u64 *addin, int addin_src,
