@@ -134,6 +134,10 @@ int he355_relinearize_rescale(he355_ctx *ctx, int L, uint64_t n, const uint64_t 
 int he355_rescale(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_in, uint64_t *d_out);         /* -> [n][size][L-1][N] */
 int he355_apply_galois(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, uint32_t galois_elt, uint64_t *d_out);
 int he355_rotate(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, int step, uint64_t *d_out);
+/* d_out = d_addend + rotate(d_in, step): the rotate + add_inplace pair of the row-major MatMult inner loop
+ * (src/benchmarks/bfv/seal_bfv_matmult_row_benchmark.cpp:525-531) and of accumulateCKKS/BFV (src/engine/seal_context.cpp:337-338,
+ * 302-303) as one pipeline.  d_addend may be d_out (add in place) when the step has its own Galois key; d_in may be neither. */
+int he355_rotate_add(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, int step, const uint64_t *d_addend, uint64_t *d_out);
 /* accumulateCKKS: in place log-tree sum of the first `count` slots; d_tmp: scratch slab of the same size */
 int he355_accumulate(he355_ctx *ctx, int L, uint64_t n, uint64_t *d_inout, uint64_t count, uint64_t *d_tmp);
 /* ---- client side on the device: encryptor()->encrypt (ckks eltwise .cpp:242, bfv eltwise .cpp:233) and

@@ -263,12 +263,16 @@ AB::Handle MatMultRowLatencyBenchmark::operate(AB::Handle h_remote_packed, const
         HeContextWrapper::check(he355_relinearize(ctx, L, nA, c3->d, base->d), "relinearize");                         // :516
         HeContextWrapper::check(he355_sync(ctx), "synchronise");
     }
-    he355_indexer pw{0, 0, 1, 1, 0};
-    HeContextWrapper::check(he355_rotate(ctx, L, nA, base->d, 0, res.C->d), "copy");                                   // result[i] = base (:519)
+    // result[i] = base (:519), then result[i] += rotate_rows(base, j * spacers) (:525-531): each rotate + add_inplace pair is one
+    // he355_rotate_add pipeline writing the running sum into the other of two slabs (the step may go through several Galois keys).
+    std::shared_ptr<DeviceCiphers> sum = dim2 > 1 ? base : res.C, next = res.C;
+    if (dim2 <= 1) HeContextWrapper::check(he355_rotate(ctx, L, nA, base->d, 0, res.C->d), "copy");
     for (std::uint64_t j = 1; j < dim2; ++j) {
-        HeContextWrapper::check(he355_rotate(ctx, L, nA, base->d, (int)j * spacers, rotated->d), "rotate_rows");      // :525-529
-        HeContextWrapper::check(he355_add(ctx, L, 2, nA, res.C->d, rotated->d, pw, res.C->d), "add_inplace");         // :531
+        HeContextWrapper::check(he355_rotate_add(ctx, L, nA, base->d, (int)j * spacers, sum->d, next->d), "rotate_rows+add_inplace");
+        if (sum == base) sum = rotated; // base stays the rotation source: never written
+        std::swap(sum, next);
     }
+    res.C = sum;
     HeContextWrapper::check(he355_sync(ctx), "synchronise");
     return this->getEngine().createHandle<decltype(res)>(sizeof(res), 0, std::move(res));
 }

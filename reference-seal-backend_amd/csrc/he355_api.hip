@@ -545,7 +545,9 @@ public:
         }
         HIPCHECK(hipGetLastError());
     }
-    void apply_galois(int L, u64 n, const u64 *in, uint32_t elt, u64 *out)
+    // `addend` (optional, [n][2][L][N]; may alias `out`, never `in`): out = addend + galois(in) -- the add_inplace that follows
+    // a rotation in accumulateCKKS/BFV and in the row-major MatMult is folded into the first kernel of the rotation.
+    void apply_galois(int L, u64 n, const u64 *in, uint32_t elt, u64 *out, const u64 *addend = nullptr)
     {
         use();
         check_level(L);
@@ -562,7 +564,7 @@ public:
                 Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
                 KsBuffers B = S.ks;
                 B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
-                launch_bfv_galois(env_, L, nc, in + off * 2 * LN, gt, B.c01, B.c01_item_stride, B.c2n);
+                launch_bfv_galois(env_, L, nc, in + off * 2 * LN, gt, B.c01, B.c01_item_stride, B.c2n, addend ? addend + off * 2 * LN : nullptr);
                 bfv_key_switch(L, nc, S, B, key, B.c2n, LN);
             }
             HIPCHECK(hipGetLastError());
@@ -576,23 +578,27 @@ public:
             Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
             KsBuffers B = S.ks;
             B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
-            launch_k1(env_, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B);
+            launch_k1(env_, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend);
             key_switch_tail(env_, L, nc, S, B, key, false);
         }
         HIPCHECK(hipGetLastError());
     }
     // Evaluator::rotate_internal: use the key of the step if present, otherwise the NAF decomposition
-    void rotate(int L, u64 n, const u64 *in, int step, u64 *out)
+    void rotate(int L, u64 n, const u64 *in, int step, u64 *out, const u64 *addend = nullptr)
     {
         use();
         const size_t bytes = n * 2 * (size_t)L * P.N * 8;
-        if (step == 0) {
-            if (in != out) HIPCHECK(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, stream_));
-            return;
-        }
+        auto plain_copy = [&]() { // no rotation left: out = in (+ addend)
+            if (addend) {
+                Indexer ixp{};
+                ixp.pairwise = 1;
+                addsub(L, 2, n, in, addend, ixp, out, false);
+            } else if (in != out) HIPCHECK(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, stream_));
+        };
+        if (step == 0) { plain_copy(); return; }
         const uint32_t elt = P.galois_elt_from_step(step);
         if (!elt) throw std::invalid_argument("step count too large");
-        if (galois_key(elt)) { apply_galois(L, n, in, elt, out); return; }
+        if (galois_key(elt)) { apply_galois(L, n, in, elt, out, addend); return; }
         std::vector<int> naf;
         {
             const bool neg = step < 0;
@@ -608,10 +614,8 @@ public:
         std::vector<int> steps;
         for (int s : naf)
             if ((size_t)(s < 0 ? -s : s) != P.N / 2) steps.push_back(s); // a term of N/2 is no rotation
-        if (steps.empty()) {
-            HIPCHECK(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, stream_));
-            return;
-        }
+        if (steps.empty()) { plain_copy(); return; }
+        if (addend == out && steps.size() > 1) throw std::invalid_argument("rotate_add through several Galois steps cannot add in place");
         if (steps.size() > 1 && bytes > rot_tmp_bytes_) {
             HIPCHECK(hipStreamSynchronize(stream_));
             if (rot_tmp_) HIPCHECK(hipFree(rot_tmp_));
@@ -626,7 +630,7 @@ public:
             u64 *dst = ((m - 1 - t) % 2 == 0) ? out : rot_tmp_;
             const uint32_t e = P.galois_elt_from_step(steps[t]);
             if (!e || !galois_key(e)) throw std::invalid_argument("Galois key not present");
-            apply_galois(L, n, cur, e, dst);
+            apply_galois(L, n, cur, e, dst, t + 1 == m ? addend : nullptr); // the addend joins the last step only
             cur = dst;
         }
     }
@@ -641,14 +645,17 @@ public:
             if (((u64)1 << (rot - 1)) == row_count) --rot;
             Indexer ixb{};
             ixb.pairwise = 1;
+            (void)ixb;
+            u64 *cur = inout, *nxt = tmp; // ping-pong: nxt = cur + rotate(cur), one pipeline per step and no separate add
             for (int i = 0; i < rot; ++i) {
-                rotate(L, n, inout, 1 << i, tmp); // rotate_rows
-                addsub(L, 2, n, inout, tmp, ixb, inout, false);
+                rotate(L, n, cur, 1 << i, nxt, cur); // rotate_rows + add_inplace
+                std::swap(cur, nxt);
             }
             if (count > half) {
-                apply_galois(L, n, inout, (uint32_t)(2 * P.N - 1), tmp); // rotate_columns
-                addsub(L, 2, n, inout, tmp, ixb, inout, false);
+                apply_galois(L, n, cur, (uint32_t)(2 * P.N - 1), nxt, cur); // rotate_columns + add_inplace
+                std::swap(cur, nxt);
             }
+            if (cur != inout) HIPCHECK(hipMemcpyAsync(inout, cur, n * 2 * (size_t)L * P.N * 8, hipMemcpyDeviceToDevice, stream_));
             return;
         }
         const u64 slots = P.N / 2;
@@ -657,10 +664,13 @@ public:
         if (((u64)1 << (rotations - 1)) == count) --rotations;
         Indexer ix{};
         ix.pairwise = 1;
+        (void)ix;
+        u64 *cur = inout, *nxt = tmp;
         for (int i = 0; i < rotations; ++i) {
-            rotate(L, n, inout, 1 << i, tmp);
-            addsub(L, 2, n, inout, tmp, ix, inout, false);
+            rotate(L, n, cur, 1 << i, nxt, cur); // rotate_vector + add_inplace in one pipeline
+            std::swap(cur, nxt);
         }
+        if (cur != inout) HIPCHECK(hipMemcpyAsync(inout, cur, n * 2 * (size_t)L * P.N * 8, hipMemcpyDeviceToDevice, stream_));
     }
 
     // ---- BFV ------------------------------------------------------------------------------------------
@@ -1305,6 +1315,13 @@ int he355_apply_galois(he355_ctx *c, int L, uint64_t n, const uint64_t *in, uint
 int he355_rotate(he355_ctx *c, int L, uint64_t n, const uint64_t *in, int step, uint64_t *out)
 {
     return guarded([&] { dev(c).rotate(L, n, in, step, out); });
+}
+int he355_rotate_add(he355_ctx *c, int L, uint64_t n, const uint64_t *in, int step, const uint64_t *addend, uint64_t *out)
+{
+    return guarded([&] {
+        if (!addend) throw std::invalid_argument("rotate_add needs an addend");
+        dev(c).rotate(L, n, in, step, out, addend);
+    });
 }
 int he355_accumulate(he355_ctx *c, int L, uint64_t n, uint64_t *inout, uint64_t count, uint64_t *tmp)
 {

@@ -64,9 +64,10 @@ struct KsBuffers {
 };
 enum K1Mode { K1_MUL = 0, K1_CT3 = 1, K1_GALOIS = 2 };
 // K1: produce c01 / c2n / c2r for a chunk of ops.  MUL: a,b via indexer.  CT3: `a` is [n][3][L][N].
-// GALOIS: `a` is [n][2][L][N], perm = device permutation table (NTT-form gather).
+// GALOIS: `a` is [n][2][L][N], perm = device permutation table (NTT-form gather); optional addend [n][2][L][N] (indexed like `a`):
+// the rotated ciphertext starts from it, i.e. the pipeline computes addend + rotate(a).
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix,
-               const uint32_t *perm, const KsBuffers &buf);
+               const uint32_t *perm, const KsBuffers &buf, const u64 *addend = nullptr);
 // K2: finish iNTT of each digit, lift to every key prime, forward column pass -> d
 // src_is_coeff (BFV): `src` already holds coefficient-form digits [op][L][N] (op stride src_op_stride) and every
 // (prime, digit) pair is lifted, including the digit's own prime
@@ -138,7 +139,8 @@ void launch_tensor4(const KernelEnv &env, int Lx, const unsigned char *prime_of,
 // BEHZ steps (6)-(8): times t, fast floor, Shenoy-Kumaresan -> out [n][3][L][N]
 void launch_behz_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out);
 // coefficient-form Galois: c01[op][0] = sigma(in0), c01[op][1] = 0, tgt[op] = sigma(in1); gather table has the sign in bit 31
-void launch_bfv_galois(const KernelEnv &env, int L, u64 n_ops, const u64 *in, const uint32_t *gather, u64 *c01, u64 c01_item_stride, u64 *tgt);
+void launch_bfv_galois(const KernelEnv &env, int L, u64 n_ops, const u64 *in, const uint32_t *gather, u64 *c01, u64 c01_item_stride, u64 *tgt,
+                       const u64 *addend = nullptr); // addend [n][2][L][N]: out = addend + rotate(in)
 // BFV key-switch tails: finish the inverse transform of the special-prime sums and round (-> rp), then finish every data
 // prime's inverse transform, apply the floor step in coefficient form and add into c01
 void launch_bfv_tail_sp(const KernelEnv &env, u64 n_polys, const u64 *tpr, u64 *rp);

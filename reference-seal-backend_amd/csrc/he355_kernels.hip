@@ -520,6 +520,7 @@ __global__ void __launch_bounds__(kBlock) k_mul3_acc(const u64 *a, const u64 *b,
 // K1: (multiply | take ct3 | Galois-permute) + inverse row pass of the key-switch target
 // =======================================================================================================
 struct K1Args {
+    const u64 *addend; // GALOIS mode, optional: [n][2][L][N] added to the rotated ciphertext (c0' + addend0, addend1); null: (c0', 0)
     const u64 *a, *b;
     Indexer ix;
     const uint32_t *perm;
@@ -579,6 +580,14 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
             v2[r2] = p0[P1 + src];
             v1[r2] = 0;
             x[r2] = ar.from_canon(v2[r2]);
+        }
+        if (A.addend) { // out = addend + rotate(in): the ciphertext the key-switched result is added into starts from the addend
+            const u64 *ad = A.addend + (A.op_offset + op) * 2 * P1 + roff;
+            u64 a0[kRowE];
+            load_rowC(ad, lane, a0);
+            load_rowC(ad + P1, lane, v1);
+#pragma unroll
+            for (int r2 = 0; r2 < kRowE; ++r2) v0[r2] = addmod(v0[r2], a0[r2], P.q);
         }
         if (valid) { store_rowC(c0p, lane, v0); store_rowC(c1p, lane, v1); store_rowC(c2np, lane, v2); }
     }
@@ -1263,7 +1272,7 @@ __global__ void __launch_bounds__(kBlock) k_behz_floor_sk(BehzDev Z, const Prime
 
 // coefficient-form automorphism as a gather (2 polys of a size-2 ciphertext)
 __global__ void __launch_bounds__(kBlock) k_bfv_galois(const u64 *in, const uint32_t *gather, u64 *c01, u64 c01_item_stride, u64 *tgt,
-                                                       const PrimeDev *primes, int L, int logN, u64 n_ops)
+                                                       const PrimeDev *primes, int L, int logN, u64 n_ops, const u64 *addend)
 {
     const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
     const u64 o = gid & (((u64)1 << logN) - 1);
@@ -1279,8 +1288,14 @@ __global__ void __launch_bounds__(kBlock) k_bfv_galois(const u64 *in, const uint
     u64 v0 = p0[src], v1 = p0[P1 + src];
     if (g >> 31) { v0 = v0 ? q - v0 : 0; v1 = v1 ? q - v1 : 0; }
     u64 *o0 = c01 + op * c01_item_stride + (u64)i * N + o;
+    u64 w1 = 0;
+    if (addend) { // out = addend + rotate(in)
+        const u64 *ad = addend + op * 2 * P1 + (u64)i * N + o;
+        v0 = addmod(v0, ad[0], q);
+        w1 = ad[P1];
+    }
     o0[0] = v0;
-    o0[P1] = 0;
+    o0[P1] = w1;
     tgt[(op * L + i) * N + o] = v1;
 }
 
@@ -1717,11 +1732,11 @@ void launch_mul3(const KernelEnv &env, int L, u64 n_results, const u64 *a, const
 }
 
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
-               const KsBuffers &buf)
+               const KsBuffers &buf, const u64 *addend)
 {
     if (!n_ops) return;
     K1Args A;
-    A.a = a; A.b = b; A.ix = ix; A.perm = perm;
+    A.a = a; A.b = b; A.ix = ix; A.perm = perm; A.addend = addend;
     A.c01 = buf.c01; A.c01_item_stride = buf.c01_item_stride; A.c2n = buf.c2n; A.c2r = buf.c2r;
     A.n_ops = n_ops; A.op_offset = op_offset; A.L = L; A.logn1 = env.logn1; A.mode = (int)mode;
     for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine residues, pass 1: u64-engine residues
@@ -1928,13 +1943,14 @@ void launch_behz_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, co
     const u64 threads = (n_ops * 3) << logN;
     hipLaunchKernelGGL(k_behz_floor_sk, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, dq, ds, out, n_ops * 3, logN);
 }
-void launch_bfv_galois(const KernelEnv &env, int L, u64 n_ops, const u64 *in, const uint32_t *gather, u64 *c01, u64 c01_item_stride, u64 *tgt)
+void launch_bfv_galois(const KernelEnv &env, int L, u64 n_ops, const u64 *in, const uint32_t *gather, u64 *c01, u64 c01_item_stride, u64 *tgt,
+                       const u64 *addend)
 {
     if (!n_ops) return;
     const int logN = env.logn1 + kRowLog;
     const u64 threads = (n_ops * L) << logN;
     hipLaunchKernelGGL(k_bfv_galois, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, in, gather, c01, c01_item_stride, tgt, env.primes, L, logN,
-                       n_ops);
+                       n_ops, addend);
 }
 void launch_bfv_tail_sp(const KernelEnv &env, u64 n_polys, const u64 *tpr, u64 *rp)
 {

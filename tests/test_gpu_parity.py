@@ -273,6 +273,31 @@ def test_galois_rotate_accumulate(pair, be):
             e = o.galois_elt(1 << i)
             t = o.add(t, o.apply_galois(t, e, keys[e]))
         assert np.array_equal(got[r], t), r
+    # rotate_add: out = addend + rotate(in), the add folded into the rotation's first kernel
+    b = rand_cts(o, rng, 3, L)
+    db = g.to_device(b)
+    k1 = keys[o.galois_elt(1)]
+    g.rotate_add(L, 3, da, 1, db, out)
+    got = out.download((3, 2, L, N))
+    for r in range(3):
+        assert np.array_equal(got[r], o.add(b[r], o.apply_galois(a[r], o.galois_elt(1), k1))), r
+    g.rotate_add(L, 3, da, 1, db, db)  # add in place: the addend is the output
+    got = db.download((3, 2, L, N))
+    for r in range(3):
+        assert np.array_equal(got[r], o.add(b[r], o.apply_galois(a[r], o.galois_elt(1), k1))), r
+    db = g.to_device(b)
+    g.rotate_add(L, 3, da, 3, db, out)  # NAF 3 = -1 + 4: the addend joins the last step
+    got = out.download((3, 2, L, N))
+    for r in range(3):
+        t = o.apply_galois(a[r], o.galois_elt(-1), keys[o.galois_elt(-1)])
+        t = o.apply_galois(t, o.galois_elt(4), keys[o.galois_elt(4)])
+        assert np.array_equal(got[r], o.add(b[r], t)), r
+    g.rotate_add(L, 3, da, 0, db, out)  # step 0: plain add
+    got = out.download((3, 2, L, N))
+    for r in range(3):
+        assert np.array_equal(got[r], o.add(b[r], a[r])), r
+    with pytest.raises(be.HE355Error):
+        g.rotate_add(L, 3, da, 3, db, db)  # several Galois steps cannot add in place
     with pytest.raises(be.HE355Error):
         g.rotate(L, 3, da, 8, out)  # power-of-two step without a key: "Galois key not present"
 

@@ -102,6 +102,17 @@ def test_bfv_rotations_and_accumulate(pair, be):
     got = out.download((2, 2, L, N))
     for r in range(2):
         assert np.array_equal(got[r], o.apply_galois(a[r], col, keys[col]))
+    # rotate_add: out = addend + rotate_rows / rotate_columns (in), also in place
+    b = rand_cts(o, rng, 2, L)
+    db = g.to_device(b)
+    g.rotate_add(L, 2, da, 2, db, out)
+    got = out.download((2, 2, L, N))
+    for r in range(2):
+        assert np.array_equal(got[r], o.add(b[r], o.apply_galois(a[r], o.galois_elt(2), keys[o.galois_elt(2)])))
+    g.rotate_add(L, 2, da, 4, db, db)
+    got = db.download((2, 2, L, N))
+    for r in range(2):
+        assert np.array_equal(got[r], o.add(b[r], o.apply_galois(a[r], o.galois_elt(4), keys[o.galois_elt(4)])))
     # accumulateBFV(count = 6) within a row: 3 row rotations (seal_context.cpp:296-304)
     acc = g.to_device(a)
     tmp = g.alloc(2 * 2 * L * N)

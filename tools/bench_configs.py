@@ -96,10 +96,10 @@ def cfg5_bfv_matmul():
     def run():
         g.bfv_multiply(L, n, a, b, be.Context.outer(0, n, 0, 1), c3)
         g.relinearize(L, n, c3, base)
-        g.rotate(L, n, base, 0, acc)
+        cur, nxt = base, acc  # as the bridge's MatMultRow: every rotate + add_inplace pair is one rotate_add pipeline
         for j in range(1, 128):
-            g.rotate(L, n, base, j * spacers, rot)
-            g.add(L, 2, n, acc, rot, pw, acc)
+            g.rotate_add(L, n, base, j * spacers, cur, nxt)
+            cur, nxt = (nxt, rot) if cur is base else (nxt, cur)
     ms = timed(g, run, 2)
     out = dict(config="configs[4] BFV MatMul 128x128x128 N=2^15 L=3: 64 row-pair cts x (multiply, relinearize, 127 rotate_rows + add)", results=n, ms=ms,
                latency_ms_per_matrix_product=ms, key_switches_total=64 * 356)
