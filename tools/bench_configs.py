@@ -75,6 +75,34 @@ def cfg4_dot_product():
     return out
 
 
+def headline_latency():
+    """HEBench's Latency category on the headline operation (configs[2] with batch 1): one multiply + relinearize + rescale per
+    call, host-synchronised after every call (wall clock), and the same for small offline batches."""
+    import time
+    g = be.Context(be.SCHEME_CKKS, 32768, bit_sizes=be.chain_bits(16, 45), device=0)
+    L, N = g.L, g.N
+    g.set_relin_key_synthetic(7)
+    res = []
+    for n in (1, 8, 64):
+        a, b, o = g.alloc(n * 2 * L * N), g.alloc(2 * L * N), g.alloc(n * 2 * (L - 1) * N)
+        g.fill_uniform(a, n * 2 * L, list(range(L)), 1)
+        g.fill_uniform(b, 2 * L, list(range(L)), 2)
+        ix = be.Context.outer(0, n, 0, 1)
+        for _ in range(3):
+            g.multiply_relin(L, n, a, b, ix, o, rescale=True)
+        g.sync()
+        reps = 50
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.multiply_relin(L, n, a, b, ix, o, rescale=True)
+            g.sync()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        res.append(dict(config=f"configs[2] latency mode: CKKS mul+relin+rescale N=2^15 L=16, batch {n}, sync per call", results=n, ms=ms,
+                        ops_per_s=n / ms * 1e3))
+    g.close()
+    return res
+
+
 def cfg5_bfv_matmul():
     """configs[4]: BFV MatMul 128x128x128 at N=2^15, depth 3 ({60,40,40,60}): 64 row-pair ciphertexts x (BEHZ multiply + relinearize +
     127 rotate_rows(j*128) + add), rotations by non-power-of-two steps through SEAL's NAF terms (355 key switches per ciphertext)."""
@@ -138,5 +166,8 @@ def client_side():
 
 
 if __name__ == "__main__":
-    for r in [cfg1_bfv_add()] + cfg2_ckks_multiply() + [cfg4_dot_product(), cfg5_bfv_matmul()] + client_side():
-        print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
+    groups = {"cfg0": lambda: [cfg1_bfv_add()], "cfg1": cfg2_ckks_multiply, "cfg3": lambda: [cfg4_dot_product()], "cfg4": lambda: [cfg5_bfv_matmul()],
+              "latency": headline_latency, "client": client_side}
+    for name in (sys.argv[1:] or list(groups)):  # no arguments: everything
+        for r in groups[name]():
+            print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}))
