@@ -84,6 +84,7 @@ int he355_malloc(he355_ctx *ctx, uint64_t bytes, void **d_ptr);
 int he355_free(he355_ctx *ctx, void *d_ptr);
 int he355_upload(he355_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int he355_download(he355_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+int he355_copy(he355_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes); /* device to device, on the context's stream */
 int he355_sync(he355_ctx *ctx);
 /* synthetic data: fill n_polys residue polynomials with uniform residues, polynomial p using prime
  * prime_of[p % period] (throughput-mode inputs) */

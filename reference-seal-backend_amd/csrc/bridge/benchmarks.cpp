@@ -210,7 +210,7 @@ void VectorBenchmark::store(AB::Handle remote_data, AB::Handle *p_local_data, st
         // pad with zeros any excess local handles as per specifications
         std::memset(p_local_data, 0, sizeof(AB::Handle) * count);
         const std::shared_ptr<DeviceCiphers> &remote = this->getEngine().retrieveFromHandle<std::shared_ptr<DeviceCiphers>>(remote_data);
-        std::vector<Cipher> local = m_p_ctx_wrapper->download(*remote);
+        std::vector<Cipher> local = m_p_ctx_wrapper->download(remote);
         p_local_data[0] = this->getEngine().createHandle<decltype(local)>(sizeof(local), 0, std::move(local));
     }
 }

@@ -92,6 +92,72 @@ template <class V> static std::uint64_t max_len(const std::vector<std::vector<V>
     for (const auto &r : rows) m = std::max<std::uint64_t>(m, r.size());
     return m;
 }
+namespace {
+// device temporary of a batch call
+struct DevBuf {
+    he355_ctx *ctx;
+    void *p = nullptr;
+    DevBuf(he355_ctx *c, std::uint64_t bytes) : ctx(c) { HeContextWrapper::check(he355_malloc(c, bytes ? bytes : 8, &p), "device allocation"); }
+    ~DevBuf() { if (p) (void)he355_free(ctx, p); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+} // namespace
+
+std::shared_ptr<DeviceCiphers> HeContextWrapper::allocRaw(uint64_t n, uint64_t per)
+{
+    return allocResult(n, 1, (int)(per / m_params->N), 1.0);
+}
+// Host copy of an object that lives on the device (one download, kept)
+const uint64_t *HeContextWrapper::hostData(const Plain &p)
+{
+    if (p.data.empty() && p.dev) {
+        const uint64_t per = p.dev.slab->elems_per_ct(m_params->N);
+        p.data.resize(per);
+        check(he355_download(m_ctx, p.data.data(), p.dev.slab->d + p.dev.index * per, per * 8), "download");
+    }
+    return p.data.data();
+}
+const uint64_t *HeContextWrapper::hostData(const Cipher &c)
+{
+    if (c.data.empty() && c.dev) {
+        const uint64_t per = c.dev.slab->elems_per_ct(m_params->N);
+        c.data.resize(per);
+        check(he355_download(m_ctx, c.data.data(), c.dev.slab->d + c.dev.index * per, per * 8), "download");
+    }
+    return c.data.data();
+}
+// n objects of `per` words as one contiguous device range: the slab they already share (consecutive positions), or a staging
+// slab filled by device copies / uploads.
+template <class T> HeContextWrapper::Staged HeContextWrapper::stage(const std::vector<T> &items, uint64_t per)
+{
+    Staged st;
+    const uint64_t N = m_params->N;
+    bool shared = (bool)items[0].dev;
+    for (std::size_t i = 0; shared && i < items.size(); ++i)
+        shared = items[i].dev && items[i].dev.slab == items[0].dev.slab && items[i].dev.index == items[0].dev.index + i
+                 && items[i].dev.slab->elems_per_ct(N) == per;
+    if (shared) {
+        st.keep = items[0].dev.slab;
+        st.d = st.keep->d + items[0].dev.index * per;
+        return st;
+    }
+    st.keep = allocRaw(items.size(), per);
+    for (std::size_t i = 0; i < items.size(); ++i) {
+        uint64_t *dst = st.keep->d + i * per;
+        if (items[i].dev) {
+            if (items[i].dev.slab->elems_per_ct(N) != per) throw HEBenchError(HEBERROR_MSG_CLASS("object shape"), HEBENCH_ECODE_INVALID_ARGS);
+            check(he355_copy(m_ctx, dst, items[i].dev.slab->d + items[i].dev.index * per, per * 8), "device copy");
+        } else {
+            if (items[i].data.size() != per) throw HEBenchError(HEBERROR_MSG_CLASS("object shape"), HEBENCH_ECODE_INVALID_ARGS);
+            check(he355_upload(m_ctx, dst, items[i].data.data(), per * 8), "upload");
+        }
+    }
+    st.d = st.keep->d;
+    return st;
+}
+
 std::vector<Plain> HeContextWrapper::encodeBatch(const std::vector<std::vector<double>> &rows)
 {
     std::vector<Plain> out(rows.size());
@@ -106,18 +172,15 @@ std::vector<Plain> HeContextWrapper::encodeBatch(const std::vector<std::vector<d
     const std::uint64_t N = m_params->N, pl = (std::uint64_t)topLevel() * N;
     std::vector<double> flat(n * count, 0.0); // missing trailing slots are zeros, as in CKKSEncoder::encode
     for (std::uint64_t i = 0; i < n; ++i) std::copy(rows[i].begin(), rows[i].end(), flat.begin() + i * count);
-    void *dv = nullptr, *dp = nullptr;
-    check(he355_malloc(m_ctx, flat.size() * 8, &dv), "device allocation");
-    check(he355_malloc(m_ctx, n * pl * 8, &dp), "device allocation");
-    check(he355_upload(m_ctx, dv, flat.data(), flat.size() * 8), "upload");
-    check(he355_ckks_encode(m_ctx, n, static_cast<double *>(dv), count, m_scale, static_cast<uint64_t *>(dp)), "encode");
+    DevBuf dv(m_ctx, flat.size() * 8);
+    std::shared_ptr<DeviceCiphers> slab = allocRaw(n, pl);
+    check(he355_upload(m_ctx, dv.p, flat.data(), flat.size() * 8), "upload");
+    check(he355_ckks_encode(m_ctx, n, dv.as<double>(), count, m_scale, slab->d), "encode");
+    check(he355_sync(m_ctx), "synchronise");
     for (std::uint64_t i = 0; i < n; ++i) {
-        out[i].data.resize(pl);
+        out[i].dev.slab = slab; out[i].dev.index = i; // the plaintexts stay in HBM (encrypt() reads them there)
         out[i].L = topLevel(); out[i].scale = m_scale;
-        check(he355_download(m_ctx, out[i].data.data(), static_cast<uint64_t *>(dp) + i * pl, pl * 8), "download");
     }
-    (void)he355_free(m_ctx, dv);
-    (void)he355_free(m_ctx, dp);
     return out;
 }
 std::vector<Plain> HeContextWrapper::encodeBatch(const std::vector<std::vector<std::int64_t>> &rows)
@@ -134,19 +197,15 @@ std::vector<Plain> HeContextWrapper::encodeBatch(const std::vector<std::vector<s
     const std::uint64_t N = m_params->N;
     std::vector<std::int64_t> flat(n * count, 0);
     for (std::uint64_t i = 0; i < n; ++i) std::copy(rows[i].begin(), rows[i].end(), flat.begin() + i * count);
-    void *dv = nullptr, *dp = nullptr;
-    check(he355_malloc(m_ctx, flat.size() * 8, &dv), "device allocation");
-    check(he355_malloc(m_ctx, n * N * 8, &dp), "device allocation");
-    check(he355_upload(m_ctx, dv, flat.data(), flat.size() * 8), "upload");
-    check(he355_bfv_encode(m_ctx, n, static_cast<std::int64_t *>(dv), count, static_cast<uint64_t *>(dp)), "encode");
+    DevBuf dv(m_ctx, flat.size() * 8);
+    std::shared_ptr<DeviceCiphers> slab = allocRaw(n, N);
+    check(he355_upload(m_ctx, dv.p, flat.data(), flat.size() * 8), "upload");
+    check(he355_bfv_encode(m_ctx, n, dv.as<std::int64_t>(), count, slab->d), "encode");
     check(he355_sync(m_ctx), "synchronise");
     for (std::uint64_t i = 0; i < n; ++i) {
-        out[i].data.resize(N);
+        out[i].dev.slab = slab; out[i].dev.index = i;
         out[i].L = topLevel();
-        check(he355_download(m_ctx, out[i].data.data(), static_cast<uint64_t *>(dp) + i * N, N * 8), "download");
     }
-    (void)he355_free(m_ctx, dv);
-    (void)he355_free(m_ctx, dp);
     return out;
 }
 // decode: slot values of each plaintext (CKKS: N/2 doubles; BFV: N int64)
@@ -157,20 +216,16 @@ std::vector<std::vector<double>> HeContextWrapper::decodeBatchCKKS(const std::ve
     bool uniform = true;
     for (const Plain &p : plains) uniform = uniform && p.L == plains[0].L && p.scale == plains[0].scale;
     if (!clientOnDevice() || !uniform || plains[0].L > 16) {
-        for (std::size_t i = 0; i < plains.size(); ++i) m_client->ckks_decode(plains[i].data.data(), (size_t)plains[i].L, plains[i].scale, out[i].data());
+        for (std::size_t i = 0; i < plains.size(); ++i) m_client->ckks_decode(hostData(plains[i]), (size_t)plains[i].L, plains[i].scale, out[i].data());
         return out;
     }
     const int L = plains[0].L;
     const std::uint64_t N = m_params->N, n = plains.size(), pl = (std::uint64_t)L * N, half = N / 2;
-    void *dv = nullptr, *dp = nullptr;
-    check(he355_malloc(m_ctx, n * half * 8, &dv), "device allocation");
-    check(he355_malloc(m_ctx, n * pl * 8, &dp), "device allocation");
-    for (std::uint64_t i = 0; i < n; ++i) check(he355_upload(m_ctx, static_cast<uint64_t *>(dp) + i * pl, plains[i].data.data(), pl * 8), "upload");
-    check(he355_ckks_decode(m_ctx, L, n, static_cast<uint64_t *>(dp), plains[0].scale, static_cast<double *>(dv)), "decode");
+    const Staged in = stage(plains, pl);
+    DevBuf dv(m_ctx, n * half * 8);
+    check(he355_ckks_decode(m_ctx, L, n, in.d, plains[0].scale, dv.as<double>()), "decode");
     check(he355_sync(m_ctx), "synchronise");
-    for (std::uint64_t i = 0; i < n; ++i) check(he355_download(m_ctx, out[i].data(), static_cast<double *>(dv) + i * half, half * 8), "download");
-    (void)he355_free(m_ctx, dv);
-    (void)he355_free(m_ctx, dp);
+    for (std::uint64_t i = 0; i < n; ++i) check(he355_download(m_ctx, out[i].data(), dv.as<double>() + i * half, half * 8), "download");
     return out;
 }
 std::vector<std::vector<std::int64_t>> HeContextWrapper::decodeBatchBFV(const std::vector<Plain> &plains)
@@ -178,19 +233,15 @@ std::vector<std::vector<std::int64_t>> HeContextWrapper::decodeBatchBFV(const st
     std::vector<std::vector<std::int64_t>> out(plains.size(), std::vector<std::int64_t>(slot_count()));
     if (plains.empty()) return out;
     if (!clientOnDevice()) {
-        for (std::size_t i = 0; i < plains.size(); ++i) m_client->bfv_decode(plains[i].data.data(), out[i].data());
+        for (std::size_t i = 0; i < plains.size(); ++i) m_client->bfv_decode(hostData(plains[i]), out[i].data());
         return out;
     }
     const std::uint64_t N = m_params->N, n = plains.size();
-    void *dv = nullptr, *dp = nullptr;
-    check(he355_malloc(m_ctx, n * N * 8, &dv), "device allocation");
-    check(he355_malloc(m_ctx, n * N * 8, &dp), "device allocation");
-    for (std::uint64_t i = 0; i < n; ++i) check(he355_upload(m_ctx, static_cast<uint64_t *>(dp) + i * N, plains[i].data.data(), N * 8), "upload");
-    check(he355_bfv_decode(m_ctx, n, static_cast<uint64_t *>(dp), static_cast<std::int64_t *>(dv)), "decode");
+    const Staged in = stage(plains, N);
+    DevBuf dv(m_ctx, n * N * 8);
+    check(he355_bfv_decode(m_ctx, n, in.d, dv.as<std::int64_t>()), "decode");
     check(he355_sync(m_ctx), "synchronise");
-    for (std::uint64_t i = 0; i < n; ++i) check(he355_download(m_ctx, out[i].data(), static_cast<std::int64_t *>(dv) + i * N, N * 8), "download");
-    (void)he355_free(m_ctx, dv);
-    (void)he355_free(m_ctx, dp);
+    for (std::uint64_t i = 0; i < n; ++i) check(he355_download(m_ctx, out[i].data(), dv.as<std::int64_t>() + i * N, N * 8), "download");
     return out;
 }
 // Client side: on the MI355X when one is present (he355_encrypt / he355_decrypt: same bits as the host code below for the same
@@ -219,25 +270,17 @@ std::vector<Cipher> HeContextWrapper::encryptBatch(const std::vector<Plain> &pla
         for (std::size_t i = 0; i < plains.size(); ++i) out[i] = encrypt(plains[i]);
         return out;
     }
-    const std::uint64_t N = m_params->N, n = plains.size(), pl = isCKKS() ? (std::uint64_t)L * N : N, cl = 2 * (std::uint64_t)L * N;
-    void *dp = nullptr, *dc = nullptr;
-    check(he355_malloc(m_ctx, n * pl * 8, &dp), "device allocation");
-    check(he355_malloc(m_ctx, n * cl * 8, &dc), "device allocation");
-    for (std::uint64_t i = 0; i < n; ++i) {
-        if (plains[i].data.size() != pl) throw HEBenchError(HEBERROR_MSG_CLASS("plaintext shape"), HEBENCH_ECODE_INVALID_ARGS);
-        check(he355_upload(m_ctx, static_cast<uint64_t *>(dp) + i * pl, plains[i].data.data(), pl * 8), "upload");
-    }
+    const std::uint64_t N = m_params->N, n = plains.size(), pl = isCKKS() ? (std::uint64_t)L * N : N;
+    const Staged in = stage(plains, pl);
+    std::shared_ptr<DeviceCiphers> slab = allocResult(n, 2, L, plains[0].scale);
     const std::uint64_t first = m_client->encrypt_index();
-    check(he355_encrypt(m_ctx, n, static_cast<uint64_t *>(dp), m_client->encrypt_seed(), first, static_cast<uint64_t *>(dc)), "encrypt");
+    check(he355_encrypt(m_ctx, n, in.d, m_client->encrypt_seed(), first, slab->d), "encrypt");
     m_client->set_encrypt_index(first + n); // the host counter moves on exactly as if it had encrypted them
     check(he355_sync(m_ctx), "synchronise");
     for (std::uint64_t i = 0; i < n; ++i) {
-        out[i].data.resize(cl);
+        out[i].dev.slab = slab; out[i].dev.index = i; // the ciphertexts stay in HBM: load() hands the slab to operate()
         out[i].size = 2; out[i].L = L; out[i].scale = plains[i].scale;
-        check(he355_download(m_ctx, out[i].data.data(), static_cast<uint64_t *>(dc) + i * cl, cl * 8), "download");
     }
-    (void)he355_free(m_ctx, dp);
-    (void)he355_free(m_ctx, dc);
     return out;
 }
 std::vector<Plain> HeContextWrapper::decryptBatch(const std::vector<Cipher> &ciphers)
@@ -253,23 +296,17 @@ std::vector<Plain> HeContextWrapper::decryptBatch(const std::vector<Cipher> &cip
     try {
         const int L = ciphers[0].L, size = ciphers[0].size;
         const std::uint64_t N = m_params->N, n = ciphers.size(), cl = (std::uint64_t)size * L * N, pl = isCKKS() ? (std::uint64_t)L * N : N;
-        void *dp = nullptr, *dc = nullptr;
-        check(he355_malloc(m_ctx, n * pl * 8, &dp), "device allocation");
-        check(he355_malloc(m_ctx, n * cl * 8, &dc), "device allocation");
-        for (std::uint64_t i = 0; i < n; ++i) {
-            if (ciphers[i].data.size() != cl) throw HEBenchError(HEBERROR_MSG_CLASS("ciphertext shape"), HEBENCH_ECODE_INVALID_ARGS);
-            check(he355_upload(m_ctx, static_cast<uint64_t *>(dc) + i * cl, ciphers[i].data.data(), cl * 8), "upload");
-        }
-        check(he355_decrypt(m_ctx, L, size, n, static_cast<uint64_t *>(dc), static_cast<uint64_t *>(dp)), "decrypt");
+        const Staged in = stage(ciphers, cl);
+        std::shared_ptr<DeviceCiphers> slab = allocRaw(n, pl);
+        check(he355_decrypt(m_ctx, L, size, n, in.d, slab->d), "decrypt");
         check(he355_sync(m_ctx), "synchronise");
         for (std::uint64_t i = 0; i < n; ++i) {
-            out[i].data.resize(pl);
+            out[i].dev.slab = slab; out[i].dev.index = i;
             out[i].L = L; out[i].scale = ciphers[i].scale;
-            check(he355_download(m_ctx, out[i].data.data(), static_cast<uint64_t *>(dp) + i * pl, pl * 8), "download");
         }
-        (void)he355_free(m_ctx, dp);
-        (void)he355_free(m_ctx, dc);
         return out;
+    } catch (const HEBenchError &) {
+        throw;
     } catch (const std::exception &ex) {
         throw HEBenchError(ex.what(), HEB355_ECODE_HE_ERROR); // seal_context.cpp:166-169
     }
@@ -278,7 +315,7 @@ Cipher HeContextWrapper::encrypt(const Plain &plain)
 {
     if (clientOnDevice()) return encryptBatch(std::vector<Plain>{plain})[0];
     Cipher c;
-    c.data = m_client->encrypt(plain.data.data());
+    c.data = m_client->encrypt(hostData(plain));
     c.size = 2;
     c.L = topLevel();
     c.scale = plain.scale;
@@ -289,7 +326,7 @@ Plain HeContextWrapper::decrypt(const Cipher &cipher)
     if (clientOnDevice() && cipher.size >= 2 && cipher.size <= 3 && (isCKKS() || cipher.L <= 16)) return decryptBatch(std::vector<Cipher>{cipher})[0];
     try {
         Plain p;
-        p.data = m_client->decrypt(cipher.data.data(), (size_t)cipher.size, (size_t)cipher.L);
+        p.data = m_client->decrypt(hostData(cipher), (size_t)cipher.size, (size_t)cipher.L);
         p.L = cipher.L;
         p.scale = cipher.scale;
         return p;
@@ -361,24 +398,47 @@ std::shared_ptr<DeviceCiphers> HeContextWrapper::allocResult(uint64_t n, int siz
 std::shared_ptr<DeviceCiphers> HeContextWrapper::upload(const std::vector<Cipher> &cts)
 {
     if (cts.empty()) throw HEBenchError(HEBERROR_MSG_CLASS("empty operand"), HEBENCH_ECODE_INVALID_ARGS);
-    auto s = allocResult(cts.size(), cts[0].size, cts[0].L, cts[0].scale);
-    const uint64_t per = s->elems_per_ct(m_params->N);
-    for (size_t i = 0; i < cts.size(); ++i) {
-        if (cts[i].size != s->size || cts[i].L != s->L || cts[i].data.size() != per)
+    ensureDevice();
+    const uint64_t per = (uint64_t)cts[0].size * cts[0].L * m_params->N;
+    for (const Cipher &c : cts)
+        if (c.size != cts[0].size || c.L != cts[0].L || (!c.dev && c.data.size() != per))
             throw HEBenchError(HEBERROR_MSG_CLASS("operand ciphertexts differ in shape"), HEBENCH_ECODE_INVALID_ARGS);
-        check(he355_upload(m_ctx, s->d + i * per, cts[i].data.data(), per * 8), "upload");
+    const Staged st = stage(cts, per);
+    const bool whole = st.d == st.keep->d && st.keep->n == cts.size();
+    if (whole && st.keep->size == cts[0].size && st.keep->L == cts[0].L) return st.keep; // the operand's own slab: nothing moves
+    if (whole && st.keep.use_count() == 1) { // a staging slab stage() has just filled: give it the operand's shape
+        st.keep->size = cts[0].size; st.keep->L = cts[0].L; st.keep->scale = cts[0].scale;
+        check(he355_sync(m_ctx), "synchronise");
+        return st.keep;
     }
+    auto s = allocResult(cts.size(), cts[0].size, cts[0].L, cts[0].scale); // a sub-range of a larger slab
+    check(he355_copy(m_ctx, s->d, st.d, cts.size() * per * 8), "device copy");
+    check(he355_sync(m_ctx), "synchronise");
     return s;
 }
-std::vector<Cipher> HeContextWrapper::download(const DeviceCiphers &slab)
+std::shared_ptr<DeviceCiphers> HeContextWrapper::uploadPlains(const std::vector<Plain> &plains)
 {
-    const uint64_t per = slab.elems_per_ct(m_params->N);
-    std::vector<Cipher> out(slab.n);
+    std::vector<Cipher> tmp(plains.size());
+    for (std::size_t i = 0; i < plains.size(); ++i) {
+        tmp[i].dev = plains[i].dev;
+        if (!plains[i].dev) tmp[i].data = plains[i].data;
+        tmp[i].size = 1; tmp[i].L = plains[i].L; tmp[i].scale = plains[i].scale;
+    }
+    return upload(tmp);
+}
+std::vector<Cipher> HeContextWrapper::download(const std::shared_ptr<DeviceCiphers> &slab)
+{
+    std::vector<Cipher> out(slab->n);
     check(he355_sync(m_ctx), "synchronise");
-    for (uint64_t i = 0; i < slab.n; ++i) {
-        out[i].data.resize(per);
-        out[i].size = slab.size; out[i].L = slab.L; out[i].scale = slab.scale;
-        check(he355_download(m_ctx, out[i].data.data(), slab.d + i * per, per * 8), "download");
+    for (uint64_t i = 0; i < slab->n; ++i) {
+        out[i].size = slab->size; out[i].L = slab->L; out[i].scale = slab->scale;
+        if (clientOnDevice()) { // decrypt() reads the result where operate() left it
+            out[i].dev.slab = slab; out[i].dev.index = i;
+        } else {
+            const uint64_t per = slab->elems_per_ct(m_params->N);
+            out[i].data.resize(per);
+            check(he355_download(m_ctx, out[i].data.data(), slab->d + i * per, per * 8), "download");
+        }
     }
     return out;
 }

@@ -17,14 +17,25 @@
 
 namespace mi355x {
 
-// host-side objects behind the handles (the reference keeps seal::Plaintext / seal::Ciphertext there)
+// Objects behind the handles (the reference keeps seal::Plaintext / seal::Ciphertext there).  With the client side on the
+// device a plaintext / ciphertext lives in HBM from the moment encode() / encrypt() / operate() produced it: `dev` names
+// its slab and position, `data` stays empty until host code asks for it (HeContextWrapper::hostData), and load() / store()
+// pass the slab on instead of moving bytes over PCIe and back.
+struct DeviceCiphers;
+struct DevRef {
+    std::shared_ptr<DeviceCiphers> slab;
+    uint64_t index = 0;
+    explicit operator bool() const { return (bool)slab; }
+};
 struct Plain {
-    std::vector<uint64_t> data; // CKKS: [L][N] NTT form; BFV: [N] mod t
+    mutable std::vector<uint64_t> data; // CKKS: [L][N] NTT form; BFV: [N] mod t (host copy; filled lazily when `dev` is set)
+    DevRef dev;
     int L = 0;
     double scale = 1.0;
 };
 struct Cipher {
-    std::vector<uint64_t> data; // [size][L][N]
+    mutable std::vector<uint64_t> data; // [size][L][N] (host copy; filled lazily when `dev` is set)
+    DevRef dev;
     int size = 2, L = 0;
     double scale = 1.0;
 };
@@ -80,12 +91,23 @@ public:
     void needRotationKey(int step);
     void needGaloisKey(uint32_t galois_elt);
     void needDefaultGaloisKeys(); // create_galois_keys(): all +-2^k steps and the column swap (seal_context.cpp:69)
+    // load() / store(): ciphertexts that already live in one slab are passed on as that slab (no copy); host-resident ones are uploaded
     std::shared_ptr<DeviceCiphers> upload(const std::vector<Cipher> &cts);
-    std::vector<Cipher> download(const DeviceCiphers &slab);
+    std::shared_ptr<DeviceCiphers> uploadPlains(const std::vector<Plain> &plains); // as size-1 "ciphertexts" (multiply_plain / add_plain operands)
+    std::vector<Cipher> download(const std::shared_ptr<DeviceCiphers> &slab);
+    // host copy of an object (downloads it once if it lives on the device)
+    const uint64_t *hostData(const Plain &p);
+    const uint64_t *hostData(const Cipher &c);
     std::shared_ptr<DeviceCiphers> allocResult(uint64_t n, int size, int L, double scale);
     static void check(int code, const char *what); // he355 error -> HEBenchError
 
 private:
+    struct Staged { // n objects of `per` words each, contiguous in HBM
+        const uint64_t *d = nullptr;
+        std::shared_ptr<DeviceCiphers> keep;
+    };
+    template <class T> Staged stage(const std::vector<T> &items, uint64_t per);
+    std::shared_ptr<DeviceCiphers> allocRaw(uint64_t n, uint64_t per); // slab of n objects of `per` words (per a multiple of N)
     HeContextWrapper() = default;
     void init(int scheme, std::size_t N, std::size_t depth, int bits, int plain_bits);
     he355_ctx *m_ctx = nullptr;

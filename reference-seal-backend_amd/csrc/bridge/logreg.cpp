@@ -124,14 +124,16 @@ AB::Handle LogRegHornerBenchmark::encode(const AB::DataPackCollection *p_paramet
         ss << "Insufficient features for 'W'. Expected " << m_n << ", but " << pW.p_buffers[0].size / sizeof(double) << " received.";
         throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
     }
+    // W, b and every sample go through one encodeBatch call (one device launch sequence; same bits as one encodeVector each)
+    std::vector<std::vector<double>> rows;
     {
         const double *p = reinterpret_cast<const double *>(pW.p_buffers[0].p);
-        enc.W = m_p_ctx_wrapper->encodeVector(std::vector<double>(p, p + std::min<std::uint64_t>(pW.p_buffers[0].size / sizeof(double), m_p_ctx_wrapper->slot_count())));
+        rows.emplace_back(p, p + std::min<std::uint64_t>(pW.p_buffers[0].size / sizeof(double), m_p_ctx_wrapper->slot_count()));
     }
     // encodeBias (.cpp:226-242): the value in every slot
     if (pb.buffer_count < 1 || !pb.p_buffers || !pb.p_buffers[0].p || pb.p_buffers[0].size < sizeof(double))
         throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty DataPack for 'b'."), HEBENCH_ECODE_INVALID_ARGS);
-    enc.b = m_p_ctx_wrapper->encodeVector(std::vector<double>(m_p_ctx_wrapper->slot_count(), *reinterpret_cast<const double *>(pb.p_buffers[0].p)));
+    rows.emplace_back(m_p_ctx_wrapper->slot_count(), *reinterpret_cast<const double *>(pb.p_buffers[0].p));
     // encodeInputs (.cpp:244-290)
     const std::uint64_t batch = getDescriptor().category == AB::Category::Offline ? getDescriptor().cat_params.offline.data_count[LogRegHornerBenchmarkDescription::Index_X] : 1;
     if (!pX.p_buffers) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty DataPack for 'X'."), HEBENCH_ECODE_INVALID_ARGS);
@@ -151,8 +153,12 @@ AB::Handle LogRegHornerBenchmark::encode(const AB::DataPackCollection *p_paramet
             throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
         }
         const double *p = reinterpret_cast<const double *>(pX.p_buffers[s].p);
-        enc.X.push_back(m_p_ctx_wrapper->encodeVector(std::vector<double>(p, p + std::min<std::uint64_t>(cnt, m_p_ctx_wrapper->slot_count()))));
+        rows.emplace_back(p, p + std::min<std::uint64_t>(cnt, m_p_ctx_wrapper->slot_count()));
     }
+    std::vector<Plain> plains = m_p_ctx_wrapper->encodeBatch(rows);
+    enc.W = std::move(plains[0]);
+    enc.b = std::move(plains[1]);
+    enc.X.assign(std::make_move_iterator(plains.begin() + 2), std::make_move_iterator(plains.end()));
     return this->getEngine().createHandle<decltype(enc)>(sizeof(enc), EncodedOpParamsTag, std::move(enc));
 }
 
@@ -167,7 +173,7 @@ void LogRegHornerBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackCollec
     if (min_count == 0) return;
     const Plain &encoded = this->getEngine().retrieveFromHandle<Plain>(h_encoded_data, EncodedResultTag);
     std::vector<double> v(m_p_ctx_wrapper->slot_count());
-    m_p_ctx_wrapper->client().ckks_decode(encoded.data.data(), (size_t)encoded.L, encoded.scale, v.data());
+    m_p_ctx_wrapper->client().ckks_decode(m_p_ctx_wrapper->hostData(encoded), (size_t)encoded.L, encoded.scale, v.data());
     for (std::uint64_t s = 0; s < min_count && s < v.size(); ++s)
         if (result.p_buffers[s].p && result.p_buffers[s].size >= sizeof(double))
             *reinterpret_cast<double *>(result.p_buffers[s].p) = std::abs(v[s]) < 0.00005 ? 0.0 : v[s];
@@ -177,9 +183,15 @@ AB::Handle LogRegHornerBenchmark::encrypt(AB::Handle h_encoded_data)
 {
     const EncodedOpParams &p = this->getEngine().retrieveFromHandle<EncodedOpParams>(h_encoded_data, EncodedOpParamsTag);
     EncryptedOpParams c;
-    c.W = m_p_ctx_wrapper->encrypt(p.W);
-    c.b = m_p_ctx_wrapper->encrypt(p.b);
-    for (const Plain &x : p.X) c.X.push_back(m_p_ctx_wrapper->encrypt(x));
+    std::vector<Plain> all; // W, b, X[0..): the order the reference encrypts them in (the randomness counter follows it)
+    all.reserve(p.X.size() + 2);
+    all.push_back(p.W);
+    all.push_back(p.b);
+    all.insert(all.end(), p.X.begin(), p.X.end());
+    std::vector<Cipher> cts = m_p_ctx_wrapper->encryptBatch(all);
+    c.W = std::move(cts[0]);
+    c.b = std::move(cts[1]);
+    c.X.assign(std::make_move_iterator(cts.begin() + 2), std::make_move_iterator(cts.end()));
     return this->getEngine().createHandle<decltype(c)>(sizeof(c), EncryptedOpParamsTag, std::move(c));
 }
 
@@ -192,11 +204,7 @@ AB::Handle LogRegHornerBenchmark::decrypt(AB::Handle h_encrypted_data)
 
 std::shared_ptr<DeviceCiphers> LogRegHornerBenchmark::uploadPlains(const std::vector<Plain> &p)
 {
-    std::vector<Cipher> tmp(p.size());
-    for (std::size_t i = 0; i < p.size(); ++i) {
-        tmp[i].data = p[i].data; tmp[i].size = 1; tmp[i].L = p[i].L; tmp[i].scale = p[i].scale;
-    }
-    return m_p_ctx_wrapper->upload(tmp);
+    return m_p_ctx_wrapper->uploadPlains(p);
 }
 
 AB::Handle LogRegHornerBenchmark::load(const AB::Handle *p_h_local_data, std::uint64_t count)
@@ -210,13 +218,9 @@ AB::Handle LogRegHornerBenchmark::load(const AB::Handle *p_h_local_data, std::ui
     // Operands the reference creates inside operate() on the host (identity masks seal_context.cpp:383-386, encrypt_zero :361,
     // encrypt of the leading coefficient :437): they depend only on the batch size and the key, so they are prepared here.
     const std::size_t batch = c.X.size();
-    std::vector<Plain> id;
-    for (std::size_t i = 0; i < batch; ++i) {
-        std::vector<double> e(batch, 0.0);
-        e[i] = 1.0;
-        id.push_back(m_p_ctx_wrapper->encodeVector(e));
-    }
-    r.identity = uploadPlains(id);
+    std::vector<std::vector<double>> id(batch, std::vector<double>(batch, 0.0));
+    for (std::size_t i = 0; i < batch; ++i) id[i][i] = 1.0;
+    r.identity = uploadPlains(m_p_ctx_wrapper->encodeBatch(id));
     r.zero = m_p_ctx_wrapper->upload(std::vector<Cipher>{m_p_ctx_wrapper->encrypt(m_p_ctx_wrapper->encodeVector(std::vector<double>(1, 0.0)))});
     r.coeff = uploadPlains(m_plain_coeff);
     r.coeff3 = m_p_ctx_wrapper->upload(std::vector<Cipher>{m_p_ctx_wrapper->encrypt(m_plain_coeff.back())});
@@ -230,7 +234,7 @@ void LogRegHornerBenchmark::store(AB::Handle h_remote_data, AB::Handle *p_h_loca
     if (count > 0) {
         std::memset(p_h_local_data, 0, sizeof(AB::Handle) * count);
         const std::shared_ptr<DeviceCiphers> &r = this->getEngine().retrieveFromHandle<std::shared_ptr<DeviceCiphers>>(h_remote_data, EncryptedResultTag);
-        Cipher local = m_p_ctx_wrapper->download(*r).at(0);
+        Cipher local = m_p_ctx_wrapper->download(r).at(0);
         p_h_local_data[0] = this->getEngine().createHandle<decltype(local)>(sizeof(local), EncryptedResultTag, std::move(local));
     }
 }

@@ -105,18 +105,29 @@ AB::Handle MatMultCipherBatchAxisBenchmark::encode(const AB::DataPackCollection 
         if (!dp->p_buffers || !dp->p_buffers[0].p) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty buffer in data pack."), HEBENCH_ECODE_CRITICAL_ERROR);
         const std::uint64_t r = op ? cols_M0() : rows_M0(), c = op ? cols_M1() : cols_M0();
         if (dp->p_buffers[0].size < r * c * 8) throw HEBenchError(HEBERROR_MSG_CLASS("Insufficient data for matrix."), HEBENCH_ECODE_INVALID_ARGS);
-        out.m[op].resize(r * c);
-        for (std::uint64_t row = 0; row < r; ++row)
-            for (std::uint64_t col = 0; col < c; ++col) {
-                Plain &dst = op ? out.m[1][row * c + col] : out.m[0][col * r + row];
-                if (m_scheme == Scheme::CKKS) { // CKKSEncoder::encode(double, scale, plain): the value in every slot (ckks .cpp:204)
-                    const double v = reinterpret_cast<const double *>(dp->p_buffers[0].p)[row * c + col];
-                    dst = m_p_ctx_wrapper->encodeVector(std::vector<double>(m_p_ctx_wrapper->slot_count(), v));
-                } else { // BatchEncoder::encode(span of 1): slot 0 only (bfv .cpp:201-203)
-                    const std::int64_t v = reinterpret_cast<const std::int64_t *>(dp->p_buffers[0].p)[row * c + col];
-                    dst = m_p_ctx_wrapper->encodeVector(std::vector<std::int64_t>(1, v));
+        // storage order: M0 column-major, M1 row-major; encoded in groups by encodeBatch (same bits as one encodeVector per element)
+        out.m[op].reserve(r * c);
+        const std::uint64_t kGroup = 256;
+        for (std::uint64_t k0 = 0; k0 < r * c; k0 += kGroup) {
+            const std::uint64_t k1 = std::min<std::uint64_t>(r * c, k0 + kGroup);
+            std::vector<Plain> enc;
+            if (m_scheme == Scheme::CKKS) { // CKKSEncoder::encode(double, scale, plain): the value in every slot (ckks .cpp:204)
+                std::vector<std::vector<double>> vecs;
+                for (std::uint64_t k = k0; k < k1; ++k) {
+                    const std::uint64_t row = op ? k / c : k % r, col = op ? k % c : k / r;
+                    vecs.emplace_back(m_p_ctx_wrapper->slot_count(), reinterpret_cast<const double *>(dp->p_buffers[0].p)[row * c + col]);
                 }
+                enc = m_p_ctx_wrapper->encodeBatch(vecs);
+            } else { // BatchEncoder::encode(span of 1): slot 0 only (bfv .cpp:201-203)
+                std::vector<std::vector<std::int64_t>> vecs;
+                for (std::uint64_t k = k0; k < k1; ++k) {
+                    const std::uint64_t row = op ? k / c : k % r, col = op ? k % c : k / r;
+                    vecs.emplace_back(1, reinterpret_cast<const std::int64_t *>(dp->p_buffers[0].p)[row * c + col]);
+                }
+                enc = m_p_ctx_wrapper->encodeBatch(vecs);
             }
+            out.m[op].insert(out.m[op].end(), std::make_move_iterator(enc.begin()), std::make_move_iterator(enc.end()));
+        }
     }
     return this->getEngine().createHandle<decltype(out)>(sizeof(out), 0, std::move(out));
 }
@@ -132,15 +143,19 @@ void MatMultCipherBatchAxisBenchmark::decode(AB::Handle h_encoded_data, AB::Data
     if (rc.p_buffers[0].size == 0) return;
     if (!rc.p_buffers[0].p) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty buffer in data pack."), HEBENCH_ECODE_CRITICAL_ERROR);
     const std::size_t room = rc.p_buffers[0].size / 8;
-    std::vector<double> vd(m_p_ctx_wrapper->slot_count());
-    std::vector<std::int64_t> vi(m_p_ctx_wrapper->slot_count());
-    for (std::size_t k = 0; k < res.size() && k < room; ++k) { // decode as much as fits (ckks .cpp:246-262)
+    const std::size_t total = std::min(res.size(), room), kGroup = 256; // decode as much as fits (ckks .cpp:246-262), in groups
+    for (std::size_t k0 = 0; k0 < total; k0 += kGroup) {
+        const std::size_t k1 = std::min(total, k0 + kGroup);
+        const std::vector<Plain> group(res.begin() + k0, res.begin() + k1);
         if (m_scheme == Scheme::CKKS) {
-            m_p_ctx_wrapper->client().ckks_decode(res[k].data.data(), (size_t)res[k].L, res[k].scale, vd.data());
-            reinterpret_cast<double *>(rc.p_buffers[0].p)[k] = std::abs(vd[0]) < 0.00005 ? 0.0 : vd[0];
+            const std::vector<std::vector<double>> vals = m_p_ctx_wrapper->decodeBatchCKKS(group);
+            for (std::size_t k = k0; k < k1; ++k) {
+                const double v0 = vals[k - k0][0];
+                reinterpret_cast<double *>(rc.p_buffers[0].p)[k] = std::abs(v0) < 0.00005 ? 0.0 : v0;
+            }
         } else {
-            m_p_ctx_wrapper->client().bfv_decode(res[k].data.data(), vi.data());
-            reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p)[k] = vi[0];
+            const std::vector<std::vector<std::int64_t>> vals = m_p_ctx_wrapper->decodeBatchBFV(group);
+            for (std::size_t k = k0; k < k1; ++k) reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p)[k] = vals[k - k0][0];
         }
     }
 }
@@ -149,16 +164,14 @@ AB::Handle MatMultCipherBatchAxisBenchmark::encrypt(AB::Handle h_encoded_data)
 {
     const MatPlain &p = this->getEngine().retrieveFromHandle<MatPlain>(h_encoded_data);
     MatCipher c;
-    for (int op = 0; op < 2; ++op)
-        for (const Plain &pl : p.m[op]) c.m[op].push_back(m_p_ctx_wrapper->encrypt(pl));
+    for (int op = 0; op < 2; ++op) c.m[op] = m_p_ctx_wrapper->encryptBatch(p.m[op]);
     return this->getEngine().createHandle<decltype(c)>(sizeof(c), 0, std::move(c));
 }
 
 AB::Handle MatMultCipherBatchAxisBenchmark::decrypt(AB::Handle h_encrypted_data)
 {
     const std::vector<Cipher> &c = this->getEngine().retrieveFromHandle<std::vector<Cipher>>(h_encrypted_data);
-    std::vector<Plain> p;
-    for (const Cipher &ct : c) p.push_back(m_p_ctx_wrapper->decrypt(ct));
+    std::vector<Plain> p = m_p_ctx_wrapper->decryptBatch(c);
     return this->getEngine().createHandle<decltype(p)>(sizeof(p), 0, std::move(p));
 }
 
@@ -177,7 +190,7 @@ void MatMultCipherBatchAxisBenchmark::store(AB::Handle h_remote_data, AB::Handle
     if (count > 0) {
         std::memset(p_h_local_data, 0, sizeof(AB::Handle) * count);
         const std::shared_ptr<DeviceCiphers> &r = this->getEngine().retrieveFromHandle<std::shared_ptr<DeviceCiphers>>(h_remote_data);
-        std::vector<Cipher> local = m_p_ctx_wrapper->download(*r);
+        std::vector<Cipher> local = m_p_ctx_wrapper->download(r);
         p_h_local_data[0] = this->getEngine().createHandle<decltype(local)>(sizeof(local), 0, std::move(local));
     }
 }

@@ -119,14 +119,18 @@ AB::Handle MatMultRowLatencyBenchmark::encode(const AB::DataPackCollection *p_pa
         PlainPack pack;
         pack.a.rows = dim1; pack.a.cols = dim2; pack.b.rows = dim2; pack.b.cols = dim3;
         std::vector<double> va(slots, 0.0), vb(slots, 0.0);
+        std::vector<std::vector<double>> rows; // the rows of A, then B: one encodeBatch call (same bits as one encodeVector each)
         for (std::size_t i = 0; i < dim1; ++i) {
             for (std::size_t j = 0; j < dim2; ++j)
                 for (std::size_t k = 0; k < dim3; ++k) va[spacers * j + k] = m0[i * dim2 + j];
-            pack.A.push_back(m_p_ctx_wrapper->encodeVector(va));
+            rows.push_back(va);
         }
         for (std::size_t j = 0; j < dim2; ++j)
             for (std::size_t k = 0; k < dim3; ++k) vb[spacers * j + k] = m1[j * dim3 + k];
-        pack.B = m_p_ctx_wrapper->encodeVector(vb);
+        rows.push_back(vb);
+        pack.A = m_p_ctx_wrapper->encodeBatch(rows);
+        pack.B = std::move(pack.A.back());
+        pack.A.pop_back();
         return this->getEngine().createHandle<decltype(pack)>(sizeof(pack), 0, std::move(pack));
     }
     const std::int64_t *mats[2] = {reinterpret_cast<const std::int64_t *>(mats_raw[0]), reinterpret_cast<const std::int64_t *>(mats_raw[1])};
@@ -136,13 +140,14 @@ AB::Handle MatMultRowLatencyBenchmark::encode(const AB::DataPackCollection *p_pa
     // encodeM0 (.cpp:221-263): A[i][j] replicated dim3 times at slot spacers*j + k; row i in batching row 0, row i+1 in row 1.
     // The cleartext vector is reused across row pairs, exactly as the reference does.
     std::vector<std::int64_t> va(slots, 0);
+    std::vector<std::vector<std::int64_t>> rows; // the row pairs of A, then B: one encodeBatch call
     for (std::size_t i = 0; i < dim1; i += 2) {
         for (std::size_t j = 0; j < dim2; ++j)
             for (std::size_t k = 0; k < dim3; ++k) {
                 va[spacers * j + k] = mats[0][i * dim2 + j];
                 if (i + 1 < dim1) va[row_size + spacers * j + k] = mats[0][(i + 1) * dim2 + j];
             }
-        pack.A.push_back(m_p_ctx_wrapper->encodeVector(va));
+        rows.push_back(va);
     }
     // encodeM1 (.cpp:265-297): B[j][k] at spacers*j + k in both batching rows
     std::vector<std::int64_t> vb(slots, 0);
@@ -151,7 +156,10 @@ AB::Handle MatMultRowLatencyBenchmark::encode(const AB::DataPackCollection *p_pa
             vb[spacers * j + k] = mats[1][j * dim3 + k];
             vb[row_size + spacers * j + k] = mats[1][j * dim3 + k];
         }
-    pack.B = m_p_ctx_wrapper->encodeVector(vb);
+    rows.push_back(vb);
+    pack.A = m_p_ctx_wrapper->encodeBatch(rows);
+    pack.B = std::move(pack.A.back());
+    pack.A.pop_back();
     return this->getEngine().createHandle<decltype(pack)>(sizeof(pack), 0, std::move(pack));
 }
 
@@ -165,9 +173,9 @@ void MatMultRowLatencyBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackC
     if (m_scheme == Scheme::CKKS) { // decodeResult, ckks row .cpp:330-356: row i = first dim3 slots of ciphertext i, |x| < 0.00005 -> 0
         double *raw = reinterpret_cast<double *>(rc.p_buffers[0].p);
         std::size_t room = rc.p_buffers[0].size / sizeof(double), pos = 0;
-        std::vector<double> v(m_p_ctx_wrapper->slot_count());
-        for (std::size_t i = 0; i < enc.d.rows && i < enc.C.size() && pos < room; ++i) {
-            m_p_ctx_wrapper->client().ckks_decode(enc.C[i].data.data(), (size_t)enc.C[i].L, enc.C[i].scale, v.data());
+        const std::vector<std::vector<double>> vals = m_p_ctx_wrapper->decodeBatchCKKS(enc.C);
+        for (std::size_t i = 0; i < enc.d.rows && i < vals.size() && pos < room; ++i) {
+            const std::vector<double> &v = vals[i];
             for (std::size_t j = 0; j < enc.d.cols && pos < room; ++j) raw[pos++] = std::abs(v[j]) < 0.00005 ? 0.0 : v[j];
         }
         return;
@@ -176,9 +184,10 @@ void MatMultRowLatencyBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackC
     const std::size_t dim1 = enc.d.rows, dim3 = enc.d.cols, slots = m_p_ctx_wrapper->slot_count(), row_size = slots / 2;
     std::int64_t *raw = reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p);
     std::size_t room = rc.p_buffers[0].size / sizeof(std::int64_t), pos = 0;
-    std::vector<std::int64_t> v(slots);
+    const std::vector<std::vector<std::int64_t>> vals = m_p_ctx_wrapper->decodeBatchBFV(enc.C);
+    (void)slots;
     for (std::size_t i = 0; i < dim1 && pos < room; ++i) {
-        if ((i & 1) == 0) m_p_ctx_wrapper->client().bfv_decode(enc.C.at(i / 2).data.data(), v.data());
+        const std::vector<std::int64_t> &v = vals.at(i / 2);
         const std::size_t off = (i & 1) ? row_size : 0;
         for (std::size_t j = 0; j < dim3 && pos < room; ++j) raw[pos++] = v[off + j];
     }
@@ -189,8 +198,11 @@ AB::Handle MatMultRowLatencyBenchmark::encrypt(AB::Handle h_encoded_data)
     const PlainPack &p = this->getEngine().retrieveFromHandle<PlainPack>(h_encoded_data);
     CipherPack c;
     c.a = p.a; c.b = p.b;
-    for (const Plain &pl : p.A) c.A.push_back(m_p_ctx_wrapper->encrypt(pl));
-    c.B = m_p_ctx_wrapper->encrypt(p.B);
+    std::vector<Plain> all(p.A); // the rows of A, then B: the order the reference encrypts them in
+    all.push_back(p.B);
+    c.A = m_p_ctx_wrapper->encryptBatch(all);
+    c.B = std::move(c.A.back());
+    c.A.pop_back();
     return this->getEngine().createHandle<decltype(c)>(sizeof(c), 0, std::move(c));
 }
 
@@ -199,7 +211,7 @@ AB::Handle MatMultRowLatencyBenchmark::decrypt(AB::Handle h_encrypted_data)
     const ResultCipher &c = this->getEngine().retrieveFromHandle<ResultCipher>(h_encrypted_data);
     ResultPlain p;
     p.d = c.d;
-    for (const Cipher &ct : c.C) p.C.push_back(m_p_ctx_wrapper->decrypt(ct));
+    p.C = m_p_ctx_wrapper->decryptBatch(c.C);
     return this->getEngine().createHandle<decltype(p)>(sizeof(p), 0, std::move(p));
 }
 
@@ -225,7 +237,7 @@ void MatMultRowLatencyBenchmark::store(AB::Handle h_remote_data, AB::Handle *p_h
         const ResultRemote &r = this->getEngine().retrieveFromHandle<ResultRemote>(h_remote_data);
         ResultCipher c;
         c.d = r.d;
-        c.C = m_p_ctx_wrapper->download(*r.C);
+        c.C = m_p_ctx_wrapper->download(r.C);
         p_h_local_data[0] = this->getEngine().createHandle<decltype(c)>(sizeof(c), 0, std::move(c));
     }
 }

@@ -109,18 +109,19 @@ AB::Handle MatMultValBenchmark::encode(const AB::DataPackCollection *p_parameter
         if (!buf.p || buf.size < r * c * 8) throw HEBenchError(HEBERROR_MSG_CLASS("Insufficient data for M0."), HEBENCH_ECODE_INVALID_ARGS);
         // M0: one plaintext per row.  M1: transposed first (ckks .cpp:213-225), so one plaintext per column of M1.
         const std::uint64_t n_vec = op ? c : r, len = op ? r : c;
-        for (std::uint64_t v = 0; v < n_vec; ++v) {
-            if (m_scheme == Scheme::CKKS) {
-                const double *p = reinterpret_cast<const double *>(buf.p);
-                std::vector<double> vals(len);
-                for (std::uint64_t k = 0; k < len; ++k) vals[k] = op ? p[k * c + v] : p[v * c + k];
-                out.rows[op].push_back(m_p_ctx_wrapper->encodeVector(vals));
-            } else {
-                const std::int64_t *p = reinterpret_cast<const std::int64_t *>(buf.p);
-                std::vector<std::int64_t> vals(len);
-                for (std::uint64_t k = 0; k < len; ++k) vals[k] = op ? p[k * c + v] : p[v * c + k];
-                out.rows[op].push_back(m_p_ctx_wrapper->encodeVector(vals));
-            }
+        // one encodeBatch call per matrix (same bits as one encodeVector per row)
+        if (m_scheme == Scheme::CKKS) {
+            const double *p = reinterpret_cast<const double *>(buf.p);
+            std::vector<std::vector<double>> vecs(n_vec, std::vector<double>(len));
+            for (std::uint64_t v = 0; v < n_vec; ++v)
+                for (std::uint64_t k = 0; k < len; ++k) vecs[v][k] = op ? p[k * c + v] : p[v * c + k];
+            out.rows[op] = m_p_ctx_wrapper->encodeBatch(vecs);
+        } else {
+            const std::int64_t *p = reinterpret_cast<const std::int64_t *>(buf.p);
+            std::vector<std::vector<std::int64_t>> vecs(n_vec, std::vector<std::int64_t>(len));
+            for (std::uint64_t v = 0; v < n_vec; ++v)
+                for (std::uint64_t k = 0; k < len; ++k) vecs[v][k] = op ? p[k * c + v] : p[v * c + k];
+            out.rows[op] = m_p_ctx_wrapper->encodeBatch(vecs);
         }
     }
     return this->getEngine().createHandle<decltype(out)>(sizeof(out), 0, std::move(out));
@@ -134,15 +135,19 @@ void MatMultValBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackCollecti
     const AB::DataPack &rc = findDataPack(*p_native, 0);
     if (rc.buffer_count == 0 || !rc.p_buffers || !rc.p_buffers[0].p) return;
     const std::size_t room = rc.p_buffers[0].size / 8;
-    std::vector<double> vd(m_p_ctx_wrapper->slot_count());
-    std::vector<std::int64_t> vi(m_p_ctx_wrapper->slot_count());
-    for (std::size_t k = 0; k < rows_M0() * cols_M1() && k < room; ++k) {
+    const std::size_t total = std::min<std::size_t>(rows_M0() * cols_M1(), room), kGroup = 256; // decoded in groups: bounded host memory
+    for (std::size_t k0 = 0; k0 < total; k0 += kGroup) {
+        const std::size_t k1 = std::min(total, k0 + kGroup);
+        const std::vector<Plain> group(res.begin() + k0, res.begin() + k1);
         if (m_scheme == Scheme::CKKS) {
-            m_p_ctx_wrapper->client().ckks_decode(res[k].data.data(), (size_t)res[k].L, res[k].scale, vd.data());
-            reinterpret_cast<double *>(rc.p_buffers[0].p)[k] = std::abs(vd[0]) < 0.00005 ? 0.0 : vd[0]; // ckks .cpp:356-359
+            const std::vector<std::vector<double>> vals = m_p_ctx_wrapper->decodeBatchCKKS(group);
+            for (std::size_t k = k0; k < k1; ++k) {
+                const double v0 = vals[k - k0][0];
+                reinterpret_cast<double *>(rc.p_buffers[0].p)[k] = std::abs(v0) < 0.00005 ? 0.0 : v0; // ckks .cpp:356-359
+            }
         } else {
-            m_p_ctx_wrapper->client().bfv_decode(res[k].data.data(), vi.data());
-            reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p)[k] = vi[0];
+            const std::vector<std::vector<std::int64_t>> vals = m_p_ctx_wrapper->decodeBatchBFV(group);
+            for (std::size_t k = k0; k < k1; ++k) reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p)[k] = vals[k - k0][0];
         }
     }
 }
@@ -151,16 +156,14 @@ AB::Handle MatMultValBenchmark::encrypt(AB::Handle h_encoded_data)
 {
     const MatPlain &p = this->getEngine().retrieveFromHandle<MatPlain>(h_encoded_data);
     MatCipher c;
-    for (int op = 0; op < 2; ++op)
-        for (const Plain &pl : p.rows[op]) c.rows[op].push_back(m_p_ctx_wrapper->encrypt(pl));
+    for (int op = 0; op < 2; ++op) c.rows[op] = m_p_ctx_wrapper->encryptBatch(p.rows[op]);
     return this->getEngine().createHandle<decltype(c)>(sizeof(c), 0, std::move(c));
 }
 
 AB::Handle MatMultValBenchmark::decrypt(AB::Handle h_encrypted_data)
 {
     const std::vector<Cipher> &c = this->getEngine().retrieveFromHandle<std::vector<Cipher>>(h_encrypted_data);
-    std::vector<Plain> p;
-    for (const Cipher &ct : c) p.push_back(m_p_ctx_wrapper->decrypt(ct));
+    std::vector<Plain> p = m_p_ctx_wrapper->decryptBatch(c);
     return this->getEngine().createHandle<decltype(p)>(sizeof(p), 0, std::move(p));
 }
 
@@ -185,7 +188,7 @@ void MatMultValBenchmark::store(AB::Handle h_remote_data, AB::Handle *p_h_local_
     if (count > 0) {
         std::memset(p_h_local_data, 0, sizeof(AB::Handle) * count);
         const std::shared_ptr<DeviceCiphers> &r = this->getEngine().retrieveFromHandle<std::shared_ptr<DeviceCiphers>>(h_remote_data);
-        std::vector<Cipher> local = m_p_ctx_wrapper->download(*r);
+        std::vector<Cipher> local = m_p_ctx_wrapper->download(r);
         p_h_local_data[0] = this->getEngine().createHandle<decltype(local)>(sizeof(local), 0, std::move(local));
     }
 }

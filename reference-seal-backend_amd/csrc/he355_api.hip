@@ -1223,6 +1223,13 @@ int he355_download(he355_ctx *c, void *h_dst, const void *d_src, uint64_t bytes)
         HIPCHECK(hipStreamSynchronize(dev(c).stream()));
     });
 }
+int he355_copy(he355_ctx *c, void *d_dst, const void *d_src, uint64_t bytes)
+{
+    return guarded([&] {
+        dev(c).use();
+        if (bytes) HIPCHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, dev(c).stream()));
+    });
+}
 int he355_sync(he355_ctx *c) { return guarded([&] { dev(c).sync(); }); }
 int he355_fill_uniform(he355_ctx *c, uint64_t *d_dst, uint64_t n_polys, const uint8_t *prime_of, uint32_t period, uint64_t seed)
 {
