@@ -225,7 +225,9 @@ std::vector<std::vector<double>> HeContextWrapper::decodeBatchCKKS(const std::ve
     DevBuf dv(m_ctx, n * half * 8);
     check(he355_ckks_decode(m_ctx, L, n, in.d, plains[0].scale, dv.as<double>()), "decode");
     check(he355_sync(m_ctx), "synchronise");
-    for (std::uint64_t i = 0; i < n; ++i) check(he355_download(m_ctx, out[i].data(), dv.as<double>() + i * half, half * 8), "download");
+    std::vector<double> flat(n * half); // one transfer for the batch
+    check(he355_download(m_ctx, flat.data(), dv.p, flat.size() * 8), "download");
+    for (std::uint64_t i = 0; i < n; ++i) std::copy(flat.begin() + i * half, flat.begin() + (i + 1) * half, out[i].begin());
     return out;
 }
 std::vector<std::vector<std::int64_t>> HeContextWrapper::decodeBatchBFV(const std::vector<Plain> &plains)
@@ -241,7 +243,9 @@ std::vector<std::vector<std::int64_t>> HeContextWrapper::decodeBatchBFV(const st
     DevBuf dv(m_ctx, n * N * 8);
     check(he355_bfv_decode(m_ctx, n, in.d, dv.as<std::int64_t>()), "decode");
     check(he355_sync(m_ctx), "synchronise");
-    for (std::uint64_t i = 0; i < n; ++i) check(he355_download(m_ctx, out[i].data(), dv.as<std::int64_t>() + i * N, N * 8), "download");
+    std::vector<std::int64_t> flat(n * N); // one transfer for the batch
+    check(he355_download(m_ctx, flat.data(), dv.p, flat.size() * 8), "download");
+    for (std::uint64_t i = 0; i < n; ++i) std::copy(flat.begin() + i * N, flat.begin() + (i + 1) * N, out[i].begin());
     return out;
 }
 // Client side: on the MI355X when one is present (he355_encrypt / he355_decrypt: same bits as the host code below for the same
