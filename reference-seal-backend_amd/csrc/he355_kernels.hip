@@ -115,16 +115,57 @@ __device__ __forceinline__ void store_rowC(u64 *row, int lane, const u64 v[kRowE
 // Completion is covered by the issuing wave's vmcnt (s_waitcnt vmcnt(0) before the first ds_read).
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
+template <int PIECES = 8> // 1 KiB pieces of the row slot that hold data (8: a row of 64-bit words; 6: a 48-bit packed digit row)
 __device__ __forceinline__ void dma_row_to_lds(const u64 *grow, u64 *lds_row, int lane)
 {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < PIECES; ++k)
         __builtin_amdgcn_global_load_lds((glb_void_t *)(grow + (k << 7) + (lane << 1)), (lds_void_t *)(lds_row + (k << 7)), 16, 0, 0);
 }
 __device__ __forceinline__ void lds_rowA(const u64 *lds_row, int lane, u64 v[kRowE])
 {
 #pragma unroll
     for (int r = 0; r < kRowE; ++r) v[r] = lds_row[(r << 6) | lane];
+}
+
+// ---- 48-bit digit rows (fp64-engine targets) -----------------------------------------------------------
+// The digit slab is the largest HBM stream of a key switch (written once by k_k2, read once by k_k3) and the chip's mixed
+// read/write bandwidth bounds the sequence, so a digit row of an fp64-engine prime is stored in 6 of the 8 KiB of its slot:
+// a plane of 1024 low 32-bit words, then a plane of 1024 high 16-bit words, of the bit pattern of (x + kPackBias), x an
+// integer with |x| < 2^47.  The pattern's top 16 bits are then always 0x4338, so 48 bits carry the value exactly.
+#ifndef HE355_PACK_D
+#define HE355_PACK_D 1
+#endif
+constexpr bool kPackD = HE355_PACK_D != 0;
+constexpr double kPackBias = 4503599627370496.0 + 2251799813685248.0 + 140737488355328.0; // 2^52 + 2^51 + 2^47
+constexpr int kPackHiOff = 4096;                                                          // byte offset of the high plane in the slot
+__device__ __forceinline__ double unpack48(u32 lo, u32 hi16)
+{
+    union { u64 u; double d; } c;
+    c.u = ((u64)(0x43380000u | hi16) << 32) | lo;
+    return c.d - kPackBias;
+}
+__device__ __forceinline__ void store48(u64 *row, int e, double x) // element e of a packed row
+{
+    union { u64 u; double d; } c;
+    c.d = x + kPackBias;
+    reinterpret_cast<u32 *>(row)[e] = (u32)c.u;
+    reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(row) + kPackHiOff)[e] = (unsigned short)(c.u >> 32);
+}
+__device__ __forceinline__ void lds_rowA48(const u64 *lds_row, int lane, double x[kRowE])
+{
+    const u32 *lo = reinterpret_cast<const u32 *>(lds_row);
+    const unsigned short *hi = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(lds_row) + kPackHiOff);
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) x[r] = unpack48(lo[(r << 6) | lane], hi[(r << 6) | lane]);
+}
+struct Row48 { u32 lo[kRowE]; unsigned short hi[kRowE]; }; // a packed row in flight in registers (layout A)
+__device__ __forceinline__ void load_rowA48(const u64 *row, int lane, Row48 &v)
+{
+    const u32 *lo = reinterpret_cast<const u32 *>(row);
+    const unsigned short *hi = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(row) + kPackHiOff);
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) { v.lo[r] = lo[(r << 6) | lane]; v.hi[r] = hi[(r << 6) | lane]; }
 }
 
 // ---- wave-level row transforms (x in: layout A for forward, layout C for inverse) ---------------------
@@ -653,8 +694,22 @@ __device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt
             for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(c[a]);
         }
         col_fwd<ArF64, LOGN1>(ar, x, gtw(Pt.fwd));
+        if constexpr (kPackD) {
+            // 48-bit rows need |x| < 2^47.  The column pass starts from |x| < q and every stage adds at most 0.5625 q
+            // (ArF64::bfly_fwd), so after its <= 5 stages |x| < 3.82 q: below 2^47 for primes under 2^45 (the 40/45-bit
+            // primes of the reference's parameter rule); wider fp64-engine primes are re-centred first.
+            static_assert(LOGN1 <= 5, "bound above is for at most 5 column stages");
+            if ((Pt.q >> 45) == 0) {
 #pragma unroll
-        for (int a = 0; a < N1; ++a) K2_STORE(&dst[(a << kRowLog) + col], ar.to_raw(x[a]));
+                for (int a = 0; a < N1; ++a) store48(dst + (a << kRowLog), col, x[a]);
+            } else {
+#pragma unroll
+                for (int a = 0; a < N1; ++a) store48(dst + (a << kRowLog), col, ar.renorm(x[a]));
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < N1; ++a) K2_STORE(&dst[(a << kRowLog) + col], ar.to_raw(x[a]));
+        }
     } else {
         const ArU64 ar = make_ar(Pt, (ArU64 *)nullptr);
         u64 x[N1];
@@ -781,6 +836,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
     typedef typename Ar::T T;
     typedef typename Ar::Acc Acc;
     constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
+    constexpr bool kPacked = kF64 && kPackD;          // this engine's digit rows are 48-bit packed (k_k2 wrote them so)
+    constexpr int kDigitPieces = kPacked ? 6 : 8;
     // One block per CU.  Default shape (U = 1, 8 waves): two waves per SIMD, each on its own op, LDS-DMA prefetch of the next
     // row; LDS: 8 x 8.5 KiB exchange + 8 x 8 KiB DMA landing + the tile's twiddles.  (U = 2, 4 waves: one wave per SIMD with two
     // interleaved digits -- the earlier shape, kept selectable.)
@@ -854,12 +911,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         if constexpr (STAGE) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (u < nd) dma_row_to_lds(src_row(digit(u)), stage[wave][u], lane);
+                if (u < nd) dma_row_to_lds<kDigitPieces>(src_row(digit(u)), stage[wave][u], lane);
         }
         u64 vn[kRowE]; // !STAGE: the next digit's row, in flight or landed
+        Row48 vn48;
         if constexpr (!STAGE) {
             static_assert(STAGE || U == 1, "register prefetch is written for one digit per wave");
-            load_rowA(src_row(digit(0)), lane, vn);
+            if constexpr (kPacked) load_rowA48(src_row(digit(0)), lane, vn48);
+            else load_rowA(src_row(digit(0)), lane, vn);
         }
         if (has_own) {
             T x[kRowE];
@@ -893,13 +952,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             // digit rows: transform + key MAC (the last one prefetches the first correction row)
             for (int i = 0; i < nd; ++i) {
                 T x[1][kRowE];
-                u64 v[kRowE];
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's row has landed in the staging buffer
-                lds_rowA(stage[wave][0], lane, v);
+                if constexpr (kPacked) {
+                    lds_rowA48(stage[wave][0], lane, x[0]);
+                } else {
+                    u64 v[kRowE];
+                    lds_rowA(stage[wave][0], lane, v);
 #pragma unroll
-                for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
+                    for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffer drained into registers
-                dma_row_to_lds(row_ptr(i + 1), stage[wave][0], lane); // next row (digit or correction), behind this step's math
+                // next row, behind this step's math: a digit row (packed for this engine) or the first correction row (64-bit words)
+                if (i + 1 < nd) dma_row_to_lds<kDigitPieces>(row_ptr(i + 1), stage[wave][0], lane);
+                else dma_row_to_lds(row_ptr(i + 1), stage[wave][0], lane);
                 wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
                 mac_digit(x[0], digit(i));
             }
@@ -939,20 +1004,30 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         if (u < cnt) {
-                            lds_rowA(stage[wave][u], lane, v);
+                            if constexpr (kPacked) {
+                                lds_rowA48(stage[wave][u], lane, x[u]);
+                            } else {
+                                lds_rowA(stage[wave][u], lane, v);
 #pragma unroll
-                            for (int r = 0; r < kRowE; ++r) x[u][r] = ar.from_raw(v[r]);
+                                for (int r = 0; r < kRowE; ++r) x[u][r] = ar.from_raw(v[r]);
+                            }
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffers drained into registers
 #pragma unroll
                     for (int u = 0; u < U; ++u)
-                        if (i + U + u < nd) dma_row_to_lds(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
+                        if (i + U + u < nd) dma_row_to_lds<kDigitPieces>(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
                 } else {
                     asm volatile("" ::: "memory"); // keeps the LDS twiddle reads inside the loop (hoisted, they would cost 54 registers)
+                    if constexpr (kPacked) {
 #pragma unroll
-                    for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(vn[r]);
-                    if (i + 1 < nd) load_rowA(src_row(digit(i + 1)), lane, vn); // lands behind this step's math
+                        for (int r = 0; r < kRowE; ++r) x[0][r] = unpack48(vn48.lo[r], vn48.hi[r]);
+                        if (i + 1 < nd) load_rowA48(src_row(digit(i + 1)), lane, vn48); // lands behind this step's math
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(vn[r]);
+                        if (i + 1 < nd) load_rowA(src_row(digit(i + 1)), lane, vn); // lands behind this step's math
+                    }
                 }
                 if (U == 2 && cnt < U) { // odd digit count: the partner row is zeros (its products add nothing)
 #pragma unroll

@@ -522,3 +522,32 @@ def test_random_parameter_chains(be, oracle, seed):
             w = o.apply_galois(w, e, keys[e])
         assert np.array_equal(gotr[r], w), (bits, N, step, r)
     g.close()
+
+
+@pytest.mark.parametrize("N,bits", [(32768, [47, 46, 45, 44, 47]), (4096, [46, 47, 60, 46])])
+def test_wide_fp64_engine_primes(be, oracle, N, bits):
+    """46/47-bit primes still run on the fp64 engine (q < 2^47) but their lazy column-pass values no longer fit the 48-bit
+    digit rows without re-centring (k_k2 re-centres for q >= 2^45): multiply -> relinearize (-> rescale) bit-exact, at the
+    ring size with the most column stages and at a small one."""
+    rng = np.random.default_rng(4747 + N)
+    g = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, sec128=False, device=0)
+    o = oracle.Context(oracle.SCHEME_CKKS, N, bit_sizes=bits, sec128=False)
+    assert g.moduli == o.moduli
+    assert g.fp64 == [b <= 47 for b in bits]
+    L, n = g.L, 3
+    rk = o.random_kswitch_key(rng)
+    g.set_relin_key(rk)
+    a, b = rand_cts(o, rng, n, L), rand_cts(o, rng, n, L)
+    da, db = g.to_device(a), g.to_device(b)
+    out = g.alloc(n * 2 * L * N)
+    g.multiply_relin(L, n, da, db, be.Context.pairwise(), out)
+    got = out.download((n, 2, L, N))
+    want = [o.relinearize(o.multiply_ntt(a[r], b[r]), rk) for r in range(n)]
+    for r in range(n):
+        assert np.array_equal(got[r], want[r]), r
+    out2 = g.alloc(n * 2 * (L - 1) * N)
+    g.multiply_relin(L, n, da, db, be.Context.pairwise(), out2, rescale=True)
+    got2 = out2.download((n, 2, L - 1, N))
+    for r in range(n):
+        assert np.array_equal(got2[r], o.rescale(want[r])), r
+    g.close()
