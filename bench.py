@@ -171,14 +171,15 @@ def main():
         achieved = bytes_op * n * args.steps / gpu_s / 1e9
         # dominant kernel: k_k3 for the fp64-engine primes (key products of the key switch, with both floor steps finished in
         # its epilogue by default).  Algorithmic bytes per op of that kernel, in residue polynomials:
-        # n_f * L lifted-digit / own-digit rows in; fused: + 2 n_f correction rows (one combined correction per residue; the
+        # n_f * (L - 1) lifted-digit rows in (48-bit packed: 6 B per element) + n_f own-digit rows in; fused: + 2 n_f correction rows (one combined correction per residue; the
         # prime divided out has its mod-down correction) + 2 n_f c01 rows in + 2 (n_f - 1) result rows + 2 c01 rows out;
         # unfused: 2 n_f sums out.  Plus the key rows of those primes once per chunk.
         n_f = sum(1 for i in list(range(L)) + [K - 1] if ctx.fp64[i])
         fused = os.environ.get("HE355_K3_FUSE", "1") != "0"
         k3_polys = n_f * (L + 6) if fused else n_f * (L + 2)
+        k3_bytes_op = N * (6 * n_f * (L - 1) + 8 * (k3_polys - n_f * (L - 1)))
         k3_key_bytes = L * 2 * n_f * N * 8 * (n * args.steps / float(args.chunk or 256))  # once per chunk of ops
-        k3_bytes_total = k3_polys * N * 8 * n * args.steps + k3_key_bytes
+        k3_bytes_total = k3_bytes_op * n * args.steps + k3_key_bytes
         k3_gbps = k3_bytes_total / (k3_ms / 1e3) / 1e9 if k3_ms > 0 else None
         out = {
             "metric": "ciphertext-ops/sec (CKKS ct x ct mul+relin+rescale, N=2^15, L=16)",
@@ -207,7 +208,7 @@ def main():
                                              "avg_launch_ms_hip_events": round(k3_ms / max(1, k3_launches), 4),
                                              "ms_per_step": round(k3_ms / args.steps, 3),
                                              "share_of_gpu_time": round(k3_ms / gpu_ms, 3) if gpu_ms else None,
-                                             "algorithmic_bytes_per_op": k3_polys * N * 8,
+                                             "algorithmic_bytes_per_op": k3_bytes_op,
                                              "achieved_GBps": round(k3_gbps, 1) if k3_gbps else None,
                                              "frac_of_hbm_peak": round(k3_gbps * 1e9 / HBM_PEAK, 4) if k3_gbps else None,
                                              "note": "two launches per chunk (the tiles of the prime the rescale divides out, then the rest); durations "
