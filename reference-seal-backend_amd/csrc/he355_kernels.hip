@@ -60,6 +60,7 @@ constexpr int kWaves = 4;
 // Twiddle tables are reached through pointers stored in PrimeDev (HBM), which the compiler would treat as
 // generic (flat_load + full s_waitcnt per access).  They are always global memory: say so.
 __device__ __forceinline__ gtw_t gtw(const Tw16 *p) { return (gtw_t)p; }
+__device__ __forceinline__ ctw_t ctw(const Tw16 *p) { return (ctw_t)(unsigned long long)p; } // lane-uniform entries: scalar loads
 
 __device__ __forceinline__ ArU64 make_ar(const PrimeDev &p, ArU64 *)
 {
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(kBlock) k_cols_fwd(PolyView view, const PrimeD
         double x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = ar.from_canon(poly[(a << kRowLog) + col]);
-        col_fwd<ArF64, LOGN1>(ar, x, gtw(P.fwd));
+        col_fwd<ArF64, LOGN1>(ar, x, ctw(P.fwd));
 #pragma unroll
         for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = ar.to_raw(x[a]);
     } else {
@@ -355,7 +356,7 @@ __global__ void __launch_bounds__(kBlock) k_cols_fwd(PolyView view, const PrimeD
         u64 x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = poly[(a << kRowLog) + col];
-        col_fwd<ArU64, LOGN1>(ar, x, gtw(P.fwd));
+        col_fwd<ArU64, LOGN1>(ar, x, ctw(P.fwd));
 #pragma unroll
         for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = x[a];
     }
@@ -378,7 +379,7 @@ __global__ void __launch_bounds__(kBlock) k_cols_inv(PolyView view, const PrimeD
         double x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(poly[(a << kRowLog) + col]);
-        col_inv<ArF64, LOGN1>(ar, x, gtw(P.inv), P.inv_w0_scaled);
+        col_inv<ArF64, LOGN1>(ar, x, ctw(P.inv), P.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = ar.to_canon(x[a]);
     } else {
@@ -386,7 +387,7 @@ __global__ void __launch_bounds__(kBlock) k_cols_inv(PolyView view, const PrimeD
         u64 x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = poly[(a << kRowLog) + col];
-        col_inv<ArU64, LOGN1>(ar, x, gtw(P.inv), P.inv_w0_scaled);
+        col_inv<ArU64, LOGN1>(ar, x, ctw(P.inv), P.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) poly[(a << kRowLog) + col] = ar.to_canon(x[a]);
     }
@@ -693,7 +694,7 @@ __device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt
 #pragma unroll
             for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(c[a]);
         }
-        col_fwd<ArF64, LOGN1>(ar, x, gtw(Pt.fwd));
+        col_fwd<ArF64, LOGN1>(ar, x, ctw(Pt.fwd));
         if constexpr (kPackD) {
             // 48-bit rows need |x| < 2^47.  The column pass starts from |x| < q and every stage adds at most 0.5625 q
             // (ArF64::bfly_fwd), so after its <= 5 stages |x| < 3.82 q: below 2^47 for primes under 2^45 (the 40/45-bit
@@ -721,7 +722,7 @@ __device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt
 #pragma unroll
             for (int a = 0; a < N1; ++a) x[a] = c[a];
         }
-        col_fwd<ArU64, LOGN1>(ar, x, gtw(Pt.fwd));
+        col_fwd<ArU64, LOGN1>(ar, x, ctw(Pt.fwd));
 #pragma unroll
         for (int a = 0; a < N1; ++a) K2_STORE(&dst[(a << kRowLog) + col], x[a]);
     }
@@ -749,7 +750,7 @@ __global__ void __launch_bounds__(kBlock, K2_WAVES) k_k2(K2Args A, const PrimeDe
         double x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
-        col_inv<ArF64, LOGN1>(ar, x, gtw(Pj.inv), Pj.inv_w0_scaled);
+        col_inv<ArF64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     } else {
@@ -757,7 +758,7 @@ __global__ void __launch_bounds__(kBlock, K2_WAVES) k_k2(K2Args A, const PrimeDe
         u64 x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
-        col_inv<ArU64, LOGN1>(ar, x, gtw(Pj.inv), Pj.inv_w0_scaled);
+        col_inv<ArU64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     }
@@ -1098,7 +1099,7 @@ __global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const Pr
         double x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
-        col_inv<ArF64, LOGN1>(ar, x, gtw(Ps.inv), Ps.inv_w0_scaled);
+        col_inv<ArF64, LOGN1>(ar, x, ctw(Ps.inv), Ps.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     } else {
@@ -1106,7 +1107,7 @@ __global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const Pr
         u64 x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
-        col_inv<ArU64, LOGN1>(ar, x, gtw(Ps.inv), Ps.inv_w0_scaled);
+        col_inv<ArU64, LOGN1>(ar, x, ctw(Ps.inv), Ps.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     }
@@ -1127,7 +1128,7 @@ __global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const Pr
             double x[N1];
 #pragma unroll
             for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(dl[a]);
-            col_fwd<ArF64, LOGN1>(ar, x, gtw(Pi.fwd));
+            col_fwd<ArF64, LOGN1>(ar, x, ctw(Pi.fwd));
             if (A.addin) {
                 const FloorConst fa = A.fc[A.addin_src * A.K + i];
                 const u64 *ad = A.addin + (poly * A.addin_ntgt + i) * N;
@@ -1138,7 +1139,7 @@ __global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const Pr
             for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = ar.to_raw(x[a]);
         } else {
             const ArU64 ar = make_ar(Pi, (ArU64 *)nullptr);
-            col_fwd<ArU64, LOGN1>(ar, dl, gtw(Pi.fwd));
+            col_fwd<ArU64, LOGN1>(ar, dl, ctw(Pi.fwd));
             if (A.addin) {
                 const FloorConst fa = A.fc[A.addin_src * A.K + i];
                 const u64 *ad = A.addin + (poly * A.addin_ntgt + i) * N;
@@ -1391,7 +1392,7 @@ __global__ void __launch_bounds__(kBlock) k_bfv_tail_sp(const u64 *tpr, u64 *rp,
         double x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
-        col_inv<ArF64, LOGN1>(ar, x, gtw(Ps.inv), Ps.inv_w0_scaled);
+        col_inv<ArF64, LOGN1>(ar, x, ctw(Ps.inv), Ps.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     } else {
@@ -1399,7 +1400,7 @@ __global__ void __launch_bounds__(kBlock) k_bfv_tail_sp(const u64 *tpr, u64 *rp,
         u64 x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
-        col_inv<ArU64, LOGN1>(ar, x, gtw(Ps.inv), Ps.inv_w0_scaled);
+        col_inv<ArU64, LOGN1>(ar, x, ctw(Ps.inv), Ps.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     }
@@ -1431,7 +1432,7 @@ __global__ void __launch_bounds__(kBlock) k_bfv_tail_fin(const u64 *t, const u64
         double x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
-        col_inv<ArF64, LOGN1>(ar, x, gtw(Pi.inv), Pi.inv_w0_scaled);
+        col_inv<ArF64, LOGN1>(ar, x, ctw(Pi.inv), Pi.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     } else {
@@ -1439,7 +1440,7 @@ __global__ void __launch_bounds__(kBlock) k_bfv_tail_fin(const u64 *t, const u64
         u64 x[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
-        col_inv<ArU64, LOGN1>(ar, x, gtw(Pi.inv), Pi.inv_w0_scaled);
+        col_inv<ArU64, LOGN1>(ar, x, ctw(Pi.inv), Pi.inv_w0_scaled);
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
     }

@@ -86,6 +86,20 @@ HE_HD Tw16 tw_load(gtw_t p, u32 i)
     return t;
 }
 #endif
+#if defined(__HIP__)
+// The same table through the constant address space: an entry whose index is the same in every lane (all column-pass
+// twiddles are) becomes a scalar load into SGPRs -- no vector registers, no vector-memory latency in front of the butterflies.
+// Only for memory no kernel writes while the reader runs (the per-prime twiddle tables).
+typedef const __attribute__((address_space(4))) he_u64x2 *ctw_t;
+HE_HD Tw16 tw_load(ctw_t p, u32 i)
+{
+    const he_u64x2 v = p[i];
+    Tw16 t;
+    t.a = v.x;
+    t.b = v.y;
+    return t;
+}
+#endif
 template <class P> struct TwTable {
     P base;
     u32 rowbase;
