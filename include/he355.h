@@ -135,6 +135,10 @@ int he355_relinearize_rescale(he355_ctx *ctx, int L, uint64_t n, const uint64_t 
 int he355_rescale(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_in, uint64_t *d_out);         /* -> [n][size][L-1][N] */
 int he355_apply_galois(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, uint32_t galois_elt, uint64_t *d_out);
 int he355_rotate(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, int step, uint64_t *d_out);
+/* d_out[i] = rotate(d_in[i], h_steps[i]), i < n: the rotate_vector(dot_i, -i) loop of collapseCKKS (src/engine/seal_context.cpp:389-392)
+ * as batched key switches (ciphertexts that need the same Galois element at the same point of their NAF sequence go together).
+ * h_steps: host array of n steps.  Not in place. */
+int he355_rotate_each(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, const int32_t *h_steps, uint64_t *d_out);
 /* d_out = d_addend + rotate(d_in, step): the rotate + add_inplace pair of the row-major MatMult inner loop
  * (src/benchmarks/bfv/seal_bfv_matmult_row_benchmark.cpp:525-531) and of accumulateCKKS/BFV (src/engine/seal_context.cpp:337-338,
  * 302-303) as one pipeline.  d_addend may be d_out (add in place) when the step has its own Galois key; d_in may be neither. */

@@ -99,6 +99,7 @@ def lib():
             "he355_apply_galois": (i32, [vp, i32, u64, vp, u32, vp]),
             "he355_rotate": (i32, [vp, i32, u64, vp, i32, vp]),
             "he355_rotate_add": (i32, [vp, i32, u64, vp, i32, vp, vp]),
+            "he355_rotate_each": (i32, [vp, i32, u64, vp, vp, vp]),
             "he355_accumulate": (i32, [vp, i32, u64, vp, u64, vp]),
             "he355_ntt_forward": (i32, [vp, vp, u64, u8p, u32]),
             "he355_ntt_inverse": (i32, [vp, vp, u64, u8p, u32]),
@@ -122,7 +123,7 @@ C_ABI_SYMBOLS = [
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",
     "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_keygen_relin", "he355_keygen_galois", "he355_ckks_encode", "he355_ckks_decode",
-    "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_accumulate",
+    "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_rotate_each", "he355_accumulate",
     "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk",
 ]
 
@@ -332,6 +333,10 @@ class Context:
 
     def rotate(self, L, n, inp, step, out):
         _check(lib().he355_rotate(self.h, L, n, inp.ptr, step, out.ptr))
+
+    def rotate_each(self, L, n, inp, steps, out):
+        arr = (C.c_int32 * n)(*[int(v) for v in steps])
+        _check(lib().he355_rotate_each(self.h, L, n, inp.ptr, arr, out.ptr))
 
     def rotate_add(self, L, n, inp, step, addend, out):
         _check(lib().he355_rotate_add(self.h, L, n, inp.ptr, step, addend.ptr, out.ptr))

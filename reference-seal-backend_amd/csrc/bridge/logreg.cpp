@@ -280,9 +280,11 @@ AB::Handle LogRegHornerBenchmark::operate(AB::Handle h_remote_packed, const AB::
     // ---- collapseCKKS(dots, rotate) (seal_context.cpp:349-415): slot i of the result <- slot 0 of dot_i ---------------
     const int L1 = L - 1, L2 = L - 2;
     std::shared_ptr<DeviceCiphers> rot = cw.allocResult(batch, 2, L1, dots1->scale);
-    const std::uint64_t per1 = 2 * (std::uint64_t)L1 * N;
-    for (std::uint64_t i = 0; i < batch; ++i) // rotate_vector(dot_i, -i); i = 0 is the copy
-        chk(he355_rotate(ctx, L1, 1, dots1->d + i * per1, -(int)i, rot->d + i * per1), "rotate_vector");
+    {
+        std::vector<std::int32_t> steps(batch); // rotate_vector(dot_i, -i) for every sample (i = 0 is the copy), as batched key switches
+        for (std::uint64_t i = 0; i < batch; ++i) steps[i] = -(std::int32_t)i;
+        chk(he355_rotate_each(ctx, L1, batch, dots1->d, steps.data(), rot->d), "rotate_vector");
+    }
     std::shared_ptr<DeviceCiphers> id1 = dropTo(in.identity, L1);                         // mod_switch_to_inplace(plain, tmp.parms_id())
     chk(he355_multiply_plain(ctx, L1, 2, batch, rot->d, id1->d, pairwise, rot->d), "multiply_plain"); // relinearize_inplace: size 2, nothing to do
     // terms [0, batch) = rescaled masked rotations, term batch = Enc(0), term batch+1 = bias; all at level L2, scales pinned to `scale`

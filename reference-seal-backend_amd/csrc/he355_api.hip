@@ -634,6 +634,73 @@ public:
             cur = dst;
         }
     }
+    // NAF terms of a rotation step in the order Evaluator::rotate_internal applies them (least significant first; a term of
+    // N/2 is no rotation); a step with its own Galois key is one term
+    std::vector<int> rotation_terms(int step)
+    {
+        std::vector<int> terms;
+        if (step == 0) return terms;
+        const uint32_t elt = P.galois_elt_from_step(step);
+        if (!elt) throw std::invalid_argument("step count too large");
+        if (galois_key(elt)) { terms.push_back(step); return terms; }
+        const bool neg = step < 0;
+        long v = neg ? -(long)step : step;
+        int n_naf = 0;
+        for (int i = 0; v; ++i) {
+            const int zi = (v & 1) ? 2 - (int)(v & 3) : 0;
+            v = (v - zi) >> 1;
+            if (!zi) continue;
+            ++n_naf;
+            const long t = (neg ? -zi : zi) * (1L << i);
+            if ((size_t)(t < 0 ? -t : t) != P.N / 2) terms.push_back((int)t);
+        }
+        if (n_naf == 1) throw std::invalid_argument("Galois key not present");
+        for (int t : terms) {
+            const uint32_t e = P.galois_elt_from_step(t);
+            if (!e || !galois_key(e)) throw std::invalid_argument("Galois key not present");
+        }
+        return terms;
+    }
+    // out[i] = rotate(in[i], steps[i]): the rotate_vector(dot_i, -i) loop of collapseCKKS (seal_context.cpp:389-392).  Every
+    // ciphertext goes through its own NAF terms in its own order; ciphertexts whose t-th term is the same Galois element are
+    // gathered and key-switched as one batch (a loop of single-ciphertext rotations is latency-bound: ~1 ms each at N=2^14).
+    void rotate_each(int L, u64 n, const u64 *in, const int *steps, u64 *out)
+    {
+        use();
+        check_level(L);
+        if (!n) return;
+        if (in == out) throw std::invalid_argument("rotate_each cannot run in place");
+        const size_t per = 2 * (size_t)L * P.N, bytes = n * per * 8;
+        std::vector<std::vector<int>> terms(n);
+        size_t depth = 0;
+        for (u64 i = 0; i < n; ++i) {
+            terms[i] = rotation_terms(steps[i]);
+            depth = std::max(depth, terms[i].size());
+        }
+        HIPCHECK(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, stream_));
+        if (!depth) return;
+        require_keyswitch();
+        if (2 * bytes > rot_tmp_bytes_) {
+            HIPCHECK(hipStreamSynchronize(stream_));
+            if (rot_tmp_) HIPCHECK(hipFree(rot_tmp_));
+            rot_tmp_ = nullptr; rot_tmp_bytes_ = 0;
+            HIPCHECK(hipMalloc(&rot_tmp_, 2 * bytes));
+            rot_tmp_bytes_ = 2 * bytes;
+        }
+        u64 *ga = rot_tmp_, *gb = rot_tmp_ + n * per;
+        for (size_t t = 0; t < depth; ++t) {
+            std::map<uint32_t, std::vector<uint32_t>> groups; // Galois element -> ciphertexts whose t-th term it is
+            for (u64 i = 0; i < n; ++i)
+                if (t < terms[i].size()) groups[P.galois_elt_from_step(terms[i][t])].push_back((uint32_t)i);
+            for (const auto &g : groups) {
+                const u64 m = g.second.size();
+                launch_move_cts(env_, ga, out, g.second.data(), m, per, false);
+                apply_galois(L, m, ga, g.first, gb);
+                launch_move_cts(env_, out, gb, g.second.data(), m, per, true);
+            }
+        }
+        HIPCHECK(hipGetLastError());
+    }
     // SEALContextWrapper::accumulateCKKS (seal_context.cpp:321-347), count > 0
     void accumulate(int L, u64 n, u64 *inout, u64 count, u64 *tmp)
     {
@@ -1322,6 +1389,13 @@ int he355_apply_galois(he355_ctx *c, int L, uint64_t n, const uint64_t *in, uint
 int he355_rotate(he355_ctx *c, int L, uint64_t n, const uint64_t *in, int step, uint64_t *out)
 {
     return guarded([&] { dev(c).rotate(L, n, in, step, out); });
+}
+int he355_rotate_each(he355_ctx *c, int L, uint64_t n, const uint64_t *in, const int32_t *steps, uint64_t *out)
+{
+    return guarded([&] {
+        if (n && !steps) throw std::invalid_argument("rotate_each needs one step per ciphertext");
+        dev(c).rotate_each(L, n, in, steps, out);
+    });
 }
 int he355_rotate_add(he355_ctx *c, int L, uint64_t n, const uint64_t *in, int step, const uint64_t *addend, uint64_t *out)
 {

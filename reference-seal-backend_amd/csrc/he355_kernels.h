@@ -62,6 +62,9 @@ struct KsBuffers {
     u64 *tpr;   // [C][2][N]      the same after the inverse row pass (raw)
     u64 *e;     // [C][2][L][N]   mod-down corrections after the forward column pass (raw of prime i)
 };
+constexpr int kMoveListCap = 64;
+// whole ciphertexts by index list (host array): gather dst[g] = src[idx[g]], scatter dst[idx[g]] = src[g], g < n
+void launch_move_cts(const KernelEnv &env, u64 *dst, const u64 *src, const uint32_t *idx, u64 n, u64 elems_per_ct, bool scatter);
 enum K1Mode { K1_MUL = 0, K1_CT3 = 1, K1_GALOIS = 2 };
 // K1: produce c01 / c2n / c2r for a chunk of ops.  MUL: a,b via indexer.  CT3: `a` is [n][3][L][N].
 // GALOIS: `a` is [n][2][L][N], perm = device permutation table (NTT-form gather); optional addend [n][2][L][N] (indexed like `a`):

@@ -478,6 +478,21 @@ __global__ void __launch_bounds__(kBlock) k_sum_cts(const u64 *in, u64 *out, con
     reinterpret_cast<ulonglong2 *>(out + (p << logN))[e2] = s;
 }
 
+// Gather / scatter of whole ciphertexts by an index list held in the kernel arguments (rotate_each groups the ciphertexts
+// that need the same Galois element): gather: dst[g] = src[idx[g]]; scatter: dst[idx[g]] = src[g].  16 B per lane.
+struct MoveList {
+    uint32_t idx[kMoveListCap];
+};
+__global__ void __launch_bounds__(kBlock) k_move_cts(u64 *dst, const u64 *src, MoveList list, u64 pairs_per_ct, int scatter)
+{
+    const u64 g = blockIdx.y;
+    const u64 e2 = (u64)blockIdx.x * kBlock + threadIdx.x;
+    if (e2 >= pairs_per_ct) return;
+    const u64 i = list.idx[g];
+    const u64 s = (scatter ? g : i) * pairs_per_ct + e2, d = (scatter ? i : g) * pairs_per_ct + e2;
+    reinterpret_cast<ulonglong2 *>(dst)[d] = reinterpret_cast<const ulonglong2 *>(src)[s];
+}
+
 // Evaluator::multiply, CKKS, size 2 x 2 -> 3 (dyadic tensor).  One thread = 2 coefficients of one residue.
 template <class Ar>
 __device__ __forceinline__ void mul3_pair(const Ar &ar, const ulonglong2 a0, const ulonglong2 a1, const ulonglong2 b0, const ulonglong2 b1,
@@ -1788,6 +1803,19 @@ void launch_sum_cts(const KernelEnv &env, int L, int size, u64 n_terms, const u6
     const int logN = env.logn1 + kRowLog;
     const u64 threads = ((u64)size * L) << (logN - 1);
     hipLaunchKernelGGL(k_sum_cts, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, in, out, env.primes, L, size * L, logN, n_terms);
+}
+
+void launch_move_cts(const KernelEnv &env, u64 *dst, const u64 *src, const uint32_t *idx, u64 n, u64 elems_per_ct, bool scatter)
+{
+    const u64 pairs = elems_per_ct / 2;
+    for (u64 off = 0; off < n; off += kMoveListCap) {
+        const u64 m = std::min<u64>(kMoveListCap, n - off);
+        MoveList list;
+        for (u64 g = 0; g < m; ++g) list.idx[g] = idx[off + g];
+        // gather: compact rows [off, off+m) of dst; scatter: compact rows [off, off+m) of src
+        hipLaunchKernelGGL(k_move_cts, dim3(grid_for(pairs, kBlock), (unsigned)m), dim3(kBlock), 0, env.stream, scatter ? dst : dst + off * elems_per_ct,
+                           scatter ? src + off * elems_per_ct : src, list, pairs, scatter ? 1 : 0);
+    }
 }
 
 void launch_mul3_acc(const KernelEnv &env, int L, u64 rows, u64 cols, int inner, const u64 *a, u64 a_stride_i, u64 a_stride_k, const u64 *b,

@@ -551,3 +551,48 @@ def test_wide_fp64_engine_primes(be, oracle, N, bits):
     for r in range(n):
         assert np.array_equal(got2[r], o.rescale(want[r])), r
     g.close()
+
+
+def _naf_terms(step, N):
+    """SEAL's NAF terms of a rotation step, least significant first (Evaluator::rotate_internal); a term of N/2 is no rotation."""
+    neg, x, i, out = step < 0, abs(step), 0, []
+    while x:
+        z = 2 - (x & 3) if x & 1 else 0
+        x = (x - z) >> 1
+        if z and (1 << i) != N // 2:
+            out.append((-z if neg else z) * (1 << i))
+        i += 1
+    return out
+
+
+def test_rotate_each_batches_by_galois_element(pair, be):
+    """he355_rotate_each: ciphertext i rotated by its own step (collapseCKKS's rotate_vector(dot_i, -i) loop), key switches batched
+    per Galois element: equal to rotating one ciphertext at a time, which is the oracle's apply_galois chain of the NAF terms."""
+    g, o, rng = pair
+    L, N = g.L, g.N
+    keys = {}
+    for k in range(4):
+        for s in (1 << k, -(1 << k)):
+            e = o.galois_elt(s)
+            keys[e] = o.random_kswitch_key(rng)
+            g.set_galois_key(e, keys[e])
+    steps = [0, -1, -2, -3, -4, -5, -6, -7, 3, 5, 8, -10]
+    n = len(steps)
+    a = rand_cts(o, rng, n, L)
+    da = g.to_device(a)
+    out = g.alloc(n * 2 * L * N)
+    g.rotate_each(L, n, da, steps, out)
+    got = out.download((n, 2, L, N))
+    for r, s in enumerate(steps):
+        w = a[r]
+        terms = [s] if s and o.galois_elt(s) in keys else _naf_terms(s, N)
+        for t in terms:
+            w = o.apply_galois(w, o.galois_elt(t), keys[o.galois_elt(t)])
+        assert np.array_equal(got[r], w), (r, s)
+    one = g.alloc(2 * L * N)
+    g.rotate(L, 1, g.to_device(a[5:6]), steps[5], one)  # and equal to the single-ciphertext rotation
+    assert np.array_equal(one.download((1, 2, L, N))[0], got[5])
+    with pytest.raises(be.HE355Error):
+        g.rotate_each(L, 2, da, [1, 16], out)  # 16: no key, a single NAF term
+    with pytest.raises(be.HE355Error):
+        g.rotate_each(L, n, da, steps, da)  # not in place
