@@ -711,11 +711,16 @@ __device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt
         }
         col_fwd<ArF64, LOGN1>(ar, x, ctw(Pt.fwd));
         if constexpr (kPackD) {
-            // 48-bit rows need |x| < 2^47.  The column pass starts from |x| < q and every stage adds at most 0.5625 q
-            // (ArF64::bfly_fwd), so after its <= 5 stages |x| < 3.82 q: below 2^47 for primes under 2^45 (the 40/45-bit
-            // primes of the reference's parameter rule); wider fp64-engine primes are re-centred first.
-            static_assert(LOGN1 <= 5, "bound above is for at most 5 column stages");
-            if ((Pt.q >> 45) == 0) {
+            // 48-bit rows need |x| < 2^47.  The column pass starts from |x| < m0 (the lift above: q_t after an integer reduction,
+            // q_t/2 + 1 after a re-centring, q_j <= 2 q_t otherwise) and a stage takes the bound m to m + q (1/2 + m 2^-51)
+            // (ArF64::bfly_fwd).  For the 40/45-bit primes of the reference's parameter rule the result stays below 2^47
+            // (3.66 q from m0 = q < 2^45); where it does not (wider fp64-engine primes, a digit prime well above the target)
+            // the values are re-centred first.  The test is the same in every lane.
+            double m = (Pj.q >> 52) ? (double)Pt.q : (Pj.q > 2 * Pt.q ? 0.5 * (double)Pt.q + 1.0 : (double)Pj.q);
+#pragma unroll
+            for (int st = 0; st < LOGN1; ++st) m += (double)Pt.q * (0.5 + m * 4.440892098500626e-16); // 2^-51
+            const bool fits = m * 1.0000001 < 140737488355328.0;                                         // 2^47
+            if (fits) {
 #pragma unroll
                 for (int a = 0; a < N1; ++a) store48(dst + (a << kRowLog), col, x[a]);
             } else {
