@@ -267,7 +267,8 @@ AB::Handle VectorBenchmark::operate(AB::Handle h_remote_packed, const AB::Parame
         break;
     }
     default:
-        throw HEBenchError(HEBERROR_MSG_CLASS("Operation not supported."), HEBENCH_ECODE_INVALID_ARGS);
+        // the reference's two element-wise classes word this differently (bfv eltwise .cpp:329, ckks eltwise .cpp:346)
+        throw HEBenchError(HEBERROR_MSG_CLASS(m_scheme == Scheme::BFV ? "Operation not implimented." : "Operation not supported."), HEBENCH_ECODE_INVALID_ARGS);
     }
     HeContextWrapper::check(he355_sync(ctx), "synchronise"); // operate() returns with the result complete, as the reference's does
     return this->getEngine().createHandle<decltype(result)>(sizeof(result), 0, std::move(result));

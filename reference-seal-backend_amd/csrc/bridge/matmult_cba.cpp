@@ -36,6 +36,8 @@ hebench::cpp::BaseBenchmark *MatMultCipherBatchAxisBenchmarkDescription::createB
 {
     if (!p_params)
         throw HEBenchError(HEBERROR_MSG_CLASS("Invalid empty workload parameters. Matrix Multiplication requires parameters."), HEBENCH_ECODE_INVALID_ARGS);
+    if ((m_descriptor.cipher_param_mask & 0x03) != 0x03) // all cipher (bfv cipherbatchaxis .cpp:63-75)
+        throw HEBenchError(HEBERROR_MSG_CLASS("Cipher/plain combination of operation parameters requested is not supported."), HEBENCH_ECODE_INVALID_ARGS);
     return new MatMultCipherBatchAxisBenchmark(engine, m_descriptor, *p_params, m_scheme);
 }
 void MatMultCipherBatchAxisBenchmarkDescription::destroyBenchmark(hebench::cpp::BaseBenchmark *p_bench)
@@ -203,6 +205,8 @@ AB::Handle MatMultCipherBatchAxisBenchmark::operate(AB::Handle h_remote_packed, 
         if (p_param_indexers[i].batch_size > 1) throw HEBenchError(HEBERROR_MSG_CLASS("Batch size must be 1 for latency test."), HEBENCH_ECODE_INVALID_ARGS);
     }
     const MatRemote &in = this->getEngine().retrieveFromHandle<MatRemote>(h_remote_packed);
+    if (!in.m[0] || !in.m[1]) // .cpp:371-373
+        throw HEBenchError(HEBERROR_MSG_CLASS("Insufficient number of arguments for operation parameters."), HEBENCH_ECODE_INVALID_ARGS);
     he355_ctx *ctx = m_p_ctx_wrapper->raw();
     const int L = in.m[0]->L;
     const std::uint64_t r0 = rows_M0(), c0 = cols_M0(), c1 = cols_M1(), n = r0 * c1;

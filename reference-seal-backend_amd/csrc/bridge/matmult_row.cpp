@@ -106,10 +106,12 @@ AB::Handle MatMultRowLatencyBenchmark::encode(const AB::DataPackCollection *p_pa
         const std::uint64_t r = op ? cols_M0() : rows_M0(), cl = op ? cols_M1() : cols_M0();
         const AB::DataPack &dp = findDataPack(*p_parameters, op);
         if (dp.buffer_count < 1)
-            throw HEBenchError(HEBERROR_MSG_CLASS("Latency test requires, at least, 1 sample per operation parameter."), HEBENCH_ECODE_INVALID_ARGS);
+            // (the reference's text names parameter 0 for either operand: bfv row .cpp:192, ckks row .cpp:193)
+            throw HEBenchError(HEBERROR_MSG_CLASS("Latency test requires, at least, 1 sample per operation parameter. None found for operation parameter 0."),
+                               HEBENCH_ECODE_INVALID_ARGS);
         if (!dp.p_buffers || !dp.p_buffers[0].p) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty buffer in data pack."), HEBENCH_ECODE_CRITICAL_ERROR);
         if (dp.p_buffers[0].size / sizeof(std::int64_t) < r * cl)
-            throw HEBenchError(HEBERROR_MSG_CLASS("Insufficient data for parameter sample."), HEBENCH_ECODE_CRITICAL_ERROR);
+            throw HEBenchError(HEBERROR_MSG_CLASS("Insufficient data for parameter 0 sample."), HEBENCH_ECODE_CRITICAL_ERROR); // :203 / :204
         mats_raw[op] = dp.p_buffers[0].p;
     }
     const std::size_t dim1 = rows_M0(), dim2 = cols_M0(), dim3 = cols_M1();
@@ -170,6 +172,7 @@ void MatMultRowLatencyBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackC
     const AB::DataPack &rc = findDataPack(*p_native, 0);
     if (rc.buffer_count == 0 || !rc.p_buffers[0].p) return;
     const ResultPlain &enc = this->getEngine().retrieveFromHandle<ResultPlain>(h_encoded_data);
+    if (enc.C.empty()) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty handle 'h_encoded_data'."), HEBENCH_ECODE_CRITICAL_ERROR); // bfv row .cpp:314-316
     if (m_scheme == Scheme::CKKS) { // decodeResult, ckks row .cpp:330-356: row i = first dim3 slots of ciphertext i, |x| < 0.00005 -> 0
         double *raw = reinterpret_cast<double *>(rc.p_buffers[0].p);
         std::size_t room = rc.p_buffers[0].size / sizeof(double), pos = 0;

@@ -185,6 +185,8 @@ AB::Handle MatMultValBenchmark::load(const AB::Handle *p_h_local_data, std::uint
 
 void MatMultValBenchmark::store(AB::Handle h_remote_data, AB::Handle *p_h_local_data, std::uint64_t count)
 {
+    if (count > 0 && !p_h_local_data) // bfv matmultval .cpp:418-420
+        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid null array of handles: \"p_local_data\""), HEBENCH_ECODE_INVALID_ARGS);
     if (count > 0) {
         std::memset(p_h_local_data, 0, sizeof(AB::Handle) * count);
         const std::shared_ptr<DeviceCiphers> &r = this->getEngine().retrieveFromHandle<std::shared_ptr<DeviceCiphers>>(h_remote_data);

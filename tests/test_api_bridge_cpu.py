@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from hebench_harness import (Backend, BridgeError, ECODE_INVALID_ARGS, LATENCY, OFFLINE, SCHEME_BFV, SCHEME_CKKS, W_ADD, W_DOT, W_MUL, W_LOGREG3,
+from hebench_harness import (Backend, BridgeError, ECODE_CRITICAL, ECODE_INVALID_ARGS, LATENCY, OFFLINE, SCHEME_BFV, SCHEME_CKKS, W_ADD, W_DOT, W_MUL, W_LOGREG3,
                              DT_FLOAT64, DT_INT64, Handle)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -126,4 +126,27 @@ def test_client_side_then_loud_failure_at_load(backend):
     assert code == ECODE_INVALID_ARGS
     for h in (hp, hc):
         backend.destroy(h)
+    backend.destroy(hb)
+
+
+def test_matmult_row_encode_errors_are_the_references(backend):
+    """Error text and code of the row-major MatMult's encode(), as the reference words them (bfv row .cpp:190-204: the text names
+    parameter 0 for either operand; an undersized sample is a CRITICAL error, a missing one INVALID_ARGS)."""
+    bench = [b for b in backend.benchmarks() if b["desc"].workload == 0 and b["desc"].other == 2 and b["desc"].scheme == SCHEME_BFV][0]
+    hb = backend.create(bench, [("rows_M0", 4), ("cols_M0", 3), ("cols_M1", 2), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 3),
+                                ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)])
+    a, b = np.zeros((1, 12), dtype=np.int64), np.zeros((1, 6), dtype=np.int64)
+    h = Handle()
+    dpc, keep = backend.pack([a, np.zeros((1, 5), dtype=np.int64)])  # second operand one value short
+    with pytest.raises(BridgeError) as ei:
+        backend.chk(backend.L.encode(hb, C.byref(dpc), C.byref(h)))
+    assert ei.value.code == ECODE_CRITICAL and "Insufficient data for parameter 0 sample." in str(ei.value)
+    dpc, keep = backend.pack([a, np.zeros((0, 6), dtype=np.int64)])  # no sample for the second operand
+    with pytest.raises(BridgeError) as ei:
+        backend.chk(backend.L.encode(hb, C.byref(dpc), C.byref(h)))
+    assert ei.value.code == ECODE_INVALID_ARGS
+    assert "Latency test requires, at least, 1 sample per operation parameter. None found for operation parameter 0." in str(ei.value)
+    dpc, keep = backend.pack([a, b])  # and the well-formed call goes through (host-side encoders without a GPU)
+    backend.chk(backend.L.encode(hb, C.byref(dpc), C.byref(h)))
+    backend.L.destroyHandle(h)
     backend.destroy(hb)
