@@ -77,8 +77,9 @@ std::string VectorBenchmarkDescription::getBenchmarkDescription(const AB::Worklo
     for (std::size_t i = 1; i < multiplicative_depth; ++i) ss << ", " << coeff_modulus_bits;
     ss << ", 60" << std::endl;
     if (m_scheme == Scheme::CKKS) ss << ", , Scale, 2^" << extra_bits << std::endl;
-    else ss << ", , Plain modulus bits, " << extra_bits << std::endl;
+    else ss << ", , Plain Text Modulus Bits, " << extra_bits << std::endl; // bfv eltwise .cpp:111, bfv dot .cpp:105
     ss << ", Algorithm, " << AlgorithmName << ", " << AlgorithmDescription << std::endl
+       << HeContextWrapper::threadsRow(p_w_params->params[Index_NumThreads].u_param, m_descriptor.category == AB::Category::Latency) << std::endl
        << ", Device, AMD Instinct MI355X (HIP; batch mapped to the grid, no host threads)";
     return ss.str();
 }

@@ -1,6 +1,8 @@
 // he_context.cpp — see he_context.h
 #include "he_context.h"
 
+#include <thread>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -386,6 +388,13 @@ void HeContextWrapper::needDefaultGaloisKeys()
     uint32_t elts[64];
     const uint64_t n = he355_galois_elts_all(m_ctx, elts, 64);
     for (uint64_t i = 0; i < n && i < 64; ++i) needGaloisKey(elts[i]);
+}
+
+std::string HeContextWrapper::threadsRow(std::uint64_t requested, bool force_one)
+{
+    std::uint64_t n = force_one ? 1 : requested;
+    if (n == 0) n = std::max(1u, std::thread::hardware_concurrency()); // omp_get_max_threads() in the reference
+    return ", Number of threads, " + std::to_string(n);
 }
 
 std::shared_ptr<DeviceCiphers> HeContextWrapper::allocResult(uint64_t n, int size, int L, double scale)

@@ -100,6 +100,10 @@ public:
     const uint64_t *hostData(const Cipher &c);
     std::shared_ptr<DeviceCiphers> allocResult(uint64_t n, int size, int L, double scale);
     static void check(int code, const char *what); // he355 error -> HEBenchError
+    // The ", Number of threads, N" row every description of the reference ends with (e.g. ckks eltwise .cpp:97-112): Latency
+    // forces 1 where the reference does, a value <= 0 means every hardware thread.  Kept for report compatibility (the GPU path
+    // does not use host threads; the device row follows it).
+    static std::string threadsRow(std::uint64_t requested, bool force_one);
 
 private:
     struct Staged { // n objects of `per` words each, contiguous in HBM

@@ -67,6 +67,7 @@ std::string LogRegHornerBenchmarkDescription::getBenchmarkDescription(const AB::
     ss << ", 60" << std::endl
        << ", , Scale, 2^" << p_w_params->params[Index_ScaleExponentBits].u_param << std::endl
        << ", Algorithm, " << AlgorithmName << ", " << AlgorithmDescription << std::endl
+       << HeContextWrapper::threadsRow(p_w_params->params[Index_NumThreads].u_param, m_descriptor.category == AB::Category::Latency) << std::endl
        << ", Device, AMD Instinct MI355X (HIP; input samples batched on the grid)";
     return ss.str();
 }

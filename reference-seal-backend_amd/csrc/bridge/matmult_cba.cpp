@@ -58,6 +58,7 @@ std::string MatMultCipherBatchAxisBenchmarkDescription::getBenchmarkDescription(
     if (m_scheme == Scheme::CKKS) ss << ", , Scale, 2^" << p_w_params->params[Index_ScaleExponentBits].u_param << std::endl;
     else ss << ", , Plain Modulus, " << p_w_params->params[Index_ScaleExponentBits].u_param << std::endl;
     ss << ", Algorithm, " << AlgorithmName << ", " << AlgorithmDescription << std::endl
+       << HeContextWrapper::threadsRow(p_w_params->params[Index_NumThreads].u_param, false) << std::endl // the matrix workloads keep the requested count (bfv row .cpp:89-91)
        << ", Device, AMD Instinct MI355X (HIP; all result elements as one batch)";
     return ss.str();
 }

@@ -55,6 +55,7 @@ std::string MatMultValBenchmarkDescription::getBenchmarkDescription(const AB::Wo
     if (m_scheme == Scheme::CKKS) ss << ", , Scale, 2^" << p_w_params->params[Index_ScaleExponentBits].u_param << std::endl;
     else ss << ", , Plain Modulus, " << p_w_params->params[Index_ScaleExponentBits].u_param << std::endl;
     ss << ", Algorithm, " << AlgorithmName << ", " << AlgorithmDescription << std::endl
+       << HeContextWrapper::threadsRow(p_w_params->params[Index_NumThreads].u_param, false) << std::endl // the matrix workloads keep the requested count (bfv row .cpp:89-91)
        << ", Device, AMD Instinct MI355X (HIP; all (row, column) pairs as one batch)";
     return ss.str();
 }

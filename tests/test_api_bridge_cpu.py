@@ -84,6 +84,19 @@ def test_description_text(backend):
                                        ("ScaleBits", 45), ("NumThreads", 0)])
     assert ", , Poly modulus degree, 8192" in txt and ", , Coefficient Modulus, 60, 45, 45, 60" in txt and ", , Scale, 2^45" in txt
     assert ", Algorithm, Vector, One vector per ciphertext" in txt
+    # the reference's rows in the reference's order (ckks eltwise .cpp:104-112); the device row comes after them
+    rows = [r for r in txt.splitlines() if r.startswith(",")]
+    assert [r for r in rows if r.startswith(", Number of threads, ")], txt
+    assert txt.index(", Algorithm, ") < txt.index(", Number of threads, ") < txt.index(", Device, ")
+    lat = backend.description_text(backend.find(W_ADD, SCHEME_CKKS, LATENCY), [("n", 10), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 3),
+                                                                             ("CoefficientModulusBits", 45), ("ScaleBits", 45), ("NumThreads", 7)])
+    assert ", Number of threads, 1" in lat  # Latency forces one thread (.cpp:98-99)
+    off = backend.description_text(b, [("n", 10), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 3), ("CoefficientModulusBits", 45),
+                                       ("ScaleBits", 45), ("NumThreads", 7)])
+    assert ", Number of threads, 7" in off
+    bfv = backend.description_text(backend.find(W_ADD, SCHEME_BFV, OFFLINE), [("n", 10), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 3),
+                                                                            ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)])
+    assert ", , Plain Text Modulus Bits, 20" in bfv  # bfv eltwise .cpp:111
 
 
 def test_argument_validation_codes(backend):
