@@ -14,8 +14,8 @@ class LogRegHornerBenchmarkDescription : public hebench::cpp::BenchmarkDescripti
 public:
     HEBERROR_DECLARE_CLASS_NAME(LogRegHornerBenchmarkDescription)
     static constexpr std::int64_t LogRegOtherID = 0x01;
-    static constexpr const char *AlgorithmName = "EvalPoly";
-    static constexpr const char *AlgorithmDescription = "using Horner method for polynomial evaluation";
+    static constexpr const char *AlgorithmName = "HornerPolyEval";                                                                       // ckks logreg .h
+    static constexpr const char *AlgorithmDescription = "Horner method for polynomial evaluation, single input vector per ciphertext";
     enum : std::uint64_t { Index_W = 0, Index_b, Index_X, NumOpParams };
     enum : std::uint64_t { Index_n = 0, Index_PolyModulusDegree, Index_NumCoefficientModuli, Index_CoefficientModulusBits, Index_ScaleExponentBits,
                            Index_NumThreads, NumWorkloadParams };

@@ -13,7 +13,7 @@ class MatMultCipherBatchAxisBenchmarkDescription : public hebench::cpp::Benchmar
 public:
     HEBERROR_DECLARE_CLASS_NAME(MatMultCipherBatchAxisBenchmarkDescription)
     static constexpr std::int64_t MatMultOtherID = 0x01;
-    static constexpr const char *AlgorithmName = "MatMultCipherBatchAxis";
+    static constexpr const char *AlgorithmName = "CipherBatchAxis"; // the reference's strings (they name report rows)
     static constexpr const char *AlgorithmDescription = "One matrix element per ciphertext";
     enum : std::uint64_t { Index_rows_M0 = 0, Index_cols_M0, Index_cols_M1, Index_PolyModulusDegree, Index_NumCoefficientModuli,
                            Index_CoefficientModulusBits, Index_ScaleExponentBits /* BFV: PlainModulusBits */, Index_NumThreads, NumWorkloadParams };

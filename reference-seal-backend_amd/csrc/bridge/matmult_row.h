@@ -14,8 +14,8 @@ class MatMultRowBenchmarkDescription : public hebench::cpp::BenchmarkDescription
 public:
     HEBERROR_DECLARE_CLASS_NAME(MatMultRowBenchmarkDescription)
     static constexpr std::int64_t MatMultRowOtherID = 2;
-    static constexpr const char *AlgorithmName = "MatMultRow";
-    static constexpr const char *AlgorithmDescription = "Two rows of the first matrix per ciphertext, second matrix in one ciphertext";
+    static constexpr const char *AlgorithmName = "MatMulRow"; // sic, the reference's spelling
+    static constexpr const char *AlgorithmDescription = ""; // empty in the reference (bfv row .h); BFV: two rows of M0 per ciphertext, M1 in one
     static constexpr std::size_t NumOpParams = 2;
     enum : std::uint64_t { // bfv row .h:34-50
         Index_rows_M0 = 0,

@@ -26,7 +26,7 @@ MatMultValBenchmarkDescription::MatMultValBenchmarkDescription(Scheme scheme) : 
     w.add<std::uint64_t>(8, "cols_M1");
     w.add<std::uint64_t>(8192, "PolyModulusDegree");
     w.add<std::uint64_t>(2, "MultiplicativeDepth");
-    w.add<std::uint64_t>(scheme == Scheme::CKKS ? 45 : 40, "CoefficientModulusBits");
+    w.add<std::uint64_t>(scheme == Scheme::CKKS ? 45 : 40, scheme == Scheme::CKKS ? "CoefficientMudulusBits" : "CoefficientModulusBits"); // sic: ckks matmultval .cpp:50
     if (scheme == Scheme::CKKS) w.add<std::uint64_t>(45, "ScaleBits");
     else w.add<std::uint64_t>(20, "PlainModulusBits");
     w.add<std::uint64_t>(0, "NumThreads");

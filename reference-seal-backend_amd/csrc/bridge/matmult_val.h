@@ -14,7 +14,7 @@ public:
     HEBERROR_DECLARE_CLASS_NAME(MatMultValBenchmarkDescription)
     static constexpr std::int64_t MatMultValOtherID = 0;
     static constexpr const char *AlgorithmName = "MatMultVal";
-    static constexpr const char *AlgorithmDescription = "One matrix row per ciphertext";
+    static constexpr const char *AlgorithmDescription = "One matrix row per ciphertext, Encode transposes second matrix";
     enum : std::uint64_t { Index_rows_M0 = 0, Index_cols_M0, Index_cols_M1, Index_PolyModulusDegree, Index_NumCoefficientModuli,
                            Index_CoefficientModulusBits, Index_ScaleExponentBits /* BFV: PlainModulusBits */, Index_NumThreads, NumWorkloadParams };
     explicit MatMultValBenchmarkDescription(Scheme scheme);

@@ -56,12 +56,23 @@ def test_engine_registration(backend):
                           (SCHEME_CKKS, [("MultiplicativeDepth", 3), ("CoefficientModulusBits", 45), ("ScaleBits", 45)])])
     mv = sorted((b["desc"].scheme, b["defaults"][0][4:7]) for b in bs if b["desc"].workload == 0 and b["desc"].other == 0)  # MatMultValOtherID
     assert mv == sorted([(SCHEME_BFV, [("MultiplicativeDepth", 2), ("CoefficientModulusBits", 40), ("PlainModulusBits", 20)]),
-                         (SCHEME_CKKS, [("MultiplicativeDepth", 2), ("CoefficientModulusBits", 45), ("ScaleBits", 45)])])
+                         (SCHEME_CKKS, [("MultiplicativeDepth", 2), ("CoefficientMudulusBits", 45), ("ScaleBits", 45)])])  # sic: ckks matmultval .cpp:50
     mm = [b for b in bs if b["desc"].workload == 0 and b["desc"].other == 2 and b["desc"].scheme == SCHEME_BFV][0]  # MatMultRowOtherID
     mc = [b for b in bs if b["desc"].workload == 0 and b["desc"].other == 2 and b["desc"].scheme == SCHEME_CKKS][0]
     assert mc["defaults"][0][4:7] == [("MultiplicativeDepth", 3), ("CoefficientModulusBits", 45), ("ScaleBits", 45)]
     assert mm["defaults"][0] == [("rows_M0", 10), ("cols_M0", 9), ("cols_M1", 8), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 3),
                                  ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)]
+    # algorithm name / description rows, as the reference's headers define them (they name rows of the harness's report)
+    algo = {}
+    for b in bs:
+        txt = backend.description_text(b, b["defaults"][0])
+        row = [r for r in txt.splitlines() if r.startswith(", Algorithm, ")][0]
+        algo[(b["desc"].workload, b["desc"].other)] = row
+    assert algo[(0, 0)] == ", Algorithm, MatMultVal, One matrix row per ciphertext, Encode transposes second matrix"
+    assert algo[(0, 1)] == ", Algorithm, CipherBatchAxis, One matrix element per ciphertext"
+    assert algo[(0, 2)] == ", Algorithm, MatMulRow, "
+    assert algo[(W_LOGREG3, 1)] == ", Algorithm, HornerPolyEval, Horner method for polynomial evaluation, single input vector per ciphertext"
+    assert algo[(W_ADD, 0)] == ", Algorithm, Vector, One vector per ciphertext"
     for b in bs:
         d = b["desc"]
         assert d.cipher_param_mask == 0xFFFFFFFF and d.security == 0 and d.other in ((0, 1, 2) if d.workload == 0 else (1,) if d.workload == W_LOGREG3 else (0,))
