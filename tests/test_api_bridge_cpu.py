@@ -42,6 +42,12 @@ def test_engine_registration(backend):
     want = sorted([(w, s, c) for w in (W_ADD, W_MUL, W_DOT) for s in (SCHEME_BFV, SCHEME_CKKS) for c in (LATENCY, OFFLINE)] + [(0, SCHEME_BFV, LATENCY)] * 3 + [(0, SCHEME_CKKS, LATENCY)] * 3
                   + [(W_LOGREG3, SCHEME_CKKS, LATENCY), (W_LOGREG3, SCHEME_CKKS, OFFLINE)])
     assert got == want and len(bs) == 20  # all 20 of the reference's descriptors (seal_engine.cpp:108-151)
+    # ... in the reference's order: a harness configuration file addresses a benchmark by its position in this list
+    order = [(b["desc"].workload, b["desc"].scheme, b["desc"].category, b["desc"].other) for b in bs]
+    B, K = SCHEME_BFV, SCHEME_CKKS
+    assert order == ([(w, s, c, 0) for w in (W_ADD, W_MUL, W_DOT) for c in (LATENCY, OFFLINE) for s in (B, K)]
+                     + [(0, B, LATENCY, 1), (0, K, LATENCY, 1), (0, B, LATENCY, 0), (0, K, LATENCY, 0), (0, B, LATENCY, 2), (0, K, LATENCY, 2)]
+                     + [(W_LOGREG3, K, LATENCY, 1), (W_LOGREG3, K, OFFLINE, 1)])
     for c in (LATENCY, OFFLINE):
         lr = backend.find(W_LOGREG3, SCHEME_CKKS, c)
         assert lr["desc"].other == 1 and lr["desc"].data_type == DT_FLOAT64  # LogRegOtherID
