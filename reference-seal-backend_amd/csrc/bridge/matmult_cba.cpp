@@ -200,7 +200,11 @@ void MatMultCipherBatchAxisBenchmark::store(AB::Handle h_remote_data, AB::Handle
 
 AB::Handle MatMultCipherBatchAxisBenchmark::operate(AB::Handle h_remote_packed, const AB::ParameterIndexer *p_param_indexers, std::uint64_t indexers_count)
 {
-    if (indexers_count < 2) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid number of indexers. Expected 2."), HEBENCH_ECODE_INVALID_ARGS);
+    if (indexers_count < std::uint64_t(2)) { // ckks cipherbatchaxis .cpp:352-358
+        std::stringstream ss;
+        ss << "Invalid number of indexers. Expected " << std::uint64_t(2) << ", but " << indexers_count << " received." << std::endl;
+        throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
+    }
     for (int i = 0; i < 2; ++i) {
         if (p_param_indexers[i].value_index > 0) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected index in parameter indexer."), HEBENCH_ECODE_INVALID_ARGS);
         if (p_param_indexers[i].batch_size > 1) throw HEBenchError(HEBERROR_MSG_CLASS("Batch size must be 1 for latency test."), HEBENCH_ECODE_INVALID_ARGS);

@@ -131,8 +131,11 @@ AB::Handle MatMultValBenchmark::encode(const AB::DataPackCollection *p_parameter
 void MatMultValBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackCollection *p_native)
 {
     const std::vector<Plain> &res = this->getEngine().retrieveFromHandle<std::vector<Plain>>(h_encoded_data); // row-major rows_M0 x cols_M1
-    if (res.size() < rows_M0() * cols_M1())
-        throw HEBenchError(HEBERROR_MSG_CLASS("Invalid number of rows in encoded result."), HEBENCH_ECODE_INVALID_ARGS);
+    if (res.size() < rows_M0() * cols_M1()) { // the reference keeps rows of columns (ckks matmultval .cpp:322-338); here the result is flat, row-major
+        std::stringstream ss;
+        ss << "Invalid number of rows in encoded result. Expected " << rows_M0() << ", but received " << res.size() / std::max<std::uint64_t>(1, cols_M1()) << ".";
+        throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
+    }
     const AB::DataPack &rc = findDataPack(*p_native, 0);
     if (rc.buffer_count == 0 || !rc.p_buffers || !rc.p_buffers[0].p) return;
     const std::size_t room = rc.p_buffers[0].size / 8;
@@ -198,11 +201,18 @@ void MatMultValBenchmark::store(AB::Handle h_remote_data, AB::Handle *p_h_local_
 
 AB::Handle MatMultValBenchmark::operate(AB::Handle h_remote_packed, const AB::ParameterIndexer *p_param_indexers, std::uint64_t indexers_count)
 {
-    if (indexers_count < 2) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid number of indexers. Expected 2."), HEBENCH_ECODE_INVALID_ARGS);
-    for (int i = 0; i < 2; ++i) {
-        if (p_param_indexers[i].value_index > 0) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected index in parameter indexer."), HEBENCH_ECODE_INVALID_ARGS);
-        if (p_param_indexers[i].batch_size != 1) throw HEBenchError(HEBERROR_MSG_CLASS("Batch size must be 1 for latency test."), HEBENCH_ECODE_INVALID_ARGS);
+    if (indexers_count < std::uint64_t(2)) { // ckks matmultval .cpp:436-442
+        std::stringstream ss;
+        ss << "Invalid number of indexers. Expected " << std::uint64_t(2) << ", but " << indexers_count << " received." << std::endl;
+        throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
     }
+    for (std::size_t i = 0; i < std::uint64_t(2); ++i)
+        if (p_param_indexers[i].value_index > 0 || p_param_indexers[i].batch_size != 1) { // :450-459
+            std::stringstream ss;
+            ss << "Invalid parameter indexer for operation parameter " << i << ". Expected index in range [0, 1), but [" << p_param_indexers[i].value_index << ", "
+               << p_param_indexers[i].batch_size << ") received.";
+            throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
+        }
     const MatRemote &in = this->getEngine().retrieveFromHandle<MatRemote>(h_remote_packed);
     he355_ctx *ctx = m_p_ctx_wrapper->raw();
     const int L = in.m[0]->L;
