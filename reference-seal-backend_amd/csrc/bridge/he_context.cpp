@@ -213,11 +213,12 @@ std::vector<Plain> HeContextWrapper::encodeBatch(const std::vector<std::vector<s
 // decode: slot values of each plaintext (CKKS: N/2 doubles; BFV: N int64)
 std::vector<std::vector<double>> HeContextWrapper::decodeBatchCKKS(const std::vector<Plain> &plains)
 {
-    std::vector<std::vector<double>> out(plains.size(), std::vector<double>(slot_count()));
+    std::vector<std::vector<double>> out;
     if (plains.empty()) return out;
     bool uniform = true;
     for (const Plain &p : plains) uniform = uniform && p.L == plains[0].L && p.scale == plains[0].scale;
     if (!clientOnDevice() || !uniform || plains[0].L > 16) {
+        out.assign(plains.size(), std::vector<double>(slot_count()));
         for (std::size_t i = 0; i < plains.size(); ++i) m_client->ckks_decode(hostData(plains[i]), (size_t)plains[i].L, plains[i].scale, out[i].data());
         return out;
     }
@@ -227,16 +228,19 @@ std::vector<std::vector<double>> HeContextWrapper::decodeBatchCKKS(const std::ve
     DevBuf dv(m_ctx, n * half * 8);
     check(he355_ckks_decode(m_ctx, L, n, in.d, plains[0].scale, dv.as<double>()), "decode");
     check(he355_sync(m_ctx), "synchronise");
-    std::vector<double> flat(n * half); // one transfer for the batch
-    check(he355_download(m_ctx, flat.data(), dv.p, flat.size() * 8), "download");
-    for (std::uint64_t i = 0; i < n; ++i) std::copy(flat.begin() + i * half, flat.begin() + (i + 1) * half, out[i].begin());
+    // one transfer for the batch into memory nobody zero-fills first, then one construction per result (no second pass)
+    std::unique_ptr<double[]> flat(new double[n * half]);
+    check(he355_download(m_ctx, flat.get(), dv.p, n * half * 8), "download");
+    out.reserve(n);
+    for (std::uint64_t i = 0; i < n; ++i) out.emplace_back(flat.get() + i * half, flat.get() + (i + 1) * half);
     return out;
 }
 std::vector<std::vector<std::int64_t>> HeContextWrapper::decodeBatchBFV(const std::vector<Plain> &plains)
 {
-    std::vector<std::vector<std::int64_t>> out(plains.size(), std::vector<std::int64_t>(slot_count()));
+    std::vector<std::vector<std::int64_t>> out;
     if (plains.empty()) return out;
     if (!clientOnDevice()) {
+        out.assign(plains.size(), std::vector<std::int64_t>(slot_count()));
         for (std::size_t i = 0; i < plains.size(); ++i) m_client->bfv_decode(hostData(plains[i]), out[i].data());
         return out;
     }
@@ -245,9 +249,10 @@ std::vector<std::vector<std::int64_t>> HeContextWrapper::decodeBatchBFV(const st
     DevBuf dv(m_ctx, n * N * 8);
     check(he355_bfv_decode(m_ctx, n, in.d, dv.as<std::int64_t>()), "decode");
     check(he355_sync(m_ctx), "synchronise");
-    std::vector<std::int64_t> flat(n * N); // one transfer for the batch
-    check(he355_download(m_ctx, flat.data(), dv.p, flat.size() * 8), "download");
-    for (std::uint64_t i = 0; i < n; ++i) std::copy(flat.begin() + i * N, flat.begin() + (i + 1) * N, out[i].begin());
+    std::unique_ptr<std::int64_t[]> flat(new std::int64_t[n * N]); // one transfer for the batch, no zero-fill, one construction per result
+    check(he355_download(m_ctx, flat.get(), dv.p, n * N * 8), "download");
+    out.reserve(n);
+    for (std::uint64_t i = 0; i < n; ++i) out.emplace_back(flat.get() + i * N, flat.get() + (i + 1) * N);
     return out;
 }
 // Client side: on the MI355X when one is present (he355_encrypt / he355_decrypt: same bits as the host code below for the same
