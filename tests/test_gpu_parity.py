@@ -596,3 +596,50 @@ def test_rotate_each_batches_by_galois_element(pair, be):
         g.rotate_each(L, 2, da, [1, 16], out)  # 16: no key, a single NAF term
     with pytest.raises(be.HE355Error):
         g.rotate_each(L, n, da, steps, da)  # not in place
+
+
+def test_pipeline_regression_fixture_gpu(be, oracle):
+    """The HIP path reproduces tests/golden/pipeline_sha256.json (checksums of the pipeline outputs on seeded inputs, generated by
+    tests/golden/make_pipeline_vectors.py): the committed fixture both the oracle (CPU suite) and the device are held to."""
+    import hashlib
+    import importlib.util
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_pipeline_vectors", os.path.join(here, "golden", "make_pipeline_vectors.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    want = json.load(open(os.path.join(here, "golden", "pipeline_sha256.json")))
+
+    def sha(buf, shape):
+        return hashlib.sha256(np.ascontiguousarray(buf.download(shape), dtype=np.uint64).tobytes()).hexdigest()
+
+    for case in gen.CASES:
+        ckks = case["scheme"] == "ckks"
+        o = oracle.Context(oracle.SCHEME_CKKS if ckks else oracle.SCHEME_BFV, case["N"], bit_sizes=case["bits"], plain_bits=case.get("plain_bits", 0), sec128=False)
+        g = be.Context(be.SCHEME_CKKS if ckks else be.SCHEME_BFV, case["N"], bit_sizes=case["bits"], plain_bits=case.get("plain_bits", 0), sec128=False, device=0)
+        exp = want[case["name"]]
+        assert [int(q) for q in g.moduli] == exp["moduli"]
+        L, a, b, rk, gk = gen.inputs(o, case)
+        n, N = case["n"], case["N"]
+        da, db = g.to_device(a), g.to_device(b)
+        g.set_relin_key(rk)
+        elt = g.galois_elt(1)
+        g.set_galois_key(elt, gk)
+        pw = be.Context.pairwise()
+        out = g.alloc(n * 2 * L * N)
+        if ckks:
+            g.multiply_relin(L, n, da, db, pw, out)
+            assert sha(out, (n, 2, L, N)) == exp["multiply_relin"], case["name"]
+            out2 = g.alloc(n * 2 * (L - 1) * N)
+            g.multiply_relin(L, n, da, db, pw, out2, rescale=True)
+            assert sha(out2, (n, 2, L - 1, N)) == exp["multiply_relin_rescale"], case["name"]
+        else:
+            c3 = g.alloc(n * 3 * L * N)
+            g.bfv_multiply(L, n, da, db, pw, c3)
+            g.relinearize(L, n, c3, out)
+            assert sha(out, (n, 2, L, N)) == exp["bfv_multiply_relin"], case["name"]
+        g.add(L, 2, n, da, db, pw, out)
+        assert sha(out, (n, 2, L, N)) == exp["add"], case["name"]
+        g.apply_galois(L, n, da, elt, out)
+        assert sha(out, (n, 2, L, N)) == exp["rotate_1"], case["name"]
+        g.close()

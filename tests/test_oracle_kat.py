@@ -260,3 +260,21 @@ def test_bfv_rotate_rows_columns(bfv_env):
     elt = ctx.galois_elt(0)
     r = ctx.apply_galois(e["cx"], elt, ctx.keygen_galois(e["sk"], elt, 52))
     assert np.array_equal(_bfv_dec(e, r).reshape(2, N // 2), x[::-1])
+
+
+def _golden_pipeline():
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_pipeline_vectors", os.path.join(here, "golden", "make_pipeline_vectors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, json.load(open(os.path.join(here, "golden", "pipeline_sha256.json")))
+
+
+def test_pipeline_regression_fixture(oracle):
+    """tests/golden/pipeline_sha256.json: the oracle reproduces the committed checksums of its own outputs on seeded inputs (a
+    regression pin of this repository's arithmetic across rounds, not a SEAL vector); the GPU path is held to the same file in
+    tests/test_gpu_parity.py::test_pipeline_regression_fixture_gpu."""
+    gen, want = _golden_pipeline()
+    for case in gen.CASES:
+        assert gen.expected(oracle, case) == want[case["name"]], case["name"]
