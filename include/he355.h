@@ -143,8 +143,18 @@ int he355_rotate_each(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, c
  * (src/benchmarks/bfv/seal_bfv_matmult_row_benchmark.cpp:525-531) and of accumulateCKKS/BFV (src/engine/seal_context.cpp:337-338,
  * 302-303) as one pipeline.  d_addend may be d_out (add in place) when the step has its own Galois key; d_in may be neither. */
 int he355_rotate_add(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, int step, const uint64_t *d_addend, uint64_t *d_out);
-/* accumulateCKKS: in place log-tree sum of the first `count` slots; d_tmp: scratch slab of the same size */
+/* accumulateCKKS / accumulateBFV: in place log-tree sum of the first `count` slots; d_tmp: scratch slab of the same size.
+ * count == 0 is the reference's else-branch (src/engine/seal_context.cpp:312-316, 341-344): every ciphertext is replaced by a
+ * FRESH encryption of zero (Encryptor::encrypt_zero; needs the public key; L must be the top level, as SEAL returns a
+ * top-level ciphertext there).  The randomness comes from the context's own stream: seeded from the OS, or pinned with
+ * he355_set_zero_stream (ciphertext r then equals he355_encrypt_zero(seed, first_index + r)). */
 int he355_accumulate(he355_ctx *ctx, int L, uint64_t n, uint64_t *d_inout, uint64_t count, uint64_t *d_tmp);
+/* Encryptor::encrypt_zero at the first data level: d_out [n][2][Ltop][N]; streams as he355_encrypt */
+int he355_encrypt_zero(he355_ctx *ctx, uint64_t n, uint64_t seed, uint64_t first_index, uint64_t *d_out);
+int he355_set_zero_stream(he355_ctx *ctx, uint64_t seed, uint64_t first_index);
+/* Introspection: the API-Bridge ABI (enumerators, sizes, offsets, header used) this library was compiled with, as JSON; returns the
+ * size needed including the terminator (csrc/bridge/abi_check.cpp).  A harness binding can check its own numbers against it. */
+uint64_t he355_bridge_abi(char *p_buffer, uint64_t size);
 /* ---- client side on the device: encryptor()->encrypt (ckks eltwise .cpp:242, bfv eltwise .cpp:233) and
  * SEALContextWrapper::decrypt (src/engine/seal_context.cpp:265-287), batched.  Keys: host arrays in SEAL layout, NTT form:
  * public key [2][K][N], secret key [K][N].  Randomness of he355_encrypt is counter-based: ciphertext r draws u, e0, e1 from

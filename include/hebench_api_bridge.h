@@ -10,8 +10,15 @@
  * hebench_cpp is present in this image, so this header is written from the way the reference USES the types
  * (every field below is referenced in /root/reference/src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp or
  * src/engine/seal_engine.cpp, cited per item) plus knowledge of the public api-bridge sources.
- * [UPSTREAM-UNVERIFIED]: enum numeric values, HEBENCH_MAX_* sizes and struct padding must be re-checked
- * against the real header on first contact with a real test_harness (SURVEY.md §7 "hard parts").
+ * [UPSTREAM-UNVERIFIED]: enum numeric values, HEBENCH_MAX_* sizes and struct padding are recollections of the public
+ * api-bridge v0.8 header (Workload and DataType numbered from 1, EltwiseMultiply before EltwiseAdd), not a copy of it.
+ * Drop-in compatibility with a real test_harness therefore stays unverified until the library has been built against
+ * the real header, which the build supports directly:
+ *     make -C reference-seal-backend_amd/csrc HEBENCH_API_BRIDGE_DIR=<api-bridge checkout or install prefix>
+ * then compiles every bridge source against <dir>/include/hebench/api_bridge/api.h instead of this file (the sources use
+ * symbolic names only), and csrc/bridge/abi_check.cpp turns any difference in a size, an offset or an enumerator between
+ * the two headers into a compile error.  he355_bridge_abi() (same file) exports the numbers the library was built with;
+ * tests/test_api_bridge_cpu.py holds the in-repo harness to them.
  */
 #ifndef HEBENCH_API_BRIDGE_CLEANROOM_H
 #define HEBENCH_API_BRIDGE_CLEANROOM_H
@@ -62,9 +69,9 @@ typedef struct ParameterIndexer { /* ckks eltwise .cpp:322,334-335 */
 } ParameterIndexer;
 
 typedef enum Workload { /* seal_engine.cpp:108-151 */
-    MatrixMultiply = 0,
-    EltwiseAdd,
+    MatrixMultiply = 1,
     EltwiseMultiply,
+    EltwiseAdd,
     DotProduct,
     LogisticRegression,
     LogisticRegression_PolyD3,
@@ -72,7 +79,7 @@ typedef enum Workload { /* seal_engine.cpp:108-151 */
     LogisticRegression_PolyD7,
     Generic
 } Workload;
-typedef enum DataType { Int32 = 0, Int64, Float32, Float64 } DataType; /* ckks eltwise .cpp:34, bfv eltwise .cpp:34 */
+typedef enum DataType { Int32 = 1, Int64, Float32, Float64 } DataType; /* ckks eltwise .cpp:34, bfv eltwise .cpp:34 */
 typedef enum Category { Latency = 0, Offline } Category;               /* ckks eltwise .cpp:38,43 */
 
 typedef struct CategoryParams { /* ckks eltwise .cpp:39-45 */
@@ -108,9 +115,16 @@ typedef struct BenchmarkDescriptor { /* ckks eltwise .cpp:32-56 */
     int64_t other;
 } BenchmarkDescriptor;
 
-typedef enum WorkloadParamType { WP_Int64 = 0, WP_UInt64, WP_Float64 } WorkloadParamType;
+#ifdef __cplusplus
+namespace WorkloadParamType { /* as upstream: the enumerators live in a namespace of the enum's name */
+enum WorkloadParamType { Int64 = 0, UInt64, Float64 };
+}
+typedef WorkloadParamType::WorkloadParamType WorkloadParamTypeT;
+#else
+typedef enum WorkloadParamType { WP_Int64 = 0, WP_UInt64, WP_Float64 } WorkloadParamTypeT;
+#endif
 typedef struct WorkloadParam { /* params[i].u_param: ckks eltwise .cpp:93-97 */
-    WorkloadParamType data_type;
+    WorkloadParamTypeT data_type;
     char name[HEBENCH_MAX_BUFFER_SIZE];
     union {
         int64_t i_param;

@@ -15,7 +15,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhebench_mi355x_backend.so")
+# HE355_LIB_PATH selects another build of the same library (A/B timing of kernel variants, sanitizer builds): the product
+# file is never swapped in place
+LIB_PATH = os.environ.get("HE355_LIB_PATH") or os.path.join(_HERE, "lib", "libhebench_mi355x_backend.so")
 
 SCHEME_BFV, SCHEME_CKKS = 1, 2
 OK, E_INVALID_ARGS, E_PARAMS, E_DEVICE = 0, 1, 2, 3
@@ -101,11 +103,14 @@ def lib():
             "he355_rotate_add": (i32, [vp, i32, u64, vp, i32, vp, vp]),
             "he355_rotate_each": (i32, [vp, i32, u64, vp, vp, vp]),
             "he355_accumulate": (i32, [vp, i32, u64, vp, u64, vp]),
+            "he355_encrypt_zero": (i32, [vp, u64, u64, u64, vp]),
+            "he355_set_zero_stream": (i32, [vp, u64, u64]),
             "he355_ntt_forward": (i32, [vp, vp, u64, u8p, u32]),
             "he355_ntt_inverse": (i32, [vp, vp, u64, u8p, u32]),
             "he355_timer_begin": (i32, [vp]), "he355_timer_end": (i32, [vp, C.POINTER(C.c_float)]),
             "he355_probe_dominant_kernel": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
             "he355_set_chunk": (i32, [vp, u64]),
+            "he355_bridge_abi": (u64, [C.c_char_p, u64]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -123,8 +128,8 @@ C_ABI_SYMBOLS = [
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",
     "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_keygen_relin", "he355_keygen_galois", "he355_ckks_encode", "he355_ckks_decode",
-    "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_rotate_each", "he355_accumulate",
-    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk",
+    "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_rotate_each", "he355_accumulate", "he355_encrypt_zero", "he355_set_zero_stream",
+    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk", "he355_bridge_abi",
 ]
 
 
@@ -303,6 +308,12 @@ class Context:
 
     def encrypt(self, n, plain, seed, first_index, out):
         _check(lib().he355_encrypt(self.h, n, plain.ptr, seed, first_index, out.ptr))
+
+    def encrypt_zero(self, n, seed, first_index, out):
+        _check(lib().he355_encrypt_zero(self.h, n, seed, first_index, out.ptr))
+
+    def set_zero_stream(self, seed, first_index=0):
+        _check(lib().he355_set_zero_stream(self.h, seed, first_index))
 
     def decrypt(self, L, size, n, ct, out):
         _check(lib().he355_decrypt(self.h, L, size, n, ct.ptr, out.ptr))

@@ -7,6 +7,8 @@
 #include <cstdlib>
 
 #include <cmath>
+#include <cstdlib>
+#include <random>
 
 #include "../he355_internal.h"
 
@@ -47,7 +49,17 @@ void HeContextWrapper::init(int scheme, std::size_t N, std::size_t depth, int bi
     check(he355_ctx_create(scheme, N, chain.data(), chain.size(), plain_bits, 1, &m_ctx), "context creation");
     m_params = he355_internal_params(m_ctx);
     try {
-        m_client.reset(new he355::client::Client(*m_params, 0x5EA1C0DEull ^ (uint64_t)N ^ ((uint64_t)depth << 32)));
+        // Key generation and encryption randomness: seeded from the operating system, as SEAL's default factory is
+        // (seal_context.cpp:52-55 create the keys from it); HE355_SEED=<integer> pins the streams (tests, reproducible reports).
+        // The sampler itself (client/sampler.h) is a counter-based generator of benchmark grade, not a vetted CSPRNG.
+        uint64_t seed;
+        if (const char *env = std::getenv("HE355_SEED")) {
+            seed = std::strtoull(env, nullptr, 0) ^ (uint64_t)N ^ ((uint64_t)depth << 32);
+        } else {
+            std::random_device rd;
+            seed = ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+        }
+        m_client.reset(new he355::client::Client(*m_params, seed));
     } catch (const std::exception &ex) {
         throw HEBenchError(ex.what(), HEB355_ECODE_HE_ERROR);
     }

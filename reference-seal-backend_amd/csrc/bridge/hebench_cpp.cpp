@@ -20,8 +20,8 @@ std::string BenchmarkDescription::getBenchmarkDescription(const APIBridge::Workl
             const auto &p = p_w_params->params[i];
             ss << std::endl << ", , " << p.name << ", ";
             switch (p.data_type) {
-            case APIBridge::WP_Int64: ss << p.i_param; break;
-            case APIBridge::WP_UInt64: ss << p.u_param; break;
+            case APIBridge::WorkloadParamType::Int64: ss << p.i_param; break;
+            case APIBridge::WorkloadParamType::UInt64: ss << p.u_param; break;
             default: ss << p.f_param; break;
             }
         }

@@ -19,7 +19,11 @@
 #include <unordered_map>
 #include <vector>
 
+#if defined(HEBENCH_REAL_API_HEADERS) // make HEBENCH_API_BRIDGE_DIR=...: the real api-bridge headers (include/hebench_api_bridge.h explains)
+#include "hebench/api_bridge/api.h"
+#else
 #include "../../../include/hebench_api_bridge.h"
+#endif
 
 namespace hebench {
 namespace cpp {
@@ -66,7 +70,7 @@ template <> inline void Common::add<std::uint64_t>(const std::uint64_t &value, c
 {
     APIBridge::WorkloadParam p;
     std::memset(&p, 0, sizeof(p));
-    p.data_type = APIBridge::WP_UInt64;
+    p.data_type = APIBridge::WorkloadParamType::UInt64;
     std::strncpy(p.name, name.c_str(), HEBENCH_MAX_BUFFER_SIZE - 1);
     p.u_param = value;
     m_params.push_back(p);

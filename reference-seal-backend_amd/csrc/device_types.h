@@ -4,6 +4,8 @@
 
 namespace he355 {
 
+constexpr int kMaxPrimes = 64; // primes one context can hold: key chain + BEHZ auxiliary primes + the plain modulus (per-prime tables are sized by it)
+
 // Per-prime constants + table pointers, resident in HBM (array of K entries), read wave-uniformly.
 struct PrimeDev {
     u64 q, cr0, cr1;      // Barrett (u64 engine and element-wise reductions)

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <random>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -85,10 +86,19 @@ __global__ void k_key_quotients(const u64 *key, u64 *keyq, u64 n_dk, int logN, c
 
 } // namespace
 
+// 64 bits from the operating system's entropy source (the context's own encryptions of zero; the bridge's client seeds likewise)
+static u64 os_seed()
+{
+    std::random_device rd;
+    return ((u64)rd() << 32) ^ (u64)rd();
+}
+
 class DeviceContext {
 public:
     DeviceContext(const Params &p, int device) : P(p), device_(device)
     {
+        // every per-prime table of the device side is sized kMaxPrimes (KernelEnv::prime_f64, PrimeMap, kernel argument lists)
+        if (p.K + p.aux.size() + 1 > (size_t)kMaxPrimes) throw std::invalid_argument("too many primes for one device context (key chain + auxiliary primes exceed 64)");
         int count = 0;
         hipError_t e = hipGetDeviceCount(&count);
         if (e != hipSuccess || count <= 0) throw DeviceError("no HIP device available (the MI355X backend has no CPU fallback)");
@@ -701,10 +711,22 @@ public:
         }
         HIPCHECK(hipGetLastError());
     }
-    // SEALContextWrapper::accumulateCKKS (seal_context.cpp:321-347), count > 0
+    // The stream the context's own encryptions of zero draw from (accumulate with count 0): seeded from the OS at construction,
+    // he355_set_zero_stream pins it (tests).
+    void set_zero_stream(u64 seed, u64 first_index) { zero_seed_ = seed; zero_index_ = first_index; }
+    // SEALContextWrapper::accumulateCKKS / accumulateBFV (seal_context.cpp:321-347, 289-319)
     void accumulate(int L, u64 n, u64 *inout, u64 count, u64 *tmp)
     {
-        if (count == 0) throw std::invalid_argument("accumulate with count 0 needs a fresh encryption of zero (client side)");
+        if (count == 0) {
+            // the reference's else-branch (seal_context.cpp:312-316, 341-344): encryptor()->encrypt_zero(retval) -- a FRESH encryption
+            // of zero at the first data level replaces every ciphertext.  SEAL returns it at the top level whatever the level of
+            // the input was; a slab of lower-level ciphertexts cannot hold that, so only L == Ltop is accepted here.
+            check_level(L);
+            if ((size_t)L != P.Ltop) throw std::invalid_argument("accumulate with count 0 returns top-level encryptions of zero: the slab must be at the top level");
+            encrypt(n, nullptr, zero_seed_, zero_index_, inout);
+            zero_index_ += n;
+            return;
+        }
         if (P.scheme == kSchemeBFV) { // SEALContextWrapper::accumulateBFV (seal_context.cpp:289-319)
             const u64 half = P.N / 2;
             const u64 row_count = count > half ? half : count;
@@ -848,6 +870,7 @@ public:
     }
     // Encryptor::encrypt (asymmetric) of n plaintexts: CKKS plain [n][Ltop][N] NTT form, BFV plain [n][N] mod t;
     // out [n][2][Ltop][N].  Ciphertext r uses the counter-based streams of index first_index + r (client/sampler.h).
+    // plain == nullptr: Encryptor::encrypt_zero (the plaintext term is skipped: adding the zero plaintext changes nothing).
     void encrypt(u64 n, const u64 *plain, u64 seed, u64 first_index, u64 *out)
     {
         use();
@@ -858,7 +881,7 @@ public:
         // per ciphertext: u K, e 2K, z 2K (BFV), tail 2, cols 2L polys
         u64 *base = client_scratch(cmax * (K + 2 * K + 2 * K + 2 + 2 * L) * N);
         u64 *u = base, *e = u + cmax * K * N, *z = e + cmax * 2 * K * N, *tpr = z + cmax * 2 * K * N, *cols = tpr + cmax * 2 * N;
-        u64 qdivt[16] = {0}, q_mod_t = 1;
+        u64 qdivt[kMaxPrimes] = {0}, q_mod_t = 1; // L <= K <= kMaxPrimes (constructor)
         if (!ckks) {
             const u64 t = P.plain_modulus;
             for (size_t i = 0; i < L; ++i) q_mod_t = (u64)(((u128)q_mod_t * (P.primes[i].q % t)) % t);
@@ -892,7 +915,7 @@ public:
                 }
                 Indexer pw{};
                 pw.b1 = 1; pw.pairwise = 1;
-                launch_plain_op(env_, (int)L, 2, c, o, plain + off * L * N, pw, o, 1); // c0 += plain
+                if (plain) launch_plain_op(env_, (int)L, 2, c, o, plain + off * L * N, pw, o, 1); // c0 += plain
             } else {
                 launch_enc_mul_pk(env_, c, u, d_pk_, z, false);
                 launch_ntt_inverse(env_, poly_view(z, (int)(2 * K), N, (int)K), (u32)c);
@@ -901,7 +924,7 @@ public:
                 launch_addsub(env_, (int)K, 2, c, z, e, pw, z, false);
                 if (K > 1) launch_divround_last_coeff(env_, c * 2, z, o);
                 else HIPCHECK(hipMemcpyAsync(o, z, c * 2 * N * 8, hipMemcpyDeviceToDevice, stream_));
-                launch_bfv_add_scaled_plain(env_, (int)L, c, o, plain + off * N, P.plain_modulus, q_mod_t, qdivt);
+                if (plain) launch_bfv_add_scaled_plain(env_, (int)L, c, o, plain + off * N, P.plain_modulus, q_mod_t, qdivt);
             }
         }
         HIPCHECK(hipGetLastError());
@@ -1130,6 +1153,7 @@ private:
     EncTablesDev enc_{nullptr, nullptr, nullptr};
     int *d_err_ = nullptr;
     u64 *d_pk_ = nullptr, *d_sk_ = nullptr;
+    u64 zero_seed_ = os_seed(), zero_index_ = 0;
     u64 *client_scratch_ = nullptr;
     size_t client_scratch_elems_ = 0;
     std::map<int, CrtTablesDev> crt_;
@@ -1403,6 +1427,14 @@ int he355_rotate_add(he355_ctx *c, int L, uint64_t n, const uint64_t *in, int st
         if (!addend) throw std::invalid_argument("rotate_add needs an addend");
         dev(c).rotate(L, n, in, step, out, addend);
     });
+}
+int he355_encrypt_zero(he355_ctx *c, uint64_t n, uint64_t seed, uint64_t first_index, uint64_t *d_out)
+{
+    return guarded([&] { dev(c).encrypt(n, nullptr, seed, first_index, d_out); });
+}
+int he355_set_zero_stream(he355_ctx *c, uint64_t seed, uint64_t first_index)
+{
+    return guarded([&] { dev(c).set_zero_stream(seed, first_index); });
 }
 int he355_accumulate(he355_ctx *c, int L, uint64_t n, uint64_t *inout, uint64_t count, uint64_t *tmp)
 {

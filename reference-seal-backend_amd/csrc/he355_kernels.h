@@ -31,7 +31,7 @@ struct KernelEnv {
     const FloorConst *floor_consts; // device array [K*K], entry [s*K + i]
     int N, logn1, K, Ltop, scheme;
     hipStream_t stream;
-    unsigned char prime_f64[64]; // host copy: 1 if the fp64 engine owns prime i
+    unsigned char prime_f64[kMaxPrimes]; // host copy: 1 if the fp64 engine owns prime i
 };
 
 

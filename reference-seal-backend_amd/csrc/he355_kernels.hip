@@ -16,6 +16,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 #include <type_traits>
 
 #include "he355_kernels.h"
@@ -92,24 +93,72 @@ __device__ __forceinline__ void store_rowA(u64 *row, int lane, const u64 v[kRowE
 #pragma unroll
     for (int r = 0; r < kRowE; ++r) row[(r << 6) | lane] = v[r];
 }
+// layout C (ntt_core.h elemC): registers 4c..4c+3 of a lane are 4 consecutive elements (32 bytes); the 4 lanes of a quad
+// cover 128 consecutive bytes per chunk c, quads are 512 bytes apart
 __device__ __forceinline__ void load_rowC(const u64 *row, int lane, u64 v[kRowE])
 {
+    const u64 *base = row + ((lane >> 2) << 6) + ((lane & 3) << 2);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(row + (c << 8) + (lane << 2));
+        const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(base + (c << 4));
         const ulonglong2 lo = p[0], hi = p[1];
         v[4 * c + 0] = lo.x; v[4 * c + 1] = lo.y; v[4 * c + 2] = hi.x; v[4 * c + 3] = hi.y;
     }
 }
 __device__ __forceinline__ void store_rowC(u64 *row, int lane, const u64 v[kRowE])
 {
+    u64 *base = row + ((lane >> 2) << 6) + ((lane & 3) << 2);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        ulonglong2 *p = reinterpret_cast<ulonglong2 *>(row + (c << 8) + (lane << 2));
+        ulonglong2 *p = reinterpret_cast<ulonglong2 *>(base + (c << 4));
         p[0] = make_ulonglong2(v[4 * c + 0], v[4 * c + 1]);
         p[1] = make_ulonglong2(v[4 * c + 2], v[4 * c + 3]);
     }
 }
+
+// ---- cross-lane swap steps (ntt_core.h xl_T1 / xl_T2): the device side ------------------------------------
+// HE355_XCHG selects how the two register/lane transposes of a row pass run: bit 0: B <-> C by DPP quad permutes (xl_T2),
+// bit 1: A <-> B by v_permlane32_swap / v_permlane16_swap / DPP row shifts (xl_T1); a clear bit = exchange through LDS.
+#ifndef HE355_XCHG
+#define HE355_XCHG 0
+#endif
+constexpr bool kXlT1 = (HE355_XCHG & 2) != 0, kXlT2 = (HE355_XCHG & 1) != 0;
+struct XLaneHw {
+    int lane;
+    template <int LB> __device__ __forceinline__ void step32(u32 &a, u32 &b) const
+    {
+        if constexpr (LB == 5) {
+            const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); // lanes 32..63 of a <-> lanes 0..31 of b
+            a = r[0]; b = r[1];
+        } else if constexpr (LB == 4) {
+            const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); // odd 16-lane rows of a <-> even rows of b
+            a = r[0]; b = r[1];
+        } else if constexpr (LB == 3 || LB == 2) {
+            // bank = 4 lanes of a 16-lane row: the lanes with bit LB clear read from lane + D (row_shl), the others from lane - D
+            constexpr int D = 1 << LB;
+            constexpr int lo_banks = LB == 3 ? 0x3 : 0x5, hi_banks = LB == 3 ? 0xC : 0xA;
+            const u32 nb = __builtin_amdgcn_update_dpp(b, a, 0x100 + D, 0xF, lo_banks, false);
+            const u32 na = __builtin_amdgcn_update_dpp(a, b, 0x110 + D, 0xF, hi_banks, false);
+            a = na; b = nb;
+        } else {
+            constexpr int ctrl = LB == 0 ? 0xB1 : 0x4E; // quad_perm [1,0,3,2] / [2,3,0,1]
+            const u32 pa = __builtin_amdgcn_update_dpp(0u, a, ctrl, 0xF, 0xF, true);
+            const u32 pb = __builtin_amdgcn_update_dpp(0u, b, ctrl, 0xF, 0xF, true);
+            const bool hi = (lane >> LB) & 1;
+            b = hi ? b : pa;
+            a = hi ? pb : a;
+        }
+    }
+    template <int LB, class T> __device__ __forceinline__ void step(T &a, T &b) const
+    {
+        static_assert(sizeof(T) == 8, "64-bit lane values");
+        union { T t; u32 w[2]; } ua, ub;
+        ua.t = a; ub.t = b;
+        step32<LB>(ua.w[0], ub.w[0]);
+        step32<LB>(ua.w[1], ub.w[1]);
+        a = ua.t; b = ub.t;
+    }
+};
 
 // ---- LDS-DMA: one 8 KiB row, HBM -> this wave's LDS staging buffer, no VGPRs, asynchronous -------------
 // Each global_load_lds_dwordx4 moves 64 x 16 B; the LDS image is the row in natural element order.
@@ -194,24 +243,35 @@ __device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int 
     }
     Tw16 wb[kTwB];
     gather_B(tw, lane, wb);
-    __builtin_amdgcn_sched_barrier(0);
+    XLaneHw xl{lane};
+    if constexpr (kXlT1) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) lds_store_A(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
-    HE_WAVE_SYNC();
+        for (int u = 0; u < U; ++u) xl_T1(xl, x[u]);
+    } else {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < U; ++u) lds_load_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
-    HE_WAVE_SYNC();
+        for (int u = 0; u < U; ++u) lds_store_A(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
+        HE_WAVE_SYNC();
+#pragma unroll
+        for (int u = 0; u < U; ++u) lds_load_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
+        HE_WAVE_SYNC();
+    }
     row_fwd_B<U>(ar, x, wb);
     Tw16 wc[kTwC];
     gather_C(tw, lane, wc);
     before_c();
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (kXlT2) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) lds_store_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
-    HE_WAVE_SYNC();
+        for (int u = 0; u < U; ++u) xl_T2(xl, x[u]);
+    } else {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < U; ++u) lds_load_C(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
-    HE_WAVE_SYNC();
+        for (int u = 0; u < U; ++u) lds_store_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
+        HE_WAVE_SYNC();
+#pragma unroll
+        for (int u = 0; u < U; ++u) lds_load_C(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
+        HE_WAVE_SYNC();
+    }
     row_fwd_C<U>(ar, x, wc);
 }
 template <class Ar, class TW>
@@ -225,16 +285,25 @@ __device__ __forceinline__ void wave_rows_inv(const Ar &ar, const PrimeDev &P, b
     typedef typename Ar::T T;
     T *lds = reinterpret_cast<T *>(lds_w);
     const auto itw = tw_table(gtw(P.inv), rowbase);
+    XLaneHw xl{lane};
     row_inv_C(ar, x, itw, lane);
-    lds_store_C(lds, lane, x);
-    HE_WAVE_SYNC();
-    lds_load_B(lds, lane, x);
-    HE_WAVE_SYNC();
+    if constexpr (kXlT2) {
+        xl_T2(xl, x);
+    } else {
+        lds_store_C(lds, lane, x);
+        HE_WAVE_SYNC();
+        lds_load_B(lds, lane, x);
+        HE_WAVE_SYNC();
+    }
     row_inv_B(ar, x, itw, lane);
-    lds_store_B(lds, lane, x);
-    HE_WAVE_SYNC();
-    lds_load_A(lds, lane, x);
-    HE_WAVE_SYNC();
+    if constexpr (kXlT1) {
+        xl_T1(xl, x);
+    } else {
+        lds_store_B(lds, lane, x);
+        HE_WAVE_SYNC();
+        lds_load_A(lds, lane, x);
+        HE_WAVE_SYNC();
+    }
     if (last) row_inv_A<Ar, true>(ar, x, itw, P.inv_w0_scaled);
     else row_inv_A<Ar, false>(ar, x, itw, P.inv_w0_scaled);
 }
@@ -910,8 +979,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         Acc acc0[kRowE], acc1[kRowE];
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) { acc0[r] = 0; acc1[r] = 0; }
+#if defined(HE355_ABLATE) && (HE355_ABLATE & 1) // timing experiment (wrong results): every key row is the tile's first one (L1-resident)
+        auto key_row = [&](int, int) -> const u64 * { return A.key + (u64)t * N + rowoff; };
+        auto keyq_row = [&](int, int) -> const u64 * { return A.keyq + (u64)q_slot * N + rowoff; };
+#else
         auto key_row = [&](int j, int k) -> const u64 * { return A.key + (((u64)j * 2 + k) * A.K + t) * N + rowoff; };
         auto keyq_row = [&](int j, int k) -> const u64 * { return A.keyq + (((u64)j * 2 + k) * A.n_q + q_slot) * N + rowoff; };
+#endif
         auto mac_poly = [&](Acc acc[kRowE], const T x[kRowE], int j, int k) {
             u64 kv[kRowE], kq[kRowE];
             load_rowC(key_row(j, k), lane, kv);
@@ -928,7 +1002,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         const bool has_own = A.ckks && tt < A.L;
         const int nd = A.L - (has_own ? 1 : 0);
         auto digit = [&](int i) -> int { return (has_own && i >= tt) ? i + 1 : i; };
+#if defined(HE355_ABLATE) && (HE355_ABLATE & 2) // timing experiment (wrong results): every digit row is the same row (no HBM stream)
+        auto src_row = [&](int) -> const u64 * { return A.d + (u64)wave * N + rowoff; };
+#else
         auto src_row = [&](int j) -> const u64 * { return A.d + ((op * (A.L + 1) + tt) * A.L + j) * N + rowoff; };
+#endif
         if constexpr (STAGE) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -1543,7 +1621,7 @@ __global__ void __launch_bounds__(kBlock) k_divround_last_coeff(const u64 *z, u6
 // BFV: c0 += round(q*m/t) (util/scalingvariant.cpp multiply_add_plain_with_scaling_variant); plain [n][N] mod t.
 struct ScaleVariantConst {
     u64 t, q_mod_t, thr;
-    u64 qdivt[16]; // floor(q/t) mod q_i
+    u64 qdivt[kMaxPrimes]; // floor(q/t) mod q_i
 };
 __global__ void __launch_bounds__(kBlock) k_bfv_add_scaled_plain(u64 *ct, const u64 *plain, const PrimeDev *primes, ScaleVariantConst sv, int L, int logN,
                                                                  u64 n_cts)
@@ -2116,7 +2194,8 @@ void launch_bfv_add_scaled_plain(const KernelEnv &env, int L, u64 n_cts, u64 *ct
     const int logN = env.logn1 + kRowLog;
     ScaleVariantConst sv;
     sv.t = t; sv.q_mod_t = q_mod_t; sv.thr = (t + 1) >> 1;
-    for (int i = 0; i < 16; ++i) sv.qdivt[i] = i < L ? qdivt[i] : 0;
+    if (L > kMaxPrimes) throw std::invalid_argument("too many data primes");
+    for (int i = 0; i < kMaxPrimes; ++i) sv.qdivt[i] = i < L ? qdivt[i] : 0;
     hipLaunchKernelGGL(k_bfv_add_scaled_plain, dim3(grid_for(n_cts << logN, kBlock)), dim3(kBlock), 0, env.stream, ct, plain, env.primes, sv, L, logN, n_cts);
 }
 void launch_dot_sk(const KernelEnv &env, int L, int size, u64 n_cts, const u64 *ct, const u64 *sk, u64 *out)

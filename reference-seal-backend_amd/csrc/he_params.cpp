@@ -213,7 +213,8 @@ void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t)
         gamma = ap[1];
         aux.push_back(make_prime_tables(ap[0], N, logn, false));
         for (size_t i = 0; i < Ltop; ++i) aux.push_back(make_prime_tables(ap[2 + i], N, logn, false));
-        if (K + aux.size() > (size_t)kMaxPrimes) throw std::invalid_argument("too many primes for the device prime table");
+        // + 1: the plain modulus rides along in the device prime array
+        if (K + aux.size() + 1 > (size_t)kMaxPrimes) throw std::invalid_argument("too many primes for the device prime table");
     }
 }
 

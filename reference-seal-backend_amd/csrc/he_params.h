@@ -10,13 +10,13 @@
 #include <string>
 #include <vector>
 
+#include "device_types.h"
 #include "modarith.h"
 
 namespace he355 {
 
 constexpr int kSchemeBFV = 1;  // seal::scheme_type::bfv
 constexpr int kSchemeCKKS = 2; // seal::scheme_type::ckks
-constexpr int kMaxPrimes = 64;
 
 struct PrimeTables {
     u64 q = 0;

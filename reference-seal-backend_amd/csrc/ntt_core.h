@@ -5,7 +5,10 @@
 //                   registers; its twiddles are the same for every column (wave-uniform -> SGPRs).
 //   * row pass    : 1024-point transforms over contiguous rows; ONE 64-lane wave owns one row, 16
 //                   elements per lane; the 10 stages run as 4 + 4 + 2 register-resident stages with two
-//                   LDS exchanges between them (layouts A -> B -> C below, padded against bank conflicts).
+//                   register/lane transposes between them (layouts A -> B -> C below).  A transpose is either an
+//                   exchange through LDS (padded against bank conflicts) or a sequence of cross-lane swap steps
+//                   (v_permlane32_swap / v_permlane16_swap / DPP row shifts / DPP quad permutes) that never
+//                   touches LDS: xl_T1 (A <-> B) and xl_T2 (B <-> C).
 // Forward (Cooley-Tukey, natural -> bit-reversed) = column pass then row pass; inverse (Gentleman-Sande)
 // = row pass then column pass with N^-1 folded into the last stage.  The ordering of the NTT form
 // (bit-reversed evaluations, twiddle table w[bitrev(i)] = psi^i) is the one SEAL uses, so device slabs are
@@ -33,7 +36,10 @@ HE_HD int lds_pad(int e) { return e + ((e >> 6) << 2); }
 // element index held in register r of lane `lane` under the three layouts
 HE_HD int elemA(int lane, int r) { return (r << 6) | lane; }                                   // r = bits 9..6
 HE_HD int elemB(int lane, int r) { return ((lane >> 2) << 6) | (r << 2) | (lane & 3); }       // r = bits 5..2
-HE_HD int elemC(int lane, int r) { return ((r >> 2) << 8) | (lane << 2) | (r & 3); }          // r = bits 9,8,1,0
+HE_HD int elemC(int lane, int r) { return ((lane >> 2) << 6) | ((r >> 2) << 4) | ((lane & 3) << 2) | (r & 3); } // r = bits 5,4,1,0
+// Layout B -> C moves element bits 1..0 from lane bits 1..0 into register bits 1..0 (and bits 3..2 the other way): two
+// 4x4 transposes inside every quad of lanes.  A lane then owns 4 x 4 consecutive elements; a quad owns 16 consecutive
+// elements (128 bytes) for each value of register bits 3..2.
 
 template <class T> HE_HD void lds_store_A(T *lds, int lane, const T x[kRowE])
 {
@@ -64,6 +70,37 @@ template <class T> HE_HD void lds_load_C(const T *lds, int lane, T x[kRowE])
 {
 #pragma unroll
     for (int r = 0; r < kRowE; ++r) x[r] = lds[lds_pad(elemC(lane, r))];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Register/lane transposes without LDS.  A swap step (LB, RB) exchanges lane bit LB with register bit RB of the element
+// index map: for every register pair (a = x[r], b = x[r | 1 << RB], bit RB of r clear)
+//     lanes with bit LB clear keep a and take the partner lane's a into b,
+//     lanes with bit LB set   keep b and take the partner lane's b into a        (partner = lane ^ (1 << LB)).
+// XL::step<LB>(a, b) is that exchange for one pair: v_permlane32_swap (LB 5), v_permlane16_swap (LB 4), two bank-masked
+// DPP row shifts (LB 3, 2), DPP quad permutes + selects (LB 1, 0) on the device (XLaneHw, he355_kernels.hip); the lane
+// simulator passes a recorder and replays the recorded steps over all 64 lanes (tests/csim).  Steps on disjoint bit
+// pairs commute and every step is an involution, so the same sequence runs the transpose in either direction.
+//   xl_T1: A <-> B  (register bits 3..0 <-> lane bits 5..2)
+//   xl_T2: B <-> C  (register bits 1..0 <-> lane bits 1..0)
+// ---------------------------------------------------------------------------------------------------
+template <int LB, int RB, class XL, class T> HE_HD void xl_swap_bits(XL &xl, T *x)
+{
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r)
+        if (!(r & (1 << RB))) xl.template step<LB>(x[r], x[r | (1 << RB)]);
+}
+template <class XL, class T> HE_HD void xl_T1(XL &xl, T *x)
+{
+    xl_swap_bits<5, 3>(xl, x);
+    xl_swap_bits<4, 2>(xl, x);
+    xl_swap_bits<3, 1>(xl, x);
+    xl_swap_bits<2, 0>(xl, x);
+}
+template <class XL, class T> HE_HD void xl_T2(XL &xl, T *x)
+{
+    xl_swap_bits<0, 0>(xl, x);
+    xl_swap_bits<1, 1>(xl, x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -167,13 +204,13 @@ template <class TW> HE_HD void gather_B(const TW &tw, int lane, Tw16 w[kTwB])
 }
 template <class TW> HE_HD void gather_C(const TW &tw, int lane, Tw16 w[kTwC])
 {
-    // stage 8: e >> 2 = c*64 + lane for chunk c = r >> 2 (4 entries); stage 9: e >> 1 = c*128 + lane*2 + h (8 entries)
+    // stage 8: one entry per chunk c = r >> 2 (index e >> 2 of its elements); stage 9: two per chunk (e >> 1, h = bit 1 of r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) w[c] = tw.get(8, ((u32)c << 6) | (u32)lane);
+    for (int c = 0; c < 4; ++c) w[c] = tw.get(8, (u32)elemC(lane, 4 * c) >> 2);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) w[4 + 2 * c + h] = tw.get(9, ((u32)c << 7) | ((u32)lane << 1) | (u32)h);
+        for (int h = 0; h < 2; ++h) w[4 + 2 * c + h] = tw.get(9, (u32)elemC(lane, 4 * c + 2 * h) >> 1);
 }
 // stages 0..3 on layout A (register bit 3-s' is the butterfly bit); twiddles are lane-uniform
 // One radix-2 stage over the 16 registers of U rows: butterflies (r, r | 1<<BIT) with twiddle index widx(r), issued

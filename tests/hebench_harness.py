@@ -9,10 +9,14 @@ import numpy as np
 
 MAX_BUF, MAX_OP = 256, 32
 ECODE_INVALID_ARGS, ECODE_CRITICAL = 0x7FFFFFFE, 0x7FFFFFFF
+# enumerators of include/hebench_api_bridge.h ([UPSTREAM-UNVERIFIED] recollection of api-bridge v0.8: Workload and DataType
+# are numbered from 1).  tests/test_api_bridge_cpu.py::test_harness_constants_match_the_library holds every number in this
+# file to what the library was really compiled with (he355_bridge_abi).
 LATENCY, OFFLINE = 0, 1
-W_MATMUL, W_ADD, W_MUL, W_DOT = 0, 1, 2, 3
-W_LOGREG3 = 5  # LogisticRegression_PolyD3
-DT_INT64, DT_FLOAT64 = 1, 3
+W_MATMUL, W_MUL, W_ADD, W_DOT = 1, 2, 3, 4
+W_LOGREG3 = 6  # LogisticRegression_PolyD3
+DT_INT64, DT_FLOAT64 = 2, 4
+WP_UINT64 = 1
 SCHEME_CKKS, SCHEME_BFV = 100, 101
 
 
@@ -165,7 +169,7 @@ class Backend:
     def _wparams(params):
         arr = (WorkloadParam * len(params))()
         for i, (name, v) in enumerate(params):
-            arr[i].data_type = 1
+            arr[i].data_type = WP_UINT64
             arr[i].name = name.encode()
             arr[i].u_param = v
         wp = WorkloadParams(arr, len(params))

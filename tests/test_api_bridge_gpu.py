@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from hebench_harness import Backend, LATENCY, OFFLINE, SCHEME_BFV, SCHEME_CKKS, W_ADD, W_DOT, W_MUL
+from hebench_harness import Backend, LATENCY, OFFLINE, SCHEME_BFV, SCHEME_CKKS, W_ADD, W_DOT, W_MATMUL, W_MUL
 
 pytestmark = pytest.mark.gpu
 
@@ -122,7 +122,7 @@ def _matmul(backend, dims, N, depth):
     r0, c0, c1 = dims
     rng = np.random.default_rng(sum(dims))
     A, B = rng.integers(-8, 8, (r0, c0)).astype(np.int64), rng.integers(-8, 8, (c0, c1)).astype(np.int64)
-    bench = [b for b in backend.benchmarks() if b["desc"].workload == 0 and b["desc"].other == 2 and b["desc"].scheme == SCHEME_BFV][0]
+    bench = [b for b in backend.benchmarks() if b["desc"].workload == W_MATMUL and b["desc"].other == 2 and b["desc"].scheme == SCHEME_BFV][0]
     hb = backend.create(bench, [("rows_M0", r0), ("cols_M0", c0), ("cols_M1", c1), ("PolyModulusDegree", N), ("MultiplicativeDepth", depth),
                                 ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)])
     res = backend.run(hb, [A.reshape(1, -1), B.reshape(1, -1)], r0 * c1, np.int64)
@@ -144,7 +144,7 @@ def test_bfv_matmult_row_cfg5_128(backend):
 def _matmul_val(backend, scheme, dims, N, depth, bits, other=0):
     r0, c0, c1 = dims
     rng = np.random.default_rng(sum(dims) + scheme)
-    bench = [b for b in backend.benchmarks() if b["desc"].workload == 0 and b["desc"].other == other and b["desc"].scheme == scheme][0]
+    bench = [b for b in backend.benchmarks() if b["desc"].workload == W_MATMUL and b["desc"].other == other and b["desc"].scheme == scheme][0]
     last = ("ScaleBits", bits) if scheme == SCHEME_CKKS else ("PlainModulusBits", 20)
     hb = backend.create(bench, [("rows_M0", r0), ("cols_M0", c0), ("cols_M1", c1), ("PolyModulusDegree", N), ("MultiplicativeDepth", depth),
                                 ("CoefficientModulusBits", bits), last, ("NumThreads", 0)])

@@ -121,6 +121,49 @@ def test_round_trip_through_the_evaluator(case, be):
         assert np.allclose(ho.ckks_decode(o, out.download((L, N)), scale).real, x, atol=1e-4)
 
 
+def test_encrypt_zero_and_accumulate_count_zero(case, be):
+    """accumulateCKKS / accumulateBFV with count == 0 return encryptor()->encrypt_zero (/root/reference/src/engine/
+    seal_context.cpp:312-316, 341-344): a FRESH encryption of zero at the first data level replaces each ciphertext.
+    he355_accumulate(count = 0) draws it from the context's zero stream; with the stream pinned the result is the oracle's
+    encryption of the zero plaintext under the same sampled polynomials, bit for bit, and it decrypts to zero."""
+    scheme, g, o, sk, pk, rng = case
+    N, L = g.N, g.L
+    n, seed, first = 3, 0xABCDEF, 40
+    zero_plain = np.zeros((L, N), dtype=np.uint64) if scheme == "ckks" else np.zeros(N, dtype=np.uint64)
+    want = []
+    for r in range(n):
+        su, s0, s1 = sn.enc_streams(first + r)
+        want.append(o.encrypt_explicit(pk, zero_plain, sn.sample_ternary(seed, su, N), sn.sample_cbd(seed, s0, N), sn.sample_cbd(seed, s1, N)))
+    ez = g.alloc(n * 2 * L * N)
+    g.encrypt_zero(n, seed, first, ez)
+    got = ez.download((n, 2, L, N))
+    for r in range(n):
+        assert np.array_equal(got[r], want[r]), r
+    # accumulate(count = 0): whatever the slab held is replaced
+    junk = np.stack([o.random_poly(rng, L, 2) for _ in range(n)])
+    slab, tmp = g.to_device(junk), g.alloc(n * 2 * L * N)
+    g.set_zero_stream(seed, first)
+    g.accumulate(L, n, slab, 0, tmp)
+    acc = slab.download((n, 2, L, N))
+    for r in range(n):
+        assert np.array_equal(acc[r], want[r]), r
+    # a second call continues the stream: fresh randomness, still encryptions of zero
+    g.accumulate(L, n, slab, 0, tmp)
+    acc2 = slab.download((n, 2, L, N))
+    assert not np.array_equal(acc2, acc)
+    ph = o.decrypt_phase(acc2[1], sk)
+    if scheme == "bfv":
+        assert not o.bfv_decode_phase(ph).any()
+    else:
+        q0 = o.moduli[0]
+        c0 = o.intt(0, ph[0]).astype(object)
+        c0 = np.where(c0 > q0 // 2, c0 - q0, c0)
+        assert max(abs(int(v)) for v in c0) < 2 ** 14
+    if L > 1:  # SEAL returns a top-level ciphertext there: a lower-level slab cannot hold it
+        with pytest.raises(be.HE355Error):
+            g.accumulate(L - 1, n, slab, 0, tmp)
+
+
 # ---- encoders on the device ---------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def sim():

@@ -154,6 +154,43 @@ def test_bfv_semantic_end_to_end(be, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("bits", [[40], [60]])
+def test_cfg1_literal_bfv_add_n4096_single_modulus(be, oracle, bits):
+    """BASELINE configs[0] as worded: BFV EltwiseAdd, poly_modulus_degree 4096, a single coefficient modulus, batch 1.
+    (The reference's own parameter rule cannot build it -- it always emits {60, b.., 60}, SURVEY 0.5 -- but the C ABI can:
+    one prime is both the key level and the data level, no special prime, 128-bit security gate on.)  Evaluator::add
+    (bfv eltwise .cpp:322) bit-exact against the oracle, and Enc -> add -> Dec = the cleartext sum."""
+    N = 4096
+    g = be.Context(be.SCHEME_BFV, N, bit_sizes=bits, plain_bits=20, sec128=True, device=0)
+    o = oracle.Context(oracle.SCHEME_BFV, N, bit_sizes=bits, plain_bits=20, sec128=True)
+    assert g.moduli == o.moduli and g.t == o.t == 1032193 and g.L == 1 and g.K == 1
+    rng = np.random.default_rng(bits[0])
+    a, b = o.random_poly(rng, 1, 2), o.random_poly(rng, 1, 2)
+    out = g.alloc(2 * N)
+    g.add(1, 2, 1, g.to_device(a[None]), g.to_device(b[None]), be.Context.outer(0, 1, 0, 1), out)  # batch 1 x 1
+    assert np.array_equal(out.download((2, 1, N)), o.add(a, b))
+    # semantic: real keys, device-side encryption and decryption
+    codec = oracle.BatchCodec(N, o.t)
+    sk = o.keygen_secret(1)
+    pk = o.keygen_public(sk, 2)
+    g.set_public_key(pk)
+    g.set_secret_key(sk)
+    x, y = rng.integers(-5000, 5000, N), rng.integers(-5000, 5000, N)
+    plains = np.stack([codec.encode(x), codec.encode(y)])
+    cts, s, dec = g.alloc(2 * 2 * N), g.alloc(2 * N), g.alloc(N)
+    g.encrypt(2, g.to_device(plains), 99, 0, cts)
+    g.add(1, 2, 1, cts, cts, be.Context.outer(0, 1, 1, 1), s)
+    g.decrypt(1, 2, 1, s, dec)
+    v = codec.decode(dec.download((N,)))
+    t = o.t
+    v = np.where(v > t // 2, v - t, v)
+    assert np.array_equal(v, x + y)
+    # and the oracle decrypts the device's sum to the same plaintext
+    ct = s.download((2, 1, N))
+    assert np.array_equal(o.bfv_decode_phase(o.decrypt_phase(ct, sk)), dec.download((N,)))
+    g.close()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_bfv_random_parameter_chains(be, oracle, seed):
     """Randomly drawn BFV chains (ring size, 2..5 key primes of 35..60 bits in any order, plain modulus 16..22 bits): BEHZ

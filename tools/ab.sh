@@ -1,11 +1,15 @@
 #!/bin/bash
-# A/B of two builds of the library on the same box: lib/libhebench_mi355x_backend.so against lib/alt_*.so (swapped in place).
+# A/B of library builds on the same box (usage on the GPU box: tools/ab.sh <tag> [<tag> ...]; "main" = the product).
+# Variants are built beside the product (make -C reference-seal-backend_amd/csrc VARIANT=<tag> DEFS="-D...") and selected
+# with HE355_LIB_PATH: the product file is never touched.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
-L=reference-seal-backend_amd/lib
-run() { python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 2>&1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$1', d['value'], d['ms_per_step'])"; }
-cp $L/libhebench_mi355x_backend.so /tmp/main.so
+L=$PWD/reference-seal-backend_amd/lib
+run() {
+  local tag=$1 lib=$L/alt_$1.so
+  [ "$tag" = main ] && lib=$L/libhebench_mi355x_backend.so
+  [ -f "$lib" ] || { echo "$tag: $lib missing"; return 1; }
+  HE355_LIB_PATH=$lib timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --cpu-sample 0 2>&1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$tag', d['value'], d['ms_per_step'])"
+}
 for rep in 1 2 3; do
-  cp /tmp/main.so $L/libhebench_mi355x_backend.so && run main || exit 1
-  cp $L/$1 $L/libhebench_mi355x_backend.so && run alt || exit 1
+  for tag in "$@"; do run "$tag" || exit 1; done
 done
-cp /tmp/main.so $L/libhebench_mi355x_backend.so

@@ -15,7 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from hebench_harness import (Backend, Handle, ParameterIndexer, LATENCY, OFFLINE, SCHEME_BFV, SCHEME_CKKS, W_ADD, W_DOT, W_MUL,  # noqa: E402
+from hebench_harness import (Backend, Handle, ParameterIndexer, LATENCY, OFFLINE, SCHEME_BFV, SCHEME_CKKS, W_ADD, W_DOT, W_MATMUL, W_MUL,  # noqa: E402
                              W_LOGREG3)
 
 be = importlib.import_module("reference-seal-backend_amd")
@@ -116,7 +116,7 @@ def w_matmul(b):
     rng = np.random.default_rng(5)
     r0 = c0 = c1 = 128
     A, B = rng.integers(-8, 8, (r0, c0)).astype(np.int64), rng.integers(-8, 8, (c0, c1)).astype(np.int64)
-    bench = [x for x in b.benchmarks() if x["desc"].workload == 0 and x["desc"].other == 2 and x["desc"].scheme == SCHEME_BFV][0]
+    bench = [x for x in b.benchmarks() if x["desc"].workload == W_MATMUL and x["desc"].other == 2 and x["desc"].scheme == SCHEME_BFV][0]
     hb = b.create(bench, [("rows_M0", r0), ("cols_M0", c0), ("cols_M1", c1), ("PolyModulusDegree", 32768), ("MultiplicativeDepth", 3),
                           ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)])
     res, t, nres = phases(b, hb, [A.reshape(1, -1), B.reshape(1, -1)], r0 * c1, np.int64, reps=2)
