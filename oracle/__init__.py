@@ -18,12 +18,12 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libhe_oracle.so")
 
 SCHEME_BFV = 1
 SCHEME_CKKS = 2
-OP_ADD, OP_MUL, OP_MUL_RELIN, OP_MUL_RELIN_RESCALE = 0, 1, 2, 3
+OP_ADD, OP_MUL, OP_MUL_RELIN, OP_MUL_RELIN_RESCALE, OP_DOT = 0, 1, 2, 3, 4
 
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("he_oracle.c", "he_oracle_bfv.inc", "he_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("he_oracle.c", "he_oracle_bfv.inc", "he_oracle_pipelines.inc", "he_oracle.h")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:
@@ -80,6 +80,10 @@ def lib():
             "ho_bfv_multiply": (None, [vp, sz, _u64p, _u64p, _u64p]),
             "ho_batch_op": (None, [vp, i32, sz, sz, _u64p, _u32p, _u64p, _u32p, _u64p, _u64p, i32]),
             "ho_max_threads": (i32, []),
+            "ho_rotate": (i32, [vp, sz, i32, sz, _u32p, C.POINTER(_u64p), _u64p, _u64p]),
+            "ho_accumulate": (i32, [vp, sz, sz, sz, _u32p, C.POINTER(_u64p), _u64p]),
+            "ho_batch_outer": (i32, [vp, i32, sz, sz, sz, _u64p, _u64p, _u64p, sz, _u32p, C.POINTER(_u64p), sz, _u64p, i32]),
+            "ho_bfv_matmul_rows": (i32, [vp, sz, sz, _u64p, _u64p, _u64p, sz, _u32p, C.POINTER(_u64p), sz, _u64p, i32]),
             "ho_keygen_secret": (None, [vp, u64, _u64p]),
             "ho_keygen_public": (None, [vp, _u64p, u64, _u64p]),
             "ho_keygen_kswitch": (None, [vp, _u64p, _u64p, u64, _u64p]),
@@ -258,6 +262,58 @@ class Context:
         ib = np.ascontiguousarray(idx_b, dtype=np.uint32)
         rk = _p(relin_key) if relin_key is not None else None
         lib().ho_batch_op(self.h, op, L, n, _p(a), _p32(ia), _p(b), _p32(ib), rk, _p(out), threads)
+        return out
+
+    @staticmethod
+    def _gk(galois_keys):
+        """dict {galois element: key array} -> (count, element array, pointer array); the arrays must outlive the call"""
+        galois_keys = galois_keys or {}
+        elts = np.array(sorted(galois_keys), dtype=np.uint32)
+        ptrs = (_u64p * max(1, len(elts)))(*[_p(galois_keys[int(e)]) for e in elts])
+        return len(elts), elts, ptrs
+
+    def rotate(self, ct, step, galois_keys):
+        """Evaluator::rotate_vector / rotate_rows with SEAL's NAF decomposition over the given keys"""
+        L = ct.shape[1]
+        ct = np.ascontiguousarray(ct)
+        out = np.empty_like(ct)
+        n, elts, ptrs = self._gk(galois_keys)
+        if lib().ho_rotate(self.h, L, step, n, _p32(elts) if n else None, ptrs, _p(ct), _p(out)):
+            raise KeyError("Galois key not present / step count too large")
+        return out
+
+    def accumulate(self, ct, count, galois_keys):
+        """SEALContextWrapper::accumulateCKKS / accumulateBFV (count > 0)"""
+        L = ct.shape[1]
+        out = np.ascontiguousarray(ct).copy()
+        n, elts, ptrs = self._gk(galois_keys)
+        if lib().ho_accumulate(self.h, L, count, n, _p32(elts) if n else None, ptrs, _p(out)):
+            raise KeyError("Galois key not present / count 0")
+        return out
+
+    def batch_outer(self, op, a, b, relin_key=None, galois_keys=None, count=0, threads=0):
+        """operate() of the element-wise / dot-product workloads: a [b0, 2, L, N], b [b1, 2, L, N] -> [b0*b1, size, L', N], result
+        i*b1 + x = op(a[i], b[x]); OpenMP `parallel for collapse(2)` as the reference (ckks eltwise .cpp:325)."""
+        b0, b1, L = a.shape[0], b.shape[0], a.shape[2]
+        n = b0 * b1
+        shape = {OP_ADD: (n, 2, L, self.N), OP_MUL: (n, 3, L, self.N), OP_MUL_RELIN: (n, 2, L, self.N),
+                 OP_MUL_RELIN_RESCALE: (n, 2, L - 1, self.N), OP_DOT: (n, 2, L, self.N)}[op]
+        out = np.empty(shape, dtype=np.uint64)
+        ng, elts, ptrs = self._gk(galois_keys)
+        rk = _p(relin_key) if relin_key is not None else None
+        if lib().ho_batch_outer(self.h, op, L, b0, b1, _p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), rk, ng, _p32(elts) if ng else None, ptrs,
+                                count, _p(out), threads):
+            raise KeyError("Galois key not present")
+        return out
+
+    def bfv_matmul_rows(self, A, B, relin_key, galois_keys, dim2, threads=0):
+        """MatMultRowLatencyBenchmark::matmultrow (bfv row .cpp:486-539): A [n, 2, L, N] row-pair ciphertexts, B [2, L, N]"""
+        n, L = A.shape[0], A.shape[2]
+        out = np.empty_like(A)
+        ng, elts, ptrs = self._gk(galois_keys)
+        if lib().ho_bfv_matmul_rows(self.h, L, n, _p(np.ascontiguousarray(A)), _p(np.ascontiguousarray(B)), _p(relin_key), ng, _p32(elts) if ng else None, ptrs,
+                                    dim2, _p(out), threads):
+            raise KeyError("Galois key not present")
         return out
 
     # -- keys / encryption -----------------------------------------------------------------------

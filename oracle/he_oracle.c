@@ -1046,3 +1046,4 @@ void ho_bfv_decode_phase(const ho_ctx *c, size_t L, const u64 *phase, u64 *plain
 /* BFV multiply (BEHZ) lives in he_oracle_bfv.c                                                       */
 /* ------------------------------------------------------------------------------------------------ */
 #include "he_oracle_bfv.inc"
+#include "he_oracle_pipelines.inc"

@@ -111,6 +111,17 @@ void ho_bfv_multiply(const ho_ctx *c, size_t L, const uint64_t *a, const uint64_
 void ho_batch_op(const ho_ctx *c, int op, size_t L, size_t n_results, const uint64_t *a, const uint32_t *idx_a,
                  const uint64_t *b, const uint32_t *idx_b, const uint64_t *relin_key, uint64_t *out, int threads);
 int ho_max_threads(void);
+#define HO_OP_DOT 4            /* ckks/bfv dot .cpp: multiply -> relinearize_inplace -> accumulate(count)        */
+/* Evaluator::rotate_internal with the NAF decomposition (util::naf) over the Galois keys given as (element, key) arrays */
+int ho_rotate(const ho_ctx *c, size_t L, int step, size_t n_gk, const uint32_t *gk_elts, const uint64_t *const *gk_keys, const uint64_t *in, uint64_t *out);
+/* SEALContextWrapper::accumulateCKKS / accumulateBFV, count > 0, in place on a size-2 ciphertext */
+int ho_accumulate(const ho_ctx *c, size_t L, size_t count, size_t n_gk, const uint32_t *gk_elts, const uint64_t *const *gk_keys, uint64_t *ct);
+/* operate() of the element-wise / dot-product workloads: `omp parallel for collapse(2)` over (i < b0, x < b1), result i*b1+x */
+int ho_batch_outer(const ho_ctx *c, int op, size_t L, size_t b0, size_t b1, const uint64_t *a, const uint64_t *b, const uint64_t *relin_key,
+                   size_t n_gk, const uint32_t *gk_elts, const uint64_t *const *gk_keys, size_t count, uint64_t *out, int threads);
+/* BFV MatMultRow: out[i] = sum_j rotate_rows(relin(A[i] * B), j * (N/2)/dim2), two-level parallel region as the reference's */
+int ho_bfv_matmul_rows(const ho_ctx *c, size_t L, size_t n_cts, const uint64_t *A, const uint64_t *B, const uint64_t *relin_key, size_t n_gk,
+                       const uint32_t *gk_elts, const uint64_t *const *gk_keys, size_t dim2, uint64_t *out, int threads);
 
 /* ---- keys / encryption (own sampling; distribution as SEAL: ternary secret, CBD(21) error) ------- */
 /* secret key: [K][N] NTT form */

@@ -123,6 +123,12 @@ __device__ __forceinline__ void store_rowC(u64 *row, int lane, const u64 v[kRowE
 #define HE355_XCHG 0
 #endif
 constexpr bool kXlT1 = (HE355_XCHG & 2) != 0, kXlT2 = (HE355_XCHG & 1) != 0;
+// HE355_KSHARE: K3's blocks stage the key rows of a digit step in LDS once for their eight waves (k_k3, KSHARE).  The LDS for it
+// is what the exchange buffers would take, so it needs both transposes on the cross-lane path.
+#ifndef HE355_KSHARE
+#define HE355_KSHARE 0
+#endif
+constexpr bool kKeyShare = HE355_KSHARE != 0 && kXlT1 && kXlT2;
 struct XLaneHw {
     int lane;
     template <int LB> __device__ __forceinline__ void step32(u32 &a, u32 &b) const
@@ -919,9 +925,18 @@ struct K3Args {
 // registers — the wave transforms the matching rows of the special-prime correction (forward row pass, same tile twiddles)
 // and writes (T - NTT(delta)) * P^-1 + c01 straight into c01.  Needs the special prime's sums first: the caller launches the
 // special-prime tiles, the inverse transform and k_floor_cols before the data-prime tiles.
-template <class Ar, int U, int WAVES, bool STAGE, bool FUSE = false>
+// KSHARE: the key rows of a digit step are the same for all eight waves of the block (eight ops of one (prime, row) tile), and
+// fetched by each wave from L2 right before its multiply-accumulate they cost the kernel 11 % in exposed latency (measured: a
+// build that reads every key row from one L1-resident row, profiles/r02_k3_ablation.txt).  With KSHARE the block stages them in
+// LDS once per step, one step ahead, by LDS-DMA (each wave moves 1 KiB pieces of the 2 or 4 rows: key residues, and their Shoup
+// quotients for the u64 engine) into a double buffer; one workgroup barrier per digit step hands a buffer over.  The image is
+// chunk-swizzled (kswz) so that the layout-C reads (a quad of lanes = 128 consecutive bytes, quads 512 bytes apart) are
+// conflict-free ds_read_b128.  Needs the exchange buffers' LDS, i.e. the cross-lane transposes (HE355_XCHG = 3).
+__device__ __forceinline__ u32 kswz(u32 quad) { return (quad & 1u) | ((quad & 2u) << 2); } // XOR mask on the 16-byte chunk index: 0, 1, 8, 9
+template <class Ar, int U, int WAVES, bool STAGE, bool FUSE = false, bool KSHARE = false>
 __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *primes)
 {
+    static_assert(!KSHARE || (U == 1 && STAGE && WAVES == 8), "shared key staging is written for the 8-wave staged shape");
     constexpr int kWaves = WAVES, kBlock = WAVES * 64; // this kernel's own block shape (shadows the file-wide one)
     typedef typename Ar::T T;
     typedef typename Ar::Acc Acc;
@@ -934,6 +949,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
     __shared__ u64 lds[kWaves][U][kLdsRow];
     __shared__ __attribute__((aligned(16))) u64 stage[STAGE ? kWaves : 1][STAGE ? U : 1][STAGE ? kRowN : 2];
     __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
+    constexpr int kKeyArrays = Ar::kKeyQuotient ? 4 : 2; // key rows of polynomial 0, 1 (+ their quotient rows)
+    __shared__ __attribute__((aligned(16))) u64 keybuf[KSHARE ? 2 : 1][KSHARE ? kKeyArrays : 1][KSHARE ? kRowN : 2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 n1 = 1u << A.logn1;
     const u64 N = (u64)n1 << kRowLog;
@@ -997,6 +1014,38 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             mac_poly(acc0, x, j, 0);
             mac_poly(acc1, x, j, 1);
         };
+        // KSHARE: this wave's share of the block's key rows of digit j -> keybuf[b] (wave w moves piece w of every array)
+        auto key_dma = [&](int j, int b) {
+#pragma unroll
+            for (int arr = 0; arr < kKeyArrays; ++arr) {
+                const u64 *src = arr < 2 ? key_row(j, arr) : keyq_row(j, arr - 2);
+                const u32 slot = 64u * (u32)wave + (u32)lane;     // 16-byte slot of the LDS image this lane fills
+                const u32 chunk = slot ^ kswz((slot >> 5) & 3u);  // the row's chunk that lives there
+                __builtin_amdgcn_global_load_lds((glb_void_t *)(src + 2 * chunk), (lds_void_t *)(keybuf[KSHARE ? b : 0][KSHARE ? arr : 0] + 128 * wave), 16, 0, 0);
+            }
+        };
+        auto key_lds = [&](const u64 *img, u64 kv[kRowE]) { // layout-C registers of a staged row
+            const u32 quad = (u32)lane >> 2, m = (u32)lane & 3u, swz = kswz(quad & 3u);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32 slot = quad * 32u + (((u32)c * 8u + m * 2u + (u32)h) ^ swz);
+                    const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(img)[slot];
+                    kv[4 * c + 2 * h] = v.x; kv[4 * c + 2 * h + 1] = v.y;
+                }
+        };
+        auto mac_digit_lds = [&](const T x[kRowE], int b) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                u64 kv[kRowE], kq[kRowE];
+                key_lds(keybuf[KSHARE ? b : 0][KSHARE ? k : 0], kv);
+                if constexpr (Ar::kKeyQuotient) key_lds(keybuf[KSHARE ? b : 0][KSHARE ? 2 + k : 0], kq);
+                Acc *acc = k == 0 ? acc0 : acc1;
+#pragma unroll
+                for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc[r], x[r], ar.key_in(kv[r]), Ar::kKeyQuotient ? kq[r] : 0);
+            }
+        };
         // digits that go through the forward row pass: all of them, except (CKKS) the one that lives under this very
         // prime -- that one is the NTT-form target itself and is multiplied in directly
         const bool has_own = A.ckks && tt < A.L;
@@ -1011,6 +1060,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (u < nd) dma_row_to_lds<kDigitPieces>(src_row(digit(u)), stage[wave][u], lane);
+        }
+        if constexpr (KSHARE) {
+            __syncthreads(); // every wave is done with the key buffers of the previous op-group
+            if (nd > 0) key_dma(digit(0), 0);
         }
         u64 vn[kRowE]; // !STAGE: the next digit's row, in flight or landed
         Row48 vn48;
@@ -1051,7 +1104,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             // digit rows: transform + key MAC (the last one prefetches the first correction row)
             for (int i = 0; i < nd; ++i) {
                 T x[1][kRowE];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's row has landed in the staging buffer
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's row (and this wave's share of its key rows) has landed in LDS
+                if constexpr (KSHARE) __syncthreads();            // ... and so has every other wave's share; all waves are past the previous step's MAC
                 if constexpr (kPacked) {
                     lds_rowA48(stage[wave][0], lane, x[0]);
                 } else {
@@ -1064,8 +1118,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 // next row, behind this step's math: a digit row (packed for this engine) or the first correction row (64-bit words)
                 if (i + 1 < nd) dma_row_to_lds<kDigitPieces>(row_ptr(i + 1), stage[wave][0], lane);
                 else dma_row_to_lds(row_ptr(i + 1), stage[wave][0], lane);
+                if constexpr (KSHARE) {
+                    if (i + 1 < nd) key_dma(digit(i + 1), (i + 1) & 1); // the buffer the previous step's MAC read
+                }
                 wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
-                mac_digit(x[0], digit(i));
+                if constexpr (KSHARE) mac_digit_lds(x[0], i & 1);
+                else mac_digit(x[0], digit(i));
             }
             // correction rows: transform + floor step(s)
 #pragma unroll 1
@@ -1100,6 +1158,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 if constexpr (STAGE) {
                     u64 v[kRowE];
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the rows of this step have landed in the staging buffers
+                    if constexpr (KSHARE) __syncthreads();            // and the block's key rows of this step (see the fused loop)
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         if (u < cnt) {
@@ -1116,6 +1175,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
 #pragma unroll
                     for (int u = 0; u < U; ++u)
                         if (i + U + u < nd) dma_row_to_lds<kDigitPieces>(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
+                    if constexpr (KSHARE) {
+                        if (i + 1 < nd) key_dma(digit(i + 1), (i + 1) & 1);
+                    }
                 } else {
                     asm volatile("" ::: "memory"); // keeps the LDS twiddle reads inside the loop (hoisted, they would cost 54 registers)
                     if constexpr (kPacked) {
@@ -1133,9 +1195,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                     for (int r = 0; r < kRowE; ++r) x[U - 1][r] = 0;
                 }
                 wave_rows_fwd_n<U>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
+                if constexpr (KSHARE) {
+                    mac_digit_lds(x[0], i & 1);
+                } else {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (u < cnt) mac_digit(x[u], digit(i + u));
+                    for (int u = 0; u < U; ++u)
+                        if (u < cnt) mac_digit(x[u], digit(i + u));
+                }
             }
             // Epilogue: canonical sums, NTT form, layout C.  Data primes -> t; special prime -> tp.  Where the next step is the
             // inverse transform of these very rows (the special prime always; every prime for BFV, whose key switch returns to
@@ -2034,8 +2100,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             switch (shape) {
             case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
             case 18:
-                if (fuse) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
-                else if (staged) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                if (fuse) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                else if (staged) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, false, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 else hipLaunchKernelGGL((k_k3<ArF64, 1, 8, false>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 break;
             default: throw std::runtime_error("unsupported K3 fp64 shape");
@@ -2044,8 +2110,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             switch (shape) {
             case 14: hipLaunchKernelGGL((k_k3<ArU64, 1, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
             case 18:
-                if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
-                else if (staged) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                else if (staged) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, false, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 else hipLaunchKernelGGL((k_k3<ArU64, 1, 8, false>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 break;
             default: throw std::runtime_error("unsupported K3 u64 shape");
