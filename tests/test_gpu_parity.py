@@ -643,3 +643,75 @@ def test_pipeline_regression_fixture_gpu(be, oracle):
         g.apply_galois(L, n, da, elt, out)
         assert sha(out, (n, 2, L, N)) == exp["rotate_1"], case["name"]
         g.close()
+
+
+@pytest.mark.parametrize("name", ["ckks_n1024_60_40_60", "ckks_n1024_50_45_45_50", "ckks_n2048_60_45_45_60", "bfv_n1024_60_40_60"])
+def test_exact_model_fixture_gpu(be, name):
+    """The HIP path against tests/golden/exact_vectors.json: expected outputs derived by the exact big-integer model
+    (tests/golden/exact_model.py: CRT composition, exact floors, no RNS shortcuts, no oracle code).  The oracle is held to the same
+    file on the CPU (tests/test_exact_model.py); here neither the oracle nor any CPU path is involved.  Step-by-step calls and the
+    fused sequences (multiply_relin with and without rescale, relinearize_rescale) must all land on the model's ciphertexts."""
+    import test_exact_model as tem
+    f, d = tem.case_inputs(name)
+    ckks = f["scheme"] == "ckks"
+    N, L = f["N"], d["Ltop"]
+    g = be.Context(be.SCHEME_CKKS if ckks else be.SCHEME_BFV, N, bit_sizes=f["bits"], plain_bits=0 if ckks else 20, sec128=False, device=0)
+    assert [int(q) for q in g.moduli] == d["primes"]
+    pw = be.Context.pairwise()
+    g.set_relin_key(d["rk"])
+    for elt, key in d["gk"].items():
+        g.set_galois_key(elt, key)
+
+    class HipOps:
+        def add(self, a, b):
+            out = g.alloc(a.size)
+            g.add(a.shape[1], a.shape[0], 1, g.to_device(a[None]), g.to_device(b[None]), pw, out)
+            return out.download(a.shape)
+
+        def multiply(self, a, b):
+            out = g.alloc(3 * a.shape[1] * N)
+            g.multiply(a.shape[1], 1, g.to_device(a[None]), g.to_device(b[None]), pw, out)
+            return out.download((3, a.shape[1], N))
+
+        def relinearize(self, c3, rk):
+            out = g.alloc(2 * c3.shape[1] * N)
+            g.relinearize(c3.shape[1], 1, g.to_device(np.ascontiguousarray(c3)[None]), out)
+            return out.download((2, c3.shape[1], N))
+
+        def rescale(self, ct):
+            out = g.alloc(ct.shape[0] * (ct.shape[1] - 1) * N)
+            g.rescale(ct.shape[1], ct.shape[0], 1, g.to_device(ct[None]), out)
+            return out.download((ct.shape[0], ct.shape[1] - 1, N))
+
+        def apply_galois(self, ct, elt, key):
+            out = g.alloc(ct.size)
+            g.apply_galois(ct.shape[1], 1, g.to_device(ct[None]), elt, out)
+            return out.download(ct.shape)
+
+    seen = set()
+    for opname, got in tem.run_ops(f, d, HipOps()):
+        tem.check(f, opname, got)
+        seen.add(opname)
+    assert seen == set(f["expected"])
+    da, db = g.to_device(d["a"][None]), g.to_device(d["b"][None])
+    if ckks:  # the fused kernel sequences
+        out = g.alloc(2 * L * N)
+        g.multiply_relin(L, 1, da, db, pw, out)
+        tem.check(f, "multiply_relin", out.download((2, L, N)))
+        out2 = g.alloc(2 * (L - 1) * N)
+        g.multiply_relin(L, 1, da, db, pw, out2, rescale=True)
+        tem.check(f, "multiply_relin_rescale", out2.download((2, L - 1, N)))
+        c3 = g.alloc(3 * L * N)
+        g.multiply(L, 1, da, db, pw, c3)
+        g.relinearize_rescale(L, 1, c3, out2)
+        tem.check(f, "multiply_relin_rescale", out2.download((2, L - 1, N)))
+    # Evaluator::rotate_internal without a key for step 3: the NAF terms -1, +4 through he355_rotate
+    g3 = be.Context(be.SCHEME_CKKS if ckks else be.SCHEME_BFV, N, bit_sizes=f["bits"], plain_bits=0 if ckks else 20, sec128=False, device=0)
+    for elt, key in d["gk"].items():
+        if elt != g3.galois_elt(3):
+            g3.set_galois_key(elt, key)
+    out = g3.alloc(2 * L * N)
+    g3.rotate(L, 1, g3.to_device(d["a"][None]), 3, out)
+    tem.check(f, "rotate_3_naf", out.download((2, L, N)))
+    g3.close()
+    g.close()
