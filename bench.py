@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: CKKS multiply -> relinearize -> rescale, N=2^15, L=16, batch 1024 per GPU.
+"""Benchmarks of the hot path on MI355X, one JSON line per run (rank 0).
 
-Metric (BASELINE.json): ciphertext-ops/sec, one op = one result ciphertext of the per-pair pipeline
-(multiply, relinearize_inplace, rescale_to_next_inplace — the sequence at
-/root/reference/src/benchmarks/ckks/seal_ckks_matmultval_benchmark.cpp:253-255 applied per batch element with
-the HEBench outer-product indexing of seal_ckks_element_wise_benchmark.cpp:322-336, here 1024 x 1).
+Default (the judged line) = BASELINE.json configs[2], the configuration `metric` is quoted on:
+CKKS multiply -> relinearize -> rescale, N=2^15, L=16, batch 1024 per GPU.  One op = one result ciphertext of the per-pair
+pipeline (the sequence at /root/reference/src/benchmarks/ckks/seal_ckks_matmultval_benchmark.cpp:253-255 applied per batch
+element with the HEBench outer-product indexing of seal_ckks_element_wise_benchmark.cpp:322-336).  A "step" is one pass of
+that pipeline over the rank's resident shard of the batch.
 
-A "step" is one pass of that pipeline over the whole resident batch.  Inputs (uniform residues — a uniformly
-random ciphertext is distribution-identical to a real one) and the relinearization key are
-generated in HBM before the timed region.  One process per GPU; the batch is sharded by replication of the
-workload (weak scaling: 1024 results per GPU), no data-path collective: the units are independent
-(SURVEY.md §8e).
+  --config mul_relin_rescale | eltwise_mul | dot | bfv_matmul | bfv_add     (BASELINE.json configs[2], [1], [3], [4], [0])
+  --scaling weak | strong      weak (default): --batch results PER GPU, global batch = batch x N;  strong: --batch is the GLOBAL
+                               batch, cut into contiguous blocks of operand 0 (reference-seal-backend_amd/sharding.py)
+One process per GPU (torch.distributed.run), no data-path collective: results are independent.  Every rank
+builds the same evaluation keys on its own device from the shared seed (the generators are counter-based: a pure function of
+seed and index) and fills its shard of the global operand array with the values the whole array holds there
+(he355_fill_uniform_at), so the job computes the same global batch at every world size.
 
-Prints ONE JSON line on rank 0.
+Timing: W untimed warm-up steps, barrier + synchronize, K timed steps, barrier + synchronize, MAX over ranks; `value` =
+results of all ranks / that time.  Inputs and keys are resident in HBM before the timed region.  Rank 0 at N=1 also times the
+oracle (CPU port, `cpu_baseline`) on a bounded sample; every rank pushes a small sample of ITS shard through the checker and
+compares bit for bit (`parity`): a mismatch on any rank makes the run exit non-zero.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -29,42 +36,302 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N = 32768
-DEPTH = 16
-COEFF_BITS = 45
-BATCH = 1024
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
+SEED_A, SEED_B, SEED_RELIN, SEED_GALOIS = 1234, 99, 7, 100
 
 
-def algorithmic_bytes_per_op(L: int, n: int, batch: int, K: int) -> float:
-    """read 2 cts + write 1 ct at L-1 + the relin key once per batch."""
-    ct_in = 2 * L * n * 8
-    ct_out = 2 * (L - 1) * n * 8
-    key = L * 2 * K * n * 8
-    return 2 * ct_in + ct_out + key / batch
+def load_sharding():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("he355_sharding", os.path.join(ROOT, "reference-seal-backend_amd", "sharding.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules.setdefault("he355_sharding", mod)
+    spec.loader.exec_module(mod)
+    return mod
 
 
-def cpu_baseline(be, sample_ops: int, bits):
-    """Oracle (CPU port of the SEAL-algorithm pipeline) timed on this host's cores on a bounded sample;
-    the same sample is pushed through the GPU path and compared bit-for-bit."""
-    import oracle as ho
-    o = ho.Context(ho.SCHEME_CKKS, N, bit_sizes=bits)
-    rng = np.random.default_rng(1234)
-    L = o.L
-    a = np.stack([o.random_poly(rng, L, 2) for _ in range(sample_ops)])
-    b = o.random_poly(rng, L, 2)[None]
-    rk = o.random_kswitch_key(rng)
-    threads = ho.lib().ho_max_threads()
-    idx_a = np.arange(sample_ops, dtype=np.uint32)
-    idx_b = np.zeros(sample_ops, dtype=np.uint32)
-    o.batch_op(ho.OP_MUL_RELIN_RESCALE, a[:threads], idx_a[:threads], b, idx_b[:threads], rk)  # warm-up (tables, pages)
-    times = []
-    for _ in range(3):  # median of three timed passes over the sample (after the warm-up above)
-        t0 = time.perf_counter()
-        want = o.batch_op(ho.OP_MUL_RELIN_RESCALE, a, idx_a, b, idx_b, rk)
-        times.append(time.perf_counter() - t0)
-    dt = sorted(times)[1]
-    return dict(value=sample_ops / dt, seconds=dt, cores=threads, a=a, b=b, rk=rk, want=want, total_seconds=sum(times))
+# ---------------------------------------------------------------------------------------------------------------
+# Workloads.  Each owns: the context parameters, the resident operands of this rank's shard, step(), the algorithmic
+# bytes per result, and the checker leg (oracle on a bounded sample of the shard).
+# ---------------------------------------------------------------------------------------------------------------
+class Workload:
+    name = ""
+    scheme = "ckks"
+    N = 32768
+    bits: list = []
+    plain_bits = 0
+    b1 = 1                 # operand-1 batch (replicated on every rank)
+    default_batch = 1024   # operand-0 batch per GPU (weak) / global (strong)
+    default_cpu_sample = 0
+    parity_sample = 2
+
+    def __init__(self, be, ctx, shard, args):
+        self.be, self.ctx, self.shard, self.args = be, ctx, shard, args
+        self.L, self.K = ctx.L, ctx.K
+        self.rows = shard.a_count            # operand-0 rows of this rank
+        self.n = shard.n_results             # results of this rank per step
+        self.pm = list(range(self.L))
+
+    # operand 0: this rank's rows of the global array; operand 1: replicated
+    def fill_operands(self, size=2):
+        c, L, N = self.ctx, self.L, self.N
+        self.d_a = c.alloc(max(1, self.rows) * size * L * N)
+        self.d_b = c.alloc(self.b1 * size * L * N)
+        c.fill_uniform(self.d_a, self.rows * size * L, self.pm, SEED_A, first_poly=self.shard.a_base * size * L)
+        c.fill_uniform(self.d_b, self.b1 * size * L, self.pm, SEED_B)
+        self.ix = self.be.Context.outer(0, self.rows, 0, self.b1)
+
+    def host_operands(self, rows, size=2):
+        """the first `rows` rows of this rank's operand 0 and all of operand 1, as numpy arrays (checker input)"""
+        L, N = self.L, self.N
+        a = self.d_a.download_head((rows, size, L, N))
+        b = self.d_b.download_head((self.b1, size, L, N))
+        return a, b
+
+    def key_bytes(self):
+        return self.L * 2 * self.K * self.N * 8
+
+    in_size, out_size, out_drop, n_keys = 2, 2, 0, 0  # ciphertext sizes in / out, residues dropped by the pipeline, evaluation keys touched
+
+    def compulsory_bytes_per_op(self, b0, b1):
+        """bytes that must cross HBM per result when every operand row and key is read once per batch and every result written once"""
+        poly = self.N * 8
+        ct_in, ct_out = self.in_size * self.L * poly, self.out_size * (self.L - self.out_drop) * poly
+        return ct_out + ct_in / b1 + ct_in / b0 + self.n_keys * self.key_bytes() / (b0 * b1)
+
+    def describe(self):
+        raise NotImplementedError
+
+
+class MulRelinRescale(Workload):
+    """configs[2]: multiply -> relinearize_inplace -> rescale_to_next_inplace (ckks matmultval .cpp:253-255)"""
+    name = "mul_relin_rescale"
+    out_drop, n_keys = 1, 1
+    N, depth, coeff_bits = 32768, 16, 45
+    default_batch, default_cpu_sample = 1024, 256
+
+    def setup(self):
+        c, L, N = self.ctx, self.L, self.N
+        self.fill_operands()
+        self.d_out = c.alloc(max(1, self.n) * 2 * (L - 1) * N)
+        c.set_relin_key_synthetic(SEED_RELIN)
+
+    def step(self):
+        self.ctx.multiply_relin(self.L, self.n, self.d_a, self.d_b, self.ix, self.d_out, rescale=True)
+
+    def bytes_per_op(self, global_batch):
+        """read 2 cts + write 1 ct at L-1 + the relin key once per batch = 24,780,800 B at batch 1024"""
+        L, N = self.L, self.N
+        return 2 * (2 * L * N * 8) + 2 * (L - 1) * N * 8 + self.key_bytes() / global_batch
+
+    def result_rows(self, k):
+        return self.d_out.download_head((k, 2, self.L - 1, self.N))
+
+    def checker(self, ho, o, rows, threads, passes):
+        """oracle on the first `rows` rows of the shard; returns (seconds per pass list, expected results)"""
+        a, b = self.host_operands(rows)
+        rk = synthetic_key_host(self.ctx, o, SEED_RELIN)
+        o.batch_outer(ho.OP_MUL_RELIN_RESCALE, a[:min(rows, threads)], b, rk, threads=threads)  # warm-up (tables, pages)
+        times, want = [], None
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            want = o.batch_outer(ho.OP_MUL_RELIN_RESCALE, a, b, rk, threads=threads)
+            times.append(time.perf_counter() - t0)
+        return times, want
+
+    def describe(self):
+        return (f"CKKS EltwiseMult + relinearize + rescale, N=2^15, depth 16 (L=16 data primes + 1 special) (BASELINE.json configs[2])")
+
+
+class EltwiseMul(Workload):
+    """configs[1]: Evaluator::multiply only (ckks eltwise .cpp:343), size-3 results"""
+    name = "eltwise_mul"
+    out_size = 3
+    N, depth, coeff_bits = 16384, 8, 45
+    default_batch, default_cpu_sample = 256, 256
+
+    def setup(self):
+        c, L, N = self.ctx, self.L, self.N
+        self.fill_operands()
+        self.d_out = c.alloc(max(1, self.n) * 3 * L * N)
+
+    def step(self):
+        self.ctx.multiply(self.L, self.n, self.d_a, self.d_b, self.ix, self.d_out)
+
+    def bytes_per_op(self, global_batch):
+        return 7 * self.L * self.N * 8  # SURVEY.md 8d cfg2: read 4 polys, write 3 = 7,340,032 B
+
+    def result_rows(self, k):
+        return self.d_out.download_head((k, 3, self.L, self.N))
+
+    def checker(self, ho, o, rows, threads, passes):
+        a, b = self.host_operands(rows)
+        times, want = [], None
+        o.batch_outer(ho.OP_MUL, a[:min(rows, threads)], b, threads=threads)
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            want = o.batch_outer(ho.OP_MUL, a, b, threads=threads)
+            times.append(time.perf_counter() - t0)
+        return times, want
+
+    def describe(self):
+        return "CKKS EltwiseMult (multiply only, size-3 results), N=2^14, depth 8 (L=8) (BASELINE.json configs[1])"
+
+
+class DotProduct(Workload):
+    """configs[3]: multiply -> relinearize_inplace -> accumulateCKKS(4096) (ckks dot .cpp:325-330): 13 key switches per result"""
+    name = "dot"
+    n_keys = 13
+    N, depth, coeff_bits = 32768, 16, 45
+    count = 4096
+    default_batch, default_cpu_sample = 64, 8
+    parity_sample = 1
+
+    def setup(self):
+        c, L, N = self.ctx, self.L, self.N
+        self.fill_operands()
+        self.d_out = c.alloc(max(1, self.n) * 2 * L * N)
+        self.d_tmp = c.alloc(max(1, self.n) * 2 * L * N)
+        c.set_relin_key_synthetic(SEED_RELIN)
+        self.steps_log = 12
+        for k in range(self.steps_log):
+            c.set_galois_key_synthetic(c.galois_elt(1 << k), SEED_GALOIS + k)
+
+    def step(self):
+        self.ctx.multiply_relin(self.L, self.n, self.d_a, self.d_b, self.ix, self.d_out)
+        self.ctx.accumulate(self.L, self.n, self.d_out, self.count, self.d_tmp)
+
+    def bytes_per_op(self, global_batch):
+        """16 MiB in + 8 MiB out = 25,165,824 B + (relin + 12 Galois keys) once per batch"""
+        L, N = self.L, self.N
+        return 2 * (2 * L * N * 8) + 2 * L * N * 8 + 13 * self.key_bytes() / global_batch
+
+    def result_rows(self, k):
+        return self.d_out.download_head((k, 2, self.L, self.N))
+
+    def checker(self, ho, o, rows, threads, passes):
+        a, b = self.host_operands(rows)
+        rk = synthetic_key_host(self.ctx, o, SEED_RELIN)
+        gk = {o.galois_elt(1 << k): synthetic_key_host(self.ctx, o, SEED_GALOIS + k) for k in range(self.steps_log)}
+        times, want = [], None
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            want = o.batch_outer(ho.OP_DOT, a, b, rk, gk, self.count, threads=threads)
+            times.append(time.perf_counter() - t0)
+        return times, want
+
+    def describe(self):
+        return ("CKKS DotProduct, vector length 4096: multiply + relinearize + 12 x (rotate 2^i + add), N=2^15, depth 16 (L=16), 13 key switches per "
+                "result (BASELINE.json configs[3])")
+
+
+class BfvMatMul(Workload):
+    """configs[4]: BFV MatMultRow 128x128x128 (bfv row .cpp:486-539): per row-pair ciphertext multiply + relinearize + 127 rotate_rows
+    (j * 128, NAF-decomposed: 355 key switches) + add.  One op = one result (row-pair) ciphertext; 64 per matrix product."""
+    name = "bfv_matmul"
+    n_keys = 29
+    scheme = "bfv"
+    N, bits, plain_bits = 32768, [60, 40, 40, 60], 20
+    dim = 128
+    default_batch, default_cpu_sample = 64, 2
+    parity_sample = 1
+
+    def setup(self):
+        c, L, N = self.ctx, self.L, self.N
+        self.fill_operands()
+        n = max(1, self.n)
+        self.c3, self.base, self.rot, self.acc = c.alloc(n * 3 * L * N), c.alloc(n * 2 * L * N), c.alloc(n * 2 * L * N), c.alloc(n * 2 * L * N)
+        c.set_relin_key_synthetic(SEED_RELIN)
+        self.gk_steps = []
+        k = 0
+        while (1 << k) < N // 2:  # the default Galois key set: +-2^k row rotations (create_galois_keys, seal_context.cpp:69)
+            self.gk_steps += [1 << k, -(1 << k)]
+            k += 1
+        for i, s in enumerate(self.gk_steps):
+            c.set_galois_key_synthetic(c.galois_elt(s), SEED_GALOIS + i)
+        self.spacers = (N // 2) // self.dim
+        self.result = None
+
+    def step(self):
+        c, L, n = self.ctx, self.L, self.n
+        c.bfv_multiply(L, n, self.d_a, self.d_b, self.ix, self.c3)
+        c.relinearize(L, n, self.c3, self.base)
+        cur, nxt = self.base, self.acc  # every rotate + add_inplace pair is one rotate_add pipeline (bridge/matmult_row.cpp)
+        for j in range(1, self.dim):
+            c.rotate_add(L, n, self.base, j * self.spacers, cur, nxt)
+            cur, nxt = (nxt, self.rot) if cur is self.base else (nxt, cur)
+        self.result = cur
+
+    def bytes_per_op(self, global_batch):
+        """per result ciphertext: read A[i] and write the result (2 x 2 L N 8), + B and the keys (relin + 28 Galois) once per batch"""
+        L, N = self.L, self.N
+        ct = 2 * L * N * 8
+        return 2 * ct + (ct + (1 + len(self.gk_steps)) * self.key_bytes()) / global_batch
+
+    def result_rows(self, k):
+        return self.result.download_head((k, 2, self.L, self.N))
+
+    def checker(self, ho, o, rows, threads, passes):
+        a, b = self.host_operands(rows)
+        rk = synthetic_key_host(self.ctx, o, SEED_RELIN)
+        gk = {o.galois_elt(s): synthetic_key_host(self.ctx, o, SEED_GALOIS + i) for i, s in enumerate(self.gk_steps)}
+        times, want = [], None
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            want = o.bfv_matmul_rows(a, b[0], rk, gk, self.dim, threads=threads)
+            times.append(time.perf_counter() - t0)
+        return times, want
+
+    def describe(self):
+        return ("BFV MatMul 128x128x128 (MatMultRow): 64 row-pair ciphertexts x (BEHZ multiply + relinearize + 127 rotate_rows + add), N=2^15, "
+                "{60,40,40,60}, 356 key switches per result ciphertext (BASELINE.json configs[4])")
+
+
+class BfvAdd(Workload):
+    """configs[0] at the reference's default parameters (N=8192, {60,40,60}: SURVEY.md 8d; the literal N=4096 single-modulus case is a
+    parity test, tests/test_gpu_parity_bfv.py): Evaluator::add (bfv eltwise .cpp:322)"""
+    name = "bfv_add"
+    scheme = "bfv"
+    N, bits, plain_bits = 8192, [60, 40, 60], 20
+    default_batch, default_cpu_sample = 4096, 1024
+
+    def setup(self):
+        c, L, N = self.ctx, self.L, self.N
+        self.b1 = 1
+        self.fill_operands()
+        self.d_out = c.alloc(max(1, self.n) * 2 * L * N)
+
+    def step(self):
+        self.ctx.add(self.L, 2, self.n, self.d_a, self.d_b, self.ix, self.d_out)
+
+    def bytes_per_op(self, global_batch):
+        return 3 * 2 * self.L * self.N * 8  # read 2 cts (operand 1 from cache after the first result), write 1
+
+    def result_rows(self, k):
+        return self.d_out.download_head((k, 2, self.L, self.N))
+
+    def checker(self, ho, o, rows, threads, passes):
+        a, b = self.host_operands(rows)
+        times, want = [], None
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            want = o.batch_outer(ho.OP_ADD, a, b, threads=threads)
+            times.append(time.perf_counter() - t0)
+        return times, want
+
+    def describe(self):
+        return "BFV EltwiseAdd at the reference's defaults N=8192, {60,40,60} (L=2) (BASELINE.json configs[0])"
+
+
+WORKLOADS = {w.name: w for w in (MulRelinRescale, EltwiseMul, DotProduct, BfvMatMul, BfvAdd)}
+
+
+def synthetic_key_host(ctx, o, seed):
+    """The synthetic evaluation key he355_set_*_key_synthetic(seed) builds on the device, regenerated on the host for the checker:
+    the same counter-based stream (he355_fill_uniform over the key's [L][2][K][N] polynomials, prime = polynomial index mod K)."""
+    L, K, N = ctx.L, ctx.K, ctx.N
+    buf = ctx.alloc(L * 2 * K * N)
+    ctx.fill_uniform(buf, L * 2 * K, list(range(K)), seed)
+    return buf.download((L, 2, K, N)).copy()
 
 
 def main():
@@ -72,10 +339,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=BATCH, help="results per GPU per step")
+    ap.add_argument("--config", choices=list(WORKLOADS), default="mul_relin_rescale")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--batch", type=int, default=0, help="operand-0 batch: per GPU (weak) or global (strong); 0: the configuration's own")
     ap.add_argument("--chunk", type=int, default=0, help="ops per kernel sequence (0: library default)")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="ops in the CPU-baseline sample (0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="results in the CPU-baseline sample (-1: the configuration's own, 0: skip)")
+    ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of the CPU baseline (median reported)")
+    ap.add_argument("--parity-sample", type=int, default=-1, help="results every rank checks against the oracle (-1: the configuration's own, 0: skip)")
+    ap.add_argument("--profile-mode", action="store_true", help="only warm-up + timed steps on the GPU (no CPU baseline, no parity sample, no extra "
+                                                                "single-stream step): what rocprofv3 traces and PMC passes should see")
     args = ap.parse_args()
+    if args.profile_mode:
+        args.cpu_sample, args.parity_sample = 0, 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -98,25 +373,19 @@ def main():
             dist.init_process_group(backend=backend)
 
     be = importlib.import_module("reference-seal-backend_amd")
-    bits = be.chain_bits(DEPTH, COEFF_BITS)
-    ctx = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, device=device)
-    L, K = ctx.L, ctx.K
-    n = args.batch
+    sharding = load_sharding()
+    W = WORKLOADS[args.config]
+    bits = W.bits or be.chain_bits(W.depth, W.coeff_bits)
+    ctx = be.Context(be.SCHEME_CKKS if W.scheme == "ckks" else be.SCHEME_BFV, W.N, bit_sizes=bits, plain_bits=W.plain_bits, device=device)
     if args.chunk:
         ctx.set_chunk(args.chunk)
 
-    # ---- resident inputs (HBM) ----
-    pm = list(range(L))
-    d_a = ctx.alloc(n * 2 * L * N)
-    d_b = ctx.alloc(1 * 2 * L * N)
-    d_out = ctx.alloc(n * 2 * (L - 1) * N)
-    ctx.fill_uniform(d_a, n * 2 * L, pm, 1234 + rank)
-    ctx.fill_uniform(d_b, 2 * L, pm, 99 + rank)
-    ctx.set_relin_key_synthetic(7)
-    ix = be.Context.outer(0, n, 0, 1)
-
-    def step():
-        ctx.multiply_relin(L, n, d_a, d_b, ix, d_out, rescale=True)
+    batch = args.batch or W.default_batch
+    global_b0 = batch * world if args.scaling == "weak" else batch
+    shard = sharding.shard_outer_product(global_b0, W.b1, world, rank)  # contiguous block of operand-0 rows; operand 1 and keys replicated
+    wl = W(be, ctx, shard, args)
+    wl.setup()
+    n = wl.n
 
     def barrier():
         ctx.sync()
@@ -125,64 +394,115 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        step()
+        wl.step()
     barrier()
     ctx.timer_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        wl.step()
     gpu_ms = ctx.timer_end()  # HIP events on the stream the kernels run on
-    k3_ms, k3_launches, k3_ops = ctx.probe_dominant_kernel()  # HIP events around every k_k3<fp64> launch of the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    tdev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    total_results = global_b0 * W.b1 * args.steps
+    value = total_results / elapsed
 
-    total_ops = n * args.steps * world
-    value = total_ops / elapsed
+    # ---- dominant kernel, single stream: one extra untimed step with the two-stream schedule off, HIP events around each launch ----
+    k3 = None
+    if args.config in ("mul_relin_rescale", "dot") and n > 0 and not args.profile_mode:
+        ctx.set_dual_stream(False)
+        ctx.timer_begin()
+        wl.step()
+        ss_ms = ctx.timer_end()
+        k3_ms, k3_launches, k3_ops = ctx.probe_dominant_kernel()
+        ctx.set_dual_stream(True)
+        k3 = (k3_ms, k3_launches, k3_ops, ss_ms)
 
-    cpu = None
-    parity = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:  # the CPU baseline is a single-GPU-run item (rank 0 at N=1 only)
-        cb = cpu_baseline(be, args.cpu_sample, bits)
-        # push the identical sample through the GPU path: the measured path is the checked path
-        s = args.cpu_sample
-        da, db = ctx.to_device(cb["a"]), ctx.to_device(cb["b"])
-        ctx.set_relin_key(cb["rk"])
-        do = ctx.alloc(s * 2 * (L - 1) * N)
-        ctx.multiply_relin(L, s, da, db, be.Context.outer(0, s, 0, 1), do, rescale=True)
-        parity = bool(np.array_equal(do.download(cb["want"].shape), cb["want"]))
-        cpu = {"value": round(cb["value"], 3), "unit": "ciphertext-ops/sec", "cores": cb["cores"], "kind": "port",
-               "sample": f"{s} of the {n} results of one step (same parameters, uniform residues), "
-                         f"median of 3 passes, {cb['seconds']:.2f} s wall each ({cb['total_seconds']:.1f} s in all) on {cb['cores']} OpenMP threads; "
-                         "in-repo SEAL-algorithm restatement, SEAL v3.7.2 unavailable offline"}
+    # ---- checker legs: every rank checks a sample of ITS shard; rank 0 at N=1 times the CPU baseline ----
+    parity, cpu, checksum = None, None, None
+    psample = W.parity_sample if args.parity_sample < 0 else args.parity_sample
+    csample = W.default_cpu_sample if args.cpu_sample < 0 else args.cpu_sample
+    do_cpu = rank == 0 and world == 1 and csample > 0
+    rows_checked = 0
+    if n > 0 and (do_cpu or psample > 0):
+        import oracle as ho  # the checker: never inside the timed region, never the thing measured except as `cpu_baseline`
+        o = ho.Context(ho.SCHEME_CKKS if W.scheme == "ckks" else ho.SCHEME_BFV, W.N, bit_sizes=bits, plain_bits=W.plain_bits)
+        assert [int(q) for q in o.moduli] == [int(q) for q in ctx.moduli]
+        cores = ho.lib().ho_max_threads()
+        threads = cores if world == 1 else max(1, cores // world)
+        res_wanted = csample if do_cpu else psample
+        rows_checked = min(wl.rows, max(1, -(-res_wanted // W.b1)))  # whole operand-0 rows
+        wl.step()  # (the extra single-stream step above left the same results; this keeps the legs independent of it)
+        ctx.sync()
+        times, want = wl.checker(ho, o, rows_checked, threads, args.cpu_passes if do_cpu else 1)
+        got = wl.result_rows(rows_checked * W.b1)
+        parity = bool(np.array_equal(got, want))
+        if do_cpu:
+            med = sorted(times)[len(times) // 2]
+            cpu = {"value": round(rows_checked * W.b1 / med, 3), "unit": "ciphertext-ops/sec", "cores": threads, "kind": "port",
+                   "nproc": os.cpu_count(),
+                   "sample": f"{rows_checked * W.b1} of the {n} results of one step (the first rows of the resident batch, same parameters and keys), "
+                             f"median of {len(times)} timed passes after one warm-up, {med:.2f} s each ({sum(times):.1f} s in all) on {threads} OpenMP threads, "
+                             "loop shape `omp parallel for collapse(2)` as the reference's operate(); in-repo SEAL-algorithm restatement "
+                             "(oracle/he_oracle.c), SEAL v3.7.2 unavailable offline"}
+    if n > 0:
+        checksum = hashlib.sha256(np.ascontiguousarray(wl.result_rows(min(n, 4))).tobytes()).hexdigest()[:16]
+
+    # every rank's verdict reaches rank 0
+    flags = [1 if parity is None else int(parity), rows_checked * W.b1]
+    if world > 1:
+        t = torch.tensor(flags, dtype=torch.int64, device=tdev)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [[int(v) for v in g.tolist()] for g in gathered]
+    else:
+        per_rank = [flags]
+    all_ok = all(p[0] == 1 for p in per_rank)
 
     if rank == 0:
-        bytes_op = algorithmic_bytes_per_op(L, N, n, K)
-        gpu_s = gpu_ms / 1e3
-        # HBM bytes per op from the PMC passes of the same command (tools/profile_round.sh -> profiles/r01_hbm_traffic.json:
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath) and n == BATCH:
-            traffic = json.load(open(tpath))["hbm_bytes_per_op"] * n
-        achieved = bytes_op * n * args.steps / gpu_s / 1e9
-        # dominant kernel: k_k3 for the fp64-engine primes (key products of the key switch, with both floor steps finished in
-        # its epilogue by default).  Algorithmic bytes per op of that kernel, in residue polynomials:
-        # n_f * (L - 1) lifted-digit rows in (48-bit packed: 6 B per element) + n_f own-digit rows in; fused: + 2 n_f correction rows (one combined correction per residue; the
-        # prime divided out has its mod-down correction) + 2 n_f c01 rows in + 2 (n_f - 1) result rows + 2 c01 rows out;
-        # unfused: 2 n_f sums out.  Plus the key rows of those primes once per chunk.
-        n_f = sum(1 for i in list(range(L)) + [K - 1] if ctx.fp64[i])
-        fused = os.environ.get("HE355_K3_FUSE", "1") != "0"
-        k3_polys = n_f * (L + 6) if fused else n_f * (L + 2)
-        k3_bytes_op = N * (6 * n_f * (L - 1) + 8 * (k3_polys - n_f * (L - 1)))
-        k3_key_bytes = L * 2 * n_f * N * 8 * (n * args.steps / float(args.chunk or 256))  # once per chunk of ops
-        k3_bytes_total = k3_bytes_op * n * args.steps + k3_key_bytes
-        k3_gbps = k3_bytes_total / (k3_ms / 1e3) / 1e9 if k3_ms > 0 else None
+        bytes_op = wl.bytes_per_op(global_b0 * W.b1)
+        achieved = bytes_op * total_results / elapsed / 1e9 / world  # per GPU: the roofline is one GPU's HBM
+        # SURVEY.md 8d prices every result with both operands read; in a b0 x 1 outer product operand 1 is ONE ciphertext that stays in
+        # cache, so the bytes that must cross HBM are fewer: operands read once per batch, results written once
+        comp_op = wl.compulsory_bytes_per_op(global_b0, W.b1)
+        tref = None
+        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+        if args.config == "mul_relin_rescale" and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            tref = {"file": "profiles/r02_hbm_traffic.json", "hbm_bytes_per_op": tj.get("hbm_bytes_per_op"),
+                    "note": "PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate runs) of an earlier invocation of this command (tools/profile_round.sh): "
+                            "not measured in this run"}
+        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5),
+                "traffic": None, "traffic_source": tref,
+                "algorithmic_bytes_per_op": round(bytes_op, 1),
+                "compulsory_bytes_per_op": round(comp_op, 1), "frac_of_compulsory": round(comp_op * total_results / elapsed / world / HBM_PEAK, 5),
+                "kernel": "whole kernel sequence of the step (per GPU); the dominant kernel's own figures are under dominant_kernel",
+                "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 3),
+                "note": "algorithmic bytes (SURVEY.md 8d) x results / time / 8 TB/s, per GPU.  Key switching is bound by VALU issue (64-bit modular "
+                        "butterflies), not HBM: SURVEY.md 0.6, DESIGN.md 5"}
+        if k3 is not None and k3[1] > 0:
+            k3_ms, k3_launches, k3_ops, ss_ms = k3
+            L, K, N = wl.L, wl.K, W.N
+            n_f = sum(1 for i in list(range(L)) + [K - 1] if ctx.fp64[i])
+            fused = os.environ.get("HE355_K3_FUSE", "1") != "0"
+            # per key switch, in residue polynomials of the fp64-engine primes: (L - 1) lifted-digit rows (48-bit packed, 6 B per element)
+            # + 1 own-digit row; fused floor steps: + 2 correction rows + 2 c01 rows in + 2 result rows out; unfused: 2 sums out
+            polys8 = n_f * (1 + (6 if fused else 2))
+            k3_bytes_ks = N * (6 * n_f * (L - 1) + 8 * polys8)
+            roof["dominant_kernel"] = {
+                "name": "k_k3<ArF64> (forward row pass of the lifted digits + key MAC + fused floor steps, fp64-engine primes)",
+                "measured": "one extra untimed step with the two-stream schedule off (he355_set_dual_stream(0)): HIP events around every launch",
+                "launches_per_step": k3_launches, "key_switches_per_step": k3_ops // max(1, (2 if args.config == "mul_relin_rescale" else 1)),
+                "ms_per_step_single_stream": round(k3_ms, 3), "avg_launch_ms": round(k3_ms / k3_launches, 4),
+                "step_ms_single_stream": round(ss_ms, 3),
+                "algorithmic_bytes_per_key_switch": k3_bytes_ks,
+                "note": "two launches per chunk with the fused rescale (the tiles of the prime divided out, then the rest)"}
         out = {
-            "metric": "ciphertext-ops/sec (CKKS ct x ct mul+relin+rescale, N=2^15, L=16)",
+            "metric": "ciphertext-ops/sec" + (" (CKKS ct x ct mul+relin+rescale, N=2^15, L=16)" if args.config == "mul_relin_rescale" else f" ({args.config})"),
             "value": round(value, 2),
             "unit": "ciphertext-ops/sec",
             "n_gpus": world,
@@ -190,38 +510,27 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "u64 (exact fp64-FMA engine for the 45-bit primes, u64 Harvey for the 60-bit primes)",
-            "data": "synthetic (uniform residues generated in HBM; synthetic relinearization key)",
-            "config": {"workload": "CKKS EltwiseMult + relinearize + rescale, N=2^15, depth 16 (L=16 data primes + 1 special), "
-                                   f"batch {n}x1 per GPU (BASELINE.json configs[2])",
-                       "poly_modulus_degree": N, "coeff_modulus_bits": bits, "batch_per_gpu": n, "global_batch": n * world,
-                       "parallelism": f"batch-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(achieved * 1e9 / HBM_PEAK, 5), "traffic": traffic,
-                         "traffic_note": "HBM bytes per step (1024 ops) from PMC counters; algorithmic bytes per step = %d" % int(bytes_op * n),
-                         "kernel": "mul->relin->rescale kernel sequence per chunk (k_k1, k_k2, k_k3 special prime, k_floor_cols, k_k3 data primes with fused mod-down, k_floor_cols, k_floor_rows)",
-                         "algorithmic_bytes_per_op": bytes_op,
-                         "dominant_kernel": {"name": "k_k3<ArF64> (forward row pass of the lifted digits + key MAC + fused floor steps, fp64-engine primes)",
-                                             "launches": k3_launches, "total_ms_hip_events": round(k3_ms, 3),
-                                             "avg_launch_ms_hip_events": round(k3_ms / max(1, k3_launches), 4),
-                                             "ms_per_step": round(k3_ms / args.steps, 3),
-                                             "share_of_gpu_time": round(k3_ms / gpu_ms, 3) if gpu_ms else None,
-                                             "algorithmic_bytes_per_op": k3_bytes_op,
-                                             "achieved_GBps": round(k3_gbps, 1) if k3_gbps else None,
-                                             "frac_of_hbm_peak": round(k3_gbps * 1e9 / HBM_PEAK, 4) if k3_gbps else None,
-                                             "note": "two launches per chunk (the tiles of the prime the rescale divides out, then the rest); durations "
-                                                     "overlap the other stream's kernels (two-stream schedule), as in the rocprofv3 kernel trace of the same command"},
-                         "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 3),
-                         "note": "expected binding resource is the VALU (64-bit modular butterflies), not HBM: SURVEY.md §0.6"},
+            "dtype": "u64 (exact fp64-FMA engine for primes < 2^47, u64 Harvey/Shoup for the 60-bit primes)",
+            "data": "synthetic (uniform residues generated in HBM; synthetic evaluation keys; the same global batch at every world size)",
+            "config": {"workload": wl.describe(), "poly_modulus_degree": W.N, "coeff_modulus_bits": bits,
+                       "batch": f"{global_b0} x {W.b1} results globally, rank r owns a contiguous block of operand-0 rows (sharding.shard_outer_product)",
+                       "batch_per_gpu": n, "global_batch": global_b0 * W.b1,
+                       "parallelism": f"batch-sharded x{world}, keys and operand 1 replicated (built per device from the shared seed), no data-path collective"},
+            "roofline": roof,
             "cpu_baseline": cpu,
-            "parity_checked_in_run": parity,
+            "parity": {"checked_in_run": all_ok if any(p[1] for p in per_rank) else None,
+                       "per_rank": [{"rank": r, "ok": bool(p[0]), "results_checked": p[1]} for r, p in enumerate(per_rank)],
+                       "against": "oracle (CPU restatement) on the first rows of each rank's shard, bit for bit"},
+            "results_checksum_rank0": checksum,
         }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
     ctx.close()
+    if not all_ok:
+        raise SystemExit("parity check failed: the HIP path's results differ from the oracle's (see parity.per_rank)")
 
 
 if __name__ == "__main__":

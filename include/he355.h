@@ -89,6 +89,8 @@ int he355_sync(he355_ctx *ctx);
 /* synthetic data: fill n_polys residue polynomials with uniform residues, polynomial p using prime
  * prime_of[p % period] (throughput-mode inputs) */
 int he355_fill_uniform(he355_ctx *ctx, uint64_t *d_dst, uint64_t n_polys, const uint8_t *prime_of, uint32_t period, uint64_t seed);
+/* the same stream from polynomial `first_poly` on: a rank's shard of a batch holds what the whole batch would hold there */
+int he355_fill_uniform_at(he355_ctx *ctx, uint64_t *d_dst, uint64_t n_polys, const uint8_t *prime_of, uint32_t period, uint64_t seed, uint64_t first_poly);
 
 /* ---- evaluation keys: host arrays [L_top digits][2][K][N], NTT form (SEAL KSwitchKeys layout) ---- */
 int he355_set_relin_key(he355_ctx *ctx, const uint64_t *h_key);
@@ -184,6 +186,7 @@ int he355_timer_end(he355_ctx *ctx, float *elapsed_ms);
  * between he355_timer_begin and he355_timer_end: summed duration, number of launches and ops they covered */
 int he355_probe_dominant_kernel(he355_ctx *ctx, float *total_ms, uint64_t *launches, uint64_t *ops);
 /* ---- tuning ---- */
+int he355_set_dual_stream(he355_ctx *ctx, int on); /* chunks alternate between two HIP streams (default 1; HE355_DUAL_STREAM=0); 0: per-kernel timings without overlap */
 int he355_set_chunk(he355_ctx *ctx, uint64_t ops_per_chunk); /* ops processed per kernel sequence, default 256 (scratch ~ 117 MiB/op at N=2^15, L=16) */
 
 #ifdef __cplusplus

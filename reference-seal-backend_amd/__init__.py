@@ -74,6 +74,8 @@ def lib():
             "he355_copy": (i32, [vp, vp, vp, u64]),
             "he355_sync": (i32, [vp]),
             "he355_fill_uniform": (i32, [vp, vp, u64, u8p, u32, u64]),
+            "he355_fill_uniform_at": (i32, [vp, vp, u64, u8p, u32, u64, u64]),
+            "he355_set_dual_stream": (i32, [vp, i32]),
             "he355_set_relin_key": (i32, [vp, _u64p]), "he355_set_galois_key": (i32, [vp, u32, _u64p]),
             "he355_set_relin_key_synthetic": (i32, [vp, u64]),
             "he355_set_galois_key_synthetic": (i32, [vp, u32, u64]),
@@ -124,7 +126,7 @@ C_ABI_SYMBOLS = [
     "he355_key_modulus_count", "he355_data_modulus_count", "he355_modulus", "he355_plain_modulus",
     "he355_prime_uses_fp64", "he355_galois_elt_from_step", "he355_galois_elts_all", "he355_device_count",
     "he355_device_init", "he355_malloc", "he355_free", "he355_upload", "he355_download", "he355_copy", "he355_sync",
-    "he355_fill_uniform", "he355_set_relin_key", "he355_set_galois_key", "he355_set_relin_key_synthetic",
+    "he355_fill_uniform", "he355_fill_uniform_at", "he355_set_dual_stream", "he355_set_relin_key", "he355_set_galois_key", "he355_set_relin_key_synthetic",
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",
     "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_keygen_relin", "he355_keygen_galois", "he355_ckks_encode", "he355_ckks_decode",
@@ -162,6 +164,15 @@ class DeviceBuffer:
         out = np.empty(self.n, dtype=np.uint64)
         _check(lib().he355_download(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes))
         return out.reshape(shape) if shape is not None else out
+
+    def download_head(self, shape) -> np.ndarray:
+        """the first prod(shape) elements only (a sample of a large slab without moving the whole slab over PCIe)"""
+        k = int(np.prod(shape))
+        assert 0 <= k <= self.n, (k, self.n)
+        out = np.empty(k, dtype=np.uint64)
+        if k:
+            _check(lib().he355_download(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes))
+        return out.reshape(shape)
 
     def free(self):
         if self.ptr:
@@ -219,9 +230,12 @@ class Context:
     def to_device(self, arr: np.ndarray) -> DeviceBuffer:
         return self.alloc(arr.size).upload(arr)
 
-    def fill_uniform(self, buf: DeviceBuffer, n_polys: int, prime_of, seed: int):
+    def fill_uniform(self, buf: DeviceBuffer, n_polys: int, prime_of, seed: int, first_poly: int = 0):
         pm = (C.c_uint8 * len(prime_of))(*prime_of)
-        _check(lib().he355_fill_uniform(self.h, buf.ptr, n_polys, pm, len(prime_of), seed))
+        _check(lib().he355_fill_uniform_at(self.h, buf.ptr, n_polys, pm, len(prime_of), seed, first_poly))
+
+    def set_dual_stream(self, on: bool):
+        _check(lib().he355_set_dual_stream(self.h, int(on)))
 
     def sync(self):
         _check(lib().he355_sync(self.h))

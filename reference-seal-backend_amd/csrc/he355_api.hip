@@ -50,13 +50,15 @@ struct PrimeMap {
 };
 
 // uniform-looking residues in [0, q): counter-based generator, value = floor(rand64 * q / 2^64)
-__global__ void k_fill_uniform(u64 *dst, u64 n_polys, int logN, const PrimeDev *primes, PrimeMap pm, u64 seed)
+// first_poly: index of dst's first polynomial in the whole (virtual) array the stream belongs to -- a shard of a batch filled with
+// its offset holds exactly the values the full batch would hold there, whatever the number of shards
+__global__ void k_fill_uniform(u64 *dst, u64 n_polys, int logN, const PrimeDev *primes, PrimeMap pm, u64 seed, u64 first_poly)
 {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 poly = gid >> logN;
     if (poly >= n_polys) return;
-    const u64 q = primes[pm.prime_of[poly % pm.period]].q;
-    dst[gid] = mulhi64(splitmix64(seed ^ splitmix64(gid)), q);
+    const u64 q = primes[pm.prime_of[(first_poly + poly) % pm.period]].q;
+    dst[gid] = mulhi64(splitmix64(seed ^ splitmix64(gid + (first_poly << logN))), q);
 }
 // key residues of fp64-engine primes are kept as doubles in HBM (exact: q < 2^47)
 __global__ void k_key_to_engine(u64 *key, u64 n_polys, int logN, const PrimeDev *primes, int K)
@@ -217,7 +219,7 @@ public:
         pm.period = (u32)P.K;
         for (size_t i = 0; i < P.K; ++i) pm.prime_of[i] = (unsigned char)i;
         const u64 n_polys = P.Ltop * 2 * P.K, total = n_polys * P.N;
-        hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, *slot, n_polys, P.logn, d_primes_, pm, seed);
+        hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, *slot, n_polys, P.logn, d_primes_, pm, seed, (u64)0);
         key_finish(*slot);
     }
     // KeyGenerator on the device: the key for key_id 1 (relinearization) or 2 + galois_elt, from the secret key set with
@@ -283,7 +285,8 @@ public:
         return d;
     }
 
-    void fill_uniform(u64 *dst, u64 n_polys, const uint8_t *prime_of, u32 period, u64 seed)
+    void set_dual_stream(bool on) { dual_stream_ = on; }
+    void fill_uniform(u64 *dst, u64 n_polys, const uint8_t *prime_of, u32 period, u64 seed, u64 first_poly = 0)
     {
         use();
         if (period == 0 || period > 64) throw std::invalid_argument("prime map period must be in [1, 64]");
@@ -294,7 +297,7 @@ public:
             pm.prime_of[i] = prime_of[i];
         }
         const u64 total = n_polys * P.N;
-        hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, dst, n_polys, P.logn, d_primes_, pm, seed);
+        hipLaunchKernelGGL(k_fill_uniform, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, dst, n_polys, P.logn, d_primes_, pm, seed, first_poly);
         HIPCHECK(hipGetLastError());
     }
 
@@ -1326,6 +1329,11 @@ int he355_fill_uniform(he355_ctx *c, uint64_t *d_dst, uint64_t n_polys, const ui
 {
     return guarded([&] { dev(c).fill_uniform(d_dst, n_polys, prime_of, period, seed); });
 }
+int he355_fill_uniform_at(he355_ctx *c, uint64_t *d_dst, uint64_t n_polys, const uint8_t *prime_of, uint32_t period, uint64_t seed, uint64_t first_poly)
+{
+    return guarded([&] { dev(c).fill_uniform(d_dst, n_polys, prime_of, period, seed, first_poly); });
+}
+int he355_set_dual_stream(he355_ctx *c, int on) { return guarded([&] { dev(c).set_dual_stream(on != 0); }); }
 int he355_set_relin_key(he355_ctx *c, const uint64_t *h_key)
 {
     return guarded([&] { dev(c).key_from_host(dev(c).relin_slot(), h_key); });

@@ -4,6 +4,7 @@ results and size-independent properties — at BASELINE.json's full sizes.  Inte
 bit-exact equality (np.array_equal), no tolerance anywhere."""
 import importlib
 import os
+import sys
 import zlib
 
 import numpy as np
@@ -715,3 +716,41 @@ def test_exact_model_fixture_gpu(be, name):
     tem.check(f, "rotate_3_naf", out.download((2, L, N)))
     g3.close()
     g.close()
+
+
+def test_shards_hold_the_global_batch_and_replicated_keys_agree(be):
+    """Multi-GPU bench path (bench.py, sharding.shard_outer_product): a rank's shard, filled with its offset into the global operand
+    array (he355_fill_uniform_at), holds exactly the rows the whole array holds there; two contexts that build their synthetic
+    relinearization key from the same seed compute bit-identical results (keys are replicated by construction: the generators are
+    pure functions of seed and index), and a sharded job's results are the slices of the unsharded job's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("he355_sharding_t", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                  "reference-seal-backend_amd", "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    sys.modules["he355_sharding_t"] = sharding
+    spec.loader.exec_module(sharding)
+    N, bits, b0 = 4096, [60, 45, 45, 60], 7
+    whole = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, sec128=False, device=0)
+    L = whole.L
+    pm = list(range(L))
+    da, db = whole.alloc(b0 * 2 * L * N), whole.alloc(2 * L * N)
+    whole.fill_uniform(da, b0 * 2 * L, pm, 1234)
+    whole.fill_uniform(db, 2 * L, pm, 99)
+    whole.set_relin_key_synthetic(7)
+    out = whole.alloc(b0 * 2 * (L - 1) * N)
+    whole.multiply_relin(L, b0, da, db, be.Context.outer(0, b0, 0, 1), out, rescale=True)
+    a_all, r_all = da.download((b0, 2, L, N)), out.download((b0, 2, L - 1, N))
+    for world in (2, 3):
+        for rank in range(world):
+            sh = sharding.shard_outer_product(b0, 1, world, rank)
+            g = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, sec128=False, device=0)  # another "device": its own context, keys, streams
+            sa, sb = g.alloc(max(1, sh.a_count) * 2 * L * N), g.alloc(2 * L * N)
+            g.fill_uniform(sa, sh.a_count * 2 * L, pm, 1234, first_poly=sh.a_base * 2 * L)
+            g.fill_uniform(sb, 2 * L, pm, 99)
+            g.set_relin_key_synthetic(7)
+            assert np.array_equal(sa.download_head((sh.a_count, 2, L, N)), a_all[sh.a_base:sh.a_base + sh.a_count])
+            so = g.alloc(max(1, sh.n_results) * 2 * (L - 1) * N)
+            g.multiply_relin(L, sh.n_results, sa, sb, be.Context.outer(0, sh.a_count, 0, 1), so, rescale=True)
+            assert np.array_equal(so.download_head((sh.n_results, 2, L - 1, N)), r_all[sh.first_result:sh.first_result + sh.n_results]), (world, rank)
+            g.close()
+    whole.close()

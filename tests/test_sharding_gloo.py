@@ -1,5 +1,8 @@
-"""N > 1 path on the CPU: two gloo ranks shard an outer-product batch, exchange their shard descriptors and
-timings the way bench.py does (barrier, MAX over ranks), and check the shards tile the result range exactly."""
+"""N > 1 path on the CPU: two gloo ranks shard an outer-product batch with the very call bench.py makes
+(sharding.shard_outer_product on the global batch: batch x world for weak scaling, batch for strong), exchange their shard
+descriptors and timings the way bench.py does (barrier, MAX over ranks, all_gather of the per-rank parity flags), and check
+that the shards tile the result range exactly and that the operand-0 fill offsets (he355_fill_uniform_at first_poly) tile the
+global operand array."""
 import importlib.util
 import os
 import sys
@@ -57,3 +60,21 @@ def test_two_rank_sharding(b0, b1):
     assert covered == list(range(b0 * b1))  # every result exactly once, in order, no overlap
     mod = _load_sharding()
     assert mod.aggregate_throughput([s[1] for s in shards], [0.01, 0.02]) == pytest.approx(b0 * b1 / 0.02)
+
+
+def test_bench_shards_are_world_size_independent():
+    """bench.py: rank r fills rows [a_base, a_base + a_count) of the GLOBAL operand-0 array (first_poly = a_base * 2 * L), so the union
+    over ranks is the same array at every world size; strong scaling keeps the global batch, weak scaling multiplies it."""
+    mod = _load_sharding()
+    L = 16
+    for world in (1, 2, 4, 8):
+        for scaling, batch in (("weak", 1024), ("strong", 1024), ("strong", 1001)):
+            g = batch * world if scaling == "weak" else batch
+            shards = [mod.shard_outer_product(g, 1, world, r) for r in range(world)]
+            polys = []
+            for sh in shards:
+                first = sh.a_base * 2 * L
+                polys += list(range(first, first + sh.a_count * 2 * L))
+            assert polys == list(range(g * 2 * L))
+            assert sum(sh.n_results for sh in shards) == g
+            assert max(sh.n_results for sh in shards) - min(sh.n_results for sh in shards) <= 1  # balanced to one row

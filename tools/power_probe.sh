@@ -1,7 +1,7 @@
 #!/bin/bash
 # Samples clocks and power while the headline bench runs (usage: tools/power_probe.sh)
 cd "$GRAFT_REPO_ROOT"
-python3 bench.py --steps 40 --warmup 2 --cpu-sample 0 > gpurun_out/pp_bench.json 2> gpurun_out/pp_bench.err &
+python3 bench.py --steps 40 --warmup 2 --profile-mode > gpurun_out/pp_bench.json 2> gpurun_out/pp_bench.err &
 BP=$!
 sleep 25
 for i in 1 2 3 4 5 6; do
