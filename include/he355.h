@@ -85,6 +85,10 @@ int he355_free(he355_ctx *ctx, void *d_ptr);
 int he355_upload(he355_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int he355_download(he355_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
 int he355_copy(he355_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes); /* device to device, on the context's stream */
+/* device memory of src_ctx's GPU -> device memory of dst_ctx's GPU (hipMemcpyPeer over xGMI; also valid when both contexts sit on the
+ * same GPU).  Both contexts are synchronised first, the copy is complete on return.  Used at load() / store() by the bridge's
+ * multi-device path: operand replicas out, result parts back; never inside operate(). */
+int he355_copy_peer(he355_ctx *dst_ctx, void *d_dst, he355_ctx *src_ctx, const void *d_src, uint64_t bytes);
 int he355_sync(he355_ctx *ctx);
 /* synthetic data: fill n_polys residue polynomials with uniform residues, polynomial p using prime
  * prime_of[p % period] (throughput-mode inputs) */

@@ -72,6 +72,7 @@ def lib():
             "he355_malloc": (i32, [vp, u64, vpp]), "he355_free": (i32, [vp, vp]),
             "he355_upload": (i32, [vp, vp, vp, u64]), "he355_download": (i32, [vp, vp, vp, u64]),
             "he355_copy": (i32, [vp, vp, vp, u64]),
+            "he355_copy_peer": (i32, [vp, vp, vp, vp, u64]),
             "he355_sync": (i32, [vp]),
             "he355_fill_uniform": (i32, [vp, vp, u64, u8p, u32, u64]),
             "he355_fill_uniform_at": (i32, [vp, vp, u64, u8p, u32, u64, u64]),
@@ -125,7 +126,7 @@ C_ABI_SYMBOLS = [
     "he355_last_error", "he355_ctx_create", "he355_ctx_create_primes", "he355_ctx_destroy", "he355_poly_degree",
     "he355_key_modulus_count", "he355_data_modulus_count", "he355_modulus", "he355_plain_modulus",
     "he355_prime_uses_fp64", "he355_galois_elt_from_step", "he355_galois_elts_all", "he355_device_count",
-    "he355_device_init", "he355_malloc", "he355_free", "he355_upload", "he355_download", "he355_copy", "he355_sync",
+    "he355_device_init", "he355_malloc", "he355_free", "he355_upload", "he355_download", "he355_copy", "he355_copy_peer", "he355_sync",
     "he355_fill_uniform", "he355_fill_uniform_at", "he355_set_dual_stream", "he355_set_relin_key", "he355_set_galois_key", "he355_set_relin_key_synthetic",
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",

@@ -48,6 +48,9 @@ VectorBenchmarkDescription::VectorBenchmarkDescription(Scheme scheme, AB::Catego
     if (scheme == Scheme::CKKS) w.add<std::uint64_t>(dot ? 40 : 45, "ScaleBits");
     else w.add<std::uint64_t>(20, "PlainModulusBits");
     w.add<std::uint64_t>(0, "NumThreads"); // kept so existing HEBench YAML configs load; the GPU path ignores it
+    // The parameter sets stay exactly the reference's six (an existing HEBench YAML must keep loading: the wrapper rejects a set
+    // shorter than the declared one).  The number of GPUs one operate() is spread over comes from HE355_NUM_DEVICES, or from an
+    // optional seventh parameter "NumDevices" when a caller supplies one (multi_device.h).
     this->addDefaultParameters(w);
 }
 
@@ -81,6 +84,8 @@ std::string VectorBenchmarkDescription::getBenchmarkDescription(const AB::Worklo
     ss << ", Algorithm, " << AlgorithmName << ", " << AlgorithmDescription << std::endl
        << HeContextWrapper::threadsRow(p_w_params->params[Index_NumThreads].u_param, m_descriptor.category == AB::Category::Latency) << std::endl
        << ", Device, AMD Instinct MI355X (HIP; batch mapped to the grid, no host threads)";
+    const int n_dev = DeviceGroup::resolveCount(p_w_params->count > Index_NumDevices ? p_w_params->params[Index_NumDevices].u_param : 0);
+    if (n_dev > 1 || p_w_params->count > Index_NumDevices) ss << std::endl << ", Number of devices, " << n_dev;
     return ss.str();
 }
 
@@ -108,6 +113,10 @@ VectorBenchmark::VectorBenchmark(hebench::cpp::BaseEngine &engine, const AB::Ben
     const std::size_t slot_count = m_p_ctx_wrapper->slot_count();
     if (m_w_params.n() > slot_count)
         throw HEBenchError(HEBERROR_MSG_CLASS("Vector size cannot be greater than " + std::to_string(slot_count) + "."), HEBENCH_ECODE_INVALID_ARGS);
+    if (bench_params.count > VectorBenchmarkDescription::Index_NumDevices)
+        m_num_devices = DeviceGroup::resolveCount(m_w_params.get<std::uint64_t>(VectorBenchmarkDescription::Index_NumDevices));
+    else
+        m_num_devices = DeviceGroup::resolveCount(0);
 }
 
 AB::Handle VectorBenchmark::encode(const AB::DataPackCollection *p_parameters)
@@ -187,8 +196,8 @@ AB::Handle VectorBenchmark::load(const AB::Handle *p_local_data, std::uint64_t c
         throw HEBenchError(HEBERROR_MSG_CLASS("Invalid number of handles. Expected 1."), HEBENCH_ECODE_INVALID_ARGS);
     assert(p_local_data);
     const std::vector<std::vector<Cipher>> &local = this->getEngine().retrieveFromHandle<std::vector<std::vector<Cipher>>>(p_local_data[0]);
-    std::vector<std::shared_ptr<DeviceCiphers>> remote;
-    for (const auto &operand : local) remote.push_back(m_p_ctx_wrapper->upload(operand));
+    RemotePack remote;
+    for (const auto &operand : local) remote.ops.push_back(m_p_ctx_wrapper->upload(operand));
     if (this->getDescriptor().workload == AB::Workload::DotProduct) {
         m_p_ctx_wrapper->needRelinKey();
         // accumulateCKKS(n) / accumulateBFV(n): rotations by 2^i, i < bit_count(count) (seal_context.cpp:331-339, 295-304);
@@ -199,6 +208,16 @@ AB::Handle VectorBenchmark::load(const AB::Handle *p_local_data, std::uint64_t c
         if (((std::uint64_t)1 << (rotations - 1)) == cnt) --rotations;
         for (int i = 0; i < rotations; ++i) m_p_ctx_wrapper->needRotationKey(1 << i);
         if (m_scheme == Scheme::BFV && m_w_params.n() > row) m_p_ctx_wrapper->needRotationKey(0);
+    }
+    if (m_num_devices > 1) {
+        // the batch loop of operate() is spread over the group's devices: every device gets the evaluation keys (generated there from
+        // the shared seed) and a replica of both operands (hipMemcpyPeer over xGMI), here, outside the timed call
+        if (!m_group) m_group = DeviceGroup::create(m_p_ctx_wrapper, m_num_devices);
+        m_group->syncKeys();
+        remote.replicas.resize((std::size_t)m_group->size());
+        remote.replicas[0] = remote.ops;
+        for (int d = 1; d < m_group->size(); ++d)
+            for (const auto &op : remote.ops) remote.replicas[(std::size_t)d].push_back(m_group->replicate(d, op));
     }
     return this->getEngine().createHandle<decltype(remote)>(sizeof(remote), 0, std::move(remote));
 }
@@ -225,8 +244,8 @@ AB::Handle VectorBenchmark::operate(AB::Handle h_remote_packed, const AB::Parame
         ss << "Invalid number of indexers. Expected " << VectorBenchmarkDescription::NumOpParams << ", but " << indexers_count << " received." << std::endl;
         throw HEBenchError(HEBERROR_MSG_CLASS(ss.str()), HEBENCH_ECODE_INVALID_ARGS);
     }
-    const std::vector<std::shared_ptr<DeviceCiphers>> &params =
-        this->getEngine().retrieveFromHandle<std::vector<std::shared_ptr<DeviceCiphers>>>(h_remote_packed);
+    const RemotePack &pack = this->getEngine().retrieveFromHandle<RemotePack>(h_remote_packed);
+    const std::vector<std::shared_ptr<DeviceCiphers>> &params = pack.ops;
     if (params.size() < 2) throw HEBenchError(HEBERROR_MSG_CLASS("Invalid remote operand pack."), HEBENCH_ECODE_INVALID_ARGS);
     const DeviceCiphers &p0 = *params[0], &p1 = *params[1];
     const std::uint64_t b0 = p_param_indexers[0].batch_size, b1 = p_param_indexers[1].batch_size;
@@ -239,31 +258,71 @@ AB::Handle VectorBenchmark::operate(AB::Handle h_remote_packed, const AB::Parame
     ix.b1 = b1 ? b1 : 1;
     ix.pairwise = 0;
     ix.reserved = 0;
-    he355_ctx *ctx = m_p_ctx_wrapper->raw();
-    const int L = p0.L;
     std::shared_ptr<DeviceCiphers> result;
+    if (pack.replicas.size() > 1 && b0 > 1) {
+        // Contiguous blocks of operand-0 rows, one per device, one host thread each (the reference spreads the same loop over
+        // NumThreads OpenMP threads, ckks eltwise .cpp:325).  Device 0 writes straight into the result slab; the other devices'
+        // blocks stay where they were computed until store() gathers them: no copy and no collective inside the timed call.
+        const int out_size = this->getDescriptor().workload == AB::Workload::EltwiseMultiply ? 3 : 2;
+        const double out_scale = this->getDescriptor().workload == AB::Workload::EltwiseAdd ? p0.scale : p0.scale * p1.scale;
+        result = m_p_ctx_wrapper->allocResult(n, out_size, p0.L, out_scale);
+        std::vector<std::shared_ptr<DeviceCiphers>> parts((std::size_t)m_group->size());
+        std::vector<std::uint64_t> firsts((std::size_t)m_group->size(), 0);
+        m_group->parallel([&](int d) {
+            std::uint64_t first = 0, rows = 0;
+            DeviceGroup::rowsOf(b0, m_group->size(), d, first, rows);
+            firsts[(std::size_t)d] = first * ix.b1;
+            if (!rows) return;
+            he355_indexer ixd = ix;
+            ixd.a_base += first;
+            const auto &ops = pack.replicas[(std::size_t)d];
+            parts[(std::size_t)d] = operateOn(m_group->ctx(d), m_group.get(), d, *ops[0], *ops[1], ixd, rows * ix.b1, d == 0 ? result : nullptr, first * ix.b1);
+        });
+        for (int d = 1; d < m_group->size(); ++d)
+            if (parts[(std::size_t)d]) result->parts.push_back(DeviceCiphers::Part{parts[(std::size_t)d], firsts[(std::size_t)d]});
+    } else {
+        result = operateOn(m_p_ctx_wrapper->raw(), nullptr, 0, p0, p1, ix, n, nullptr, 0);
+    }
+    return this->getEngine().createHandle<decltype(result)>(sizeof(result), 0, std::move(result));
+}
+
+// the per-device body of operate(): n results from operand slabs p0, p1 resident on `ctx`'s device.  `into` (device 0 of a group):
+// write at result offset `into_offset` of that slab instead of allocating one.
+std::shared_ptr<DeviceCiphers> VectorBenchmark::operateOn(he355_ctx *ctx, DeviceGroup *group, int device, const DeviceCiphers &p0, const DeviceCiphers &p1,
+                                                          he355_indexer ix, std::uint64_t n, std::shared_ptr<DeviceCiphers> into, std::uint64_t into_offset)
+{
+    const int L = p0.L;
+    auto alloc = [&](std::uint64_t cnt, int size, double scale) {
+        return group ? group->alloc(device, cnt, size, L, scale) : m_p_ctx_wrapper->allocResult(cnt, size, L, scale);
+    };
+    std::shared_ptr<DeviceCiphers> result = into;
+    uint64_t *out = nullptr;
+    auto target = [&](int size, double scale) {
+        if (!result) result = alloc(n, size, scale);
+        out = into ? into->d + into_offset * (std::uint64_t)size * L * m_p_ctx_wrapper->params().N : result->d;
+    };
     switch (this->getDescriptor().workload) {
     case AB::Workload::EltwiseAdd:
-        result = m_p_ctx_wrapper->allocResult(n, 2, L, p0.scale);
-        HeContextWrapper::check(he355_add(ctx, L, 2, n, p0.d, p1.d, ix, result->d), "add");
+        target(2, p0.scale);
+        HeContextWrapper::check(he355_add(ctx, L, 2, n, p0.d, p1.d, ix, out), "add");
         break;
     case AB::Workload::EltwiseMultiply: // multiply only: the size-3 result is decrypted as is (ckks eltwise .cpp:342-344, bfv :324-326)
-        result = m_p_ctx_wrapper->allocResult(n, 3, L, p0.scale * p1.scale);
-        if (m_scheme == Scheme::CKKS) HeContextWrapper::check(he355_multiply(ctx, L, n, p0.d, p1.d, ix, result->d), "multiply");
-        else HeContextWrapper::check(he355_bfv_multiply(ctx, L, n, p0.d, p1.d, ix, result->d), "multiply");
+        target(3, p0.scale * p1.scale);
+        if (m_scheme == Scheme::CKKS) HeContextWrapper::check(he355_multiply(ctx, L, n, p0.d, p1.d, ix, out), "multiply");
+        else HeContextWrapper::check(he355_bfv_multiply(ctx, L, n, p0.d, p1.d, ix, out), "multiply");
         break;
     case AB::Workload::DotProduct: { // multiply -> relinearize_inplace -> accumulate(n)  (ckks dot .cpp:325-330, bfv dot .cpp:311-315)
-        result = m_p_ctx_wrapper->allocResult(n, 2, L, p0.scale * p1.scale);
+        target(2, p0.scale * p1.scale);
         if (m_scheme == Scheme::CKKS) {
-            HeContextWrapper::check(he355_multiply_relin(ctx, L, n, p0.d, p1.d, ix, 0, result->d), "multiply+relinearize");
+            HeContextWrapper::check(he355_multiply_relin(ctx, L, n, p0.d, p1.d, ix, 0, out), "multiply+relinearize");
         } else {
-            std::shared_ptr<DeviceCiphers> c3 = m_p_ctx_wrapper->allocResult(n, 3, L, 1.0);
+            std::shared_ptr<DeviceCiphers> c3 = alloc(n, 3, 1.0);
             HeContextWrapper::check(he355_bfv_multiply(ctx, L, n, p0.d, p1.d, ix, c3->d), "multiply");
-            HeContextWrapper::check(he355_relinearize(ctx, L, n, c3->d, result->d), "relinearize");
+            HeContextWrapper::check(he355_relinearize(ctx, L, n, c3->d, out), "relinearize");
             HeContextWrapper::check(he355_sync(ctx), "synchronise");
         }
-        std::shared_ptr<DeviceCiphers> tmp = m_p_ctx_wrapper->allocResult(n, 2, L, result->scale);
-        HeContextWrapper::check(he355_accumulate(ctx, L, n, result->d, m_w_params.n(), tmp->d), "accumulate");
+        std::shared_ptr<DeviceCiphers> tmp = alloc(n, 2, result->scale);
+        HeContextWrapper::check(he355_accumulate(ctx, L, n, out, m_w_params.n(), tmp->d), "accumulate");
         HeContextWrapper::check(he355_sync(ctx), "synchronise");
         break;
     }
@@ -272,5 +331,5 @@ AB::Handle VectorBenchmark::operate(AB::Handle h_remote_packed, const AB::Parame
         throw HEBenchError(HEBERROR_MSG_CLASS(m_scheme == Scheme::BFV ? "Operation not implimented." : "Operation not supported."), HEBENCH_ECODE_INVALID_ARGS);
     }
     HeContextWrapper::check(he355_sync(ctx), "synchronise"); // operate() returns with the result complete, as the reference's does
-    return this->getEngine().createHandle<decltype(result)>(sizeof(result), 0, std::move(result));
+    return result;
 }

@@ -7,6 +7,7 @@
 // over seal::Evaluator calls with OpenMP.
 #pragma once
 #include "he_context.h"
+#include "multi_device.h"
 
 namespace mi355x {
 
@@ -27,7 +28,10 @@ public:
         Index_CoefficientModulusBits,
         Index_ScaleExponentBits, // BFV: PlainModulusBits
         Index_NumThreads,
-        NumWorkloadParams
+        NumWorkloadParams,
+        // optional trailing parameter, NOT part of the declared defaults: GPUs one operate() call is spread over;
+        // absent or 0 = HE355_NUM_DEVICES, else 1.  The declared parameter sets stay the reference's six.
+        Index_NumDevices = NumWorkloadParams
     };
     VectorBenchmarkDescription(Scheme scheme, hebench::APIBridge::Category category, hebench::APIBridge::Workload op);
     hebench::cpp::BaseBenchmark *createBenchmark(hebench::cpp::BaseEngine &engine, const hebench::APIBridge::WorkloadParams *p_params) override;
@@ -56,10 +60,20 @@ public:
                                        std::uint64_t indexers_count) override;
     std::int64_t classTag() const override { return BaseBenchmark::classTag() | VectorBenchmark::tag; }
 
+    // what load() hands to operate(): the operand slabs on the primary device and, with NumDevices > 1, their replicas
+    struct RemotePack {
+        std::vector<std::shared_ptr<DeviceCiphers>> ops;                    // [operand] on the primary device
+        std::vector<std::vector<std::shared_ptr<DeviceCiphers>>> replicas;  // [device][operand]; [0] = ops
+    };
+
 private:
+    std::shared_ptr<DeviceCiphers> operateOn(he355_ctx *ctx, DeviceGroup *group, int device, const DeviceCiphers &p0, const DeviceCiphers &p1,
+                                             he355_indexer ix, std::uint64_t n, std::shared_ptr<DeviceCiphers> into, std::uint64_t into_offset);
     Scheme m_scheme;
     HeContextWrapper::Ptr m_p_ctx_wrapper;
     hebench::cpp::WorkloadParams::VectorSize m_w_params;
+    int m_num_devices = 1;
+    std::shared_ptr<DeviceGroup> m_group;
 };
 
 } // namespace mi355x

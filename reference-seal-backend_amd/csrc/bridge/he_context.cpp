@@ -1,5 +1,6 @@
 // he_context.cpp — see he_context.h
 #include "he_context.h"
+#include "multi_device.h"
 
 #include <thread>
 
@@ -30,7 +31,9 @@ void HeContextWrapper::check(int code, const char *what)
 
 DeviceCiphers::~DeviceCiphers()
 {
-    if (d && ctx) he355_free(ctx->raw(), d);
+    if (!d) return;
+    if (group) he355_free(group->ctx(device), d); // a slab on another device of a group
+    else if (ctx) he355_free(ctx->raw(), d);
 }
 
 HeContextWrapper::~HeContextWrapper()
@@ -47,6 +50,7 @@ void HeContextWrapper::init(int scheme, std::size_t N, std::size_t depth, int bi
     chain.push_back(60);
     // any failure here is what the reference reports as HEBSEAL_ECODE_SEAL_ERROR (seal_context.cpp:94-97,123-126)
     check(he355_ctx_create(scheme, N, chain.data(), chain.size(), plain_bits, 1, &m_ctx), "context creation");
+    m_scheme_id = scheme; m_chain = chain; m_plain_bits = plain_bits;
     m_params = he355_internal_params(m_ctx);
     try {
         // Key generation and encryption randomness: seeded from the operating system, as SEAL's default factory is
@@ -368,7 +372,26 @@ void HeContextWrapper::ensureDevice()
     if (dev && *dev) ordinal = std::atoi(dev);
     else if (lr && *lr && he355_device_count(&count) == 0 && count > 0) ordinal = std::atoi(lr) % count;
     check(he355_device_init(m_ctx, ordinal), "device initialisation");
+    m_ordinal = ordinal;
     m_device = true;
+}
+std::vector<uint32_t> HeContextWrapper::galoisKeysReady() const
+{
+    std::vector<uint32_t> v;
+    for (const auto &kv : m_galois) v.push_back(kv.first);
+    return v;
+}
+// store() of a multi-device result: the parts come home over xGMI (hipMemcpyPeer), outside the timed operate()
+void HeContextWrapper::gatherParts(const std::shared_ptr<DeviceCiphers> &slab)
+{
+    if (slab->parts.empty()) return;
+    const uint64_t per = slab->elems_per_ct(m_params->N);
+    for (const auto &p : slab->parts) {
+        if (!p.slab->n) continue;
+        he355_ctx *src = p.slab->group ? p.slab->group->ctx(p.slab->device) : m_ctx;
+        check(he355_copy_peer(m_ctx, slab->d + p.first * per, src, p.slab->d, p.slab->n * per * 8), "gather of a result part");
+    }
+    slab->parts.clear();
 }
 void HeContextWrapper::needRelinKey()
 {
@@ -459,6 +482,7 @@ std::shared_ptr<DeviceCiphers> HeContextWrapper::uploadPlains(const std::vector<
 std::vector<Cipher> HeContextWrapper::download(const std::shared_ptr<DeviceCiphers> &slab)
 {
     std::vector<Cipher> out(slab->n);
+    gatherParts(slab);
     check(he355_sync(m_ctx), "synchronise");
     for (uint64_t i = 0; i < slab->n; ++i) {
         out[i].size = slab->size; out[i].L = slab->L; out[i].scale = slab->scale;

@@ -41,12 +41,20 @@ struct Cipher {
 };
 // remote (HBM) slab of n ciphertexts of identical shape
 class HeContextWrapper;
+class DeviceGroup;
 struct DeviceCiphers {
     std::shared_ptr<HeContextWrapper> ctx;
     uint64_t *d = nullptr;
     uint64_t n = 0;
     int size = 2, L = 0;
     double scale = 1.0;
+    // multi-device operate() (multi_device.h): a slab that lives on another device of the group is owned through `group` / `device`;
+    // a result computed in parts names them here (part p holds results [first, first + slab->n)) and `d` is gathered from them at
+    // store() (HeContextWrapper::download), never inside the timed operate()
+    std::shared_ptr<DeviceGroup> group;
+    int device = 0;
+    struct Part { std::shared_ptr<DeviceCiphers> slab; uint64_t first = 0; };
+    std::vector<Part> parts;
     DeviceCiphers() = default;
     DeviceCiphers(const DeviceCiphers &) = delete;
     DeviceCiphers &operator=(const DeviceCiphers &) = delete;
@@ -64,6 +72,14 @@ public:
     ~HeContextWrapper();
 
     he355_ctx *raw() { return m_ctx; }
+    // what the context was created from (a device group builds the same context on its other devices)
+    int schemeId() const { return m_scheme_id; }
+    const std::vector<int32_t> &chainBits() const { return m_chain; }
+    int plainBits() const { return m_plain_bits; }
+    int deviceOrdinal() const { return m_ordinal; }
+    bool relinKeyReady() const { return m_relin; }
+    std::vector<uint32_t> galoisKeysReady() const;
+    void gatherParts(const std::shared_ptr<DeviceCiphers> &slab); // multi-device result -> one slab on this context's device
     he355::client::Client &client() { return *m_client; }
     const he355::Params &params() const { return *m_params; }
     std::size_t slot_count() const { return m_client->slot_count(); }
@@ -115,6 +131,8 @@ private:
     HeContextWrapper() = default;
     void init(int scheme, std::size_t N, std::size_t depth, int bits, int plain_bits);
     he355_ctx *m_ctx = nullptr;
+    int m_scheme_id = 0, m_plain_bits = 0, m_ordinal = 0;
+    std::vector<int32_t> m_chain;
     const he355::Params *m_params = nullptr;
     std::unique_ptr<he355::client::Client> m_client;
     double m_scale = 1.0;

@@ -192,6 +192,7 @@ public:
 
     void use() { HIPCHECK(hipSetDevice(device_)); }
     hipStream_t stream() const { return stream_; }
+    int device() const { return device_; }
     const KernelEnv &env() const { return env_; }
     void set_chunk(size_t c) { chunk_ = c ? c : 1; }
 
@@ -1322,6 +1323,17 @@ int he355_copy(he355_ctx *c, void *d_dst, const void *d_src, uint64_t bytes)
     return guarded([&] {
         dev(c).use();
         if (bytes) HIPCHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, dev(c).stream()));
+    });
+}
+int he355_copy_peer(he355_ctx *dst_ctx, void *d_dst, he355_ctx *src_ctx, const void *d_src, uint64_t bytes)
+{
+    return guarded([&] {
+        // both contexts' streams are drained first (the source must be complete, the destination idle); the copy itself is
+        // synchronous: load() / store() use it outside the timed operate()
+        dev(src_ctx).sync();
+        dev(dst_ctx).sync();
+        dev(dst_ctx).use();
+        if (bytes) HIPCHECK(hipMemcpyPeer(d_dst, dev(dst_ctx).device(), d_src, dev(src_ctx).device(), bytes));
     });
 }
 int he355_sync(he355_ctx *c) { return guarded([&] { dev(c).sync(); }); }

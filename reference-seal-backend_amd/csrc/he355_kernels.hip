@@ -865,6 +865,71 @@ __global__ void __launch_bounds__(kBlock, K2_WAVES) k_k2(K2Args A, const PrimeDe
     }
 }
 
+// K2 split in two (HE355_K2_SPLIT): k_k2a finishes the inverse transform of every digit in place (column pass, canonical
+// coefficients), k_k2b lifts ONE digit to ONE target prime per block.  A k_k2b lane holds one column of one target (32 values)
+// instead of the source column plus a target column, so four waves fit a SIMD where k_k2 fits two; the 17 blocks that read the
+// same 64 KiB source tile are dealt to the same XCD back to back (block index = (group * targets + tt) * 8 + xcd), so the tile
+// comes from that XCD's L2 after its first read.
+#ifndef HE355_K2_SPLIT
+#define HE355_K2_SPLIT 0
+#endif
+#ifndef K2B_WAVES
+#define K2B_WAVES 4
+#endif
+template <int LOGN1>
+__global__ void __launch_bounds__(kBlock) k_k2a(u64 *c2r, u64 op_stride, u64 n_ops, int L, const PrimeDev *primes)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    const u64 oj = blockIdx.x >> 2;
+    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
+    const int j = (int)(oj % L);
+    const u64 op = oj / L;
+    if (op >= n_ops) return;
+    u64 *src = c2r + op * op_stride + (u64)j * N;
+    const PrimeDev &Pj = primes[j];
+    if (Pj.f64) {
+        const ArF64 ar = make_ar(Pj, (ArF64 *)nullptr);
+        double x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
+        col_inv<ArF64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) src[(a << kRowLog) + col] = ar.to_canon(x[a]);
+    } else {
+        const ArU64 ar = make_ar(Pj, (ArU64 *)nullptr);
+        u64 x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
+        col_inv<ArU64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) src[(a << kRowLog) + col] = ar.to_canon(x[a]);
+    }
+}
+template <int LOGN1>
+__global__ void __launch_bounds__(kBlock, K2B_WAVES) k_k2b(K2Args A, const PrimeDev *primes)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    const u32 nt = (u32)A.L + 1;
+    const u64 xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+    const u64 tile = (s / nt) * 8 + xcd; // (op, digit, column block)
+    const int tt = (int)(s % nt);
+    if (tile >= A.n_ops * A.L * 4) return;
+    const int col = (int)((tile & 3) << 8) | threadIdx.x;
+    const u64 oj = tile >> 2;
+    const int j = (int)(oj % A.L);
+    const u64 op = oj / A.L;
+    if (A.ckks && tt == j) return; // CKKS: digit j under its own prime is the NTT-form input itself
+    const u64 *src = A.c2r + op * A.src_op_stride + (u64)j * N;
+    u64 c[N1];
+#pragma unroll
+    for (int a = 0; a < N1; ++a) c[a] = src[(a << kRowLog) + col]; // canonical coefficients of digit j (k_k2a, or BFV's coefficient-form target)
+    const int t = (tt == A.L) ? A.K - 1 : tt;
+    u64 *dst = A.d + ((op * (A.L + 1) + tt) * A.L + j) * N;
+    k2_target<LOGN1>(primes[j], primes[t], c, dst, col);
+}
+
 // =======================================================================================================
 // K3: per (op, key prime tt, row): sum over digits j of NTT_tt(digit j) * key_j[k][tt]
 // =======================================================================================================
@@ -2019,6 +2084,33 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     A.src_op_stride = src ? src_op_stride : (u64)L * env.N;
     A.src_is_coeff = src ? 1 : 0;
     A.d = buf.d; A.n_ops = n_ops; A.L = L; A.K = env.K; A.ckks = env.scheme == 2;
+    static const int split_env = getenv("HE355_K2_SPLIT") ? atoi(getenv("HE355_K2_SPLIT")) : HE355_K2_SPLIT;
+    if (split_env) {
+        // finish the inverse transform in place (nothing to do when the target is in coefficient form already or the row pass was
+        // the whole transform), then one (digit, target prime, column block) per block
+        const unsigned ga = (unsigned)(n_ops * L * 4);
+        if (!src && env.logn1 > 0) {
+            switch (env.logn1) {
+            case 1: hipLaunchKernelGGL(k_k2a<1>, dim3(ga), dim3(kBlock), 0, env.stream, buf.c2r, A.src_op_stride, n_ops, L, env.primes); break;
+            case 2: hipLaunchKernelGGL(k_k2a<2>, dim3(ga), dim3(kBlock), 0, env.stream, buf.c2r, A.src_op_stride, n_ops, L, env.primes); break;
+            case 3: hipLaunchKernelGGL(k_k2a<3>, dim3(ga), dim3(kBlock), 0, env.stream, buf.c2r, A.src_op_stride, n_ops, L, env.primes); break;
+            case 4: hipLaunchKernelGGL(k_k2a<4>, dim3(ga), dim3(kBlock), 0, env.stream, buf.c2r, A.src_op_stride, n_ops, L, env.primes); break;
+            case 5: hipLaunchKernelGGL(k_k2a<5>, dim3(ga), dim3(kBlock), 0, env.stream, buf.c2r, A.src_op_stride, n_ops, L, env.primes); break;
+            }
+        }
+        A.src_is_coeff = 1;
+        const u64 tiles = n_ops * L * 4;
+        const unsigned gb = (unsigned)(((tiles + 7) / 8) * (u64)(L + 1) * 8);
+        switch (env.logn1) {
+        case 0: hipLaunchKernelGGL(k_k2b<0>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 1: hipLaunchKernelGGL(k_k2b<1>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 2: hipLaunchKernelGGL(k_k2b<2>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 3: hipLaunchKernelGGL(k_k2b<3>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 4: hipLaunchKernelGGL(k_k2b<4>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 5: hipLaunchKernelGGL(k_k2b<5>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        }
+        return;
+    }
     const unsigned g = (unsigned)(n_ops * L * 4);
     switch (env.logn1) {
     case 0: hipLaunchKernelGGL(k_k2<0>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;

@@ -87,6 +87,7 @@ def test_engine_registration(backend):
             assert d.cat_params.latency.warmup_iterations_count == 1 and d.cat_params.min_test_time_ms == 0
     # default workload parameters: SURVEY.md App. C
     ck = backend.find(W_MUL, SCHEME_CKKS, OFFLINE)["defaults"][0]
+    # exactly the reference's six parameters in the reference's order (ckks eltwise .h:31-42): NumDevices is an optional extra, not a default
     assert ck == [("n", 1000), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 2), ("CoefficientModulusBits", 45), ("ScaleBits", 45), ("NumThreads", 0)]
     dot = backend.find(W_DOT, SCHEME_CKKS, LATENCY)["defaults"][0]
     assert dot[0] == ("n", 100) and dot[3] == ("CoefficientModulusBits", 40)
@@ -111,6 +112,10 @@ def test_description_text(backend):
     off = backend.description_text(b, [("n", 10), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 3), ("CoefficientModulusBits", 45),
                                        ("ScaleBits", 45), ("NumThreads", 7)])
     assert ", Number of threads, 7" in off
+    assert ", Number of devices" not in off  # a reference-style parameter set (six parameters) is described as the reference describes it
+    dev = backend.description_text(b, [("n", 10), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 3), ("CoefficientModulusBits", 45),
+                                       ("ScaleBits", 45), ("NumThreads", 0), ("NumDevices", 1)])
+    assert dev.rstrip().endswith(", Number of devices, 1")
     bfv = backend.description_text(backend.find(W_ADD, SCHEME_BFV, OFFLINE), [("n", 10), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 3),
                                                                             ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0)])
     assert ", , Plain Text Modulus Bits, 20" in bfv  # bfv eltwise .cpp:111

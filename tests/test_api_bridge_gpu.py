@@ -242,3 +242,35 @@ def test_client_side_on_device_equals_client_side_on_host(backend, scheme):
         assert np.allclose(res[0], want, atol=1e-4)
     else:
         assert np.array_equal(res[0], _centre(want, 1032193))
+
+
+@pytest.mark.parametrize("ndev", [1, 2, 3])
+def test_operate_spread_over_a_device_group(backend, monkeypatch, ndev):
+    """One operate() over NumDevices GPUs inside one process (csrc/bridge/multi_device.h): contiguous blocks of operand-0 rows per
+    device, keys generated on every device from the shared seed, operands replicated at load(), result parts gathered at store().
+    HE355_LOGICAL_DEVICES lets this one-GPU box run a 2- and a 3-device group (logical device d -> physical d mod 1): contexts, keys,
+    replicas, host threads, parts and the gather are all exercised; results must equal the single-device run's and the cleartext's.
+    Uneven splits (5 rows over 3 devices; 2 rows over 3 devices leaves one device idle) and all three vector workloads."""
+    monkeypatch.setenv("HE355_LOGICAL_DEVICES", "3")
+    rng = np.random.default_rng(40 + ndev)
+    n = 64
+    a, b = rng.uniform(-1, 1, (5, n)), rng.uniform(-1, 1, (2, n))
+    for w, want, tol in ((W_ADD, (a[:, None, :] + b[None, :, :]).reshape(10, n), 1e-4), (W_MUL, (a[:, None, :] * b[None, :, :]).reshape(10, n), 1e-4)):
+        hb = backend.create(backend.find(w, SCHEME_CKKS, OFFLINE), ckks_params(n) + [("NumDevices", ndev)], (5, 2))
+        res = backend.run(hb, [a, b], n, np.float64)
+        assert np.allclose(res, want, atol=tol), (w, ndev)
+        backend.destroy(hb)
+    hb = backend.create(backend.find(W_DOT, SCHEME_CKKS, OFFLINE), ckks_params(n, bits=40, scale=40) + [("NumDevices", ndev)], (2, 2))
+    res = backend.run(hb, [a[:2], b], 1, np.float64)
+    assert np.allclose(res, (a[:2] @ b.T).reshape(4, 1), atol=1e-3), ndev
+    backend.destroy(hb)
+    # BFV: exact integers, so the group's result must equal the cleartext bit for bit
+    x, y = rng.integers(-500, 500, (4, n)), rng.integers(-500, 500, (3, n))
+    bfv = [("n", n), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 2), ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0),
+           ("NumDevices", ndev)]
+    hb = backend.create(backend.find(W_MUL, SCHEME_BFV, OFFLINE), bfv, (4, 3))
+    res = backend.run(hb, [x, y], n, np.int64)
+    assert np.array_equal(res, (x[:, None, :] * y[None, :, :]).reshape(12, n)), ndev
+    backend.destroy(hb)
+    txt = backend.description_text(backend.find(W_ADD, SCHEME_CKKS, OFFLINE), ckks_params(n) + [("NumDevices", ndev)])
+    assert txt.rstrip().endswith(f", Number of devices, {ndev}")
