@@ -201,12 +201,23 @@ __device__ __forceinline__ double unpack48(u32 lo, u32 hi16)
     c.u = ((u64)(0x43380000u | hi16) << 32) | lo;
     return c.d - kPackBias;
 }
+// HE355_K2_ABLATE (timing experiments, wrong results): 1 = no stores at all (the values are folded into one store per target so that
+// the arithmetic stays), 2 = no high-plane stores, 4 = stores of a constant (no arithmetic feeds them)
+#ifndef HE355_K2_ABLATE
+#define HE355_K2_ABLATE 0
+#endif
 __device__ __forceinline__ void store48(u64 *row, int e, double x) // element e of a packed row
 {
     union { u64 u; double d; } c;
     c.d = x + kPackBias;
+#if HE355_K2_ABLATE & 1
+    if (c.u == 0x1234567ull) reinterpret_cast<u32 *>(row)[e] = (u32)c.u; // never true for real data: keeps the arithmetic, drops the store
+#else
     reinterpret_cast<u32 *>(row)[e] = (u32)c.u;
+#if !(HE355_K2_ABLATE & 2)
     reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(row) + kPackHiOff)[e] = (unsigned short)(c.u >> 32);
+#endif
+#endif
 }
 __device__ __forceinline__ void lds_rowA48(const u64 *lds_row, int lane, double x[kRowE])
 {
@@ -784,7 +795,9 @@ __device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt
 #pragma unroll
             for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(c[a]);
         }
+#if !(HE355_K2_ABLATE & 4)
         col_fwd<ArF64, LOGN1>(ar, x, ctw(Pt.fwd));
+#endif
         if constexpr (kPackD) {
             // 48-bit rows need |x| < 2^47.  The column pass starts from |x| < m0 (the lift above: q_t after an integer reduction,
             // q_t/2 + 1 after a re-centring, q_j <= 2 q_t otherwise) and a stage takes the bound m to m + q (1/2 + m 2^-51)
