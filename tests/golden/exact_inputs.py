@@ -11,6 +11,7 @@ CASES = [
     dict(name="ckks_n1024_50_45_45_50", scheme="ckks", N=1024, bits=[50, 45, 45, 50], seed=0xE0A2),  # two fp64-engine data primes
     dict(name="ckks_n2048_60_45_45_60", scheme="ckks", N=2048, bits=[60, 45, 45, 60], seed=0xE0A3),  # N1 = 2: column pass + row pass
     dict(name="bfv_n1024_60_40_60", scheme="bfv", N=1024, bits=[60, 40, 60], seed=0xE0B1),
+    dict(name="bfv_n2048_60_40_40_60", scheme="bfv", N=2048, bits=[60, 40, 40, 60], seed=0xE0B2),  # three data primes, N1 = 2
 ]
 
 

@@ -14,8 +14,15 @@ share (Harvey butterflies, Barrett/Shoup reductions, per-prime correction terms)
   * rescale         floor((x + floor(q_last/2)) / q_last) mod q_i, x the representative in [0, Q_L) (App. A.6).
   * Galois          a(X) -> a(X^g) on coefficients (X^N = -1), then the key switch of the second polynomial (App. A.8).
 
-BFV's BEHZ multiply is not an exact function of the residues (its result depends on the representatives the base
-conversions pick) and is therefore not modelled here; BFV key switching, rotation and addition are.
+  * BFV multiply    BEHZ (Bajard-Eynard-Hasan-Zucca) as an INTEGER statement.  The result is not floor(t c1 c2 / Q) of the residues —
+                    it depends on the representatives the base conversions pick — but it is a closed integer formula once those
+                    are named: x' = (v + Q r) / m~ with v = sum_i [x_i m~ (Q/q_i)^-1]_{q_i} (Q/q_i) (fast base conversion, no
+                    correction), r = [-v Q^-1]_{m~} centred, m~ = 2^32 (an exact division: the small Montgomery reduction);
+                    D = tensor of the x' over Z[X]/(X^N+1); u = sum_i [(t D)_i (Q/q_i)^-1]_{q_i} (Q/q_i);
+                    result = ((t D - u) / Q) mod q_j (exact division again: the fast floor), which the Shenoy-Kumaresan step
+                    returns exactly whatever auxiliary base B is used (it only has to be large enough).  `bfv_multiply` below
+                    computes that with big integers — no auxiliary primes, no NTT — so it checks the oracle's whole BEHZ pipeline,
+                    base choice included, against the algorithm's integer meaning.
 
 Data layouts are SEAL's: ciphertext [size][L][N], key [L digits][2][K][N] in NTT form, key prime K-1 = special prime.
 """
@@ -241,3 +248,53 @@ class Model:
         ks = self.key_switch_coeff(r[1], gkey)
         res0 = [[(r[0][i][n] + ks[0][i][n]) % self.R.primes[i] for n in range(self.N)] for i in range(L)]
         return [self.from_coeff(res0), self.from_coeff(ks[1])]
+
+    # ---- BFV ct x ct multiply: the BEHZ pipeline as integer arithmetic (see the module docstring) ------------------------
+    def bfv_multiply(self, a, b, t: int):
+        assert not self.ntt_form
+        L, N = len(a[0]), self.N
+        idx = list(range(L))
+        primes = [self.R.primes[i] for i in idx]
+        Q = 1
+        for q in primes:
+            Q *= q
+        MT = 1 << 32
+        punct = [Q // q for q in primes]
+        inv_punct = [pow(pq % q, q - 2, q) for pq, q in zip(punct, primes)]
+        Qinv_mt = pow(Q, -1, MT)
+
+        def representative(poly):  # [L][N] residues -> integer coefficients x' = SmMRq(FastBconv_mtilde(x))
+            out = []
+            for n in range(N):
+                v = sum((poly[i][n] * MT % primes[i]) * inv_punct[i] % primes[i] * punct[i] for i in idx)
+                r = (-v * Qinv_mt) % MT
+                if r >= MT // 2:
+                    r -= MT
+                num = v + Q * r
+                assert num % MT == 0
+                out.append(num // MT)
+            return out
+
+        xa, xb = [representative(p) for p in a], [representative(p) for p in b]
+        bound = max(max(abs(v) for v in p) for p in xa + xb)
+        M = 1 << ((2 * bound * bound * N).bit_length() + 2)  # products computed mod M and re-centred: exact over Z
+
+        def zmul(x, y):
+            z = self.R.negacyclic_mul([v % M for v in x], [v % M for v in y], M)
+            return [v - M if v >= M // 2 else v for v in z]
+
+        d0 = zmul(xa[0], xb[0])
+        d1 = [p + q for p, q in zip(zmul(xa[0], xb[1]), zmul(xa[1], xb[0]))]
+        d2 = zmul(xa[1], xb[1])
+        out = []
+        for d in (d0, d1, d2):
+            res = [[0] * N for _ in idx]
+            for n in range(N):
+                td = t * d[n]
+                u = sum((td % primes[i]) * inv_punct[i] % primes[i] * punct[i] for i in idx)
+                assert (td - u) % Q == 0
+                f = (td - u) // Q
+                for i in idx:
+                    res[i][n] = f % primes[i]
+            out.append(res)
+        return out

@@ -3,8 +3,8 @@
 
 The fixture pins, bit for bit, what the oracle (CPU suite: tests/test_exact_model.py) and the HIP path (GPU suite:
 tests/test_gpu_parity.py::test_exact_model_fixture_gpu) must produce for multiply, relinearize, rescale, the fused
-multiply -> relinearize -> rescale sequence, lower-level key switching, and Galois rotations (single element and the two-term
-NAF rotation by 3), CKKS and BFV.  Expected outputs are stored as SHA-256 of the little-endian u64 array plus the first
+multiply -> relinearize -> rescale sequence, lower-level key switching, Galois rotations (single element and the two-term
+NAF rotation by 3), CKKS and BFV, and BFV's BEHZ ct x ct multiply (as the integer formula of exact_model.py).  Expected outputs are stored as SHA-256 of the little-endian u64 array plus the first
 coefficients of every residue polynomial (for diagnosis).  Prime chains come from the sympy restatement of
 CoeffModulus::Create (make_primes.py), not from the oracle.
 
@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import exact_inputs as xi  # noqa: E402
 from exact_model import Model  # noqa: E402
-from make_primes import coeff_modulus_create  # noqa: E402
+from make_primes import coeff_modulus_create, get_primes  # noqa: E402
 
 
 def digest(nested):
@@ -87,6 +87,11 @@ def run_case(case):
     else:
         c3 = xi.ciphertext(seed, 4, primes, Ltop, 3, N)  # BFV: key switching works on any size-3 ciphertext (coefficient form)
         put("relinearize", M.relinearize(c3, rk))
+        t = get_primes(2 * N, 20, 1)[0]  # PlainModulus::Batching(N, 20) (seal_context.cpp:118)
+        out["plain_modulus"] = t
+        m3 = M.bfv_multiply(a, b, t)     # BEHZ as integer arithmetic
+        put("bfv_multiply", m3)
+        put("bfv_multiply_relin", M.relinearize(m3, rk))
         put("rotate_columns", M.apply_galois(a, 2 * N - 1, gk[2 * N - 1]))
     r1 = M.apply_galois(a, g1, gk[g1])
     put("rotate_1", r1)

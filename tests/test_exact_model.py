@@ -62,6 +62,9 @@ def run_ops(f, d, ops):
             yield "relinearize_one_level_down", ops.relinearize(np.ascontiguousarray(c3[:, :d["Ltop"] - 1]), rk)
     else:
         yield "relinearize", ops.relinearize(d["c3"], rk)
+        m3 = ops.multiply(a, b)  # BEHZ
+        yield "bfv_multiply", m3
+        yield "bfv_multiply_relin", ops.relinearize(m3, rk)
         yield "rotate_columns", ops.apply_galois(a, ge["conj"], gk[ge["conj"]])
     yield "rotate_1", ops.apply_galois(a, ge["1"], gk[ge["1"]])
     yield "rotate_3_naf", ops.apply_galois(ops.apply_galois(a, ge["-1"], gk[ge["-1"]]), ge["4"], gk[ge["4"]])
@@ -72,7 +75,7 @@ class OracleOps:
         self.o = o
 
     def add(self, a, b): return self.o.add(a, b)
-    def multiply(self, a, b): return self.o.multiply_ntt(a, b)
+    def multiply(self, a, b): return self.o.multiply_ntt(a, b) if self.o.scheme == 2 else self.o.bfv_multiply(a, b)
     def relinearize(self, c3, rk): return self.o.relinearize(c3, rk)
     def rescale(self, ct): return self.o.rescale(ct)
     def apply_galois(self, ct, elt, key): return self.o.apply_galois(ct, elt, key)
@@ -84,6 +87,7 @@ def test_oracle_reproduces_the_exact_model(oracle, name):
     sid = oracle.SCHEME_CKKS if f["scheme"] == "ckks" else oracle.SCHEME_BFV
     o = oracle.Context(sid, f["N"], bit_sizes=f["bits"], plain_bits=20 if f["scheme"] == "bfv" else 0, sec128=False)
     assert [int(q) for q in o.moduli] == d["primes"]                       # CoeffModulus::Create, from the sympy restatement
+    assert f["scheme"] == "ckks" or int(o.t) == f["plain_modulus"]
     assert [o.root(i) for i in range(len(d["primes"]))] == [int(p, 16) for p in f["psi"]]  # the minimal primitive 2N-th roots
     assert {s: o.galois_elt(int(s)) for s in ("1", "-1", "4")} == {s: f["galois_elts"][s] for s in ("1", "-1", "4")}
     seen = set()

@@ -646,7 +646,8 @@ def test_pipeline_regression_fixture_gpu(be, oracle):
         g.close()
 
 
-@pytest.mark.parametrize("name", ["ckks_n1024_60_40_60", "ckks_n1024_50_45_45_50", "ckks_n2048_60_45_45_60", "bfv_n1024_60_40_60"])
+@pytest.mark.parametrize("name", ["ckks_n1024_60_40_60", "ckks_n1024_50_45_45_50", "ckks_n2048_60_45_45_60", "bfv_n1024_60_40_60",
+                                  "bfv_n2048_60_40_40_60"])
 def test_exact_model_fixture_gpu(be, name):
     """The HIP path against tests/golden/exact_vectors.json: expected outputs derived by the exact big-integer model
     (tests/golden/exact_model.py: CRT composition, exact floors, no RNS shortcuts, no oracle code).  The oracle is held to the same
@@ -669,9 +670,9 @@ def test_exact_model_fixture_gpu(be, name):
             g.add(a.shape[1], a.shape[0], 1, g.to_device(a[None]), g.to_device(b[None]), pw, out)
             return out.download(a.shape)
 
-        def multiply(self, a, b):
+        def multiply(self, a, b):  # CKKS: dyadic tensor; BFV: BEHZ, held to the integer formula of exact_model.bfv_multiply
             out = g.alloc(3 * a.shape[1] * N)
-            g.multiply(a.shape[1], 1, g.to_device(a[None]), g.to_device(b[None]), pw, out)
+            (g.multiply if ckks else g.bfv_multiply)(a.shape[1], 1, g.to_device(a[None]), g.to_device(b[None]), pw, out)
             return out.download((3, a.shape[1], N))
 
         def relinearize(self, c3, rk):
