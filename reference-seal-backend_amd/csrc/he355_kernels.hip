@@ -3,12 +3,13 @@
 //
 // Work decomposition (one residue polynomial = N = N1 x 1024 coefficients):
 //   * row kernels   : one 64-lane WAVE owns one 1024-element row, 16 elements per lane in VGPRs, the ten
-//                     stages run 4+4+2 in registers with two LDS exchanges (ntt_core.h); a workgroup is four
-//                     such waves (four rows of the same residue) and 34 KiB of LDS.
+//                     stages run 4+4+2 in registers with two register/lane transposes between them (ntt_core.h):
+//                     LDS exchanges by default, cross-lane swap steps (permlane / DPP) selectable (HE355_XCHG);
+//                     a workgroup is four such waves (four rows of the same residue) and 34 KiB of LDS.
 //   * column kernels: one LANE owns one stride-1024 column (N1 <= 32 values in VGPRs); twiddles of a column
 //                     pass are wave-uniform, so they come through scalar loads.
 // Global accesses are coalesced: layout A reads/writes 512 contiguous bytes per wave instruction, layout C
-// moves 16 B per lane (two dwordx4 per 32-byte lane segment).
+// moves 16 B per lane (two dwordx4 per 32-byte lane segment; a quad of lanes covers one 128-byte line).
 // Reference semantics implemented here: SEAL Evaluator::{add, multiply (CKKS), relinearize_inplace,
 // rescale_to_next_inplace, rotate_vector} as called from /root/reference/src/benchmarks/ckks/*.cpp and
 // src/engine/seal_context.cpp (see include/he355.h for the call-site map).
