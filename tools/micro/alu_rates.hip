@@ -85,6 +85,26 @@ __device__ __forceinline__ void bfly_shoup(u64 &X, u64 &Y, u64 W, u64 Wp, u64 q,
     X = x + T;
     Y = x - T + two_q;
 }
+// (a2) the same with the correction of X hoisted out of the butterfly: values grow by 2q per stage (product in [0,2q)), one
+//      conditional subtraction of 8q per element every 7 stages keeps them below 16q < 2^64 (q < 2^60)
+__device__ __forceinline__ void bfly_shoup_wide(u64 &X, u64 &Y, u64 W, u64 Wp, u64 q, u64 two_q)
+{
+    u64 Q = __umul64hi(Wp, Y);
+    u64 T = W * Y - Q * q;
+    u64 x = X;
+    X = x + T;
+    Y = x - T + two_q;
+}
+// (a3) approximate quotient: the low x low partial product's carry is dropped (quotient up to 2 too small, product in [0,4q))
+__device__ __forceinline__ void bfly_shoup_approx(u64 &X, u64 &Y, u64 W, u64 Wp, u64 q, u64 four_q)
+{
+    const u32 y0 = (u32)Y, y1 = (u32)(Y >> 32), w0 = (u32)Wp, w1 = (u32)(Wp >> 32);
+    u64 Q = (u64)y1 * w1 + __umulhi(y1, w0) + __umulhi(y0, w1);
+    u64 T = W * Y - Q * q;
+    u64 x = X;
+    X = x + T;
+    Y = x - T + four_q;
+}
 // (b) integer Montgomery butterfly (twiddle in Montgomery form), lazy [0,2q) on T
 __device__ __forceinline__ void bfly_mont(u64 &X, u64 &Y, u64 Wm, u64 qinv, u64 q, u64 two_q)
 {
@@ -113,7 +133,36 @@ __global__ void __launch_bounds__(256) k_bfly(u64 *out, u64 seed, u64 q, u64 aux
 {
     const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
     const u64 two_q = q << 1;
-    if (V < 2) {
+    if (V == 3 || V == 4) { // wide lazy ranges: periodic correction instead of one per butterfly
+        u64 x[ILP];
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) x[i] = (seed * (tid + 1) + i * 0x9E3779B97F4A7C15ull) % q;
+        u64 W = (seed ^ 0x5555) % q, Wp = aux;
+        const u64 eight_q = q << 3, four_q = q << 2;
+        for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+            for (int i = 0; i < ILP; i += 2) {
+                if (V == 3) bfly_shoup_wide(x[i], x[i + 1], W, Wp, q, two_q);
+                else bfly_shoup_approx(x[i], x[i + 1], W, Wp, q, four_q);
+            }
+            u64 t = x[1];
+#pragma unroll
+            for (int i = 1; i + 2 < ILP; i += 2) x[i] = x[i + 2];
+            x[ILP - 1] = t;
+            const int period = V == 3 ? 7 : 3;
+            if (it % period == period - 1) {
+#pragma unroll
+                for (int i = 0; i < ILP; ++i) {
+                    x[i] = x[i] >= eight_q ? x[i] - eight_q : x[i];
+                    if (V == 4) x[i] = x[i] >= four_q ? x[i] - four_q : x[i];
+                }
+            }
+        }
+        u64 acc = 0;
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) acc += x[i];
+        if (acc == 0x1234567) out[tid] = acc;
+    } else if (V < 2) {
         u64 x[ILP];
 #pragma unroll
         for (int i = 0; i < ILP; ++i) x[i] = (seed * (tid + 1) + i * 0x9E3779B97F4A7C15ull) % q;
@@ -195,6 +244,8 @@ int main()
     RUNB(0, q60, Wp60, "bfly_shoup_u64")
     RUNB(1, q60, inv64(q60), "bfly_mont_u64")
     RUNB(2, q45, 0, "bfly_fp64_q45")
+    RUNB(3, q60, Wp60, "bfly_shoup_u64_wide7")   // correction every 7 stages instead of per butterfly
+    RUNB(4, q60, Wp60, "bfly_shoup_u64_approx3") // approximate quotient, two-step correction every 3 stages
     // occupancy sweep: waves per SIMD = blocks per CU (256-thread blocks -> 1 wave per SIMD per block)
     for (int bpc = 1; bpc <= 8; bpc *= 2) {
         const int blk = p.multiProcessorCount * bpc;
