@@ -374,6 +374,22 @@ public:
             // special prime first, its correction through the column pass, then the data primes with the mod-down finished
             // inside K3 (the sums never go to HBM)
             launch_k3(env_, L, nc, B, key, K3_SPECIAL_ONLY);
+            static const bool fc_merge = !(getenv("HE355_FC_MERGE") && getenv("HE355_FC_MERGE")[0] == '0');
+            if (rescale_out && L >= 2 && fc_merge) {
+                // Mod-down + rescale with ONE column pass per target as well: only the prime the rescale divides out needs the
+                // mod-down correction by itself (its tiles run first, mod-down only); for every other prime the two corrections are
+                // combined in coefficient form, delta2 + P^-1 * delta1, inside one k_floor_cols launch that reads both sources (the
+                // special prime's sums and the divided-out prime's tail) -- 16 column passes per polynomial instead of 31, and the
+                // mod-down correction slab is neither written for those primes nor read back.
+                launch_floor_cols(env_, SP, 1, nc * 2, B.tpr, B.e, nullptr, 0, 0, /*tgt_first*/ L - 1, /*dst_ntgt*/ L);
+                K3Fuse last{B.e, B.c01, B.c01_item_stride, L - 1, L, nullptr, nullptr};
+                launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &last);
+                launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
+                launch_floor_cols(env_, L - 1, L - 1, nc * 2, S.rlr, S.f, nullptr, 0, 0, 0, L - 1, /*src2*/ B.tpr, SP);
+                K3Fuse rest{B.e, B.c01, B.c01_item_stride, 0, L - 1, S.f, rescale_out};
+                launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &rest);
+                return true;
+            }
             launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
             if (rescale_out && L >= 2) {
                 // ... and the rescale too: the last data prime's tiles first (mod-down only), their inverse transform and the

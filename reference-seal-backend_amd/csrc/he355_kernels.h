@@ -99,7 +99,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
 // addin (optional): the column-passed correction of an earlier floor step [n_polys][addin_ntgt][N], folded in scaled by
 // addin_src^-1 mod q_i (mod-down + rescale then share one row transform per residue)
 void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst, const u64 *addin = nullptr,
-                       int addin_src = 0, int addin_ntgt = 0);
+                       int addin_src = 0, int addin_ntgt = 0, int tgt_first = 0, int dst_ntgt = 0, const u64 *src2 = nullptr, int src2_prime = 0);
 // floor step, row half: out[(op,k,i)] = (tsrc[(op,k,i)] - NTT(dst_cols[(op,k,i)])) * s^-1 (+ addend) mod q_i.
 // Strides are in u64 elements.  If tail_prime >= 0 the rows of that prime additionally go through the
 // inverse row pass into tail[(op,k)] (next floor step's source).

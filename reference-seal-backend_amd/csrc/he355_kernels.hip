@@ -1319,22 +1319,24 @@ struct FloorColsArgs {
     u64 *dst;
     int src_prime, n_tgt, K;
     const FloorConst *fc;
+    int tgt_first, dst_ntgt; // targets [tgt_first, tgt_first + n_tgt) of a destination slab laid out for dst_ntgt targets
     // optional: an earlier floor step's column-passed correction [n_polys][addin_ntgt][N] (raw of the target prime) is folded in,
     // scaled by addin_src^-1 mod q_i: the two corrections of mod-down + rescale then need ONE row transform (both passes are linear)
     const u64 *addin;
     int addin_src, addin_ntgt;
+    // optional (HE355_FC_MERGE): the earlier floor step's SOURCE instead ([n_polys][N], after the inverse row pass, prime src2_prime):
+    // its correction is formed here in coefficient form and folded in BEFORE the column pass, delta = delta2 + src2^-1 * delta1 mod q_i,
+    // so both floor steps share ONE column pass per target as well (the pass is linear) and the earlier correction slab is neither
+    // written for these targets nor read back
+    const u64 *src2;
+    int src2_prime;
 };
 
+// canonical coefficients + floor(s/2) of one column of a source residue after its inverse row pass
 template <int LOGN1>
-__global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const PrimeDev *primes)
+__device__ __forceinline__ void floor_source_column(const PrimeDev &Ps, const u64 *src, int col, u64 c[1 << LOGN1])
 {
     constexpr int N1 = 1 << LOGN1;
-    constexpr u64 N = (u64)N1 << kRowLog;
-    const u64 poly = blockIdx.x >> 2;
-    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
-    const u64 *src = A.src + poly * N;
-    const PrimeDev &Ps = primes[A.src_prime];
-    u64 c[N1];
     if (LOGN1 == 0) {
         c[0] = src[col];
     } else if (Ps.f64) {
@@ -1357,12 +1359,37 @@ __global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const Pr
     const u64 qs = Ps.q, half = qs >> 1;
 #pragma unroll
     for (int a = 0; a < N1; ++a) c[a] = addmod(c[a], half, qs);
-    for (int i = 0; i < A.n_tgt; ++i) {
+}
+
+template <int LOGN1, bool MERGE>
+__global__ void __launch_bounds__(kBlock, 2) k_floor_cols(FloorColsArgs A, const PrimeDev *primes)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    const u64 poly = blockIdx.x >> 2;
+    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
+    const PrimeDev &Ps = primes[A.src_prime];
+    u64 c[N1];
+    floor_source_column<LOGN1>(Ps, A.src + poly * N, col, c);
+    const u64 qs = Ps.q;
+    // MERGE: the second source's column is parked in LDS (one 8-byte word per (row, thread): conflict-free), not in 64 more
+    // registers -- with both columns in registers the kernel needs 298 and runs at one wave per SIMD, or spills at two
+    __shared__ u64 park[MERGE ? N1 : 1][MERGE ? kBlock : 1];
+    u64 qs2 = 0;
+    if constexpr (MERGE) {
+        u64 c2[N1];
+        floor_source_column<LOGN1>(primes[A.src2_prime], A.src2 + poly * N, col, c2);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) park[a][threadIdx.x] = c2[a];
+        qs2 = primes[A.src2_prime].q;
+        // each thread reads back only what it wrote itself: no barrier needed
+    }
+    for (int i = A.tgt_first; i < A.tgt_first + A.n_tgt; ++i) {
         const PrimeDev &Pi = primes[i];
         const u64 qi = Pi.q;
         const u64 half_i = A.fc[A.src_prime * A.K + i].half_mod;
         const ModU64 mi = make_modu(Pi);
-        u64 *dst = A.dst + (poly * A.n_tgt + i) * N;
+        u64 *dst = A.dst + (poly * A.dst_ntgt + i) * N;
         u64 dl[N1];
 #pragma unroll
         for (int a = 0; a < N1; ++a) dl[a] = submod(qs > qi ? barrett64(c[a], mi) : c[a], half_i, qi);
@@ -1371,6 +1398,15 @@ __global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const Pr
             double x[N1];
 #pragma unroll
             for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(dl[a]);
+            if constexpr (MERGE) { // x = delta2 + src2^-1 * delta1 (centred product: |x| < 1.5 q + 1, the column pass's bound holds)
+                const FloorConst f2 = A.fc[A.src2_prime * A.K + i];
+#pragma unroll
+                for (int a = 0; a < N1; ++a) {
+                    const u64 v2 = park[a][threadIdx.x];
+                    const u64 d1 = submod(qs2 > qi ? barrett64(v2, mi) : v2, f2.half_mod, qi);
+                    x[a] += ar.mulmod_c(u52_to_f64(d1), f2.inv_d, f2.inv_i);
+                }
+            }
             col_fwd<ArF64, LOGN1>(ar, x, ctw(Pi.fwd));
             if (A.addin) {
                 const FloorConst fa = A.fc[A.addin_src * A.K + i];
@@ -1382,6 +1418,15 @@ __global__ void __launch_bounds__(kBlock) k_floor_cols(FloorColsArgs A, const Pr
             for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = ar.to_raw(x[a]);
         } else {
             const ArU64 ar = make_ar(Pi, (ArU64 *)nullptr);
+            if constexpr (MERGE) { // [0,q) + [0,q): a valid lazy input of the column pass
+                const FloorConst f2 = A.fc[A.src2_prime * A.K + i];
+#pragma unroll
+                for (int a = 0; a < N1; ++a) {
+                    const u64 v2 = park[a][threadIdx.x];
+                    const u64 d1 = submod(qs2 > qi ? barrett64(v2, mi) : v2, f2.half_mod, qi);
+                    dl[a] += mul_shoup(d1, f2.inv, f2.inv_shoup, qi);
+                }
+            }
             col_fwd<ArU64, LOGN1>(ar, dl, ctw(Pi.fwd));
             if (A.addin) {
                 const FloorConst fa = A.fc[A.addin_src * A.K + i];
@@ -2229,20 +2274,33 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
 }
 
 void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst, const u64 *addin, int addin_src,
-                       int addin_ntgt)
+                       int addin_ntgt, int tgt_first, int dst_ntgt, const u64 *src2, int src2_prime)
 {
-    if (!n_polys) return;
+    if (!n_polys || n_tgt <= 0) return;
     FloorColsArgs A;
     A.src = src; A.dst = dst; A.src_prime = src_prime; A.n_tgt = n_tgt; A.K = env.K; A.fc = env.floor_consts;
+    A.tgt_first = tgt_first; A.dst_ntgt = dst_ntgt > 0 ? dst_ntgt : n_tgt;
     A.addin = addin; A.addin_src = addin_src; A.addin_ntgt = addin_ntgt;
+    A.src2 = src2; A.src2_prime = src2_prime;
     const unsigned g = (unsigned)(n_polys * 4);
+    if (src2) {
+        switch (env.logn1) {
+        case 0: hipLaunchKernelGGL((k_floor_cols<0, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 1: hipLaunchKernelGGL((k_floor_cols<1, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 2: hipLaunchKernelGGL((k_floor_cols<2, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 3: hipLaunchKernelGGL((k_floor_cols<3, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 4: hipLaunchKernelGGL((k_floor_cols<4, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 5: hipLaunchKernelGGL((k_floor_cols<5, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        }
+        return;
+    }
     switch (env.logn1) {
-    case 0: hipLaunchKernelGGL(k_floor_cols<0>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 1: hipLaunchKernelGGL(k_floor_cols<1>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 2: hipLaunchKernelGGL(k_floor_cols<2>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 3: hipLaunchKernelGGL(k_floor_cols<3>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 4: hipLaunchKernelGGL(k_floor_cols<4>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 5: hipLaunchKernelGGL(k_floor_cols<5>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 0: hipLaunchKernelGGL((k_floor_cols<0, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 1: hipLaunchKernelGGL((k_floor_cols<1, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 2: hipLaunchKernelGGL((k_floor_cols<2, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 3: hipLaunchKernelGGL((k_floor_cols<3, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 4: hipLaunchKernelGGL((k_floor_cols<4, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+    case 5: hipLaunchKernelGGL((k_floor_cols<5, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
     }
 }
 
