@@ -17,6 +17,13 @@ struct PrimeDev {
     Tw16 inv_w0_scaled;
     int f64;              // 1: ArF64 engine owns this prime
     int pad_;
+    // k_k2n, this prime as the DIGIT prime j: how the digit's column enters the forward column pass of fp64-engine target prime t
+    // (bit t).  k2_direct: as it is (q_j < 2^52, q_j <= 2 q_t) and the 48-bit row format holds the result; k2_lift: after a
+    // re-centring (q_j > 2 q_t) or an integer reduction (q_j >= 2^52), result fits too; neither bit: the general path.
+    u64 k2_direct, k2_lift;
+    // fp64 engine: the column passes' twiddles as bare doubles, [0,32) = w of fwd[0..31], [32,64) = w of inv[0..31] (a column pass of
+    // N1 <= 32 rows uses entries 1 .. N1-1).  Inside the struct: one scalar load away from the prime index.  u64 engine: zeros
+    alignas(64) double colw[64];
 };
 
 // How result r picks its operands (HEBench outer product, ckks eltwise .cpp:334-336, or pairwise)

@@ -136,8 +136,23 @@ public:
             d.qd = af.q; d.qinv = af.qinv; d.ninv_d = af.ninv; d.ninv_i = af.ninv_i;
             d.fwd = dfwd; d.inv = dinv; d.inv_w0_scaled = pt.inv_w0_scaled;
             d.f64 = pt.f64 ? 1 : 0; d.pad_ = 0;
+            for (size_t k = 0; k < 64; ++k) d.colw[k] = 0.0;
+            if (pt.f64)
+                for (size_t k = 0; k < 32 && k < N; ++k) { d.colw[k] = ArF64::tw_w(pt.fwd[k]); d.colw[32 + k] = ArF64::tw_w(pt.inv[k]); }
+            d.k2_direct = d.k2_lift = 0;
             env_.prime_f64[i] = pt.f64 ? 1 : 0;
         }
+        // k_k2n's lift classes per (digit prime j, fp64-engine target prime t) -- the same rule the kernel's general path evaluates
+        for (size_t j = 0; j < K; ++j)
+            for (size_t t = 0; t < K; ++t) {
+                if (!P.primes[t].f64) continue;
+                const u64 qj = P.primes[j].q, qt = P.primes[t].q;
+                const bool df = (qj >> 52) == 0, direct = df && !(qj > 2 * qt);
+                double m = df ? (direct ? (double)qj : 0.5 * (double)qt + 1.0) : (double)qt;
+                for (int st = 0; st < P.logn1; ++st) m += (double)qt * (0.5 + m * 4.440892098500626e-16);
+                if (!(m * 1.0000001 < 140737488355328.0)) continue;
+                (direct ? pd[j].k2_direct : pd[j].k2_lift) |= (u64)1 << t;
+            }
         HIPCHECK(hipMalloc(&d_primes_, n_all * sizeof(PrimeDev)));
         HIPCHECK(hipMemcpy(d_primes_, pd.data(), n_all * sizeof(PrimeDev), hipMemcpyHostToDevice));
         std::vector<FloorConst> fc(K * K);

@@ -768,6 +768,9 @@ struct K2Args {
     u64 *d;
     u64 n_ops;
     int L, K, ckks, src_is_coeff;
+    u64 f64_mask; // bit t: key prime t belongs to the fp64 engine
+    int ablate;  // timing experiments (wrong results): 1 = every target's rows land in the slab region of target 0 (no HBM write stream), 2 = no u64-engine targets
+    int xcd_map; // k_k2n: the four column blocks of one (op, digit) run on the same XCD (blocks b and b + 8 share one)
 };
 
 // The digit slab is written once and read once, much later and by other CUs (a chunk of it is gigabytes): HE355_K2_NT=1
@@ -877,6 +880,350 @@ __global__ void __launch_bounds__(kBlock, K2_WAVES) k_k2(K2Args A, const PrimeDe
         u64 *dst = A.d + ((op * (A.L + 1) + tt) * A.L + j) * N;
         k2_target<LOGN1>(Pj, primes[t], c, dst, col);
     }
+}
+
+// ---- K2, second form (round 3) --------------------------------------------------------------------------
+// Same job and same slab contents as k_k2; what changed is everything around the butterflies, which in k_k2 cost as many VALU
+// instructions as the butterflies themselves (ISA count per fp64 target and lane: 640 butterfly instructions out of ~1000):
+//   * the digit column is held in the form the targets consume: canonical doubles when q_j < 2^52 (every target of the fp64
+//     engine then reads it as is; the two u64-engine targets convert back), integers only for a 60-bit digit;
+//   * column twiddles come from PrimeDev::colw (bare doubles): 62 scalar registers per target instead of 124 -- k_k2 spilled 63
+//     SGPRs into VGPR lanes and paid ~106 v_readlane / v_writelane per target for it;
+//   * the first stage reads the digit column and writes the target column (no copy of 32 values per target), the last stage
+//     produces the 48-bit patterns directly (col_fwd_w, BIAS);
+//   * every store address is (scalar row base) + (one per-lane 32-bit offset computed once per kernel): the slab pointer of the
+//     target is made wave-uniform explicitly, the row bases advance on the scalar unit -- k_k2 spent two 64-bit VALU additions
+//     (and the wait states of their carry chains) per store, ~170 instructions per target.
+typedef const __attribute__((address_space(4))) double *cdw_t;
+__device__ __forceinline__ cdw_t cdw(const double *p) { return (cdw_t)(unsigned long long)p; }
+// Buffer resource over one polynomial's row slots (wave-uniform base made explicit with v_readfirstlane): a store through it is
+// buffer_store ... v_off, s[rsrc], s_off offen -- address = base + (scalar row offset) + (per-lane 32-bit offset computed once per
+// kernel), no VALU instruction per store.
+typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+constexpr u32 kSlotBytes = kRowN * 8; // one row slot of a slab
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t poly_rsrc(const void *p, u32 bytes)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+}
+// 48-bit pattern rows of one polynomial: row a in slot a, low words at lane offset off4 = 4 * col, high half-words at
+// off2h = kPackHiOff + 2 * col
+template <int N1> __device__ __forceinline__ void store_pattern_rows(__amdgpu_buffer_rsrc_t dst, u32 off4, u32 off2h, const double x[N1])
+{
+#pragma unroll
+    for (int a = 0; a < N1; ++a) {
+        union { u64 u; double d; } c;
+        c.d = x[a];
+        __builtin_amdgcn_raw_buffer_store_b32((u32)c.u, dst, (int)off4, a * (int)kSlotBytes, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(c.u >> 32), dst, (int)off2h, a * (int)kSlotBytes, 0);
+    }
+}
+template <int N1> __device__ __forceinline__ void store_word_rows(__amdgpu_buffer_rsrc_t dst, u32 off8, const u64 x[N1])
+{
+#pragma unroll
+    for (int a = 0; a < N1; ++a) {
+        u32x2_t v;
+        v.x = (u32)x[a]; v.y = (u32)(x[a] >> 32);
+        __builtin_amdgcn_raw_buffer_store_b64(v, dst, (int)off8, a * (int)kSlotBytes, 0);
+    }
+}
+// HE355_K2_WIDE: the pattern rows of a wave's 64 columns go through a 12 KiB LDS tile (8 KiB of low words, 4 KiB of high half-words,
+// row-major) and leave as 16-byte stores: 8 + 4 buffer_store_dwordx4 of 1 KiB per target instead of 32 + 32 stores of 256 / 128 bytes.
+// Only the issuing wave touches its tile (wavefront-scope hand-off).  lane_lo / lane_hi: the per-lane byte offsets of the 16-byte
+// pieces inside a group of 4 (low plane) / 8 (high plane) rows, wave's column offset included.
+#ifndef HE355_K2_WIDE
+#define HE355_K2_WIDE 1
+#endif
+constexpr bool kK2Wide = HE355_K2_WIDE != 0;
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+template <int N1>
+__device__ __forceinline__ void store_pattern_rows_wide(__amdgpu_buffer_rsrc_t dst, unsigned char *tile, int lane, u32 lane_lo, u32 lane_hi, const double x[N1])
+{
+    static_assert(N1 % 8 == 0, "written for whole groups of 8 rows");
+    u32 *lo = reinterpret_cast<u32 *>(tile);
+    unsigned short *hi = reinterpret_cast<unsigned short *>(tile + N1 * 256);
+#pragma unroll
+    for (int a = 0; a < N1; ++a) {
+        union { u64 u; double d; } c;
+        c.d = x[a];
+        lo[a * 64 + lane] = (u32)c.u;
+        hi[a * 64 + lane] = (unsigned short)(c.u >> 32);
+    }
+    HE_WAVE_SYNC();
+    const u32x4_t *lo4 = reinterpret_cast<const u32x4_t *>(tile);
+    const u32x4_t *hi4 = reinterpret_cast<const u32x4_t *>(tile + N1 * 256);
+    // all reads first, into registers of their own (left to itself the scheduler chains read -> wait -> store through one register quad)
+    u32x4_t vl[N1 / 4], vh[N1 / 8];
+#pragma unroll
+    for (int k = 0; k < N1 / 4; ++k) vl[k] = lo4[k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < N1 / 8; ++k) vh[k] = hi4[k * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < N1 / 4; ++k) // 4 rows x 256 bytes per instruction
+        __builtin_amdgcn_raw_buffer_store_b128(vl[k], dst, (int)lane_lo, k * 4 * (int)kSlotBytes, 0);
+#pragma unroll
+    for (int k = 0; k < N1 / 8; ++k) // 8 rows x 128 bytes per instruction
+        __builtin_amdgcn_raw_buffer_store_b128(vh[k], dst, (int)lane_hi, k * 8 * (int)kSlotBytes, 0);
+    HE_WAVE_SYNC(); // the tile is free again for the next target
+}
+// worst-case magnitude after the forward column pass of the fp64 engine from inputs |x| < m0 (ArF64::bfly_fwd: m -> m + q (1/2 + m 2^-51))
+template <int LOGN1> __device__ __forceinline__ bool fits_48(double m0, double q)
+{
+    double m = m0;
+#pragma unroll
+    for (int st = 0; st < LOGN1; ++st) m += q * (0.5 + m * 4.440892098500626e-16); // 2^-51
+    return m * 1.0000001 < 140737488355328.0;                                        // 2^47
+}
+
+// Per-target constants come through the constant address space (scalar loads): a vector load of a PrimeDev field would put an
+// s_waitcnt vmcnt(0) -- i.e. the full HBM write latency of the previous target's stores -- in front of every target.
+typedef const __attribute__((address_space(4))) PrimeDev *cprime_t;
+typedef double d16_t __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) d16_t *cd16_t;
+__device__ __forceinline__ d16_t load_colw16(cprime_t cp, int t, int first) { return *(cd16_t)(unsigned long long)&cp[t].colw[first]; }
+
+// Targets of the fp64 engine on the fast path (host-built masks PrimeDev::k2_direct / k2_lift of the digit's prime: the 48-bit row
+// format holds the column pass's output).  One iteration per target prime t in `mask` (bit = prime index), software-pipelined
+// over the scalar loads: the twiddles of stages 0..3 (entries 0..15) and the modulus constants of the NEXT target are requested
+// before the current target's last stage and its stores, the 16 entries of stage 4 at the top of the target, behind stages 0..3 --
+// as the compiler places them (one s_load + s_waitcnt lgkmcnt(0) per stage) each target waited five scalar-load latencies.
+// DIRECT: the column enters as it is; else it is lifted first (re-centred, or reduced with integers from a 60-bit digit: DF false).
+template <int LOGN1, bool DF, bool DIRECT, class Store>
+__device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev *primes, int j, u64 op, u64 mask,
+                                                 const typename std::conditional<DF, double, u64>::type (&c)[1 << LOGN1], Store store_rows)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    constexpr int LA = LOGN1 < 4 ? LOGN1 : 4; // stages served by entries 0..15
+    static_assert(DF || !DIRECT, "an integer digit is always lifted");
+    if (!mask) return;
+    const cprime_t cp = (cprime_t)(unsigned long long)primes;
+    u64 m = mask;
+    int t = __builtin_ctzll(m);
+    d16_t wa = load_colw16(cp, t, 0);
+    double qd = cp[t].qd, qinv = cp[t].qinv;
+    // Scalar loads return out of order, so every wait on one is lgkmcnt(0), a wait on all of them.  The waits are therefore placed by
+    // hand where nothing young is in flight: here, and before the next target's prefetch below (the stage-4 entries, requested at the
+    // top of the target, landed long before); the tile's LDS traffic then covers the prefetch.
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+    for (;;) {
+        m &= m - 1;
+        const int tn = m ? __builtin_ctzll(m) : t;
+        d16_t wb = wa;
+        if constexpr (LOGN1 == 5) wb = load_colw16(cp, t, 16);
+        __builtin_amdgcn_sched_barrier(0);
+        ArF64 ar;
+        ar.q = qd; ar.qinv = qinv; ar.ninv = 0; ar.ninv_i = 0;
+        double x[N1];
+        if constexpr (!DIRECT) {
+            if constexpr (DF) {
+#pragma unroll
+                for (int a = 0; a < N1; ++a) x[a] = ar.renorm(c[a]);
+            } else {
+                ModU64 mt;
+                mt.q = cp[t].q; mt.cr0 = cp[t].cr0; mt.cr1 = cp[t].cr1;
+#pragma unroll
+                for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(barrett64(c[a], mt));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < LA; ++s) {
+            const int gap = N1 >> (s + 1);
+#pragma unroll
+            for (int a = 0; a < N1; ++a) {
+                if (a & gap) continue;
+                const double w = wa[(1 << s) + (a / (2 * gap))];
+                double X, Y;
+                if (DIRECT && s == 0) { X = (double)c[a]; Y = (double)c[a + gap]; }
+                else { X = x[a]; Y = x[a + gap]; }
+                const double tw = ar.mulmod_vv(Y, w);
+                if (s == LOGN1 - 1) {
+                    const double xb = X + kPackBias;
+                    x[a] = xb + tw; x[a + gap] = xb - tw;
+                } else {
+                    x[a] = X + tw; x[a + gap] = X - tw;
+                }
+            }
+        }
+        // the next target's first twiddles and constants: in flight behind the last stage and the stores
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): this target's stage-4 entries
+        const d16_t wa_n = load_colw16(cp, tn, 0);
+        const double qd_n = cp[tn].qd, qinv_n = cp[tn].qinv;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LOGN1 == 5) {
+#pragma unroll
+            for (int a = 0; a < N1; a += 2) {
+                const double tw = ar.mulmod_vv(x[a + 1], wb[a >> 1]);
+                const double xb = x[a] + kPackBias;
+                x[a] = xb + tw; x[a + 1] = xb - tw;
+            }
+        }
+        if constexpr (LOGN1 == 0) x[0] = (DIRECT ? (double)c[0] : x[0]) + kPackBias;
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the prefetch had the last stage to land; the tile's LDS traffic then waits by count
+        const int tt = t == A.K - 1 ? A.L : t;
+        store_rows(poly_rsrc(A.d + ((op * (A.L + 1) + ((A.ablate & 1) ? 0 : tt)) * A.L + j) * N, (u32)N1 * kSlotBytes), x);
+        if (!m) break;
+        t = tn; wa = wa_n; qd = qd_n; qinv = qinv_n;
+    }
+}
+
+// Targets of the fp64 engine.  DF: the digit's canonical coefficients are held as doubles (q_j < 2^52), else as integers.
+template <int LOGN1, bool DF>
+__device__ __forceinline__ void k2n_targets_f64(const K2Args &A, const PrimeDev *primes, const PrimeDev &Pj, int j, u64 op,
+                                                const typename std::conditional<DF, double, u64>::type (&c)[1 << LOGN1], int col, unsigned char *tile)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    constexpr bool kWide = kK2Wide && kPackD && N1 >= 8;
+    const u32 off8 = (u32)col << 3, off4 = (u32)col << 2, off2h = ((u32)col << 1) + kPackHiOff;
+    const int lane = col & 63;
+    const u32 wc = (u32)col & ~63u; // the wave's first column
+    const u32 lane_lo = ((u32)lane >> 4) * kSlotBytes + (wc << 2) + (((u32)lane & 15u) << 4);
+    const u32 lane_hi = ((u32)lane >> 3) * kSlotBytes + kPackHiOff + (wc << 1) + (((u32)lane & 7u) << 4);
+    auto store_rows = [&](__amdgpu_buffer_rsrc_t dst, const double (&x)[N1]) {
+        if constexpr (kWide) store_pattern_rows_wide<N1>(dst, tile, lane, lane_lo, lane_hi, x);
+        else store_pattern_rows<N1>(dst, off4, off2h, x);
+    };
+    // this launch's targets by prime index: data primes [0, L) and the special prime, without the digit's own prime (CKKS: that
+    // digit is the NTT-form input itself)
+    const cprime_t cp = (cprime_t)(unsigned long long)primes;
+    u64 level = (A.L >= 64 ? ~(u64)0 : (((u64)1 << A.L) - 1)) | ((u64)1 << (A.K - 1));
+    if (A.ckks) level &= ~((u64)1 << j);
+    const u64 f64_targets = A.f64_mask & level;
+    u64 direct = 0, lift = 0;
+    if constexpr (kPackD) { direct = cp[j].k2_direct & f64_targets; lift = cp[j].k2_lift & f64_targets; }
+    if constexpr (DF) k2n_fast_targets<LOGN1, DF, true>(A, primes, j, op, direct, c, store_rows);
+    k2n_fast_targets<LOGN1, DF, false>(A, primes, j, op, DF ? lift : (lift | direct), c, store_rows);
+    // the general path: any lift, results re-centred before they are packed (wider fp64-engine primes), or 64-bit rows (HE355_PACK_D=0)
+    for (u64 m = f64_targets & ~(direct | lift); m; m &= m - 1) {
+        const int t = __builtin_ctzll(m), tt = t == A.K - 1 ? A.L : t;
+        const PrimeDev &Pt = primes[t];
+        const __amdgpu_buffer_rsrc_t dst = poly_rsrc(A.d + ((op * (A.L + 1) + tt) * A.L + j) * N, (u32)N1 * kSlotBytes);
+        const ArF64 ar = make_ar(Pt, (ArF64 *)nullptr);
+        const cdw_t cw = cdw(Pt.colw);
+        double x[N1];
+        if constexpr (DF) {
+            const bool recentre = Pj.q > 2 * Pt.q;
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = recentre ? ar.renorm(c[a]) : c[a];
+        } else {
+            const ModU64 mt = make_modu(Pt);
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(barrett64(c[a], mt));
+        }
+        col_fwd_w<LOGN1, false>(ar, [&](int a) { return x[a]; }, x, cw, 0.0);
+        if constexpr (kPackD) {
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = ar.renorm(x[a]) + kPackBias;
+            store_rows(dst, x);
+        } else {
+            u64 v[N1];
+#pragma unroll
+            for (int a = 0; a < N1; ++a) v[a] = ar.to_raw(x[a]);
+            store_word_rows<N1>(dst, off8, v);
+        }
+    }
+}
+// Targets of the u64 engine, from the digit's canonical coefficients as integers.
+template <int LOGN1>
+__device__ __forceinline__ void k2n_targets_u64(const K2Args &A, const PrimeDev *primes, const PrimeDev &Pj, int j, u64 op, const u64 (&c)[1 << LOGN1], int col)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    const u32 off8 = (u32)col << 3;
+    u64 level = (A.L >= 64 ? ~(u64)0 : (((u64)1 << A.L) - 1)) | ((u64)1 << (A.K - 1));
+    if (A.ckks) level &= ~((u64)1 << j);
+    if (A.ablate & 2) level = 0;
+    for (u64 m = ~A.f64_mask & level; m; m &= m - 1) {
+        const int t = __builtin_ctzll(m), tt = t == A.K - 1 ? A.L : t;
+        const PrimeDev &Pt = primes[t];
+        const __amdgpu_buffer_rsrc_t dst = poly_rsrc(A.d + ((op * (A.L + 1) + ((A.ablate & 1) ? 0 : tt)) * A.L + j) * N, (u32)N1 * kSlotBytes);
+        const ArU64 ar = make_ar(Pt, (ArU64 *)nullptr);
+        u64 x[N1];
+        if (Pj.q > Pt.q) {
+            const ModU64 mt = make_modu(Pt);
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = barrett64(c[a], mt);
+        } else {
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = c[a];
+        }
+        col_fwd<ArU64, LOGN1>(ar, x, ctw(Pt.fwd));
+        store_word_rows<N1>(dst, off8, x);
+    }
+}
+
+#ifndef K2N_WAVES
+#define K2N_WAVES 3
+#endif
+template <int LOGN1>
+__global__ void __launch_bounds__(kBlock, K2N_WAVES) k_k2n(K2Args A, const PrimeDev *primes)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    u64 oj = blockIdx.x >> 2;
+    u32 cb = blockIdx.x & 3;
+    if (A.xcd_map) {
+        const u64 s = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+        oj = (s >> 2) * 8 + xcd;
+        cb = (u32)(s & 3);
+        if (oj >= A.n_ops * A.L) return; // whole block
+    }
+    const int col = (int)(cb << 8) | threadIdx.x;
+    const u32 oj32 = (u32)oj; // n_ops * L < 2^32
+    const int j = (int)__builtin_amdgcn_readfirstlane(oj32 % (u32)A.L);
+    const u64 op = __builtin_amdgcn_readfirstlane(oj32 / (u32)A.L);
+    const u64 *src = A.c2r + op * A.src_op_stride + (u64)j * N;
+    const PrimeDev &Pj = primes[j];
+    const bool coeff_in = A.src_is_coeff || LOGN1 == 0; // BFV: coefficient form already; N = 1024: the row pass was the whole inverse
+    constexpr bool kTile = kK2Wide && kPackD && N1 >= 8;
+    __shared__ __attribute__((aligned(16))) unsigned char tiles[kTile ? kWaves : 1][kTile ? N1 * 384 : 16];
+    unsigned char *tile = tiles[kTile ? threadIdx.x >> 6 : 0];
+    if (Pj.q >> 52) { // a 60-bit digit: integers
+        u64 c[N1];
+        if (coeff_in) {
+#pragma unroll
+            for (int a = 0; a < N1; ++a) c[a] = src[(a << kRowLog) + col];
+        } else {
+            const ArU64 ar = make_ar(Pj, (ArU64 *)nullptr);
+            u64 x[N1];
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
+            col_inv<ArU64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
+#pragma unroll
+            for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
+        }
+        k2n_targets_f64<LOGN1, false>(A, primes, Pj, j, op, c, col, tile);
+        k2n_targets_u64<LOGN1>(A, primes, Pj, j, op, c, col);
+        return;
+    }
+    double c[N1];
+    if (coeff_in) {
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = u52_to_f64(src[(a << kRowLog) + col]);
+    } else if (Pj.f64) {
+        const ArF64 ar = make_ar(Pj, (ArF64 *)nullptr);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = ar.from_raw(src[(a << kRowLog) + col]);
+        col_inv<ArF64, LOGN1>(ar, c, ctw(Pj.inv), Pj.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = ar.canon(c[a]);
+    } else { // a u64-engine prime below 2^52
+        const ArU64 ar = make_ar(Pj, (ArU64 *)nullptr);
+        u64 x[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
+        col_inv<ArU64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = u52_to_f64(ar.to_canon(x[a]));
+    }
+    k2n_targets_f64<LOGN1, true>(A, primes, Pj, j, op, c, col, tile);
+    u64 cu[N1]; // the fp64 targets are done: the column continues as integers (the doubles die here)
+#pragma unroll
+    for (int a = 0; a < N1; ++a) cu[a] = f64_to_u52(c[a]);
+    k2n_targets_u64<LOGN1>(A, primes, Pj, j, op, cu, col);
 }
 
 // K2 split in two (HE355_K2_SPLIT): k_k2a finishes the inverse transform of every digit in place (column pass, canonical
@@ -2143,6 +2490,8 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     A.src_op_stride = src ? src_op_stride : (u64)L * env.N;
     A.src_is_coeff = src ? 1 : 0;
     A.d = buf.d; A.n_ops = n_ops; A.L = L; A.K = env.K; A.ckks = env.scheme == 2;
+    A.f64_mask = 0; A.ablate = 0; A.xcd_map = 0;
+    for (int t = 0; t < env.K; ++t) A.f64_mask |= (u64)(env.prime_f64[t] != 0) << t;
     static const int split_env = getenv("HE355_K2_SPLIT") ? atoi(getenv("HE355_K2_SPLIT")) : HE355_K2_SPLIT;
     if (split_env) {
         // finish the inverse transform in place (nothing to do when the target is in coefficient form already or the row pass was
@@ -2170,7 +2519,24 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         }
         return;
     }
-    const unsigned g = (unsigned)(n_ops * L * 4);
+    unsigned g = (unsigned)(n_ops * L * 4);
+    static const bool k2_new = !(getenv("HE355_K2_NEW") && getenv("HE355_K2_NEW")[0] == '0');
+    static const bool k2_xcd = getenv("HE355_K2_XCD") && getenv("HE355_K2_XCD")[0] == '1';
+    A.xcd_map = k2_new && k2_xcd;
+    static const int k2_abl = getenv("HE355_K2_ABL") ? atoi(getenv("HE355_K2_ABL")) : 0;
+    A.ablate = k2_abl;
+    if (A.xcd_map) g = (unsigned)(((n_ops * L + 7) / 8) * 8 * 4);
+    if (k2_new) {
+        switch (env.logn1) {
+        case 0: hipLaunchKernelGGL(k_k2n<0>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 1: hipLaunchKernelGGL(k_k2n<1>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 2: hipLaunchKernelGGL(k_k2n<2>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 3: hipLaunchKernelGGL(k_k2n<3>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 4: hipLaunchKernelGGL(k_k2n<4>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 5: hipLaunchKernelGGL(k_k2n<5>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        }
+        return;
+    }
     switch (env.logn1) {
     case 0: hipLaunchKernelGGL(k_k2<0>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
     case 1: hipLaunchKernelGGL(k_k2<1>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;

@@ -205,15 +205,16 @@ struct ArF64 {
         c.d = x;
         return c.u;
     }
-    // any integer |x| < 2^52 -> canonical [0,q)
-    HE_HD u64 to_canon(T x) const
+    // any integer |x| < 2^52 -> canonical [0,q), as a double / as an integer
+    HE_HD T canon(T x) const
     {
         double c = __builtin_floor(x * qinv);
         double r = __builtin_fma(-c, q, x);
         if (r < 0.0) r += q;
         if (r >= q) r -= q;
-        return f64_to_u52(r);
+        return r;
     }
+    HE_HD u64 to_canon(T x) const { return f64_to_u52(canon(x)); }
     // y*w mod q, centred: |result| <= q*(1/2 + |y|*2^-51); tw.a = w, tw.b = fl(w/q) as doubles
     HE_HD T mulmod_c(T y, double w, double winv) const
     {

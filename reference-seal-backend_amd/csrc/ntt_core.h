@@ -363,6 +363,42 @@ template <class Ar, int LOGN1, class TW> HE_HD void col_fwd(const Ar &ar, typena
         }
     }
 }
+// The fp64 engine's forward column pass as the digit-lift kernels run it: same butterflies in the same order as col_fwd<ArF64>, with
+//   * the twiddles as bare doubles (PrimeDev::colw: 8 bytes per entry in scalar registers instead of 16),
+//   * the first stage reading its inputs through in(a) (the lifted source column is kept for the next target prime, so the
+//     stage writes x out of place instead of transforming a copy),
+//   * BIAS: the last stage adds `bias` to both outputs, (X + bias) +- t.  With bias = kPackBias (he355_kernels.hip) and
+//     |X +- t| < 2^47 every sum is an integer in [2^52, 2^53), hence exact, and the outputs are the 48-bit row patterns themselves:
+//     one addition per butterfly instead of one per element.
+template <int LOGN1, bool BIAS, class In, class TW> HE_HD void col_fwd_w(const ArF64 &ar, In in, double x[1 << LOGN1], TW cw, double bias)
+{
+    constexpr int N1 = 1 << LOGN1;
+    if (LOGN1 == 0) {
+        x[0] = BIAS ? in(0) + bias : in(0);
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < LOGN1; ++s) {
+        const int gap = N1 >> (s + 1);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) {
+            if (a & gap) continue;
+            const double w = cw[(1 << s) + (a / (2 * gap))];
+            const double X = s == 0 ? in(a) : x[a];
+            const double Y = s == 0 ? in(a + gap) : x[a + gap];
+            const double t = ar.mulmod_vv(Y, w);
+            if (BIAS && s == LOGN1 - 1) {
+                const double xb = X + bias;
+                x[a] = xb + t;
+                x[a + gap] = xb - t;
+            } else {
+                x[a] = X + t;
+                x[a + gap] = X - t;
+            }
+        }
+    }
+}
+
 // inverse column pass; the very last stage (s == 0) folds N^-1: w0_scaled = itw[1] * N^-1
 template <class Ar, int LOGN1, class TW> HE_HD void col_inv(const Ar &ar, typename Ar::T x[1 << LOGN1], TW itw, const Tw16 &w0_scaled)
 {
