@@ -130,6 +130,15 @@ constexpr bool kXlT1 = (HE355_XCHG & 2) != 0, kXlT2 = (HE355_XCHG & 1) != 0;
 #define HE355_KSHARE 0
 #endif
 constexpr bool kKeyShare = HE355_KSHARE != 0 && kXlT1 && kXlT2;
+// HE355_KEY_EARLY: the fused fp64 K3 requests a digit's two key rows before the second exchange of its row transform
+#ifndef HE355_KEY_EARLY
+#define HE355_KEY_EARLY 1
+#endif
+constexpr bool kKeyEarly = HE355_KEY_EARLY != 0;
+#ifndef HE355_MAC_G
+#define HE355_MAC_G 4
+#endif
+constexpr int kMacG = HE355_MAC_G; // key products issued together (2 polynomials x kMacG / 2 elements)
 struct XLaneHw {
     int lane;
     template <int LB> __device__ __forceinline__ void step32(u32 &a, u32 &b) const
@@ -172,12 +181,29 @@ struct XLaneHw {
 // Completion is covered by the issuing wave's vmcnt (s_waitcnt vmcnt(0) before the first ds_read).
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
+// HE355_DMA_ASM (default): the instruction is issued from inline assembly, i.e. hidden from the compiler's wait-count insertion.
+// Through the builtin, every ds_read that follows a DMA in program order gets an s_waitcnt vmcnt(0) in front of it whenever the
+// compiler cannot rule out that it reads the landing buffer -- in k_k3 that is the first LDS exchange of the row transform, a third
+// of the way into the step the DMA was meant to hide behind (ISA of round 2's kernel).  The kernels wait for a landing buffer
+// themselves (asm volatile s_waitcnt vmcnt(0) before they read it); vector-memory results return in issue order, so the waits the
+// compiler places for its own, younger loads stay sufficient.  M0 (LDS base of the DMA) is used by nothing else in these kernels.
+#ifndef HE355_DMA_ASM
+#define HE355_DMA_ASM 1
+#endif
 template <int PIECES = 8> // 1 KiB pieces of the row slot that hold data (8: a row of 64-bit words; 6: a 48-bit packed digit row)
 __device__ __forceinline__ void dma_row_to_lds(const u64 *grow, u64 *lds_row, int lane)
 {
+#if HE355_DMA_ASM
+    const u32 lbase = __builtin_amdgcn_readfirstlane((u32)(unsigned long long)(lds_void_t *)lds_row);
+    const u64 *g = grow + (lane << 1);
+#pragma unroll
+    for (int k = 0; k < PIECES; ++k)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lbase + (u32)(k << 10)), "v"(g + (k << 7)) : "memory");
+#else
 #pragma unroll
     for (int k = 0; k < PIECES; ++k)
         __builtin_amdgcn_global_load_lds((glb_void_t *)(grow + (k << 7) + (lane << 1)), (lds_void_t *)(lds_row + (k << 7)), 16, 0, 0);
+#endif
 }
 __device__ __forceinline__ void lds_rowA(const u64 *lds_row, int lane, u64 v[kRowE])
 {
@@ -769,7 +795,7 @@ struct K2Args {
     u64 n_ops;
     int L, K, ckks, src_is_coeff;
     u64 f64_mask; // bit t: key prime t belongs to the fp64 engine
-    int ablate;  // timing experiments (wrong results): 1 = every target's rows land in the slab region of target 0 (no HBM write stream), 2 = no u64-engine targets
+    int ablate;  // timing experiments (wrong results): 1 = every target's rows land in the slab region of target 0 (no HBM write stream), 2 = no u64-engine targets, 4 = no stores for the fp64 targets
     int xcd_map; // k_k2n: the four column blocks of one (op, digit) run on the same XCD (blocks b and b + 8 share one)
 };
 
@@ -979,6 +1005,11 @@ template <int LOGN1> __device__ __forceinline__ bool fits_48(double m0, double q
 
 // Per-target constants come through the constant address space (scalar loads): a vector load of a PrimeDev field would put an
 // s_waitcnt vmcnt(0) -- i.e. the full HBM write latency of the previous target's stores -- in front of every target.
+// butterflies of a column-pass stage issued together (interleaved dependent chains, ArF64::mulmod_vv_g)
+#ifndef HE355_K2_G
+#define HE355_K2_G 2
+#endif
+constexpr int kK2G = HE355_K2_G;
 typedef const __attribute__((address_space(4))) PrimeDev *cprime_t;
 typedef double d16_t __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) d16_t *cd16_t;
@@ -1031,19 +1062,28 @@ __device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev
 #pragma unroll
         for (int s = 0; s < LA; ++s) {
             const int gap = N1 >> (s + 1);
+            // the stage's N1/2 butterflies, kK2G at a time (interleaved instruction chains)
+            constexpr int G = (N1 / 2) % kK2G == 0 ? kK2G : 1;
 #pragma unroll
-            for (int a = 0; a < N1; ++a) {
-                if (a & gap) continue;
-                const double w = wa[(1 << s) + (a / (2 * gap))];
-                double X, Y;
-                if (DIRECT && s == 0) { X = (double)c[a]; Y = (double)c[a + gap]; }
-                else { X = x[a]; Y = x[a + gap]; }
-                const double tw = ar.mulmod_vv(Y, w);
-                if (s == LOGN1 - 1) {
-                    const double xb = X + kPackBias;
-                    x[a] = xb + tw; x[a + gap] = xb - tw;
-                } else {
-                    x[a] = X + tw; x[a + gap] = X - tw;
+            for (int b0 = 0; b0 < N1 / 2; b0 += G) {
+                double X[G], Y[G], W[G], tw[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const int b = b0 + k, a = ((b / gap) * 2 * gap) + (b % gap); // butterfly b of the stage: rows a, a + gap
+                    W[k] = wa[(1 << s) + (a / (2 * gap))];
+                    if (DIRECT && s == 0) { X[k] = (double)c[a]; Y[k] = (double)c[a + gap]; }
+                    else { X[k] = x[a]; Y[k] = x[a + gap]; }
+                }
+                ar.template mulmod_vv_g<G>(Y, W, tw);
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const int b = b0 + k, a = ((b / gap) * 2 * gap) + (b % gap);
+                    if (s == LOGN1 - 1) {
+                        const double xb = X[k] + kPackBias;
+                        x[a] = xb + tw[k]; x[a + gap] = xb - tw[k];
+                    } else {
+                        x[a] = X[k] + tw[k]; x[a + gap] = X[k] - tw[k];
+                    }
                 }
             }
         }
@@ -1053,11 +1093,18 @@ __device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev
         const double qd_n = cp[tn].qd, qinv_n = cp[tn].qinv;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LOGN1 == 5) {
+            constexpr int G = kK2G;
 #pragma unroll
-            for (int a = 0; a < N1; a += 2) {
-                const double tw = ar.mulmod_vv(x[a + 1], wb[a >> 1]);
-                const double xb = x[a] + kPackBias;
-                x[a] = xb + tw; x[a + 1] = xb - tw;
+            for (int a0 = 0; a0 < N1; a0 += 2 * G) {
+                double Y[G], W[G], tw[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) { Y[k] = x[a0 + 2 * k + 1]; W[k] = wb[(a0 >> 1) + k]; }
+                ar.template mulmod_vv_g<G>(Y, W, tw);
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const double xb = x[a0 + 2 * k] + kPackBias;
+                    x[a0 + 2 * k] = xb + tw[k]; x[a0 + 2 * k + 1] = xb - tw[k];
+                }
             }
         }
         if constexpr (LOGN1 == 0) x[0] = (DIRECT ? (double)c[0] : x[0]) + kPackBias;
@@ -1083,6 +1130,13 @@ __device__ __forceinline__ void k2n_targets_f64(const K2Args &A, const PrimeDev 
     const u32 lane_lo = ((u32)lane >> 4) * kSlotBytes + (wc << 2) + (((u32)lane & 15u) << 4);
     const u32 lane_hi = ((u32)lane >> 3) * kSlotBytes + kPackHiOff + (wc << 1) + (((u32)lane & 7u) << 4);
     auto store_rows = [&](__amdgpu_buffer_rsrc_t dst, const double (&x)[N1]) {
+        if (A.ablate & 4) { // timing experiment: no stores (one lane keeps the values alive)
+            double sum = 0;
+#pragma unroll
+            for (int a = 0; a < N1; ++a) sum += x[a];
+            if (sum == 1.2345) __builtin_amdgcn_raw_buffer_store_b32(1u, dst, 0, 0, 0);
+            return;
+        }
         if constexpr (kWide) store_pattern_rows_wide<N1>(dst, tile, lane, lane_lo, lane_hi, x);
         else store_pattern_rows<N1>(dst, off4, off2h, x);
     };
@@ -1547,9 +1601,34 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 if constexpr (KSHARE) {
                     if (i + 1 < nd) key_dma(digit(i + 1), (i + 1) & 1); // the buffer the previous step's MAC read
                 }
-                wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
-                if constexpr (KSHARE) mac_digit_lds(x[0], i & 1);
-                else mac_digit(x[0], digit(i));
+                if constexpr (kKeyEarly && !KSHARE && !Ar::kKeyQuotient) {
+                    // both key rows of the digit are requested before the second exchange (the hook runs after phase B's math): they
+                    // land behind the exchange and phase C instead of in front of the multiply-accumulate, which used to wait out
+                    // two L2 round trips per step (poly 0, then poly 1)
+                    u64 kv0[kRowE], kv1[kRowE];
+                    const int j = digit(i);
+                    wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, [&]() { load_rowC(key_row(j, 0), lane, kv0); load_rowC(key_row(j, 1), lane, kv1); }, wa_pre);
+                    // the 32 products, kMacG at a time (interleaved chains: at two waves per SIMD a serial chain issues at 3/4 of the
+                    // pipe's rate)
+                    if constexpr (kF64) {
+#pragma unroll
+                        for (int r0 = 0; r0 < kRowE; r0 += kMacG / 2) {
+                            double xs[kMacG], ks[kMacG], pr[kMacG];
+#pragma unroll
+                            for (int k = 0; k < kMacG / 2; ++k) {
+                                xs[2 * k] = x[0][r0 + k]; ks[2 * k] = ar.key_in(kv0[r0 + k]);
+                                xs[2 * k + 1] = x[0][r0 + k]; ks[2 * k + 1] = ar.key_in(kv1[r0 + k]);
+                            }
+                            ar.template mulmod_vv_g<kMacG>(xs, ks, pr);
+#pragma unroll
+                            for (int k = 0; k < kMacG / 2; ++k) { acc0[r0 + k] += pr[2 * k]; acc1[r0 + k] += pr[2 * k + 1]; }
+                        }
+                    }
+                } else {
+                    wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
+                    if constexpr (KSHARE) mac_digit_lds(x[0], i & 1);
+                    else mac_digit(x[0], digit(i));
+                }
             }
             // correction rows: transform + floor step(s)
 #pragma unroll 1

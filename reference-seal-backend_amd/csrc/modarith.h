@@ -233,6 +233,31 @@ struct ArF64 {
         double d = __builtin_fma(-c, q, h);
         return d + l;
     }
+    // G independent products x[k]*y[k] mod q, same results as G calls of mulmod_vv, issued level by level: a dependent fp64
+    // instruction can issue ~11 cycles after its producer on MI355X (tools/micro/dp_latency.hip: one wave running one chain issues
+    // every 5.5 ns, two interleaved chains every 2.9 ns, the pipe's rate is one per 2.0 ns), and the compiler's own order is one
+    // serial chain per product, so with two or three waves per SIMD the chains must be interleaved by hand to fill the pipe.
+    template <int G> HE_HD void mulmod_vv_g(const T (&x)[G], const T (&y)[G], T (&out)[G]) const
+    {
+        double h[G], l[G], c[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) h[k] = x[k] * y[k];
+        HE_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < G; ++k) c[k] = h[k] * qinv;
+#pragma unroll
+        for (int k = 0; k < G; ++k) l[k] = __builtin_fma(x[k], y[k], -h[k]);
+        HE_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < G; ++k) c[k] = __builtin_rint(c[k]);
+        HE_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < G; ++k) h[k] = __builtin_fma(-c[k], q, h[k]);
+        HE_SCHED_FENCE();
+#pragma unroll
+        for (int k = 0; k < G; ++k) out[k] = h[k] + l[k];
+        HE_SCHED_FENCE();
+    }
     // integer |x| < 2q -> canonical [0,q) as double
     HE_HD T canon2(T x) const
     {
