@@ -21,6 +21,7 @@ struct PrimeDev {
     // (bit t).  k2_direct: as it is (q_j < 2^52, q_j <= 2 q_t) and the 48-bit row format holds the result; k2_lift: after a
     // re-centring (q_j > 2 q_t) or an integer reduction (q_j >= 2^52), result fits too; neither bit: the general path.
     u64 k2_direct, k2_lift;
+    double pow32;         // 2^32 mod q: a 64-bit residue of a wider prime enters the fp64 engine as hi * pow32 + lo (k_floor_colsn)
     // fp64 engine: the column passes' twiddles as bare doubles, [0,32) = w of fwd[0..31], [32,64) = w of inv[0..31] (a column pass of
     // N1 <= 32 rows uses entries 1 .. N1-1).  Inside the struct: one scalar load away from the prime index.  u64 engine: zeros
     alignas(64) double colw[64];

@@ -140,6 +140,7 @@ public:
             if (pt.f64)
                 for (size_t k = 0; k < 32 && k < N; ++k) { d.colw[k] = ArF64::tw_w(pt.fwd[k]); d.colw[32 + k] = ArF64::tw_w(pt.inv[k]); }
             d.k2_direct = d.k2_lift = 0;
+            d.pow32 = (double)((((u64)1) << 32) % pt.q);
             env_.prime_f64[i] = pt.f64 ? 1 : 0;
         }
         // k_k2n's lift classes per (digit prime j, fp64-engine target prime t) -- the same rule the kernel's general path evaluates

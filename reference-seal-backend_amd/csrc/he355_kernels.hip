@@ -1756,6 +1756,7 @@ struct FloorColsArgs {
     // written for these targets nor read back
     const u64 *src2;
     int src2_prime;
+    u64 f64_mask; // bit i: key prime i belongs to the fp64 engine (k_floor_colsn)
 };
 
 // canonical coefficients + floor(s/2) of one column of a source residue after its inverse row pass
@@ -1866,6 +1867,178 @@ __global__ void __launch_bounds__(kBlock, 2) k_floor_cols(FloorColsArgs A, const
 #pragma unroll
             for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = dl[a];
         }
+    }
+}
+
+// ---- floor step, column half, second form (round 3) ---------------------------------------------------
+// Same outputs up to the lazy representative (consumers read the rows as lazy raw values).  What changed against k_floor_cols:
+//   * the corrections are formed in the target's own engine instead of with 64-bit Barrett reductions: under an fp64-engine target
+//     a source residue below 2^52 enters as the double it is (re-centred only where q_s > 2 q_i), a wider one as
+//     hi * (2^32 mod q_i) + lo, one exact fp64 product (8 instructions instead of ~35 per element for the 60-bit special prime);
+//   * per-target constants sit in a small LDS table filled once per block (wave-uniform ds_reads, no scalar registers), the column
+//     twiddles come from PrimeDev::colw through the same software pipeline as k_k2n's, rows leave through buffer stores whose
+//     addresses cost no VALU instruction.
+struct FcnConsts { // one per target prime, as the fp64 engine wants them
+    double half1, half2;   // floor(s/2) mod q_i for the source / the merged earlier source
+    double inv2, inv2_i;   // src2^-1 mod q_i and fl(inv2 / q_i)
+    double pow32, qd, qinv;
+    double recentre;       // bit 0: source 1 needs re-centring (q_s > 2 q_i), bit 1: source 2 does
+};
+__device__ __forceinline__ double lift_wide(const ArF64 &ar, u64 v, double pow32) // canonical v of a prime >= 2^52 -> lazy value, |.| < q/2 + 2^32 + 1
+{
+    return ar.mulmod_vv((double)(u32)(v >> 32), pow32) + (double)(u32)v;
+}
+
+// WIDE1: source 1 is held as integers (q_s >= 2^52), else as doubles
+template <int LOGN1, bool MERGE, bool WIDE1>
+__device__ __forceinline__ void fcn_targets_f64(const FloorColsArgs &A, const PrimeDev *primes, u64 poly, int col, u64 mask,
+                                                const typename std::conditional<WIDE1, u64, double>::type (&c)[1 << LOGN1],
+                                                const u64 *park /* [N1][kBlock] when MERGE */, bool wide2, const FcnConsts *ctab)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    constexpr int LA = LOGN1 < 4 ? LOGN1 : 4;
+    if (!mask) return;
+    const u32 off8 = (u32)col << 3;
+    const cprime_t cp = (cprime_t)(unsigned long long)primes;
+    u64 m = mask;
+    int t = __builtin_ctzll(m);
+    d16_t wa = load_colw16(cp, t, 0);
+    FcnConsts k = ctab[t];
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0), see k2n_fast_targets
+    for (;;) {
+        m &= m - 1;
+        const int tn = m ? __builtin_ctzll(m) : t;
+        d16_t wb = wa;
+        if constexpr (LOGN1 == 5) wb = load_colw16(cp, t, 16);
+        __builtin_amdgcn_sched_barrier(0);
+        ArF64 ar;
+        ar.q = k.qd; ar.qinv = k.qinv; ar.ninv = 0; ar.ninv_i = 0;
+        const int flags = (int)k.recentre;
+        double x[N1];
+        // delta2 = [source 1]_{q_i} - floor(s/2)
+#pragma unroll
+        for (int a = 0; a < N1; ++a) {
+            double v;
+            if constexpr (WIDE1) v = lift_wide(ar, c[a], k.pow32);
+            else v = (flags & 1) ? ar.renorm((double)c[a]) : (double)c[a];
+            x[a] = v - k.half1;
+        }
+        if constexpr (MERGE) { // + src2^-1 * delta1, delta1 = [source 2]_{q_i} - floor(src2/2)
+#pragma unroll
+            for (int a = 0; a < N1; ++a) {
+                const u64 v2 = park[a * kBlock + threadIdx.x];
+                double v;
+                if (wide2) v = lift_wide(ar, v2, k.pow32);
+                else { v = u52_to_f64(v2); if (flags & 2) v = ar.renorm(v); }
+                x[a] += ar.mulmod_c(v - k.half2, k.inv2, k.inv2_i);
+            }
+        }
+        // the next target's constants (LDS table): requested here, needed after the stores
+        const FcnConsts kn = ctab[tn];
+#pragma unroll
+        for (int s = 0; s < LA; ++s) {
+            const int gap = N1 >> (s + 1);
+#pragma unroll
+            for (int a = 0; a < N1; ++a) {
+                if (a & gap) continue;
+                const double tw = ar.mulmod_vv(x[a + gap], wa[(1 << s) + (a / (2 * gap))]);
+                const double X = x[a];
+                x[a] = X + tw; x[a + gap] = X - tw;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the stage-4 entries (and the constants just read)
+        const d16_t wa_n = load_colw16(cp, tn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LOGN1 == 5) {
+#pragma unroll
+            for (int a = 0; a < N1; a += 2) {
+                const double tw = ar.mulmod_vv(x[a + 1], wb[a >> 1]);
+                const double X = x[a];
+                x[a] = X + tw; x[a + 1] = X - tw;
+            }
+        }
+        u64 v[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) v[a] = ar.to_raw(x[a]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        store_word_rows<N1>(poly_rsrc(A.dst + (poly * A.dst_ntgt + t) * N, (u32)N1 * kSlotBytes), off8, v);
+        if (!m) break;
+        t = tn; wa = wa_n; k = kn;
+    }
+}
+
+template <int LOGN1, bool MERGE>
+__global__ void __launch_bounds__(kBlock, 2) k_floor_colsn(FloorColsArgs A, const PrimeDev *primes)
+{
+    constexpr int N1 = 1 << LOGN1;
+    constexpr u64 N = (u64)N1 << kRowLog;
+    const u64 poly = blockIdx.x >> 2;
+    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
+    __shared__ u64 park[MERGE ? N1 : 1][MERGE ? kBlock : 1];
+    __shared__ FcnConsts ctab[kMaxPrimes];
+    const PrimeDev &Ps = primes[A.src_prime];
+    const u64 qs = Ps.q, qs2 = MERGE ? primes[A.src2_prime].q : 0;
+    if ((int)threadIdx.x >= A.tgt_first && (int)threadIdx.x < A.tgt_first + A.n_tgt) { // this block's constants, one thread per target
+        const int i = threadIdx.x;
+        const PrimeDev &Pi = primes[i];
+        FcnConsts k;
+        k.half1 = (double)A.fc[A.src_prime * A.K + i].half_mod;
+        k.half2 = 0; k.inv2 = 0; k.inv2_i = 0;
+        int flags = qs > 2 * Pi.q ? 1 : 0;
+        if (MERGE) {
+            const FloorConst f2 = A.fc[A.src2_prime * A.K + i];
+            k.half2 = (double)f2.half_mod; k.inv2 = f2.inv_d; k.inv2_i = f2.inv_i;
+            flags |= qs2 > 2 * Pi.q ? 2 : 0;
+        }
+        k.pow32 = Pi.pow32; k.qd = Pi.qd; k.qinv = Pi.qinv; k.recentre = (double)flags;
+        ctab[i] = k;
+    }
+    u64 c[N1];
+    floor_source_column<LOGN1>(Ps, A.src + poly * N, col, c);
+    if constexpr (MERGE) {
+        u64 c2[N1];
+        floor_source_column<LOGN1>(primes[A.src2_prime], A.src2 + poly * N, col, c2);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) park[a][threadIdx.x] = c2[a]; // each thread reads back only what it wrote itself
+    }
+    __syncthreads(); // the constants table
+    u64 tgt = ((A.tgt_first + A.n_tgt >= 64 ? ~(u64)0 : (((u64)1 << (A.tgt_first + A.n_tgt)) - 1))) & ~(((u64)1 << A.tgt_first) - 1);
+    const u64 f64t = tgt & A.f64_mask;
+    const bool wide2 = MERGE && (qs2 >> 52) != 0;
+    if (qs >> 52) {
+        fcn_targets_f64<LOGN1, MERGE, true>(A, primes, poly, col, f64t, c, &park[0][0], wide2, ctab);
+    } else {
+        double cd[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) cd[a] = u52_to_f64(c[a]);
+        fcn_targets_f64<LOGN1, MERGE, false>(A, primes, poly, col, f64t, cd, &park[0][0], wide2, ctab);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) c[a] = f64_to_u52(cd[a]);
+    }
+    // u64-engine targets: integers throughout (as k_floor_cols)
+    const u32 off8 = (u32)col << 3;
+    for (u64 m = tgt & ~A.f64_mask; m; m &= m - 1) {
+        const int i = __builtin_ctzll(m);
+        const PrimeDev &Pi = primes[i];
+        const u64 qi = Pi.q;
+        const u64 half_i = A.fc[A.src_prime * A.K + i].half_mod;
+        const ModU64 mi = make_modu(Pi);
+        const ArU64 ar = make_ar(Pi, (ArU64 *)nullptr);
+        u64 dl[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) dl[a] = submod(qs > qi ? barrett64(c[a], mi) : c[a], half_i, qi);
+        if constexpr (MERGE) { // [0,q) + [0,q): a valid lazy input of the column pass
+            const FloorConst f2 = A.fc[A.src2_prime * A.K + i];
+#pragma unroll
+            for (int a = 0; a < N1; ++a) {
+                const u64 v2 = park[a][threadIdx.x];
+                const u64 d1 = submod(qs2 > qi ? barrett64(v2, mi) : v2, f2.half_mod, qi);
+                dl[a] += mul_shoup(d1, f2.inv, f2.inv_shoup, qi);
+            }
+        }
+        col_fwd<ArU64, LOGN1>(ar, dl, ctw(Pi.fwd));
+        store_word_rows<N1>(poly_rsrc(A.dst + (poly * A.dst_ntgt + i) * N, (u32)N1 * kSlotBytes), off8, dl);
     }
 }
 
@@ -2728,6 +2901,19 @@ void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_pol
     A.addin = addin; A.addin_src = addin_src; A.addin_ntgt = addin_ntgt;
     A.src2 = src2; A.src2_prime = src2_prime;
     const unsigned g = (unsigned)(n_polys * 4);
+    A.f64_mask = 0;
+    for (int t = 0; t < env.K; ++t) A.f64_mask |= (u64)(env.prime_f64[t] != 0) << t;
+    static const bool fc_new = !(getenv("HE355_FC_NEW") && getenv("HE355_FC_NEW")[0] == '0');
+    if (fc_new && !addin) {
+#define HE355_FCN(L1)                                                                                                          \
+    case L1:                                                                                                                   \
+        if (src2) hipLaunchKernelGGL((k_floor_colsn<L1, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);          \
+        else hipLaunchKernelGGL((k_floor_colsn<L1, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);              \
+        break;
+        switch (env.logn1) { HE355_FCN(0) HE355_FCN(1) HE355_FCN(2) HE355_FCN(3) HE355_FCN(4) HE355_FCN(5) }
+#undef HE355_FCN
+        return;
+    }
     if (src2) {
         switch (env.logn1) {
         case 0: hipLaunchKernelGGL((k_floor_cols<0, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
