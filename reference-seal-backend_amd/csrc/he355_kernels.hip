@@ -920,6 +920,11 @@ __global__ void __launch_bounds__(kBlock, K2_WAVES) k_k2(K2Args A, const PrimeDe
 //   * every store address is (scalar row base) + (one per-lane 32-bit offset computed once per kernel): the slab pointer of the
 //     target is made wave-uniform explicitly, the row bases advance on the scalar unit -- k_k2 spent two 64-bit VALU additions
 //     (and the wait states of their carry chains) per store, ~170 instructions per target.
+// canonical v of a prime >= 2^52 as a lazy value of the fp64 engine: hi * 2^32 + lo == hi * pow32 + lo (mod q), |result| < q/2 + 2^32 + 1
+__device__ __forceinline__ double lift_wide(const ArF64 &ar, u64 v, double pow32)
+{
+    return ar.mulmod_vv((double)(u32)(v >> 32), pow32) + (double)(u32)v;
+}
 typedef const __attribute__((address_space(4))) double *cdw_t;
 __device__ __forceinline__ cdw_t cdw(const double *p) { return (cdw_t)(unsigned long long)p; }
 // Buffer resource over one polynomial's row slots (wave-uniform base made explicit with v_readfirstlane): a store through it is
@@ -1052,11 +1057,10 @@ __device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev
             if constexpr (DF) {
 #pragma unroll
                 for (int a = 0; a < N1; ++a) x[a] = ar.renorm(c[a]);
-            } else {
-                ModU64 mt;
-                mt.q = cp[t].q; mt.cr0 = cp[t].cr0; mt.cr1 = cp[t].cr1;
+            } else { // a 60-bit digit: hi * (2^32 mod q_t) + lo, one exact fp64 product (lift_wide) instead of a 64-bit Barrett reduction
+                const double pow32 = cp[t].pow32;
 #pragma unroll
-                for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(barrett64(c[a], mt));
+                for (int a = 0; a < N1; ++a) x[a] = lift_wide(ar, c[a], pow32);
             }
         }
 #pragma unroll
@@ -1884,10 +1888,6 @@ struct FcnConsts { // one per target prime, as the fp64 engine wants them
     double pow32, qd, qinv;
     double recentre;       // bit 0: source 1 needs re-centring (q_s > 2 q_i), bit 1: source 2 does
 };
-__device__ __forceinline__ double lift_wide(const ArF64 &ar, u64 v, double pow32) // canonical v of a prime >= 2^52 -> lazy value, |.| < q/2 + 2^32 + 1
-{
-    return ar.mulmod_vv((double)(u32)(v >> 32), pow32) + (double)(u32)v;
-}
 
 // WIDE1: source 1 is held as integers (q_s >= 2^52), else as doubles
 template <int LOGN1, bool MERGE, bool WIDE1>
