@@ -142,6 +142,42 @@ class MulRelinRescale(Workload):
         return (f"CKKS EltwiseMult + relinearize + rescale, N=2^15, depth 16 (L=16 data primes + 1 special) (BASELINE.json configs[2])")
 
 
+class MulRelin(MulRelinRescale):
+    """`metric` as literally worded: multiply -> relinearize_inplace, no rescale (size-2 result at level L)"""
+    name = "mul_relin"
+    out_drop = 0
+
+    def setup(self):
+        c, L, N = self.ctx, self.L, self.N
+        self.fill_operands()
+        self.d_out = c.alloc(max(1, self.n) * 2 * L * N)
+        c.set_relin_key_synthetic(SEED_RELIN)
+
+    def step(self):
+        self.ctx.multiply_relin(self.L, self.n, self.d_a, self.d_b, self.ix, self.d_out, rescale=False)
+
+    def bytes_per_op(self, global_batch):
+        L, N = self.L, self.N
+        return 3 * (2 * L * N * 8) + self.key_bytes() / global_batch  # read 2 cts, write 1 at the same level, the key once per batch
+
+    def result_rows(self, k):
+        return self.d_out.download_head((k, 2, self.L, self.N))
+
+    def checker(self, ho, o, rows, threads, passes):
+        a, b = self.host_operands(rows)
+        rk = synthetic_key_host(self.ctx, o, SEED_RELIN)
+        o.batch_outer(ho.OP_MUL_RELIN, a[:min(rows, threads)], b, rk, threads=threads)
+        times, want = [], None
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            want = o.batch_outer(ho.OP_MUL_RELIN, a, b, rk, threads=threads)
+            times.append(time.perf_counter() - t0)
+        return times, want
+
+    def describe(self):
+        return "CKKS EltwiseMult + relinearize (no rescale), N=2^15, depth 16 (L=16 data primes + 1 special): BASELINE.json `metric` as worded"
+
+
 class EltwiseMul(Workload):
     """configs[1]: Evaluator::multiply only (ckks eltwise .cpp:343), size-3 results"""
     name = "eltwise_mul"
@@ -322,7 +358,7 @@ class BfvAdd(Workload):
         return "BFV EltwiseAdd at the reference's defaults N=8192, {60,40,60} (L=2) (BASELINE.json configs[0])"
 
 
-WORKLOADS = {w.name: w for w in (MulRelinRescale, EltwiseMul, DotProduct, BfvMatMul, BfvAdd)}
+WORKLOADS = {w.name: w for w in (MulRelinRescale, MulRelin, EltwiseMul, DotProduct, BfvMatMul, BfvAdd)}
 
 
 def synthetic_key_host(ctx, o, seed):
@@ -332,6 +368,48 @@ def synthetic_key_host(ctx, o, seed):
     buf = ctx.alloc(L * 2 * K * N)
     ctx.fill_uniform(buf, L * 2 * K, list(range(K)), seed)
     return buf.download((L, 2, K, N)).copy()
+
+
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher around it: this process -- which has made no GPU call -- starts the N ranks
+    as a child (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`, one rank per GPU),
+    relays their output (rank 0 prints the JSON line) and returns the child's exit code.  Under torch.distributed.run
+    (WORLD_SIZE set) main() runs as a rank and this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def dry_run(args, rank, world, dist, torch) -> int:
+    """The N>1 path without a GPU: rendezvous over gloo, the shard every rank would own, one JSON line from rank 0."""
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    W = WORKLOADS[args.config]
+    batch = args.batch or W.default_batch
+    global_b0 = batch * world if args.scaling == "weak" else batch
+    sh = load_sharding().shard_outer_product(global_b0, W.b1, world, rank)
+    mine = torch.tensor([rank, sh.a_base, sh.a_count, sh.n_results], dtype=torch.int64)
+    rows = [mine]
+    if world > 1:
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        dist.barrier()
+    if rank == 0:
+        shards = [{"rank": int(r[0]), "a_base": int(r[1]), "a_count": int(r[2]), "n_results": int(r[3])} for r in rows]
+        print(json.dumps({"dry_run": True, "n_gpus": world, "config": args.config, "scaling": args.scaling, "global_b0": global_b0, "b1": W.b1,
+                          "shards": shards}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -346,12 +424,16 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="results in the CPU-baseline sample (-1: the configuration's own, 0: skip)")
     ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of the CPU baseline (median reported)")
     ap.add_argument("--parity-sample", type=int, default=-1, help="results every rank checks against the oracle (-1: the configuration's own, 0: skip)")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / sharding only: the ranks meet (gloo), every rank computes its shard of "
+                                                           "the global batch, rank 0 prints them; no GPU is touched (what the CPU test of the N>1 path runs)")
     ap.add_argument("--profile-mode", action="store_true", help="only warm-up + timed steps on the GPU (no CPU baseline, no parity sample, no extra "
                                                                 "single-stream step): what rocprofv3 traces and PMC passes should see")
     args = ap.parse_args()
     if args.profile_mode:
         args.cpu_sample, args.parity_sample = 0, 0
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))  # plain `python bench.py --gpus N`: this process becomes the launcher
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -360,6 +442,8 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.dry_run:
+        raise SystemExit(dry_run(args, rank, world, dist, torch))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # one rank per GPU; HE355_BENCH_BACKEND=gloo lets several ranks share one GPU for rehearsals on a 1-GPU box
@@ -413,7 +497,7 @@ def main():
 
     # ---- dominant kernel, single stream: one extra untimed step with the two-stream schedule off, HIP events around each launch ----
     k3 = None
-    if args.config in ("mul_relin_rescale", "dot") and n > 0 and not args.profile_mode:
+    if args.config in ("mul_relin_rescale", "mul_relin", "dot") and n > 0 and not args.profile_mode:
         ctx.set_dual_stream(False)
         ctx.timer_begin()
         wl.step()

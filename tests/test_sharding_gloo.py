@@ -78,3 +78,54 @@ def test_bench_shards_are_world_size_independent():
             assert polys == list(range(g * 2 * L))
             assert sum(sh.n_results for sh in shards) == g
             assert max(sh.n_results for sh in shards) - min(sh.n_results for sh in shards) <= 1  # balanced to one row
+
+
+def _bench(*argv, env=None, timeout=180):
+    import json
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):  # as the driver calls it: no launcher around it
+        e.pop(k, None)
+    e.update(env or {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it (how the driver runs N=1): the process starts its own two
+    ranks, they rendezvous (gloo), every rank computes its shard of the global batch, rank 0 prints one JSON line."""
+    for scaling, batch, b0 in (("strong", 7, 7), ("weak", 5, 10)):
+        p, doc = _bench("--gpus", "2", "--dry-run", "--scaling", scaling, "--batch", str(batch), env={"HE355_BENCH_BACKEND": "gloo"})
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert doc["dry_run"] and doc["n_gpus"] == 2 and doc["global_b0"] == b0
+        want = [_load_sharding().shard_outer_product(b0, 1, 2, r) for r in range(2)]
+        assert [(s["rank"], s["a_base"], s["a_count"], s["n_results"]) for s in doc["shards"]] == [(w.rank, w.a_base, w.a_count, w.n_results) for w in want]
+        assert sum(s["a_count"] for s in doc["shards"]) == b0  # the shards tile the global batch
+
+
+def test_bench_self_launch_propagates_failure():
+    """Without --dry-run the ranks need a GPU: on a box without one every rank exits loudly (no CPU fallback) and the launcher
+    returns non-zero; on a GPU box two gloo ranks share the card and the run succeeds."""
+    import torch
+    p, doc = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2", "--cpu-sample", "0", "--parity-sample", "1",
+                    env={"HE355_BENCH_BACKEND": "gloo"}, timeout=600)
+    if torch.cuda.is_available():
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert doc["n_gpus"] == 2 and doc["parity"]["checked_in_run"] is True
+    else:
+        assert p.returncode != 0 and doc is None
+        assert "no HIP device" in p.stderr or "needs an MI355X" in p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_the_gpu_through_the_self_launch_path():
+    """The N>1 compute path on the one-GPU box: `python bench.py --gpus 2` (no launcher), two gloo ranks on the same card, each on its
+    own shard of the global batch with its own parity sample against the oracle."""
+    p, doc = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "6", "--scaling", "strong", "--cpu-sample", "0",
+                    "--parity-sample", "1", env={"HE355_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert doc["n_gpus"] == 2 and doc["config"]["global_batch"] == 6
+    assert doc["parity"]["checked_in_run"] is True and [r["ok"] for r in doc["parity"]["per_rank"]] == [True, True]
