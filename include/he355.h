@@ -149,6 +149,13 @@ int he355_rotate_each(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, c
  * (src/benchmarks/bfv/seal_bfv_matmult_row_benchmark.cpp:525-531) and of accumulateCKKS/BFV (src/engine/seal_context.cpp:337-338,
  * 302-303) as one pipeline.  d_addend may be d_out (add in place) when the step has its own Galois key; d_in may be neither. */
 int he355_rotate_add(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, int step, const uint64_t *d_addend, uint64_t *d_out);
+/* d_out = d_in + sum_j rotate(d_in, h_steps[j]), j < n_steps: the whole inner loop of the row-major MatMult
+ * (src/benchmarks/bfv/seal_bfv_matmult_row_benchmark.cpp:519-531, src/benchmarks/ckks/seal_ckks_matmult_row_benchmark.cpp:502-514).  Each rotation
+ * is Evaluator::rotate_internal's (own Galois key, else NAF terms least significant first); rotations whose term sequences share a
+ * prefix share that prefix's ciphertext, which is computed once -- bit-identical to the unshared loop.  *key_switches (optional):
+ * Galois key switches issued per ciphertext.  h_steps: host array.  Not in place. */
+int he355_rotate_sum(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_in, const int32_t *h_steps, uint64_t n_steps, uint64_t *d_out,
+                     uint64_t *key_switches);
 /* accumulateCKKS / accumulateBFV: in place log-tree sum of the first `count` slots; d_tmp: scratch slab of the same size.
  * count == 0 is the reference's else-branch (src/engine/seal_context.cpp:312-316, 341-344): every ciphertext is replaced by a
  * FRESH encryption of zero (Encryptor::encrypt_zero; needs the public key; L must be the top level, as SEAL returns a
@@ -161,6 +168,9 @@ int he355_set_zero_stream(he355_ctx *ctx, uint64_t seed, uint64_t first_index);
 /* Introspection: the API-Bridge ABI (enumerators, sizes, offsets, header used) this library was compiled with, as JSON; returns the
  * size needed including the terminator (csrc/bridge/abi_check.cpp).  A harness binding can check its own numbers against it. */
 uint64_t he355_bridge_abi(char *p_buffer, uint64_t size);
+/* Introspection: bytes the most recent multi-device load() of the bridge moved to device `device` (> 0) for operand 0 / 1
+ * (csrc/bridge/multi_device.cpp): operand 0 travels in per-device blocks, operand 1 whole. */
+uint64_t he355_bridge_group_load_bytes(int device, int operand);
 /* ---- client side on the device: encryptor()->encrypt (ckks eltwise .cpp:242, bfv eltwise .cpp:233) and
  * SEALContextWrapper::decrypt (src/engine/seal_context.cpp:265-287), batched.  Keys: host arrays in SEAL layout, NTT form:
  * public key [2][K][N], secret key [K][N].  Randomness of he355_encrypt is counter-based: ciphertext r draws u, e0, e1 from

@@ -105,6 +105,7 @@ def lib():
             "he355_rotate": (i32, [vp, i32, u64, vp, i32, vp]),
             "he355_rotate_add": (i32, [vp, i32, u64, vp, i32, vp, vp]),
             "he355_rotate_each": (i32, [vp, i32, u64, vp, vp, vp]),
+            "he355_rotate_sum": (i32, [vp, i32, u64, vp, vp, u64, vp, vp]),
             "he355_accumulate": (i32, [vp, i32, u64, vp, u64, vp]),
             "he355_encrypt_zero": (i32, [vp, u64, u64, u64, vp]),
             "he355_set_zero_stream": (i32, [vp, u64, u64]),
@@ -114,6 +115,7 @@ def lib():
             "he355_probe_dominant_kernel": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
             "he355_set_chunk": (i32, [vp, u64]),
             "he355_bridge_abi": (u64, [C.c_char_p, u64]),
+            "he355_bridge_group_load_bytes": (u64, [i32, i32]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -131,8 +133,8 @@ C_ABI_SYMBOLS = [
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",
     "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_keygen_relin", "he355_keygen_galois", "he355_ckks_encode", "he355_ckks_decode",
-    "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_rotate_each", "he355_accumulate", "he355_encrypt_zero", "he355_set_zero_stream",
-    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk", "he355_bridge_abi",
+    "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_rotate_each", "he355_rotate_sum", "he355_accumulate", "he355_encrypt_zero", "he355_set_zero_stream",
+    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk", "he355_bridge_abi", "he355_bridge_group_load_bytes",
 ]
 
 
@@ -363,6 +365,13 @@ class Context:
     def rotate_each(self, L, n, inp, steps, out):
         arr = (C.c_int32 * n)(*[int(v) for v in steps])
         _check(lib().he355_rotate_each(self.h, L, n, inp.ptr, arr, out.ptr))
+
+    def rotate_sum(self, L, n, inp, steps, out):
+        """out = inp + sum_j rotate(inp, steps[j]) with shared NAF prefixes; returns the Galois key switches issued per ciphertext"""
+        arr = (C.c_int32 * len(steps))(*[int(v) for v in steps])
+        ks = C.c_uint64(0)
+        _check(lib().he355_rotate_sum(self.h, L, n, inp.ptr, arr, len(steps), out.ptr, C.byref(ks)))
+        return int(ks.value)
 
     def rotate_add(self, L, n, inp, step, addend, out):
         _check(lib().he355_rotate_add(self.h, L, n, inp.ptr, step, addend.ptr, out.ptr))

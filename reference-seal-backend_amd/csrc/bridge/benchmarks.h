@@ -63,7 +63,9 @@ public:
     // what load() hands to operate(): the operand slabs on the primary device and, with NumDevices > 1, their replicas
     struct RemotePack {
         std::vector<std::shared_ptr<DeviceCiphers>> ops;                    // [operand] on the primary device
-        std::vector<std::vector<std::shared_ptr<DeviceCiphers>>> replicas;  // [device][operand]; [0] = ops
+        // [device][operand]; [0] = ops.  Device d > 0 holds ITS BLOCK of operand 0 (rows rowsOf(ops[0]->n, devices, d), as
+        // reference-seal-backend_amd/sharding.py cuts them) and all of operand 1
+        std::vector<std::vector<std::shared_ptr<DeviceCiphers>>> replicas;
     };
 
 private:

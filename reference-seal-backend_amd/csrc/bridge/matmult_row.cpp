@@ -88,6 +88,7 @@ MatMultRowLatencyBenchmark::MatMultRowLatencyBenchmark(hebench::cpp::BaseEngine 
     const std::uint64_t depth = m_w[MatMultRowBenchmarkDescription::Index_NumCoefficientModuli];
     const int bits = (int)m_w[MatMultRowBenchmarkDescription::Index_CoefficientModulusBits], extra = (int)m_w[MatMultRowBenchmarkDescription::Index_PlainModulusBits];
     m_p_ctx_wrapper = scheme == Scheme::CKKS ? HeContextWrapper::createCKKSContext(N, depth, bits, extra) : HeContextWrapper::createBFVContext(N, depth, bits, extra);
+    m_num_devices = DeviceGroup::resolveCount(0); // HE355_NUM_DEVICES: the declared workload parameters stay the reference's
 }
 
 const AB::DataPack &MatMultRowLatencyBenchmark::findDataPack(const AB::DataPackCollection &c, std::uint64_t param_position)
@@ -230,6 +231,19 @@ AB::Handle MatMultRowLatencyBenchmark::load(const AB::Handle *p_h_local_data, st
     r.B = m_p_ctx_wrapper->upload(std::vector<Cipher>{c.B});
     m_p_ctx_wrapper->needRelinKey();
     m_p_ctx_wrapper->needDefaultGaloisKeys(); // the reference creates the full default set (seal_context.cpp:69); rotations use its NAF terms
+    if (m_num_devices > 1) { // keys on every device (generated there from the shared seed), A in blocks, B whole: outside the timed call
+        if (!m_group) m_group = DeviceGroup::create(m_p_ctx_wrapper, m_num_devices);
+        m_group->syncKeys();
+        r.A_dev.assign((std::size_t)m_group->size(), nullptr);
+        r.B_dev.assign((std::size_t)m_group->size(), nullptr);
+        r.A_dev[0] = r.A; r.B_dev[0] = r.B;
+        for (int d = 1; d < m_group->size(); ++d) {
+            std::uint64_t first = 0, rows = 0;
+            DeviceGroup::rowsOf(r.A->n, m_group->size(), d, first, rows);
+            r.A_dev[(std::size_t)d] = m_group->replicateRows(d, r.A, first, rows, 0);
+            r.B_dev[(std::size_t)d] = m_group->replicateRows(d, r.B, 0, r.B->n, 1);
+        }
+    }
     return this->getEngine().createHandle<decltype(r)>(sizeof(r), 0, std::move(r));
 }
 
@@ -258,37 +272,69 @@ AB::Handle MatMultRowLatencyBenchmark::operate(AB::Handle h_remote_packed, const
         if (p_param_indexers[i].batch_size != 1) throw HEBenchError(HEBERROR_MSG_CLASS("Batch size must be 1 for latency test."), HEBENCH_ECODE_INVALID_ARGS);
     }
     const RemotePack &in = this->getEngine().retrieveFromHandle<RemotePack>(h_remote_packed);
-    he355_ctx *ctx = m_p_ctx_wrapper->raw();
-    const int L = in.A->L;
     const std::uint64_t nA = in.A->n, dim2 = in.a.cols;
     const bool ckks = m_scheme == Scheme::CKKS;
-    const int spacers = (int)((ckks ? m_p_ctx_wrapper->slot_count() : m_p_ctx_wrapper->slot_count() / 2) / dim2);
-    const double sc = ckks ? in.A->scale * in.B->scale : 1.0;
-    // matmultrow (.cpp:486-539), all row-pair ciphertexts A[i] as one batch:
-    he355_indexer ix{0, 0, 1, 0, 0}; // result i <- (A[i], B)
-    std::shared_ptr<DeviceCiphers> base = m_p_ctx_wrapper->allocResult(nA, 2, L, sc);
-    std::shared_ptr<DeviceCiphers> rotated = m_p_ctx_wrapper->allocResult(nA, 2, L, sc);
     ResultRemote res;
     res.d.rows = in.a.rows; res.d.cols = in.b.cols;
-    res.C = m_p_ctx_wrapper->allocResult(nA, 2, L, sc);
-    if (ckks) {
-        HeContextWrapper::check(he355_multiply_relin(ctx, L, nA, in.A->d, in.B->d, ix, 0, base->d), "multiply+relinearize"); // ckks row .cpp:499-500
+    if (in.A_dev.size() > 1 && nA > 1) {
+        // the row(-pair) ciphertexts are independent (bfv row .cpp:512-533; the reference nests OpenMP over them, :498-536): contiguous
+        // blocks of them per device, one host thread each; device 0 writes into the result slab, the other parts stay where they
+        // were computed until store() gathers them
+        const double sc = ckks ? in.A->scale * in.B->scale : 1.0;
+        res.C = m_p_ctx_wrapper->allocResult(nA, 2, in.A->L, sc);
+        std::vector<std::shared_ptr<DeviceCiphers>> parts(in.A_dev.size());
+        std::vector<std::uint64_t> firsts(in.A_dev.size(), 0);
+        m_group->parallel([&](int d) {
+            std::uint64_t first = 0, rows = 0;
+            DeviceGroup::rowsOf(nA, m_group->size(), d, first, rows);
+            firsts[(std::size_t)d] = first;
+            if (!rows) return;
+            if (d == 0) { // device 0 holds all of A: its block is a view
+                DeviceCiphers view;
+                view.d = in.A->d + first * in.A->elems_per_ct(m_p_ctx_wrapper->params().N);
+                view.n = rows; view.size = in.A->size; view.L = in.A->L; view.scale = in.A->scale;
+                parts[0] = rowsOn(m_group->ctx(0), m_group.get(), 0, view, *in.B, dim2, res.C, first);
+                view.d = nullptr; // not owned
+            } else {
+                parts[(std::size_t)d] = rowsOn(m_group->ctx(d), m_group.get(), d, *in.A_dev[(std::size_t)d], *in.B_dev[(std::size_t)d], dim2, nullptr, 0);
+            }
+        });
+        for (int d = 1; d < m_group->size(); ++d)
+            if (parts[(std::size_t)d]) res.C->parts.push_back(DeviceCiphers::Part{parts[(std::size_t)d], firsts[(std::size_t)d]});
     } else {
-        std::shared_ptr<DeviceCiphers> c3 = m_p_ctx_wrapper->allocResult(nA, 3, L, 1.0);
-        HeContextWrapper::check(he355_bfv_multiply(ctx, L, nA, in.A->d, in.B->d, ix, c3->d), "multiply");             // :515
-        HeContextWrapper::check(he355_relinearize(ctx, L, nA, c3->d, base->d), "relinearize");                         // :516
+        res.C = rowsOn(m_p_ctx_wrapper->raw(), nullptr, 0, *in.A, *in.B, dim2, nullptr, 0);
+    }
+    return this->getEngine().createHandle<decltype(res)>(sizeof(res), 0, std::move(res));
+}
+
+// matmultrow (bfv row .cpp:486-539, ckks row .cpp:472-523) for the ciphertexts of A resident on one device, as one batch
+std::shared_ptr<DeviceCiphers> MatMultRowLatencyBenchmark::rowsOn(he355_ctx *ctx, DeviceGroup *group, int device, const DeviceCiphers &A, const DeviceCiphers &B,
+                                                                  std::uint64_t dim2, std::shared_ptr<DeviceCiphers> into, std::uint64_t into_offset)
+{
+    const int L = A.L;
+    const std::uint64_t nA = A.n, N = m_p_ctx_wrapper->params().N;
+    const bool ckks = m_scheme == Scheme::CKKS;
+    const int spacers = (int)((ckks ? m_p_ctx_wrapper->slot_count() : m_p_ctx_wrapper->slot_count() / 2) / dim2);
+    const double sc = ckks ? A.scale * B.scale : 1.0;
+    auto alloc = [&](int size, double scale) { return group ? group->alloc(device, nA, size, L, scale) : m_p_ctx_wrapper->allocResult(nA, size, L, scale); };
+    he355_indexer ix{0, 0, 1, 0, 0}; // result i <- (A[i], B)
+    std::shared_ptr<DeviceCiphers> base = alloc(2, sc);
+    std::shared_ptr<DeviceCiphers> result = into ? into : alloc(2, sc);
+    uint64_t *out = into ? into->d + into_offset * 2 * (std::uint64_t)L * N : result->d;
+    if (ckks) {
+        HeContextWrapper::check(he355_multiply_relin(ctx, L, nA, A.d, B.d, ix, 0, base->d), "multiply+relinearize"); // ckks row .cpp:499-500
+    } else {
+        std::shared_ptr<DeviceCiphers> c3 = alloc(3, 1.0);
+        HeContextWrapper::check(he355_bfv_multiply(ctx, L, nA, A.d, B.d, ix, c3->d), "multiply");                     // :515
+        HeContextWrapper::check(he355_relinearize(ctx, L, nA, c3->d, base->d), "relinearize");                       // :516
         HeContextWrapper::check(he355_sync(ctx), "synchronise");
     }
-    // result[i] = base (:519), then result[i] += rotate_rows(base, j * spacers) (:525-531): each rotate + add_inplace pair is one
-    // he355_rotate_add pipeline writing the running sum into the other of two slabs (the step may go through several Galois keys).
-    std::shared_ptr<DeviceCiphers> sum = dim2 > 1 ? base : res.C, next = res.C;
-    if (dim2 <= 1) HeContextWrapper::check(he355_rotate(ctx, L, nA, base->d, 0, res.C->d), "copy");
-    for (std::uint64_t j = 1; j < dim2; ++j) {
-        HeContextWrapper::check(he355_rotate_add(ctx, L, nA, base->d, (int)j * spacers, sum->d, next->d), "rotate_rows+add_inplace");
-        if (sum == base) sum = rotated; // base stays the rotation source: never written
-        std::swap(sum, next);
-    }
-    res.C = sum;
+    // result[i] = base (:519), then result[i] += rotate_rows(base, j * spacers), j = 1 .. dim2-1 (:520-531): all rotations start from
+    // `base`, so the ones whose NAF term sequences share a prefix share that prefix's ciphertext (he355_rotate_sum) -- bit-identical
+    // to the loop, 127 key switches instead of 313 per ciphertext at dim2 = 128
+    std::vector<int32_t> steps;
+    for (std::uint64_t j = 1; j < dim2; ++j) steps.push_back((int32_t)((int)j * spacers));
+    HeContextWrapper::check(he355_rotate_sum(ctx, L, nA, base->d, steps.data(), steps.size(), out, nullptr), "rotate_rows+add_inplace");
     HeContextWrapper::check(he355_sync(ctx), "synchronise");
-    return this->getEngine().createHandle<decltype(res)>(sizeof(res), 0, std::move(res));
+    return result;
 }

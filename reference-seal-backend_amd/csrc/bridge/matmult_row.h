@@ -57,7 +57,12 @@ private:
     struct Dims { std::uint64_t rows = 0, cols = 0; };
     struct PlainPack { Dims a, b; std::vector<Plain> A; Plain B; };      // encode() result
     struct CipherPack { Dims a, b; std::vector<Cipher> A; Cipher B; };   // encrypt() result
-    struct RemotePack { Dims a, b; std::shared_ptr<DeviceCiphers> A, B; };
+    struct RemotePack {
+        Dims a, b;
+        std::shared_ptr<DeviceCiphers> A, B;
+        // HE355_NUM_DEVICES > 1: device d > 0 holds ITS block of the row(-pair) ciphertexts of A and all of B (MatMultRow)
+        std::vector<std::shared_ptr<DeviceCiphers>> A_dev, B_dev; // [device]; [0] = A, B
+    };
     struct ResultRemote { Dims d; std::shared_ptr<DeviceCiphers> C; };
     struct ResultCipher { Dims d; std::vector<Cipher> C; };
     struct ResultPlain { Dims d; std::vector<Plain> C; };
@@ -68,6 +73,11 @@ private:
     std::uint64_t cols_M1() const { return m_w[2]; }
     std::vector<std::uint64_t> m_w;
     HeContextWrapper::Ptr m_p_ctx_wrapper;
+    int m_num_devices = 1;
+    std::shared_ptr<DeviceGroup> m_group;
+    // the body of operate() on one device: nA ciphertexts of A (resident on ctx's device) -> their result ciphertexts
+    std::shared_ptr<DeviceCiphers> rowsOn(he355_ctx *ctx, DeviceGroup *group, int device, const DeviceCiphers &A, const DeviceCiphers &B,
+                                          std::uint64_t dim2, std::shared_ptr<DeviceCiphers> into, std::uint64_t into_offset);
 };
 
 } // namespace mi355x

@@ -48,6 +48,7 @@ std::shared_ptr<DeviceGroup> DeviceGroup::create(const HeContextWrapper::Ptr &pr
     g->m_ctx.push_back(primary->raw());
     g->m_relin.push_back(true);
     g->m_galois.emplace_back();
+    g->m_loaded.assign((std::size_t)n_devices, {0, 0});
     int physical = 0;
     HeContextWrapper::check(he355_device_count(&physical), "device count");
     const std::vector<int32_t> &chain = primary->chainBits();
@@ -106,11 +107,32 @@ std::shared_ptr<DeviceCiphers> DeviceGroup::alloc(int d, std::uint64_t n, int si
 
 std::shared_ptr<DeviceCiphers> DeviceGroup::replicate(int d, const std::shared_ptr<DeviceCiphers> &src)
 {
+    return replicateRows(d, src, 0, src->n, 1);
+}
+
+static std::mutex g_last_mtx;
+static std::vector<std::array<std::uint64_t, 2>> g_last_loaded;
+
+std::shared_ptr<DeviceCiphers> DeviceGroup::replicateRows(int d, const std::shared_ptr<DeviceCiphers> &src, std::uint64_t first, std::uint64_t count, int operand)
+{
+    if (first + count > src->n) throw HEBenchError(HEBERROR_MSG("row block out of range"), HEBENCH_ECODE_CRITICAL_ERROR);
     if (d == 0) return src;
-    auto s = alloc(d, src->n, src->size, src->L, src->scale);
-    HeContextWrapper::check(he355_copy_peer(m_ctx[(std::size_t)d], s->d, m_ctx[0], src->d, src->n * src->elems_per_ct(m_primary->params().N) * 8),
-                            "operand replication");
+    auto s = alloc(d, count, src->size, src->L, src->scale);
+    const std::uint64_t per = src->elems_per_ct(m_primary->params().N);
+    if (count)
+        HeContextWrapper::check(he355_copy_peer(m_ctx[(std::size_t)d], s->d, m_ctx[0], src->d + first * per, count * per * 8), "operand replication");
+    m_loaded[(std::size_t)d][operand & 1] += count * per * 8;
+    {
+        std::scoped_lock<std::mutex> lock(g_last_mtx);
+        g_last_loaded = m_loaded;
+    }
     return s;
+}
+
+std::uint64_t DeviceGroup::lastLoadedBytes(int d, int operand)
+{
+    std::scoped_lock<std::mutex> lock(g_last_mtx);
+    return d >= 0 && (std::size_t)d < g_last_loaded.size() ? g_last_loaded[(std::size_t)d][operand & 1] : 0;
 }
 
 void DeviceGroup::parallel(const std::function<void(int)> &fn)
@@ -131,3 +153,5 @@ void DeviceGroup::parallel(const std::function<void(int)> &fn)
     for (auto &t : threads) t.join();
     if (p_ex) std::rethrow_exception(p_ex);
 }
+
+extern "C" std::uint64_t he355_bridge_group_load_bytes(int device, int operand) { return DeviceGroup::lastLoadedBytes(device, operand); }

@@ -4,14 +4,15 @@
 //
 // A DeviceGroup owns one more he355 context per extra device, built from the primary context's parameters, with the evaluation
 // keys generated ON that device from the client's secret key and key seed (the generators are counter-based, so every device
-// holds bit-identical keys: tests/test_gpu_client.py::test_device_keygen_equals_host_keygen).  load() replicates the operand
-// slabs to every device (he355_copy_peer = hipMemcpyPeer over xGMI), operate() cuts the flattened result range [0, b0 * b1) into
+// holds bit-identical keys: tests/test_gpu_client.py::test_device_keygen_equals_host_keygen).  load() sends every device
+// ITS block of operand-0 rows and all of operand 1 (he355_copy_peer = hipMemcpyPeer over xGMI), operate() cuts the flattened result range [0, b0 * b1) into
 // contiguous blocks of operand-0 rows, one per device, each driven by its own host thread, and returns a result whose parts stay
 // where they were computed; store() gathers them.  No collective and no copy inside the timed operate().
 //
 // HE355_LOGICAL_DEVICES=<k> lets a box with fewer GPUs run a k-device group (logical device d -> physical d mod count): the whole
 // path — contexts, keys, replicas, threads, parts, gather — is then testable on one GPU (tests/test_api_bridge_gpu.py).
 #pragma once
+#include <array>
 #include <functional>
 #include <memory>
 #include <vector>
@@ -30,6 +31,12 @@ public:
     he355_ctx *ctx(int d) const { return m_ctx[(std::size_t)d]; } // d == 0: the primary's context
     void syncKeys();                                             // every key the primary holds now exists on every device
     std::shared_ptr<DeviceCiphers> replicate(int d, const std::shared_ptr<DeviceCiphers> &src); // d > 0: a copy on device d
+    // d > 0: ciphertexts [first, first + count) of src, copied to device d (the rows of operand 0 that device works on: SURVEY.md 8e,
+    // "shard operand 0, broadcast operand 1").  operand: 0 / 1, for the load statistics below.
+    std::shared_ptr<DeviceCiphers> replicateRows(int d, const std::shared_ptr<DeviceCiphers> &src, std::uint64_t first, std::uint64_t count, int operand);
+    // bytes load() moved to device d for operand 0 / 1 since the group was created (tests assert that operand 0 travels in blocks)
+    std::uint64_t loadedBytes(int d, int operand) const { return m_loaded[(std::size_t)d][operand & 1]; }
+    static std::uint64_t lastLoadedBytes(int d, int operand); // of the group that loaded most recently (he355_bridge_group_load_bytes)
     std::shared_ptr<DeviceCiphers> alloc(int d, std::uint64_t n, int size, int L, double scale);
     // rows [first, first + count) of a b0-row operand for device d (contiguous, balanced to one row: as reference-seal-backend_amd/sharding.py)
     static void rowsOf(std::uint64_t b0, int n_devices, int d, std::uint64_t &first, std::uint64_t &count);
@@ -41,6 +48,7 @@ private:
     std::vector<he355_ctx *> m_ctx;
     std::vector<bool> m_relin;
     std::vector<std::vector<uint32_t>> m_galois;
+    std::vector<std::array<std::uint64_t, 2>> m_loaded;
 };
 
 } // namespace mi355x

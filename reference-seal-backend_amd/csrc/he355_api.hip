@@ -707,6 +707,83 @@ public:
         }
         return terms;
     }
+    // out = in + sum_j rotate(in, steps[j]): the inner loop of the row-major MatMult (bfv row .cpp:519-531, ckks row .cpp:502-514:
+    // result = base; result += rotate_rows(base, j * spacers) for j = 1 .. dim2-1).  Every rotation is what Evaluator::rotate_internal
+    // computes -- the step's own Galois key if present, else its NAF terms applied least significant first -- and all of them start from
+    // the same ciphertext, so two steps whose term sequences share a prefix share that prefix's intermediate CIPHERTEXT bit for bit
+    // (same operations on the same input).  The term sequences form a trie; each node is key-switched once, from its parent's
+    // ciphertext, and added to the running sum as often as steps end there (modular additions commute, so the order of the adds is
+    // free).  For steps j * 2^k, j = 1 .. 2^m - 1, every prefix of a NAF sequence is the NAF sequence of a smaller j: 127 key
+    // switches instead of 313 for the 128-column products of BASELINE configs[4].
+    // Returns the number of key switches issued.  Not in place.
+    u64 rotate_sum(int L, u64 n, const u64 *in, const int *steps, u64 n_steps, u64 *out)
+    {
+        use();
+        check_level(L);
+        if (in == out) throw std::invalid_argument("rotate_sum cannot run in place");
+        const size_t per = 2 * (size_t)L * P.N, bytes = n * per * 8;
+        struct Node { uint32_t elt; int parent; u64 ends; std::vector<int> kids; }; // elt: the Galois element of the node's term (steps that
+                                                                                   // differ by the row length are the same rotation, same key)
+        std::vector<Node> trie(1, Node{0, -1, 0, {}}); // node 0: the input itself
+        size_t depth = 0;
+        for (u64 j = 0; j < n_steps; ++j) {
+            const std::vector<int> terms = rotation_terms(steps[j]);
+            int at = 0;
+            for (int t : terms) {
+                const uint32_t te = P.galois_elt_from_step(t);
+                int next = -1;
+                for (int k : trie[(size_t)at].kids)
+                    if (trie[(size_t)k].elt == te) { next = k; break; }
+                if (next < 0) {
+                    next = (int)trie.size();
+                    trie.push_back(Node{te, at, 0, {}});
+                    trie[(size_t)at].kids.push_back(next);
+                }
+                at = next;
+            }
+            ++trie[(size_t)at].ends;
+            depth = std::max(depth, terms.size());
+        }
+        if (!n) return 0;
+        HIPCHECK(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, stream_));
+        Indexer ixp{};
+        ixp.pairwise = 1;
+        for (u64 r = 0; r < trie[0].ends; ++r) addsub(L, 2, n, out, in, ixp, out, false); // steps of 0: the input once more
+        if (trie.size() == 1) return 0;
+        require_keyswitch();
+        // one ciphertext slab per trie level (a node's ciphertext lives until its last child is done; a leaf needs one only when
+        // several steps end there)
+        const size_t levels = depth;
+        if (levels * bytes > rot_tmp_bytes_) {
+            HIPCHECK(hipStreamSynchronize(stream_));
+            if (rot_tmp_) HIPCHECK(hipFree(rot_tmp_));
+            rot_tmp_ = nullptr; rot_tmp_bytes_ = 0;
+            HIPCHECK(hipMalloc(&rot_tmp_, levels * bytes));
+            rot_tmp_bytes_ = levels * bytes;
+        }
+        u64 switches = 0;
+        // depth-first: (node, level of the node = number of terms applied)
+        std::vector<std::pair<int, size_t>> stack;
+        for (auto it = trie[0].kids.rbegin(); it != trie[0].kids.rend(); ++it) stack.push_back({*it, 1});
+        while (!stack.empty()) {
+            const auto [id, lvl] = stack.back();
+            stack.pop_back();
+            const Node &nd = trie[(size_t)id];
+            const u64 *src = lvl == 1 ? in : rot_tmp_ + (lvl - 2) * n * per;
+            const uint32_t e = nd.elt;
+            if (nd.kids.empty() && nd.ends == 1) {
+                apply_galois(L, n, src, e, out, out); // a leaf: the add_inplace rides the Galois step (sum += rotate(parent))
+            } else {
+                u64 *mine = rot_tmp_ + (lvl - 1) * n * per;
+                apply_galois(L, n, src, e, mine);
+                for (u64 r = 0; r < nd.ends; ++r) addsub(L, 2, n, out, mine, ixp, out, false);
+                for (auto it = nd.kids.rbegin(); it != nd.kids.rend(); ++it) stack.push_back({*it, lvl + 1});
+            }
+            ++switches;
+        }
+        HIPCHECK(hipGetLastError());
+        return switches;
+    }
     // out[i] = rotate(in[i], steps[i]): the rotate_vector(dot_i, -i) loop of collapseCKKS (seal_context.cpp:389-392).  Every
     // ciphertext goes through its own NAF terms in its own order; ciphertexts whose t-th term is the same Galois element are
     // gathered and key-switched as one batch (a loop of single-ciphertext rotations is latency-bound: ~1 ms each at N=2^14).
@@ -1471,6 +1548,14 @@ int he355_rotate_each(he355_ctx *c, int L, uint64_t n, const uint64_t *in, const
     return guarded([&] {
         if (n && !steps) throw std::invalid_argument("rotate_each needs one step per ciphertext");
         dev(c).rotate_each(L, n, in, steps, out);
+    });
+}
+int he355_rotate_sum(he355_ctx *c, int L, uint64_t n, const uint64_t *in, const int32_t *steps, uint64_t n_steps, uint64_t *out, uint64_t *key_switches)
+{
+    return guarded([&] {
+        if (n_steps && !steps) throw std::invalid_argument("rotate_sum needs the steps");
+        const uint64_t k = dev(c).rotate_sum(L, n, in, steps, n_steps, out);
+        if (key_switches) *key_switches = k;
     });
 }
 int he355_rotate_add(he355_ctx *c, int L, uint64_t n, const uint64_t *in, int step, const uint64_t *addend, uint64_t *out)

@@ -2,6 +2,7 @@
 (SURVEY.md §3.5), results checked against cleartext ground truth like the harness does.  CKKS results are
 approximate by construction of the scheme: tolerance 1e-4 absolute on values in [-1,1] products/sums
 (45/40-bit scales give ~1e-7); BFV results are exact."""
+import ctypes as C
 import importlib
 import os
 
@@ -274,3 +275,29 @@ def test_operate_spread_over_a_device_group(backend, monkeypatch, ndev):
     backend.destroy(hb)
     txt = backend.description_text(backend.find(W_ADD, SCHEME_CKKS, OFFLINE), ckks_params(n) + [("NumDevices", ndev)])
     assert txt.rstrip().endswith(f", Number of devices, {ndev}")
+    if ndev > 1:
+        # load() sent every other device only ITS block of operand-0 rows (shard operand 0, broadcast operand 1): the
+        # last load was the BFV one above -- 4 rows of operand 0 over ndev devices, 3 rows of operand 1 whole
+        moved = backend.L.he355_bridge_group_load_bytes
+        moved.restype, moved.argtypes = C.c_uint64, [C.c_int, C.c_int]
+        ct = 2 * 2 * 8192 * 8  # size-2 ciphertext at L = 2 data primes, N = 8192
+        base, extra = divmod(4, ndev)
+        for d in range(1, ndev):
+            assert moved(d, 0) == (base + (1 if d < extra else 0)) * ct, (d, moved(d, 0))
+            assert moved(d, 1) == 3 * ct
+        # an operate() that indexes a portion of the batch runs on the primary device (which holds everything) and is still right
+        hb = backend.create(backend.find(W_ADD, SCHEME_CKKS, OFFLINE), ckks_params(n) + [("NumDevices", ndev)], (5, 2))
+        res = backend.run(hb, [a, b], n, np.float64, indexers=[(1, 3), (0, 2)])
+        assert np.allclose(res, (a[1:4, None, :] + b[None, :, :]).reshape(6, n), atol=1e-4)
+        backend.destroy(hb)
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+def test_matmult_row_spread_over_a_device_group(backend, monkeypatch, ndev):
+    """MatMultRow's row(-pair) ciphertexts are independent (bfv row .cpp:512-533): HE355_NUM_DEVICES spreads them over a device
+    group in contiguous blocks, B and the keys on every device (last row).  5 rows -> 3 row-pair ciphertexts (BFV) /
+    5 ciphertexts (CKKS) over 2 and 3 logical devices on this one GPU; results equal the cleartext product."""
+    monkeypatch.setenv("HE355_LOGICAL_DEVICES", "3")
+    monkeypatch.setenv("HE355_NUM_DEVICES", str(ndev))
+    _matmul(backend, (5, 8, 4), 8192, 3)
+    _matmul_val(backend, SCHEME_CKKS, (5, 8, 4), 8192, 3, 40, other=2)  # CKKS MatMultRow (one row per ciphertext)

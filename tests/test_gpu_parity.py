@@ -599,6 +599,39 @@ def test_rotate_each_batches_by_galois_element(pair, be):
         g.rotate_each(L, n, da, steps, da)  # not in place
 
 
+def test_rotate_sum_shares_naf_prefixes(pair, be):
+    """he355_rotate_sum (CKKS): out = in + sum_j rotate_vector(in, steps[j]) with every distinct NAF prefix key-switched once -- equal
+    bit for bit to the reference's loop of independent rotations + add_inplace (ckks row .cpp:502-514), fewer key switches."""
+    g, o, rng = pair
+    L, N = g.L, g.N
+    keys = {}
+    for k in range(6):
+        for s in (1 << k, -(1 << k)):
+            e = o.galois_elt(s)
+            keys[e] = o.random_kswitch_key(rng)
+            g.set_galois_key(e, keys[e])
+    steps = [2 * j for j in range(1, 12)]  # 2 .. 22: NAF terms within +-32
+    a = rand_cts(o, rng, 2, L)
+    da = g.to_device(a)
+    out = g.alloc(2 * 2 * L * N)
+    issued = g.rotate_sum(L, 2, da, steps, out)
+    got = out.download((2, 2, L, N))
+    unshared = 0
+    for r in range(2):
+        want = a[r].copy()
+        for s in steps:
+            w = a[r]
+            terms = [s] if o.galois_elt(s) in keys else _naf_terms(s, N)
+            for t in terms:
+                w = o.apply_galois(w, o.galois_elt(t), keys[o.galois_elt(t)])
+            unshared += len(terms) if r == 0 else 0
+            want = o.add(want, w)
+        assert np.array_equal(got[r], want), r
+    assert issued < unshared, (issued, unshared)
+    with pytest.raises(be.HE355Error):
+        g.rotate_sum(L, 2, da, steps, da)  # not in place
+
+
 def test_pipeline_regression_fixture_gpu(be, oracle):
     """The HIP path reproduces tests/golden/pipeline_sha256.json (checksums of the pipeline outputs on seeded inputs, generated by
     tests/golden/make_pipeline_vectors.py): the committed fixture both the oracle (CPU suite) and the device are held to."""

@@ -228,3 +228,58 @@ def test_bfv_random_parameter_chains(be, oracle, seed):
     for r in range(n):
         assert np.array_equal(gotr[r], o.apply_galois(a[r], elt, gk)), (bits, pb, N, r)
     g.close()
+
+
+def test_rotate_sum_shares_naf_prefixes_bit_for_bit(pair, be):
+    """he355_rotate_sum: out = in + sum_j rotate_rows(in, j * spacers), the inner loop of MatMultRow (bfv row .cpp:519-531), with every
+    distinct NAF prefix key-switched once.  It must equal the reference's unshared loop -- one Evaluator::rotate_internal per step,
+    each from `in` -- bit for bit (the oracle's rotate), and issue fewer key switches: for steps j * 2^k, j = 1 .. 15, the trie has 15
+    nodes while the loop runs 26 key switches."""
+    g, o, rng = pair
+    L, N = g.L, g.N
+    keys = {}
+    k = 0
+    while (1 << k) < N // 2:  # the default Galois key set of the reference: +-2^k row rotations
+        for s in (1 << k, -(1 << k)):
+            e = o.galois_elt(s)
+            keys[e] = o.random_kswitch_key(rng)
+            g.set_galois_key(e, keys[e])
+        k += 1
+    a = rand_cts(o, rng, 2, L)
+    da = g.to_device(a)
+    out = g.alloc(2 * 2 * L * N)
+    spacers = (N // 2) // 16
+    steps = [j * spacers for j in range(1, 16)]
+    issued = g.rotate_sum(L, 2, da, steps, out)
+    got = out.download((2, 2, L, N))
+    unshared = 0
+    for r in range(2):
+        want = a[r].copy()
+        for s in steps:
+            want = o.add(want, o.rotate(a[r], s, keys))
+        assert np.array_equal(got[r], want), r
+    prefixes = set()
+    for s in steps:  # the unshared loop (Evaluator::rotate_internal): the step's own key if present, else one key switch per NAF term
+        if o.galois_elt(s) in keys:  # (e.g. 12 * 32 = 384 is the rotation by -128 of a 512-slot row: same Galois element, same key)
+            terms = [s]
+        else:
+            v, i, terms = s, 0, []
+            while v:
+                zi = 2 - (v & 3) if v & 1 else 0
+                v = (v - zi) >> 1
+                if zi and abs(zi << i) != N // 2:
+                    terms.append(zi * (1 << i))
+                i += 1
+        unshared += len(terms)
+        elts = tuple(o.galois_elt(t) for t in terms)
+        prefixes |= {elts[:k] for k in range(1, len(elts) + 1)}
+    assert issued == len(prefixes) and issued < unshared, (issued, len(prefixes), unshared)
+    # duplicates, a zero step and a negative step: still the plain sum
+    steps2 = [3 * spacers, 3 * spacers, 0, -5 * spacers]
+    g.rotate_sum(L, 2, da, steps2, out)
+    got = out.download((2, 2, L, N))
+    for r in range(2):
+        want = o.add(a[r], a[r])
+        for s in (3 * spacers, 3 * spacers, -5 * spacers):
+            want = o.add(want, o.rotate(a[r], s, keys))
+        assert np.array_equal(got[r], want), r
