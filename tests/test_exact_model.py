@@ -97,3 +97,53 @@ def test_oracle_reproduces_the_exact_model(oracle, name):
     assert seen == set(f["expected"])  # every pinned output was produced
     # the NAF rotation through the oracle's own rotate_internal restatement lands on the same ciphertext
     assert sha(o.rotate(d["a"], 3, {g: k for g, k in d["gk"].items() if g != o.galois_elt(3)})) == f["expected"]["rotate_3_naf"]["sha256"]
+
+
+# ---- the sizes the bench runs (tests/golden/exact_vectors_big.json, make_exact_vectors_big.py) ------------------------------------
+BIG_PATH = os.path.join(HERE, "golden", "exact_vectors_big.json")
+BIG = json.load(open(BIG_PATH)) if os.path.exists(BIG_PATH) else {}
+
+
+def big_case_inputs(name):
+    """numpy inputs of a big fixture case (the generator used the same vectorised functions, checked there against the scalar ones)"""
+    f = BIG[name]
+    primes = [int(p, 16) for p in f["primes"]]
+    N, seed, Ltop = f["N"], f["seed"], len(primes) - 1
+    d = dict(primes=primes, N=N, Ltop=Ltop, a=xi.ciphertext_np(seed, 1, primes, Ltop, 2, N), b=xi.ciphertext_np(seed, 2, primes, Ltop, 2, N))
+    if "multiply_relin" in f["expected"]:
+        d["rk"] = xi.kswitch_key_np(seed, 3, primes, Ltop, N)
+    if "rotate_1" in f["expected"]:
+        d["g1"] = f["galois_elts"]["1"]
+        d["gk1"] = xi.kswitch_key_np(seed, 10, primes, Ltop, N)
+    return f, d
+
+
+def test_numpy_input_twins_agree_with_the_scalar_functions():
+    q = (1 << 60) - (1 << 18) + 1
+    for seed, tag, mod, n in ((0xE0C1, 1003, q, 300), (7, 3, 35184371138561, 100)):
+        assert xi.uniform_poly_np(seed, tag, mod, n).tolist() == xi.uniform_poly(seed, tag, mod, n)
+    primes = [q, 35184371138561, 1152921504606584833]
+    assert xi.ciphertext_np(5, 2, primes, 2, 2, 16).tolist() == xi.ciphertext(5, 2, primes, 2, 2, 16)
+    assert xi.kswitch_key_np(5, 3, primes, 2, 16).tolist() == xi.kswitch_key(5, 3, primes, 2, 16)
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in xi.BIG_CASES])
+def test_oracle_reproduces_the_exact_model_at_bench_sizes(oracle, name):
+    """N = 2^15 with the headline chain {60, 45 x 15, 60} (multiply, multiply -> relinearize, -> rescale, one rotation) and N = 2^14,
+    {60, 45 x 7, 60} (multiply): the oracle on the exact model's ciphertexts, bit for bit."""
+    if name not in BIG:
+        pytest.skip("fixture case not generated (tests/golden/make_exact_vectors_big.py)")
+    f, d = big_case_inputs(name)
+    o = oracle.Context(oracle.SCHEME_CKKS, f["N"], bit_sizes=f["bits"])
+    assert [int(q) for q in o.moduli] == d["primes"]
+    assert [o.root(i) for i in range(len(d["primes"]))] == [int(p, 16) for p in f["psi"]]
+    exp = f["expected"]
+    c3 = o.multiply_ntt(d["a"], d["b"])
+    check(f, "multiply", c3)
+    if "multiply_relin" in exp:
+        rl = o.relinearize(c3, d["rk"])
+        check(f, "multiply_relin", rl)
+        check(f, "multiply_relin_rescale", o.rescale(rl))
+    if "rotate_1" in exp:
+        assert o.galois_elt(1) == d["g1"]
+        check(f, "rotate_1", o.apply_galois(d["a"], d["g1"], d["gk1"]))

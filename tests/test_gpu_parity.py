@@ -752,6 +752,50 @@ def test_exact_model_fixture_gpu(be, name):
     g.close()
 
 
+@pytest.mark.parametrize("name", ["ckks_n32768_60_45x15_60", "ckks_n16384_60_45x7_60"])
+def test_exact_model_big_fixture_gpu(be, name):
+    """The HIP path at the sizes the bench runs against tests/golden/exact_vectors_big.json (exact big-integer model, no oracle):
+    N = 2^15 with the headline chain -- the fused multiply -> relinearize -> rescale sequence is the kernels of the headline
+    (k_k1, k_k2n<5>, k_k3<.., fused>, k_floor_colsn<5, merged>) -- and N = 2^14, L = 8 (configs[1]'s multiply)."""
+    import test_exact_model as tem
+    if name not in tem.BIG:
+        pytest.skip("fixture case not generated (tests/golden/make_exact_vectors_big.py)")
+    f, d = tem.big_case_inputs(name)
+    N, L = f["N"], d["Ltop"]
+    exp = f["expected"]
+    g = be.Context(be.SCHEME_CKKS, N, bit_sizes=f["bits"], device=0)
+    assert [int(q) for q in g.moduli] == d["primes"]
+    pw = be.Context.pairwise()
+    da, db = g.to_device(d["a"][None]), g.to_device(d["b"][None])
+    c3 = g.alloc(3 * L * N)
+    g.multiply(L, 1, da, db, pw, c3)
+    tem.check(f, "multiply", c3.download((3, L, N)))
+    if "multiply_relin" in exp:
+        g.set_relin_key(d["rk"])
+        out = g.alloc(2 * L * N)
+        g.multiply_relin(L, 1, da, db, pw, out)
+        tem.check(f, "multiply_relin", out.download((2, L, N)))
+        g.relinearize(L, 1, c3, out)
+        tem.check(f, "multiply_relin", out.download((2, L, N)))
+        out2 = g.alloc(2 * (L - 1) * N)
+        g.multiply_relin(L, 1, da, db, pw, out2, rescale=True)
+        tem.check(f, "multiply_relin_rescale", out2.download((2, L - 1, N)))
+        # the same op inside a batch that spans chunks and both streams: 5 copies of the pair, chunk 2
+        g.set_chunk(2)
+        a5, b5 = g.to_device(np.repeat(d["a"][None], 5, axis=0)), g.to_device(np.repeat(d["b"][None], 5, axis=0))
+        out5 = g.alloc(5 * 2 * (L - 1) * N)
+        g.multiply_relin(L, 5, a5, b5, pw, out5, rescale=True)
+        got = out5.download((5, 2, L - 1, N))
+        for r in range(5):
+            tem.check(f, "multiply_relin_rescale", got[r])
+    if "rotate_1" in exp:
+        g.set_galois_key(d["g1"], d["gk1"])
+        out = g.alloc(2 * L * N)
+        g.apply_galois(L, 1, da, d["g1"], out)
+        tem.check(f, "rotate_1", out.download((2, L, N)))
+    g.close()
+
+
 def test_shards_hold_the_global_batch_and_replicated_keys_agree(be):
     """Multi-GPU bench path (bench.py, sharding.shard_outer_product): a rank's shard, filled with its offset into the global operand
     array (he355_fill_uniform_at), holds exactly the rows the whole array holds there; two contexts that build their synthetic

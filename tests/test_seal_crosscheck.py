@@ -16,7 +16,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEAL_DIR = os.environ.get("SEAL_INSTALL_DIR", "")
 pytestmark = pytest.mark.skipif(not SEAL_DIR, reason="SEAL_INSTALL_DIR not set: Microsoft SEAL is not available offline")
 
-CASES = [("ckks", 8192, 2, 45, 45), ("ckks", 16384, 4, 45, 45), ("bfv", 8192, 2, 40, 20), ("bfv", 16384, 3, 40, 20)]
+CASES = [("ckks", 8192, 2, 45, 45), ("ckks", 16384, 4, 45, 45), ("ckks", 32768, 16, 45, 45),  # the last: the headline chain {60, 45 x 15, 60}
+         ("bfv", 8192, 2, 40, 20), ("bfv", 16384, 3, 40, 20)]
+
+
+def _pinned(meta, who):
+    """one line per case a run has pinned against SEAL itself (shown with pytest -s): what the first contact settled"""
+    ckks = meta["scheme"] == "ckks"
+    ops = "primes, add, multiply, relinearize, rescale, rotate(1), rotate(3 = -1 + 4)" if ckks else \
+          "primes, t, add, BEHZ multiply, relinearize, rotate_rows(1), rotate_rows(3 = -1 + 4)"
+    print(f"PINNED against SEAL 3.7 ({who}): {meta['scheme']} N={meta['N']} depth={meta['depth']} bits={meta['coeff_bits']}: {ops}")
+    if ckks:
+        big = " (the headline chain; exact_vectors_big.json: ckks_n32768_60_45x15_60)" if meta["N"] == 32768 and meta["depth"] == 16 else ""
+        print("  -> also pins what the exact model only derives: minimal-root choice, digit/key layout, floor directions" + big)
+    else:
+        print("  -> pins SURVEY.md App. A's recollection of BEHZ: m~ = 2^32, uncorrected fast base conversions, auxiliary base choice")
 
 
 def _run_seal(tmp_path, case):
@@ -74,6 +88,7 @@ def test_oracle_against_real_seal(oracle, tmp_path, case):
         def multiply(a, b):
             return o.multiply_ntt(a, b) if meta["scheme"] == "ckks" else o.bfv_multiply(a, b)
     _check(Ops, meta, ct, key, L)
+    _pinned(meta, "oracle, CPU")
 
 
 @pytest.mark.gpu
@@ -120,4 +135,5 @@ def test_hip_path_against_real_seal(tmp_path, case):
             g.apply_galois(c.shape[1], 1, g.to_device(c[None]), elt, out)
             return out.download(c.shape)
     _check(Ops, meta, ct, key, L)
+    _pinned(meta, "HIP path, MI355X")
     g.close()
