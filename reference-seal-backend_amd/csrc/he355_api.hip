@@ -178,6 +178,8 @@ public:
         env_.stream = stream_;
         const char *ds = std::getenv("HE355_DUAL_STREAM");
         if (ds) dual_stream_ = ds[0] != '0';
+        const char *lm = std::getenv("HE355_LATENCY_MAX");
+        if (lm) lat_max_ = (u64)std::max(0, std::atoi(lm));
         const char *ch = std::getenv("HE355_CHUNK");
         if (ch && std::atoi(ch) > 0) chunk_ = (size_t)std::atoi(ch);
     }
@@ -195,6 +197,7 @@ public:
         (void)hipFree(scratch_);
         (void)hipFree(scratch2_);
         (void)hipFree(rot_tmp_);
+        (void)hipFree(lat_part_);
         (void)hipFree(bfv_scratch_);
         (void)hipFree(client_scratch_);
         for (auto &kv : d_gather_) (void)hipFree(kv.second);
@@ -211,6 +214,7 @@ public:
     int device() const { return device_; }
     const KernelEnv &env() const { return env_; }
     void set_chunk(size_t c) { chunk_ = c ? c : 1; }
+    void set_latency_max(u64 n) { lat_max_ = n; }
 
     size_t key_elems() const { return P.Ltop * 2 * P.K * P.N; }
     size_t n_q_primes() const
@@ -384,6 +388,19 @@ public:
     {
         const size_t N = P.N, LN = (size_t)L * N;
         const int SP = (int)P.K - 1;
+        if (latency_shape(nc)) {
+            // Few ciphertexts (HEBench's Latency category is batch 1: ckks eltwise .cpp:138-141): the throughput shape would leave one
+            // wave walking all digits of a tile and one lane walking all targets of a column while the chip idles.  Same kernels,
+            // unfused, with the serial loops dealt to more blocks: targets of a column over kLatSplit blocks (k_k2n, k_floor_colsn),
+            // digits of a tile over kLatSplit single-wave blocks whose partial sums k_k3_combine adds (k_k3).
+            launch_k2(env_, L, nc, B, nullptr, 0, kLatSplit);
+            if (after_k2) HIPCHECK(hipEventRecord(after_k2, env_.stream));
+            u64 *part = latency_partials((size_t)kLatSplit * nc * 2 * (L + 1) * N);
+            launch_k3(env_, L, nc, B, key, K3_ALL, nullptr, kLatSplit, part);
+            launch_k3_combine(env_, L, nc, B, kLatSplit, part);
+            launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e, nullptr, 0, 0, 0, 0, nullptr, 0, kLatSplit);
+            return key_switch_floor_rows(env_, L, nc, S, B, with_tail);
+        }
         launch_k2(env_, L, nc, B);
         if (after_k2) HIPCHECK(hipEventRecord(after_k2, env_.stream));
         if (k3_can_fuse(env_) && B.c01_item_stride == 2 * LN) {
@@ -425,6 +442,13 @@ public:
         }
         launch_k3(env_, L, nc, B, key);
         launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
+        return key_switch_floor_rows(env_, L, nc, S, B, with_tail);
+    }
+    // the row half of the unfused mod-down: c01 += (t - NTT(e)) * P^-1, optionally starting the rescale (tail of prime L-1)
+    bool key_switch_floor_rows(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, bool with_tail)
+    {
+        const size_t LN = (size_t)L * P.N;
+        const int SP = (int)P.K - 1;
         FloorRowsArgs fr;
         fr.src_prime = SP; fr.n_tgt = L; fr.n_src = 2;
         fr.cols = B.e;
@@ -439,7 +463,7 @@ public:
     void rescale_tail(const KernelEnv &env_, int L, int size, u64 nc, const Scratch &S, const u64 *src, u64 src_op_stride, u64 *out)
     {
         const size_t N = P.N, LN = (size_t)L * N, L1N = (size_t)(L - 1) * N;
-        launch_floor_cols(env_, L - 1, L - 1, nc * size, S.rlr, S.f);
+        launch_floor_cols(env_, L - 1, L - 1, nc * size, S.rlr, S.f, nullptr, 0, 0, 0, 0, nullptr, 0, latency_shape(nc) ? kLatSplit : 1);
         FloorRowsArgs fr;
         fr.src_prime = L - 1; fr.n_tgt = L - 1; fr.n_src = size;
         fr.cols = S.f;
@@ -448,6 +472,21 @@ public:
         fr.out = out; fr.out_op_stride = (u64)size * L1N; fr.out_poly_stride = L1N;
         fr.tail_prime = -1; fr.tail = nullptr;
         launch_floor_rows(env_, nc, fr);
+    }
+    // latency shape of the key switch (key_switch_tail): batches of at most lat_max_ ciphertexts, CKKS pipeline
+    static constexpr int kLatSplit = 4;
+    bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
+    u64 *latency_partials(size_t elems)
+    {
+        if (elems * 8 > lat_part_bytes_) {
+            HIPCHECK(hipStreamSynchronize(stream_));
+            HIPCHECK(hipStreamSynchronize(stream2_));
+            if (lat_part_) HIPCHECK(hipFree(lat_part_));
+            lat_part_ = nullptr; lat_part_bytes_ = 0;
+            HIPCHECK(hipMalloc(&lat_part_, elems * 8));
+            lat_part_bytes_ = elems * 8;
+        }
+        return lat_part_;
     }
     void require_keyswitch() const
     {
@@ -1258,6 +1297,9 @@ private:
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     KernelEnv env_{};
     PrimeDev *d_primes_ = nullptr;
+    u64 *lat_part_ = nullptr;      // partial sums of the digit-split K3 (latency shape)
+    size_t lat_part_bytes_ = 0;
+    u64 lat_max_ = 4;              // largest batch that takes the latency shape (HE355_LATENCY_MAX; 0: never)
     FloorConst *d_floor_ = nullptr;
     std::vector<void *> owned_;
     u64 *d_relin_ = nullptr;
@@ -1455,6 +1497,7 @@ int he355_fill_uniform_at(he355_ctx *c, uint64_t *d_dst, uint64_t n_polys, const
     return guarded([&] { dev(c).fill_uniform(d_dst, n_polys, prime_of, period, seed, first_poly); });
 }
 int he355_set_dual_stream(he355_ctx *c, int on) { return guarded([&] { dev(c).set_dual_stream(on != 0); }); }
+int he355_set_latency_max(he355_ctx *c, uint64_t n) { return guarded([&] { dev(c).set_latency_max(n); }); }
 int he355_set_relin_key(he355_ctx *c, const uint64_t *h_key)
 {
     return guarded([&] { dev(c).key_from_host(dev(c).relin_slot(), h_key); });

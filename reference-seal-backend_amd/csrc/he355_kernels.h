@@ -74,7 +74,8 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
 // K2: finish iNTT of each digit, lift to every key prime, forward column pass -> d
 // src_is_coeff (BFV): `src` already holds coefficient-form digits [op][L][N] (op stride src_op_stride) and every
 // (prime, digit) pair is lifted, including the digit's own prime
-void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *src = nullptr, u64 src_op_stride = 0);
+// tsplit > 1 (latency shape, k_k2n): the targets of a (digit, column block) are dealt to tsplit blocks
+void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *src = nullptr, u64 src_op_stride = 0, int tsplit = 1);
 // K3: forward row pass of every (tt, j) + multiply-accumulate with the key -> t (data primes) / tpr (special)
 // BFV (env.scheme == 1): the products of ALL primes continue into the inverse row pass (t then holds raw rows)
 // `part`: all tiles, only the special prime's, or only the data primes'.  With `fuse` (data-prime tiles, CKKS, default block
@@ -93,13 +94,18 @@ struct K3Fuse {
     u64 *out;
 };
 bool k3_can_fuse(const KernelEnv &env);
-void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part = K3_ALL, const K3Fuse *fuse = nullptr);
+// n_split > 1 (latency shape, unfused only): the digits of every tile are cut into n_split groups, one single-wave block per (tile, op,
+// group), canonical partial sums -> split_part [n_split][n_ops * 2][L + 1][N]; launch_k3_combine then leaves t / tpr as the unsplit launch
+void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part = K3_ALL, const K3Fuse *fuse = nullptr,
+               int n_split = 1, u64 *split_part = nullptr);
+void launch_k3_combine(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, int n_split, const u64 *split_part);
 // floor step, column half: src [n_ops*n_src][N] raw of prime s -> r = (x + floor(s/2)) mod s ->
 // (r mod q_i - floor(s/2) mod q_i) for i < n_tgt -> forward column pass -> dst [n_ops*n_src][n_tgt][N]
 // addin (optional): the column-passed correction of an earlier floor step [n_polys][addin_ntgt][N], folded in scaled by
 // addin_src^-1 mod q_i (mod-down + rescale then share one row transform per residue)
 void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst, const u64 *addin = nullptr,
-                       int addin_src = 0, int addin_ntgt = 0, int tgt_first = 0, int dst_ntgt = 0, const u64 *src2 = nullptr, int src2_prime = 0);
+                       int addin_src = 0, int addin_ntgt = 0, int tgt_first = 0, int dst_ntgt = 0, const u64 *src2 = nullptr, int src2_prime = 0,
+                       int tsplit = 1);
 // floor step, row half: out[(op,k,i)] = (tsrc[(op,k,i)] - NTT(dst_cols[(op,k,i)])) * s^-1 (+ addend) mod q_i.
 // Strides are in u64 elements.  If tail_prime >= 0 the rows of that prime additionally go through the
 // inverse row pass into tail[(op,k)] (next floor step's source).

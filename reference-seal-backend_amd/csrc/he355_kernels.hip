@@ -796,6 +796,7 @@ struct K2Args {
     int L, K, ckks, src_is_coeff;
     u64 f64_mask; // bit t: key prime t belongs to the fp64 engine
     int ablate;  // timing experiments (wrong results): 1 = every target's rows land in the slab region of target 0 (no HBM write stream), 2 = no u64-engine targets, 4 = no stores for the fp64 targets
+    int tsplit;  // k_k2n, latency shape: the targets of a (digit, column block) are dealt to tsplit blocks (blockIdx.y)
     int xcd_map; // k_k2n: the four column blocks of one (op, digit) run on the same XCD (blocks b and b + 8 share one)
 };
 
@@ -1015,6 +1016,16 @@ template <int LOGN1> __device__ __forceinline__ bool fits_48(double m0, double q
 #define HE355_K2_G 2
 #endif
 constexpr int kK2G = HE355_K2_G;
+// every n_groups-th set bit of mask, starting with the g-th (latency shape: the targets of a column are dealt to n_groups blocks)
+__device__ __forceinline__ u64 split_mask(u64 mask, int g, int n_groups)
+{
+    if (n_groups <= 1) return mask;
+    u64 out = 0;
+    int r = 0;
+    for (u64 m = mask; m; m &= m - 1, ++r)
+        if (r % n_groups == g) out |= m & (~m + 1);
+    return out;
+}
 typedef const __attribute__((address_space(4))) PrimeDev *cprime_t;
 typedef double d16_t __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) d16_t *cd16_t;
@@ -1149,6 +1160,7 @@ __device__ __forceinline__ void k2n_targets_f64(const K2Args &A, const PrimeDev 
     const cprime_t cp = (cprime_t)(unsigned long long)primes;
     u64 level = (A.L >= 64 ? ~(u64)0 : (((u64)1 << A.L) - 1)) | ((u64)1 << (A.K - 1));
     if (A.ckks) level &= ~((u64)1 << j);
+    level = split_mask(level, (int)blockIdx.y, A.tsplit);
     const u64 f64_targets = A.f64_mask & level;
     u64 direct = 0, lift = 0;
     if constexpr (kPackD) { direct = cp[j].k2_direct & f64_targets; lift = cp[j].k2_lift & f64_targets; }
@@ -1193,6 +1205,7 @@ __device__ __forceinline__ void k2n_targets_u64(const K2Args &A, const PrimeDev 
     const u32 off8 = (u32)col << 3;
     u64 level = (A.L >= 64 ? ~(u64)0 : (((u64)1 << A.L) - 1)) | ((u64)1 << (A.K - 1));
     if (A.ckks) level &= ~((u64)1 << j);
+    level = split_mask(level, (int)blockIdx.y, A.tsplit);
     if (A.ablate & 2) level = 0;
     for (u64 m = ~A.f64_mask & level; m; m &= m - 1) {
         const int t = __builtin_ctzll(m), tt = t == A.K - 1 ? A.L : t;
@@ -1400,6 +1413,10 @@ struct K3Args {
     int L, K, logn1, ckks;
     int n_tt;
     u32 og_per_block; // consecutive op-groups one block handles on its tile
+    // latency shape (few ops): the digits of a tile are cut into n_split groups, one block each (blockIdx.y); group g writes its canonical
+    // partial sums to part[g][op * 2 + k][L + 1][N] and k_k3_combine adds them up (and runs the special prime's inverse row pass)
+    int n_split;
+    u64 *part;
     unsigned char tt_list[64];
 };
 
@@ -1535,6 +1552,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         const bool has_own = A.ckks && tt < A.L;
         const int nd = A.L - (has_own ? 1 : 0);
         auto digit = [&](int i) -> int { return (has_own && i >= tt) ? i + 1 : i; };
+        // this block's share of the transformed digits: all of them, or group blockIdx.y of n_split (unfused instantiations only)
+        const int split = FUSE ? 1 : (A.n_split > 1 ? A.n_split : 1), grp = split > 1 ? (int)blockIdx.y : 0;
+        const int i_begin = nd * grp / split, i_end = nd * (grp + 1) / split;
 #if defined(HE355_ABLATE) && (HE355_ABLATE & 2) // timing experiment (wrong results): every digit row is the same row (no HBM stream)
         auto src_row = [&](int) -> const u64 * { return A.d + (u64)wave * N + rowoff; };
 #else
@@ -1543,7 +1563,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         if constexpr (STAGE) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (u < nd) dma_row_to_lds<kDigitPieces>(src_row(digit(u)), stage[wave][u], lane);
+                if (i_begin + u < i_end) dma_row_to_lds<kDigitPieces>(src_row(digit(i_begin + u)), stage[wave][u], lane);
         }
         if constexpr (KSHARE) {
             __syncthreads(); // every wave is done with the key buffers of the previous op-group
@@ -1553,10 +1573,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         Row48 vn48;
         if constexpr (!STAGE) {
             static_assert(STAGE || U == 1, "register prefetch is written for one digit per wave");
-            if constexpr (kPacked) load_rowA48(src_row(digit(0)), lane, vn48);
-            else load_rowA(src_row(digit(0)), lane, vn);
+            if (i_begin < i_end) {
+                if constexpr (kPacked) load_rowA48(src_row(digit(i_begin)), lane, vn48);
+                else load_rowA(src_row(digit(i_begin)), lane, vn);
+            }
         }
-        if (has_own) {
+        if (has_own && grp == 0) {
             T x[kRowE];
             u64 v[kRowE];
             load_rowC(A.c2n + (op * A.L + tt) * N + rowoff, lane, v);
@@ -1661,8 +1683,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 }
             }
         } else {
-            for (int i = 0; i < nd; i += U) {
-                const int cnt = (nd - i) < U ? (nd - i) : U;
+            for (int i = i_begin; i < i_end; i += U) {
+                const int cnt = (i_end - i) < U ? (i_end - i) : U;
                 T x[U][kRowE];
                 if constexpr (STAGE) {
                     u64 v[kRowE];
@@ -1683,7 +1705,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffers drained into registers
 #pragma unroll
                     for (int u = 0; u < U; ++u)
-                        if (i + U + u < nd) dma_row_to_lds<kDigitPieces>(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
+                        if (i + U + u < i_end) dma_row_to_lds<kDigitPieces>(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
                     if constexpr (KSHARE) {
                         if (i + 1 < nd) key_dma(digit(i + 1), (i + 1) & 1);
                     }
@@ -1692,11 +1714,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                     if constexpr (kPacked) {
 #pragma unroll
                         for (int r = 0; r < kRowE; ++r) x[0][r] = unpack48(vn48.lo[r], vn48.hi[r]);
-                        if (i + 1 < nd) load_rowA48(src_row(digit(i + 1)), lane, vn48); // lands behind this step's math
+                        if (i + 1 < i_end) load_rowA48(src_row(digit(i + 1)), lane, vn48); // lands behind this step's math
                     } else {
 #pragma unroll
                         for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(vn[r]);
-                        if (i + 1 < nd) load_rowA(src_row(digit(i + 1)), lane, vn); // lands behind this step's math
+                        if (i + 1 < i_end) load_rowA(src_row(digit(i + 1)), lane, vn); // lands behind this step's math
                     }
                 }
                 if (U == 2 && cnt < U) { // odd digit count: the partner row is zeros (its products add nothing)
@@ -1723,6 +1745,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 const Acc *acc = k == 0 ? acc0 : acc1;
 #pragma unroll
                 for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc[r]);
+                if (split > 1) { // a partial sum: k_k3_combine finishes the tile
+                    if (valid) store_rowC(A.part + (((u64)grp * A.n_ops * 2 + op * 2 + k) * (A.L + 1) + tt) * N + rowoff, lane, v);
+                    continue;
+                }
                 if (!inv_here) {
                     if (valid) store_rowC(A.t + ((op * 2 + k) * A.L + tt) * N + rowoff, lane, v);
                     continue;
@@ -1738,6 +1764,66 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             }
         }
     }
+}
+
+// The sums of a digit-split k_k3 launch: part [n_split][n_ops * 2][L + 1][N] canonical -> t (data primes, canonical NTT form) and tpr
+// (special prime, after the inverse row pass), exactly what the unsplit launch leaves.  One wave per (op, k, tt, row).
+struct K3CombineArgs {
+    const u64 *part;
+    u64 *t, *tpr;
+    u64 n_ops;
+    int n_split, L, K, logn1, ckks;
+};
+__global__ void __launch_bounds__(kBlock) k_k3_combine(K3CombineArgs A, const PrimeDev *primes)
+{
+    __shared__ u64 lds[kWaves][kLdsRow];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 n1 = 1u << A.logn1;
+    const u64 N = (u64)n1 << kRowLog;
+    const u64 total = A.n_ops * 2 * (u64)(A.L + 1) * n1;
+    u64 job = (u64)blockIdx.x * kWaves + wave;
+    const bool valid = job < total;
+    if (!valid) job = total - 1;
+    const u32 a_row = (u32)(job & (n1 - 1));
+    const u64 pt = job >> A.logn1;
+    const int tt = (int)(pt % (A.L + 1));
+    const u64 ok = pt / (A.L + 1); // op * 2 + k
+    const int t = tt == A.L ? A.K - 1 : tt;
+    const PrimeDev &P = primes[t];
+    const u64 rowoff = (u64)a_row << kRowLog, q = P.q;
+    u64 v[kRowE];
+    load_rowC(A.part + (ok * (A.L + 1) + tt) * N + rowoff, lane, v);
+    for (int g = 1; g < A.n_split; ++g) {
+        u64 w[kRowE];
+        load_rowC(A.part + (((u64)g * A.n_ops * 2 + ok) * (A.L + 1) + tt) * N + rowoff, lane, w);
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) v[r] = addmod(v[r], w[r], q);
+    }
+    const bool inv_here = tt == A.L || !A.ckks;
+    if (!inv_here) {
+        if (valid) store_rowC(A.t + (ok * A.L + tt) * N + rowoff, lane, v);
+        return;
+    }
+    const bool last = A.logn1 == 0;
+    u64 *dst = tt < A.L ? A.t + (ok * A.L + tt) * N + rowoff : A.tpr + ok * N + rowoff;
+    if (P.f64) {
+        const ArF64 ar = make_ar(P, (ArF64 *)nullptr);
+        double x[kRowE];
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
+        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
+    } else {
+        const ArU64 ar = make_ar(P, (ArU64 *)nullptr);
+        u64 x[kRowE];
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) x[r] = v[r];
+        wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
+    }
+    if (valid) store_rowA(dst, lane, v);
 }
 
 // =======================================================================================================
@@ -1761,6 +1847,7 @@ struct FloorColsArgs {
     const u64 *src2;
     int src2_prime;
     u64 f64_mask; // bit i: key prime i belongs to the fp64 engine (k_floor_colsn)
+    int tsplit;   // k_floor_colsn, latency shape: the targets of a column are dealt to tsplit blocks (blockIdx.y)
 };
 
 // canonical coefficients + floor(s/2) of one column of a source residue after its inverse row pass
@@ -2004,6 +2091,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_floor_colsn(FloorColsArgs A, cons
     }
     __syncthreads(); // the constants table
     u64 tgt = ((A.tgt_first + A.n_tgt >= 64 ? ~(u64)0 : (((u64)1 << (A.tgt_first + A.n_tgt)) - 1))) & ~(((u64)1 << A.tgt_first) - 1);
+    tgt = split_mask(tgt, (int)blockIdx.y, A.tsplit);
     const u64 f64t = tgt & A.f64_mask;
     const bool wide2 = MERGE && (qs2 >> 52) != 0;
     if (qs >> 52) {
@@ -2734,7 +2822,7 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
     }
 }
 
-void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *src, u64 src_op_stride)
+void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *src, u64 src_op_stride, int tsplit)
 {
     if (!n_ops) return;
     K2Args A;
@@ -2742,7 +2830,7 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     A.src_op_stride = src ? src_op_stride : (u64)L * env.N;
     A.src_is_coeff = src ? 1 : 0;
     A.d = buf.d; A.n_ops = n_ops; A.L = L; A.K = env.K; A.ckks = env.scheme == 2;
-    A.f64_mask = 0; A.ablate = 0; A.xcd_map = 0;
+    A.f64_mask = 0; A.ablate = 0; A.xcd_map = 0; A.tsplit = tsplit > 1 ? tsplit : 1;
     for (int t = 0; t < env.K; ++t) A.f64_mask |= (u64)(env.prime_f64[t] != 0) << t;
     static const int split_env = getenv("HE355_K2_SPLIT") ? atoi(getenv("HE355_K2_SPLIT")) : HE355_K2_SPLIT;
     if (split_env) {
@@ -2779,16 +2867,18 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     A.ablate = k2_abl;
     if (A.xcd_map) g = (unsigned)(((n_ops * L + 7) / 8) * 8 * 4);
     if (k2_new) {
+        const dim3 gd(g, (unsigned)A.tsplit);
         switch (env.logn1) {
-        case 0: hipLaunchKernelGGL(k_k2n<0>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 1: hipLaunchKernelGGL(k_k2n<1>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 2: hipLaunchKernelGGL(k_k2n<2>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 3: hipLaunchKernelGGL(k_k2n<3>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 4: hipLaunchKernelGGL(k_k2n<4>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 5: hipLaunchKernelGGL(k_k2n<5>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 0: hipLaunchKernelGGL(k_k2n<0>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 1: hipLaunchKernelGGL(k_k2n<1>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 2: hipLaunchKernelGGL(k_k2n<2>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 3: hipLaunchKernelGGL(k_k2n<3>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 4: hipLaunchKernelGGL(k_k2n<4>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
+        case 5: hipLaunchKernelGGL(k_k2n<5>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
         }
         return;
     }
+    A.tsplit = 1;
     switch (env.logn1) {
     case 0: hipLaunchKernelGGL(k_k2<0>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
     case 1: hipLaunchKernelGGL(k_k2<1>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
@@ -2808,8 +2898,9 @@ bool k3_can_fuse(const KernelEnv &env)
     return !off && env.scheme == 2 && env.K >= 2 && sf == 18 && su == 18 && stage_env != 0; // the fused instantiations exist for the default shapes
 }
 
-void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part, const K3Fuse *fuse)
+void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part, const K3Fuse *fuse, int n_split, u64 *split_part)
 {
+    if (n_split > 1 && (fuse || !split_part)) throw std::runtime_error("digit-split K3: unfused launches with a partial-sum buffer only");
     const unsigned char *prime_f64 = env.prime_f64;
     if (!n_ops) return;
     if (fuse && (part != K3_DATA_ONLY || !k3_can_fuse(env))) throw std::runtime_error("fused mod-down: data-prime tiles of the default shapes only");
@@ -2821,6 +2912,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.cols2 = fuse ? fuse->cols2 : nullptr; A.out2 = fuse ? fuse->out : nullptr;
         if (fuse && fuse->cols2 && fuse->tt_hi > L - 1) throw std::runtime_error("fused rescale: only primes below the one divided out");
         A.fc = env.floor_consts;
+        A.n_split = n_split > 1 ? n_split : 1; A.part = split_part;
         A.n_tt = 0;
         A.n_q = 0;
         for (int t = 0; t < env.K; ++t) A.n_q += prime_f64[t] == 0;
@@ -2840,7 +2932,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         // block shape per engine: (interleaved digits per wave, waves per block).  HE355_K3_SHAPE=<u><w><u><w> overrides
         // (fp64 pair, then u64 pair), e.g. 2418 = fp64 U=2 x 4 waves, u64 U=1 x 8 waves.
         static const int shape_env = getenv("HE355_K3_SHAPE") ? atoi(getenv("HE355_K3_SHAPE")) : 0;
-        const int shape = pass == 0 ? (shape_env ? shape_env / 100 : HE355_K3_F64_SHAPE) : (shape_env ? shape_env % 100 : HE355_K3_U64_SHAPE);
+        int shape = pass == 0 ? (shape_env ? shape_env / 100 : HE355_K3_F64_SHAPE) : (shape_env ? shape_env % 100 : HE355_K3_U64_SHAPE);
+        if (A.n_split > 1) shape = 11; // latency shape: one wave per block, one (tile, op, digit group) each
         const int waves = shape % 10;
         const u64 n_og = (n_ops + waves - 1) / waves;
         const u64 tiles = (u64)A.n_tt << env.logn1;
@@ -2865,7 +2958,11 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         }
         static const int stage_env = getenv("HE355_K3_STAGE") ? atoi(getenv("HE355_K3_STAGE")) : HE355_K3_STAGE_DEFAULT;
         const bool staged = stage_env != 0 || shape / 10 != 1;
-        if (pass == 0) {
+        if (shape == 11) {
+            const dim3 gd(g, (unsigned)A.n_split);
+            if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 1, 1, true>), gd, dim3(64), 0, env.stream, A, env.primes);
+            else hipLaunchKernelGGL((k_k3<ArU64, 1, 1, true>), gd, dim3(64), 0, env.stream, A, env.primes);
+        } else if (pass == 0) {
             switch (shape) {
             case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
             case 18:
@@ -2891,8 +2988,18 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     // (the inverse row pass of the special-prime sums, and of every prime's sums for BFV, happened in the kernel's epilogue)
 }
 
+void launch_k3_combine(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, int n_split, const u64 *split_part)
+{
+    if (!n_ops) return;
+    K3CombineArgs A;
+    A.part = split_part; A.t = buf.t; A.tpr = buf.tpr; A.n_ops = n_ops; A.n_split = n_split; A.L = L; A.K = env.K; A.logn1 = env.logn1;
+    A.ckks = env.scheme == 2;
+    const u64 jobs = (n_ops * 2 * (u64)(L + 1)) << env.logn1;
+    hipLaunchKernelGGL(k_k3_combine, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes);
+}
+
 void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst, const u64 *addin, int addin_src,
-                       int addin_ntgt, int tgt_first, int dst_ntgt, const u64 *src2, int src2_prime)
+                       int addin_ntgt, int tgt_first, int dst_ntgt, const u64 *src2, int src2_prime, int tsplit)
 {
     if (!n_polys || n_tgt <= 0) return;
     FloorColsArgs A;
@@ -2900,6 +3007,7 @@ void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_pol
     A.tgt_first = tgt_first; A.dst_ntgt = dst_ntgt > 0 ? dst_ntgt : n_tgt;
     A.addin = addin; A.addin_src = addin_src; A.addin_ntgt = addin_ntgt;
     A.src2 = src2; A.src2_prime = src2_prime;
+    A.tsplit = tsplit > 1 ? tsplit : 1;
     const unsigned g = (unsigned)(n_polys * 4);
     A.f64_mask = 0;
     for (int t = 0; t < env.K; ++t) A.f64_mask |= (u64)(env.prime_f64[t] != 0) << t;
@@ -2907,13 +3015,14 @@ void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_pol
     if (fc_new && !addin) {
 #define HE355_FCN(L1)                                                                                                          \
     case L1:                                                                                                                   \
-        if (src2) hipLaunchKernelGGL((k_floor_colsn<L1, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);          \
-        else hipLaunchKernelGGL((k_floor_colsn<L1, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);              \
+        if (src2) hipLaunchKernelGGL((k_floor_colsn<L1, true>), dim3(g, (unsigned)A.tsplit), dim3(kBlock), 0, env.stream, A, env.primes);   \
+        else hipLaunchKernelGGL((k_floor_colsn<L1, false>), dim3(g, (unsigned)A.tsplit), dim3(kBlock), 0, env.stream, A, env.primes);       \
         break;
         switch (env.logn1) { HE355_FCN(0) HE355_FCN(1) HE355_FCN(2) HE355_FCN(3) HE355_FCN(4) HE355_FCN(5) }
 #undef HE355_FCN
         return;
     }
+    A.tsplit = 1;
     if (src2) {
         switch (env.logn1) {
         case 0: hipLaunchKernelGGL((k_floor_cols<0, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;

@@ -632,6 +632,45 @@ def test_rotate_sum_shares_naf_prefixes(pair, be):
         g.rotate_sum(L, 2, da, steps, da)  # not in place
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_latency_shape_equals_throughput_shape(pair, be, n):
+    """Key switches over few ciphertexts take the latency shape (he355_set_latency_max: targets of a column and digits of a tile dealt
+    to more blocks, partial sums combined, unfused floor steps).  Same results as the throughput shape and as the oracle, for
+    multiply -> relinearize (-> rescale), relinearize of size-3 ciphertexts, rotation and rotate_add."""
+    g, o, rng = pair
+    L, N = g.L, g.N
+    rk = o.random_kswitch_key(rng)
+    g.set_relin_key(rk)
+    e1 = o.galois_elt(1)
+    gk = o.random_kswitch_key(rng)
+    g.set_galois_key(e1, gk)
+    a, b = rand_cts(o, rng, n, L), rand_cts(o, rng, n, L)
+    da, db = g.to_device(a), g.to_device(b)
+    pw = be.Context.pairwise()
+    want_rl = [o.relinearize(o.multiply_ntt(a[r], b[r]), rk) for r in range(n)]
+    want_rot = [o.add(b[r], o.apply_galois(a[r], e1, gk)) for r in range(n)]
+    try:
+        for lat in (0, 8):
+            g.set_latency_max(lat)
+            out = g.alloc(n * 2 * L * N)
+            g.multiply_relin(L, n, da, db, pw, out)
+            got = out.download((n, 2, L, N))
+            for r in range(n):
+                assert np.array_equal(got[r], want_rl[r]), (lat, r)
+            if L >= 2:
+                out2 = g.alloc(n * 2 * (L - 1) * N)
+                g.multiply_relin(L, n, da, db, pw, out2, rescale=True)
+                got = out2.download((n, 2, L - 1, N))
+                for r in range(n):
+                    assert np.array_equal(got[r], o.rescale(want_rl[r])), (lat, r)
+            g.rotate_add(L, n, da, 1, db, out)
+            got = out.download((n, 2, L, N))
+            for r in range(n):
+                assert np.array_equal(got[r], want_rot[r]), (lat, r)
+    finally:
+        g.set_latency_max(4)
+
+
 def test_pipeline_regression_fixture_gpu(be, oracle):
     """The HIP path reproduces tests/golden/pipeline_sha256.json (checksums of the pipeline outputs on seeded inputs, generated by
     tests/golden/make_pipeline_vectors.py): the committed fixture both the oracle (CPU suite) and the device are held to."""
@@ -778,6 +817,11 @@ def test_exact_model_big_fixture_gpu(be, name):
         g.relinearize(L, 1, c3, out)
         tem.check(f, "multiply_relin", out.download((2, L, N)))
         out2 = g.alloc(2 * (L - 1) * N)
+        g.multiply_relin(L, 1, da, db, pw, out2, rescale=True)   # batch 1: the latency shape (digit-split k_k3 + combine, unfused floor steps)
+        tem.check(f, "multiply_relin_rescale", out2.download((2, L - 1, N)))
+        g.set_latency_max(0)                                       # from here on the throughput shape: the headline's fused kernels
+        g.multiply_relin(L, 1, da, db, pw, out)
+        tem.check(f, "multiply_relin", out.download((2, L, N)))
         g.multiply_relin(L, 1, da, db, pw, out2, rescale=True)
         tem.check(f, "multiply_relin_rescale", out2.download((2, L - 1, N)))
         # the same op inside a batch that spans chunks and both streams: 5 copies of the pair, chunk 2
@@ -791,8 +835,10 @@ def test_exact_model_big_fixture_gpu(be, name):
     if "rotate_1" in exp:
         g.set_galois_key(d["g1"], d["gk1"])
         out = g.alloc(2 * L * N)
-        g.apply_galois(L, 1, da, d["g1"], out)
-        tem.check(f, "rotate_1", out.download((2, L, N)))
+        for lat in (0, 4):  # throughput shape, latency shape
+            g.set_latency_max(lat)
+            g.apply_galois(L, 1, da, d["g1"], out)
+            tem.check(f, "rotate_1", out.download((2, L, N)))
     g.close()
 
 
