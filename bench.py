@@ -556,12 +556,14 @@ def main():
         # cache, so the bytes that must cross HBM are fewer: operands read once per batch, results written once
         comp_op = wl.compulsory_bytes_per_op(global_b0, W.b1)
         tref = None
-        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-        if args.config == "mul_relin_rescale" and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            tref = {"file": "profiles/r02_hbm_traffic.json", "hbm_bytes_per_op": tj.get("hbm_bytes_per_op"),
-                    "note": "PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate runs) of an earlier invocation of this command (tools/profile_round.sh): "
-                            "not measured in this run"}
+        for tname in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):  # the newest committed PMC figure of this command
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if args.config == "mul_relin_rescale" and os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                tref = {"file": "profiles/" + tname, "hbm_bytes_per_op": tj.get("hbm_bytes_per_op"),
+                        "note": "PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate runs) of an earlier invocation of this command (tools/profile_round.sh): "
+                                "not measured in this run"}
+                break
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5),
                 "traffic": None, "traffic_source": tref,
                 "algorithmic_bytes_per_op": round(bytes_op, 1),

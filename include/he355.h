@@ -202,7 +202,7 @@ int he355_probe_dominant_kernel(he355_ctx *ctx, float *total_ms, uint64_t *launc
 /* ---- tuning ---- */
 int he355_set_dual_stream(he355_ctx *ctx, int on); /* chunks alternate between two HIP streams (default 1; HE355_DUAL_STREAM=0); 0: per-kernel timings without overlap */
 /* Key switches over at most n ciphertexts take the latency shape (serial loops of the throughput kernels dealt to more blocks; HEBench's
- * Latency category is batch 1: src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:138-141).  Default 4 (HE355_LATENCY_MAX); 0: never.
+ * Latency category is batch 1: src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:138-141).  Default 8 (HE355_LATENCY_MAX); 0: never.
  * Results are bit-identical either way. */
 int he355_set_latency_max(he355_ctx *ctx, uint64_t n);
 int he355_set_chunk(he355_ctx *ctx, uint64_t ops_per_chunk); /* ops processed per kernel sequence, default 256 (scratch ~ 117 MiB/op at N=2^15, L=16) */

@@ -1299,7 +1299,7 @@ private:
     PrimeDev *d_primes_ = nullptr;
     u64 *lat_part_ = nullptr;      // partial sums of the digit-split K3 (latency shape)
     size_t lat_part_bytes_ = 0;
-    u64 lat_max_ = 4;              // largest batch that takes the latency shape (HE355_LATENCY_MAX; 0: never)
+    u64 lat_max_ = 8;              // largest batch that takes the latency shape (HE355_LATENCY_MAX; 0: never)
     FloorConst *d_floor_ = nullptr;
     std::vector<void *> owned_;
     u64 *d_relin_ = nullptr;

@@ -668,7 +668,7 @@ def test_latency_shape_equals_throughput_shape(pair, be, n):
             for r in range(n):
                 assert np.array_equal(got[r], want_rot[r]), (lat, r)
     finally:
-        g.set_latency_max(4)
+        g.set_latency_max(8)
 
 
 def test_pipeline_regression_fixture_gpu(be, oracle):

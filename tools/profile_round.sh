@@ -2,7 +2,7 @@
 # Collects the round's evidence on the GPU box: bench JSON, kernel-trace stats, PMC traffic passes.
 # usage: tools/profile_round.sh <tag>     (outputs under gpurun_out/<tag>_*)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py --steps 5 --warmup 1 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 B="python3 bench.py --steps 3 --warmup 1 --profile-mode"
@@ -15,3 +15,11 @@ python3 tools/pmc_summary.py gpurun_out/${TAG}_fetch > gpurun_out/${TAG}_pmc_fet
 python3 tools/pmc_summary.py gpurun_out/${TAG}_write > gpurun_out/${TAG}_pmc_write_per_kernel.csv
 python3 tools/pmc_summary.py gpurun_out/${TAG}_sq > gpurun_out/${TAG}_pmc_sq_per_kernel.csv
 cat gpurun_out/${TAG}_bench.json
+
+# the other key-switch configurations: kernel-trace summaries (per-kernel ms per step) and their bench lines
+for cfg in dot bfv_matmul mul_relin; do
+  python3 bench.py --config $cfg --steps 3 --warmup 1 > gpurun_out/${TAG}_bench_$cfg.json 2> gpurun_out/${TAG}_bench_$cfg.err
+  HE355_DUAL_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace_$cfg -- python3 bench.py --config $cfg --steps 2 --warmup 1 --profile-mode > gpurun_out/${TAG}_trace_$cfg.log 2>&1
+  python3 tools/kstats.py gpurun_out/${TAG}_trace_$cfg 3 > gpurun_out/${TAG}_kernels_$cfg.txt
+  cat gpurun_out/${TAG}_kernels_$cfg.txt
+done
