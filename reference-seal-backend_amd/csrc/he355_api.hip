@@ -197,7 +197,8 @@ public:
         (void)hipFree(scratch_);
         (void)hipFree(scratch2_);
         (void)hipFree(rot_tmp_);
-        (void)hipFree(lat_part_);
+        (void)hipFree(lat_part_[0]);
+        (void)hipFree(lat_part_[1]);
         (void)hipFree(bfv_scratch_);
         (void)hipFree(client_scratch_);
         for (auto &kv : d_gather_) (void)hipFree(kv.second);
@@ -395,7 +396,7 @@ public:
             // digits of a tile over kLatSplit single-wave blocks whose partial sums k_k3_combine adds (k_k3).
             launch_k2(env_, L, nc, B, nullptr, 0, kLatSplit);
             if (after_k2) HIPCHECK(hipEventRecord(after_k2, env_.stream));
-            u64 *part = latency_partials((size_t)kLatSplit * nc * 2 * (L + 1) * N);
+            u64 *part = latency_partials((size_t)kLatSplit * nc * 2 * (L + 1) * N, env_.stream == stream2_ ? 1 : 0);
             launch_k3(env_, L, nc, B, key, K3_ALL, nullptr, kLatSplit, part);
             launch_k3_combine(env_, L, nc, B, kLatSplit, part);
             launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e, nullptr, 0, 0, 0, 0, nullptr, 0, kLatSplit);
@@ -476,17 +477,17 @@ public:
     // latency shape of the key switch (key_switch_tail): batches of at most lat_max_ ciphertexts, CKKS pipeline
     static constexpr int kLatSplit = 4;
     bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
-    u64 *latency_partials(size_t elems)
+    u64 *latency_partials(size_t elems, int which) // one buffer per stream: chunks of the two streams are in flight together
     {
-        if (elems * 8 > lat_part_bytes_) {
+        if (elems * 8 > lat_part_bytes_[which]) {
             HIPCHECK(hipStreamSynchronize(stream_));
             HIPCHECK(hipStreamSynchronize(stream2_));
-            if (lat_part_) HIPCHECK(hipFree(lat_part_));
-            lat_part_ = nullptr; lat_part_bytes_ = 0;
-            HIPCHECK(hipMalloc(&lat_part_, elems * 8));
-            lat_part_bytes_ = elems * 8;
+            if (lat_part_[which]) HIPCHECK(hipFree(lat_part_[which]));
+            lat_part_[which] = nullptr; lat_part_bytes_[which] = 0;
+            HIPCHECK(hipMalloc(&lat_part_[which], elems * 8));
+            lat_part_bytes_[which] = elems * 8;
         }
-        return lat_part_;
+        return lat_part_[which];
     }
     void require_keyswitch() const
     {
@@ -1297,8 +1298,8 @@ private:
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     KernelEnv env_{};
     PrimeDev *d_primes_ = nullptr;
-    u64 *lat_part_ = nullptr;      // partial sums of the digit-split K3 (latency shape)
-    size_t lat_part_bytes_ = 0;
+    u64 *lat_part_[2] = {nullptr, nullptr}; // partial sums of the digit-split K3 (latency shape), one per stream
+    size_t lat_part_bytes_[2] = {0, 0};
     u64 lat_max_ = 8;              // largest batch that takes the latency shape (HE355_LATENCY_MAX; 0: never)
     FloorConst *d_floor_ = nullptr;
     std::vector<void *> owned_;

@@ -358,7 +358,7 @@ def test_cfg2_full_size_multiply(be, oracle):
 
 def test_cfg3_full_size_mul_relin_rescale(be, oracle):
     """configs[2] (the headline): CKKS multiply -> relinearize -> rescale, N=2^15, depth 16, batch 1024 x 1.
-    Three sampled results are checked bit-for-bit against the oracle; all 1024 are checked through a
+    32 sampled results (chunk boundaries included) are checked bit-for-bit against the oracle; all 1024 are checked through a
     size-independent property (batch position does not matter: a permuted batch gives permuted results)."""
     bits = be.chain_bits(16, 45)
     g = be.Context(be.SCHEME_CKKS, 32768, bit_sizes=bits, device=0)
@@ -379,14 +379,18 @@ def test_cfg3_full_size_mul_relin_rescale(be, oracle):
     b = db.download((1, 2, L, N))[0]
     stride_in, stride_out = 2 * L * N, 2 * (L - 1) * N
     import ctypes as C
-    for r in (0, 511, 1023):
-        a_r = np.empty(stride_in, dtype=np.uint64)
-        be._check(be.lib().he355_download(g.h, a_r.ctypes.data_as(C.c_void_p), C.c_void_p(da.ptr.value + r * stride_in * 8), a_r.nbytes))
-        got = np.empty(stride_out, dtype=np.uint64)
-        be._check(be.lib().he355_download(g.h, got.ctypes.data_as(C.c_void_p), C.c_void_p(out.ptr.value + r * stride_out * 8), got.nbytes))
-        a_r = a_r.reshape(2, L, N)
-        want = o.rescale(o.relinearize(o.multiply_ntt(a_r, b), rk))
-        assert np.array_equal(got.reshape(2, L - 1, N), want), r
+    # 32 results against the oracle (its multithreaded batch loop): the first and last rows, both sides of every chunk boundary
+    # (chunks of 256 alternate between the two streams) and a spread in between
+    rows = sorted({0, 1, 2, 63, 127, 128, 200, 254, 255, 256, 257, 300, 383, 384, 500, 510, 511, 512, 513, 600, 639, 640, 700, 766, 767, 768, 769,
+                   900, 1000, 1021, 1022, 1023})
+    a_s = np.empty((len(rows), 2, L, N), dtype=np.uint64)
+    got = np.empty((len(rows), 2, L - 1, N), dtype=np.uint64)
+    for k, r in enumerate(rows):
+        be._check(be.lib().he355_download(g.h, a_s[k].ctypes.data_as(C.c_void_p), C.c_void_p(da.ptr.value + r * stride_in * 8), a_s[k].nbytes))
+        be._check(be.lib().he355_download(g.h, got[k].ctypes.data_as(C.c_void_p), C.c_void_p(out.ptr.value + r * stride_out * 8), got[k].nbytes))
+    want = o.batch_outer(oracle.OP_MUL_RELIN_RESCALE, a_s, b[None], rk)
+    for k, r in enumerate(rows):
+        assert np.array_equal(got[k], want[k]), r
     # property over the whole batch: op r of a run that starts at value_index 512 equals op r+512 of the full run
     out_hi = g.alloc(512 * stride_out)
     g.multiply_relin(L, 512, da, db, be.Context.outer(512, 512, 0, 1), out_hi, rescale=True)
@@ -403,7 +407,7 @@ def test_cfg3_full_size_mul_relin_rescale(be, oracle):
 
 def test_cfg4_full_size_dot_product(be, oracle):
     """configs[3]: CKKS DotProduct, vector length 4096, N=2^15, L=16: multiply -> relinearize -> accumulateCKKS(4096)
-    = 1 + 12 key switches per result (seal_context.cpp:331-339).  Two results checked bit-for-bit against the oracle."""
+    = 1 + 12 key switches per result (seal_context.cpp:331-339).  All eight results checked bit-for-bit against the oracle."""
     bits = be.chain_bits(16, 45)
     g = be.Context(be.SCHEME_CKKS, 32768, bit_sizes=bits, device=0)
     o = oracle.Context(oracle.SCHEME_CKKS, 32768, bit_sizes=bits)
@@ -429,12 +433,14 @@ def test_cfg4_full_size_dot_product(be, oracle):
     g.accumulate(L, n, out, 4096, tmp)
     a, b = da.download((n, 2, L, N)), db.download((1, 2, L, N))[0]
     got = out.download((n, 2, L, N))
-    for r in (0, n - 1):
-        t = o.relinearize(o.multiply_ntt(a[r], b), rk)
-        for i in range(12):
-            e = o.galois_elt(1 << i)
-            t = o.add(t, o.apply_galois(t, e, gks[e]))
-        assert np.array_equal(got[r], t), r
+    want = o.batch_outer(oracle.OP_DOT, a, b[None], rk, gks, 4096)  # all 8 results, the oracle's own operate() loop
+    for r in range(n):
+        assert np.array_equal(got[r], want[r]), r
+    t = o.relinearize(o.multiply_ntt(a[0], b), rk)  # and the loop spelled out for one of them
+    for i in range(12):
+        e = o.galois_elt(1 << i)
+        t = o.add(t, o.apply_galois(t, e, gks[e]))
+    assert np.array_equal(got[0], t)
     g.close()
 
 
