@@ -392,14 +392,14 @@ public:
         if (latency_shape(nc)) {
             // Few ciphertexts (HEBench's Latency category is batch 1: ckks eltwise .cpp:138-141): the throughput shape would leave one
             // wave walking all digits of a tile and one lane walking all targets of a column while the chip idles.  Same kernels,
-            // unfused, with the serial loops dealt to more blocks: targets of a column over kLatSplit blocks (k_k2n, k_floor_colsn),
-            // digits of a tile over kLatSplit single-wave blocks whose partial sums k_k3_combine adds (k_k3).
-            launch_k2(env_, L, nc, B, nullptr, 0, kLatSplit);
+            // unfused, with the serial loops dealt to more blocks: targets of a column over kLatTargets blocks (k_k2n, k_floor_colsn),
+            // digits of a tile over kLatSplit (u64 engine: kLatSplitU64) single-wave blocks whose partial sums k_k3_combine adds (k_k3).
+            launch_k2(env_, L, nc, B, nullptr, 0, kLatTargets);
             if (after_k2) HIPCHECK(hipEventRecord(after_k2, env_.stream));
-            u64 *part = latency_partials((size_t)kLatSplit * nc * 2 * (L + 1) * N, env_.stream == stream2_ ? 1 : 0);
-            launch_k3(env_, L, nc, B, key, K3_ALL, nullptr, kLatSplit, part);
-            launch_k3_combine(env_, L, nc, B, kLatSplit, part);
-            launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e, nullptr, 0, 0, 0, 0, nullptr, 0, kLatSplit);
+            u64 *part = latency_partials((size_t)kLatSplitU64 * nc * 2 * (L + 1) * N, env_.stream == stream2_ ? 1 : 0);
+            launch_k3(env_, L, nc, B, key, K3_ALL, nullptr, kLatSplit, part, kLatSplitU64);
+            launch_k3_combine(env_, L, nc, B, kLatSplit, part, kLatSplitU64);
+            launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e, nullptr, 0, 0, 0, 0, nullptr, 0, kLatTargets);
             return key_switch_floor_rows(env_, L, nc, S, B, with_tail);
         }
         launch_k2(env_, L, nc, B);
@@ -464,7 +464,7 @@ public:
     void rescale_tail(const KernelEnv &env_, int L, int size, u64 nc, const Scratch &S, const u64 *src, u64 src_op_stride, u64 *out)
     {
         const size_t N = P.N, LN = (size_t)L * N, L1N = (size_t)(L - 1) * N;
-        launch_floor_cols(env_, L - 1, L - 1, nc * size, S.rlr, S.f, nullptr, 0, 0, 0, 0, nullptr, 0, latency_shape(nc) ? kLatSplit : 1);
+        launch_floor_cols(env_, L - 1, L - 1, nc * size, S.rlr, S.f, nullptr, 0, 0, 0, 0, nullptr, 0, latency_shape(nc) ? kLatTargets : 1);
         FloorRowsArgs fr;
         fr.src_prime = L - 1; fr.n_tgt = L - 1; fr.n_src = size;
         fr.cols = S.f;
@@ -475,7 +475,9 @@ public:
         launch_floor_rows(env_, nc, fr);
     }
     // latency shape of the key switch (key_switch_tail): batches of at most lat_max_ ciphertexts, CKKS pipeline
-    static constexpr int kLatSplit = 4;
+    // digit groups per fp64-engine tile (480 tiles x 4 single-wave blocks fill the chip once at batch 1), per u64-engine tile (64 tiles, rows
+    // 2.5x as long), blocks per column for the targets of k_k2n / k_floor_colsn
+    static constexpr int kLatSplit = 4, kLatSplitU64 = 8, kLatTargets = 8;
     bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
     u64 *latency_partials(size_t elems, int which) // one buffer per stream: chunks of the two streams are in flight together
     {

@@ -97,8 +97,8 @@ bool k3_can_fuse(const KernelEnv &env);
 // n_split > 1 (latency shape, unfused only): the digits of every tile are cut into n_split groups, one single-wave block per (tile, op,
 // group), canonical partial sums -> split_part [n_split][n_ops * 2][L + 1][N]; launch_k3_combine then leaves t / tpr as the unsplit launch
 void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part = K3_ALL, const K3Fuse *fuse = nullptr,
-               int n_split = 1, u64 *split_part = nullptr);
-void launch_k3_combine(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, int n_split, const u64 *split_part);
+               int n_split = 1, u64 *split_part = nullptr, int n_split_u64 = 0); // n_split_u64: groups of the u64-engine tiles (0: as n_split)
+void launch_k3_combine(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, int n_split, const u64 *split_part, int n_split_u64 = 0);
 // floor step, column half: src [n_ops*n_src][N] raw of prime s -> r = (x + floor(s/2)) mod s ->
 // (r mod q_i - floor(s/2) mod q_i) for i < n_tgt -> forward column pass -> dst [n_ops*n_src][n_tgt][N]
 // addin (optional): the column-passed correction of an earlier floor step [n_polys][addin_ntgt][N], folded in scaled by

@@ -1772,7 +1772,7 @@ struct K3CombineArgs {
     const u64 *part;
     u64 *t, *tpr;
     u64 n_ops;
-    int n_split, L, K, logn1, ckks;
+    int n_split, n_split_u64, L, K, logn1, ckks; // digit groups of the fp64-engine / u64-engine tiles
 };
 __global__ void __launch_bounds__(kBlock) k_k3_combine(K3CombineArgs A, const PrimeDev *primes)
 {
@@ -1793,7 +1793,8 @@ __global__ void __launch_bounds__(kBlock) k_k3_combine(K3CombineArgs A, const Pr
     const u64 rowoff = (u64)a_row << kRowLog, q = P.q;
     u64 v[kRowE];
     load_rowC(A.part + (ok * (A.L + 1) + tt) * N + rowoff, lane, v);
-    for (int g = 1; g < A.n_split; ++g) {
+    const int groups = P.f64 ? A.n_split : A.n_split_u64;
+    for (int g = 1; g < groups; ++g) {
         u64 w[kRowE];
         load_rowC(A.part + (((u64)g * A.n_ops * 2 + ok) * (A.L + 1) + tt) * N + rowoff, lane, w);
 #pragma unroll
@@ -2898,8 +2899,10 @@ bool k3_can_fuse(const KernelEnv &env)
     return !off && env.scheme == 2 && env.K >= 2 && sf == 18 && su == 18 && stage_env != 0; // the fused instantiations exist for the default shapes
 }
 
-void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part, const K3Fuse *fuse, int n_split, u64 *split_part)
+void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part, const K3Fuse *fuse, int n_split, u64 *split_part,
+               int n_split_u64)
 {
+    if (n_split_u64 <= 0) n_split_u64 = n_split;
     if (n_split > 1 && (fuse || !split_part)) throw std::runtime_error("digit-split K3: unfused launches with a partial-sum buffer only");
     const unsigned char *prime_f64 = env.prime_f64;
     if (!n_ops) return;
@@ -2912,7 +2915,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.cols2 = fuse ? fuse->cols2 : nullptr; A.out2 = fuse ? fuse->out : nullptr;
         if (fuse && fuse->cols2 && fuse->tt_hi > L - 1) throw std::runtime_error("fused rescale: only primes below the one divided out");
         A.fc = env.floor_consts;
-        A.n_split = n_split > 1 ? n_split : 1; A.part = split_part;
+        A.n_split = n_split > 1 ? (pass == 0 ? n_split : n_split_u64) : 1; A.part = split_part;
         A.n_tt = 0;
         A.n_q = 0;
         for (int t = 0; t < env.K; ++t) A.n_q += prime_f64[t] == 0;
@@ -2988,11 +2991,12 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     // (the inverse row pass of the special-prime sums, and of every prime's sums for BFV, happened in the kernel's epilogue)
 }
 
-void launch_k3_combine(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, int n_split, const u64 *split_part)
+void launch_k3_combine(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, int n_split, const u64 *split_part, int n_split_u64)
 {
+    if (n_split_u64 <= 0) n_split_u64 = n_split;
     if (!n_ops) return;
     K3CombineArgs A;
-    A.part = split_part; A.t = buf.t; A.tpr = buf.tpr; A.n_ops = n_ops; A.n_split = n_split; A.L = L; A.K = env.K; A.logn1 = env.logn1;
+    A.part = split_part; A.t = buf.t; A.tpr = buf.tpr; A.n_ops = n_ops; A.n_split = n_split; A.n_split_u64 = n_split_u64; A.L = L; A.K = env.K; A.logn1 = env.logn1;
     A.ckks = env.scheme == 2;
     const u64 jobs = (n_ops * 2 * (u64)(L + 1)) << env.logn1;
     hipLaunchKernelGGL(k_k3_combine, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes);
