@@ -135,6 +135,12 @@ constexpr bool kKeyShare = HE355_KSHARE != 0 && kXlT1 && kXlT2;
 #define HE355_KEY_EARLY 1
 #endif
 constexpr bool kKeyEarly = HE355_KEY_EARLY != 0;
+// HE355_LAZY_U64: k_k3 transforms the digit rows of the u64-engine key primes over the wide lazy range (one correction per row instead
+// of one per butterfly); key primes are below 2^60 (Params), the key multiply-accumulate takes any 64-bit lazy value
+#ifndef HE355_LAZY_U64
+#define HE355_LAZY_U64 1
+#endif
+constexpr bool kLazyU64 = HE355_LAZY_U64 != 0;
 #ifndef HE355_MAC_G
 #define HE355_MAC_G 4
 #endif
@@ -273,17 +279,19 @@ struct NoHook {
 // that it needs right after the transform (they then land during the exchange and phase C).
 // `wa_pre`: phase A's 15 twiddles, already gathered by the caller (they are the same for every lane, so a caller that
 // transforms many rows of one (prime, row) tile keeps them in scalar registers); null: gather them here.
-template <int U, class Ar, class TW, class Hook = NoHook>
+// LAZY (u64 engine, q < 2^60, rows entering below 4q): the wide lazy range of ntt_core.h's row_fwd_*_lazy -- results below 12q, for
+// consumers that take any 64-bit lazy value (k_k3's key multiply-accumulate); ignored by the fp64 engine.
+template <int U, class Ar, class TW, class Hook = NoHook, bool LAZY = false>
 __device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int lane, u64 (*lds_w)[kLdsRow], typename Ar::T (*x)[kRowE],
                                                 Hook before_c = Hook(), const Tw16 *wa_pre = nullptr)
 {
     typedef typename Ar::T T;
     if (wa_pre) {
-        row_fwd_A<U>(ar, x, wa_pre);
+        if constexpr (LAZY) row_fwd_A_lazy<U>(ar, x, wa_pre); else row_fwd_A<U>(ar, x, wa_pre);
     } else {
         Tw16 wa[kTwA];
         gather_A(tw, wa);
-        row_fwd_A<U>(ar, x, wa);
+        if constexpr (LAZY) row_fwd_A_lazy<U>(ar, x, wa); else row_fwd_A<U>(ar, x, wa);
     }
     Tw16 wb[kTwB];
     gather_B(tw, lane, wb);
@@ -300,7 +308,7 @@ __device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int 
         for (int u = 0; u < U; ++u) lds_load_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
         HE_WAVE_SYNC();
     }
-    row_fwd_B<U>(ar, x, wb);
+    if constexpr (LAZY) row_fwd_B_lazy<U>(ar, x, wb); else row_fwd_B<U>(ar, x, wb);
     Tw16 wc[kTwC];
     gather_C(tw, lane, wc);
     before_c();
@@ -316,7 +324,7 @@ __device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int 
         for (int u = 0; u < U; ++u) lds_load_C(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
         HE_WAVE_SYNC();
     }
-    row_fwd_C<U>(ar, x, wc);
+    if constexpr (LAZY) row_fwd_C_lazy<U>(ar, x, wc); else row_fwd_C<U>(ar, x, wc);
 }
 template <class Ar, class TW>
 __device__ __forceinline__ void wave_rows_fwd(const Ar &ar, const TW &tw, int lane, u64 *lds_w, typename Ar::T x[kRowE])
@@ -1651,7 +1659,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                         }
                     }
                 } else {
-                    wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
+                    wave_rows_fwd_n<1, Ar, decltype(twr), NoHook, kLazyU64>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
                     if constexpr (KSHARE) mac_digit_lds(x[0], i & 1);
                     else mac_digit(x[0], digit(i));
                 }
@@ -1725,7 +1733,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
 #pragma unroll
                     for (int r = 0; r < kRowE; ++r) x[U - 1][r] = 0;
                 }
-                wave_rows_fwd_n<U>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
+                wave_rows_fwd_n<U, Ar, decltype(twr), NoHook, kLazyU64>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
                 if constexpr (KSHARE) {
                     mac_digit_lds(x[0], i & 1);
                 } else {

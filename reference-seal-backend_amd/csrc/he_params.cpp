@@ -202,7 +202,8 @@ void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t)
         const u64 q = chain[i];
         for (size_t k = 0; k < i; ++k)
             if (chain[k] == q) throw std::invalid_argument("coefficient moduli must be distinct");
-        if (q >> 61 || !is_prime(q)) throw std::invalid_argument("coefficient modulus must be a prime below 2^61");
+        // SEAL's user moduli are at most 60 bits (SEAL_USER_MOD_BIT_COUNT_MAX); the u64 engine's wide lazy row pass needs 16 q <= 2^64
+        if (q >> 60 || !is_prime(q)) throw std::invalid_argument("coefficient modulus must be a prime below 2^60");
         primes[i] = make_prime_tables(q, N, logn, !force_u64 && (q >> 47) == 0);
     }
     if (scheme == kSchemeBFV) {

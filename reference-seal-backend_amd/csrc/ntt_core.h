@@ -219,7 +219,7 @@ template <class TW> HE_HD void gather_C(const TW &tw, int lane, Tw16 w[kTwC])
 #define HE355_BFLY_GROUP 2
 #endif
 constexpr int kBflyGroup = HE355_BFLY_GROUP;
-template <int U, int BIT, class Ar, class WIdx> HE_HD void row_fwd_stage(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 *w, WIdx widx)
+template <int U, int BIT, bool LAZY, class Ar, class WIdx> HE_HD void row_fwd_stage_x(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 *w, WIdx widx)
 {
     constexpr int kTotal = 8 * U, G = kBflyGroup < kTotal ? kBflyGroup : kTotal;
     static_assert(kTotal % G == 0, "group size must divide the butterflies of a stage");
@@ -233,7 +233,8 @@ template <int U, int BIT, class Ar, class WIdx> HE_HD void row_fwd_stage(const A
             const int r = ((b >> BIT) << (BIT + 1)) | (b & ((1 << BIT) - 1));    // b with a 0 inserted at BIT
             X[k] = x[u][r]; Y[k] = x[u][r | (1 << BIT)]; W[k] = w[widx(r)];
         }
-        ar.template bfly_fwd_g<G>(X, Y, W);
+        if constexpr (LAZY) ar.template bfly_fwd_lazy_g<G>(X, Y, W);
+        else ar.template bfly_fwd_g<G>(X, Y, W);
 #pragma unroll
         for (int k = 0; k < G; ++k) {
             const int b = (g0 + k) / U, u = (g0 + k) % U;
@@ -241,6 +242,10 @@ template <int U, int BIT, class Ar, class WIdx> HE_HD void row_fwd_stage(const A
             x[u][r] = X[k]; x[u][r | (1 << BIT)] = Y[k];
         }
     }
+}
+template <int U, int BIT, class Ar, class WIdx> HE_HD void row_fwd_stage(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 *w, WIdx widx)
+{
+    row_fwd_stage_x<U, BIT, false>(ar, x, w, widx);
 }
 template <int U, class Ar> HE_HD void row_fwd_A(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwA])
 {
@@ -260,6 +265,31 @@ template <int U, class Ar> HE_HD void row_fwd_C(const Ar &ar, typename Ar::T (*x
 {
     row_fwd_stage<U, 1>(ar, x, w, [](int r) { return r >> 2; });                                  // stage 8: pairs (r, r|2), twiddle of chunk c
     row_fwd_stage<U, 0>(ar, x, w, [](int r) { return 4 + 2 * (r >> 2) + ((r >> 1) & 1); });      // stage 9: pairs (r, r|1), twiddle (c, h = bit 1 of r)
+}
+// The same three phases over the wide lazy range of the u64 engine (ArU64::bfly_fwd_lazy; q < 2^60): in below 4q, A to 12q, B runs two
+// stages (16q), comes back under 4q, runs two more (8q), C to 12q.  The fp64 engine's instantiations are the plain phases.
+template <int U, class Ar> HE_HD void row_fwd_A_lazy(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwA])
+{
+    row_fwd_stage_x<U, 3, true>(ar, x, w, [](int r) { return 0 + (r >> 4); });
+    row_fwd_stage_x<U, 2, true>(ar, x, w, [](int r) { return 1 + (r >> 3); });
+    row_fwd_stage_x<U, 1, true>(ar, x, w, [](int r) { return 3 + (r >> 2); });
+    row_fwd_stage_x<U, 0, true>(ar, x, w, [](int r) { return 7 + (r >> 1); });
+}
+template <int U, class Ar> HE_HD void row_fwd_B_lazy(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwB])
+{
+    row_fwd_stage_x<U, 3, true>(ar, x, w, [](int r) { return 0 + (r >> 4); });
+    row_fwd_stage_x<U, 2, true>(ar, x, w, [](int r) { return 1 + (r >> 3); });
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < kRowE; ++r) x[u][r] = ar.reduce16_to_4q(x[u][r]);
+    row_fwd_stage_x<U, 1, true>(ar, x, w, [](int r) { return 3 + (r >> 2); });
+    row_fwd_stage_x<U, 0, true>(ar, x, w, [](int r) { return 7 + (r >> 1); });
+}
+template <int U, class Ar> HE_HD void row_fwd_C_lazy(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwC])
+{
+    row_fwd_stage_x<U, 1, true>(ar, x, w, [](int r) { return r >> 2; });
+    row_fwd_stage_x<U, 0, true>(ar, x, w, [](int r) { return 4 + 2 * (r >> 2) + ((r >> 1) & 1); });
 }
 template <class Ar, class TW> HE_HD void row_fwd_A(const Ar &ar, typename Ar::T x[kRowE], const TW &tw)
 {

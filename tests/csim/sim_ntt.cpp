@@ -8,10 +8,14 @@
 #include <type_traits>
 #include <vector>
 
+#define HE355_LANE_SIM 1 // the wide-lazy u64 butterflies report sums that leave 64 bits (modarith.h)
 #include "../../reference-seal-backend_amd/csrc/he_params.h"
 #include "../../reference-seal-backend_amd/csrc/ntt_core.h"
 
 using namespace he355;
+namespace he355 {
+int he355_sim_overflow = 0;
+}
 
 static double g_maxmag = 0; // largest |value| seen by the fp64 engine at phase boundaries
 
@@ -147,6 +151,33 @@ template <class Ar> static void rows_fwd(const Ar &ar, const PrimeTables &pt, in
         static T saved[64][kRowE];
         std::memcpy(saved, regs, sizeof(saved));
         std::vector<u64> ref(kRowN);
+        // the wide lazy range of the u64 engine (k_k3's digit rows; key primes are below 2^60): same residues, no sum leaves 64 bits
+        std::vector<u64> lazy_ref;
+        if constexpr (std::is_same<T, u64>::value) {
+            if (!(pt.q >> 60)) {
+                static u64 lz[64][1][kRowE];
+                std::vector<u64> ldl(kLdsRow);
+                he355_sim_overflow = 0;
+                for (int lane = 0; lane < 64; ++lane) {
+                    for (int r = 0; r < kRowE; ++r) lz[lane][0][r] = in_raw ? ar.from_raw(src[elemA(lane, r)]) : ar.from_canon(src[elemA(lane, r)]);
+                    Tw16 w[kTwA]; gather_A(twt, w); row_fwd_A_lazy<1>(ar, lz[lane], w);
+                }
+                for (int lane = 0; lane < 64; ++lane) lds_store_A(ldl.data(), lane, lz[lane][0]);
+                for (int lane = 0; lane < 64; ++lane) lds_load_B(ldl.data(), lane, lz[lane][0]);
+                for (int lane = 0; lane < 64; ++lane) { Tw16 w[kTwB]; gather_B(twt, lane, w); row_fwd_B_lazy<1>(ar, lz[lane], w); }
+                for (int lane = 0; lane < 64; ++lane) lds_store_B(ldl.data(), lane, lz[lane][0]);
+                for (int lane = 0; lane < 64; ++lane) lds_load_C(ldl.data(), lane, lz[lane][0]);
+                lazy_ref.resize(kRowN);
+                for (int lane = 0; lane < 64; ++lane) {
+                    Tw16 w[kTwC]; gather_C(twt, lane, w); row_fwd_C_lazy<1>(ar, lz[lane], w);
+                    for (int r = 0; r < kRowE; ++r) {
+                        if (lz[lane][0][r] >= 12 * pt.q) throw std::runtime_error("wide-lazy row pass: a result is not below 12 q");
+                        lazy_ref[elemC(lane, r)] = ar.to_canon16(lz[lane][0][r]);
+                    }
+                }
+                if (he355_sim_overflow) throw std::runtime_error("wide-lazy row pass: a sum left 64 bits");
+            }
+        }
         for (int mode = 0; mode < 4; ++mode) {
             std::memcpy(regs, saved, sizeof(saved));
             xchg(0, 1, (mode & 2) != 0, lds, regs);
@@ -160,6 +191,7 @@ template <class Ar> static void rows_fwd(const Ar &ar, const PrimeTables &pt, in
                     const u64 v = ar.to_canon(x[r]);
                     if (mode == 0) ref[elemC(lane, r)] = v;
                     else if (ref[elemC(lane, r)] != v) throw std::runtime_error("cross-lane transposes differ from the LDS exchanges (forward)");
+                    if (mode == 0 && !lazy_ref.empty() && lazy_ref[elemC(lane, r)] != v) throw std::runtime_error("wide-lazy row pass differs from the Harvey row pass");
                     out[(size_t)a * kRowN + elemC(lane, r)] = v;
                 }
                 if (pair && mode == 0) // the U=2 path's first row must agree with the single-row path
