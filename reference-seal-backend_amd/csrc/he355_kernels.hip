@@ -976,6 +976,16 @@ template <int N1> __device__ __forceinline__ void store_word_rows(__amdgpu_buffe
 #define HE355_K2_WIDE 1
 #endif
 constexpr bool kK2Wide = HE355_K2_WIDE != 0;
+// HE355_K2_STREAM: the fast path of k_k2n stores a row (dword + half-word per lane) as soon as the last stage has produced it, instead of
+// collecting the 32 rows in the LDS tile and storing them in one burst after the pass
+#ifndef HE355_K2_STREAM
+#define HE355_K2_STREAM 0
+#endif
+constexpr bool kK2Stream = HE355_K2_STREAM != 0;
+#ifndef HE355_K2_LIFTWIDE
+#define HE355_K2_LIFTWIDE 1
+#endif
+constexpr bool kK2LiftWide = HE355_K2_LIFTWIDE != 0;
 typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
 template <int N1>
 __device__ __forceinline__ void store_pattern_rows_wide(__amdgpu_buffer_rsrc_t dst, unsigned char *tile, int lane, u32 lane_lo, u32 lane_hi, const double x[N1])
@@ -1045,9 +1055,9 @@ __device__ __forceinline__ d16_t load_colw16(cprime_t cp, int t, int first) { re
 // before the current target's last stage and its stores, the 16 entries of stage 4 at the top of the target, behind stages 0..3 --
 // as the compiler places them (one s_load + s_waitcnt lgkmcnt(0) per stage) each target waited five scalar-load latencies.
 // DIRECT: the column enters as it is; else it is lifted first (re-centred, or reduced with integers from a 60-bit digit: DF false).
-template <int LOGN1, bool DF, bool DIRECT, class Store>
+template <int LOGN1, bool DF, bool DIRECT, class Store, class StoreRow>
 __device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev *primes, int j, u64 op, u64 mask,
-                                                 const typename std::conditional<DF, double, u64>::type (&c)[1 << LOGN1], Store store_rows)
+                                                 const typename std::conditional<DF, double, u64>::type (&c)[1 << LOGN1], Store store_rows, StoreRow store_row)
 {
     constexpr int N1 = 1 << LOGN1;
     constexpr u64 N = (u64)N1 << kRowLog;
@@ -1076,10 +1086,15 @@ __device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev
             if constexpr (DF) {
 #pragma unroll
                 for (int a = 0; a < N1; ++a) x[a] = ar.renorm(c[a]);
-            } else { // a 60-bit digit: hi * (2^32 mod q_t) + lo, one exact fp64 product (lift_wide) instead of a 64-bit Barrett reduction
+            } else if (kK2LiftWide) { // a 60-bit digit: hi * (2^32 mod q_t) + lo, one exact fp64 product (lift_wide) instead of a 64-bit Barrett reduction
                 const double pow32 = cp[t].pow32;
 #pragma unroll
                 for (int a = 0; a < N1; ++a) x[a] = lift_wide(ar, c[a], pow32);
+            } else {
+                ModU64 mt;
+                mt.q = cp[t].q; mt.cr0 = cp[t].cr0; mt.cr1 = cp[t].cr1;
+#pragma unroll
+                for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(barrett64(c[a], mt));
             }
         }
 #pragma unroll
@@ -1115,6 +1130,9 @@ __device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev
         const d16_t wa_n = load_colw16(cp, tn, 0);
         const double qd_n = cp[tn].qd, qinv_n = cp[tn].qinv;
         __builtin_amdgcn_sched_barrier(0);
+        const int tt = t == A.K - 1 ? A.L : t;
+        const __amdgpu_buffer_rsrc_t dst = poly_rsrc(A.d + ((op * (A.L + 1) + ((A.ablate & 1) ? 0 : tt)) * A.L + j) * N, (u32)N1 * kSlotBytes);
+        constexpr bool kStream = kK2Stream && LOGN1 == 5; // rows leave as the last stage finishes them, not as one burst after it
         if constexpr (LOGN1 == 5) {
             constexpr int G = kK2G;
 #pragma unroll
@@ -1127,13 +1145,15 @@ __device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev
                 for (int k = 0; k < G; ++k) {
                     const double xb = x[a0 + 2 * k] + kPackBias;
                     x[a0 + 2 * k] = xb + tw[k]; x[a0 + 2 * k + 1] = xb - tw[k];
+                    if constexpr (kStream) { store_row(dst, a0 + 2 * k, x[a0 + 2 * k]); store_row(dst, a0 + 2 * k + 1, x[a0 + 2 * k + 1]); }
                 }
             }
         }
         if constexpr (LOGN1 == 0) x[0] = (DIRECT ? (double)c[0] : x[0]) + kPackBias;
-        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the prefetch had the last stage to land; the tile's LDS traffic then waits by count
-        const int tt = t == A.K - 1 ? A.L : t;
-        store_rows(poly_rsrc(A.d + ((op * (A.L + 1) + ((A.ablate & 1) ? 0 : tt)) * A.L + j) * N, (u32)N1 * kSlotBytes), x);
+        if constexpr (!kStream) {
+            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the prefetch had the last stage to land; the tile's LDS traffic then waits by count
+            store_rows(dst, x);
+        }
         if (!m) break;
         t = tn; wa = wa_n; qd = qd_n; qinv = qinv_n;
     }
@@ -1172,8 +1192,14 @@ __device__ __forceinline__ void k2n_targets_f64(const K2Args &A, const PrimeDev 
     const u64 f64_targets = A.f64_mask & level;
     u64 direct = 0, lift = 0;
     if constexpr (kPackD) { direct = cp[j].k2_direct & f64_targets; lift = cp[j].k2_lift & f64_targets; }
-    if constexpr (DF) k2n_fast_targets<LOGN1, DF, true>(A, primes, j, op, direct, c, store_rows);
-    k2n_fast_targets<LOGN1, DF, false>(A, primes, j, op, DF ? lift : (lift | direct), c, store_rows);
+    auto store_row = [&](__amdgpu_buffer_rsrc_t dst, int a, double v) { // one pattern row of this lane's column
+        union { u64 u; double d; } cv;
+        cv.d = v;
+        __builtin_amdgcn_raw_buffer_store_b32((u32)cv.u, dst, (int)off4, a * (int)kSlotBytes, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(cv.u >> 32), dst, (int)off2h, a * (int)kSlotBytes, 0);
+    };
+    if constexpr (DF) k2n_fast_targets<LOGN1, DF, true>(A, primes, j, op, direct, c, store_rows, store_row);
+    k2n_fast_targets<LOGN1, DF, false>(A, primes, j, op, DF ? lift : (lift | direct), c, store_rows, store_row);
     // the general path: any lift, results re-centred before they are packed (wider fp64-engine primes), or 64-bit rows (HE355_PACK_D=0)
     for (u64 m = f64_targets & ~(direct | lift); m; m &= m - 1) {
         const int t = __builtin_ctzll(m), tt = t == A.K - 1 ? A.L : t;
@@ -1235,7 +1261,7 @@ __device__ __forceinline__ void k2n_targets_u64(const K2Args &A, const PrimeDev 
 }
 
 #ifndef K2N_WAVES
-#define K2N_WAVES 3
+#define K2N_WAVES 2
 #endif
 template <int LOGN1>
 __global__ void __launch_bounds__(kBlock, K2N_WAVES) k_k2n(K2Args A, const PrimeDev *primes)
@@ -1394,14 +1420,14 @@ stage_row_twiddles(const PrimeDev &P, const Ar &ar, u32 rowbase, unsigned char *
         double *twl = reinterpret_cast<double *>(twl_raw);
 #pragma unroll
         for (int k = 0; k < kIter; ++k)
-            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[threadIdx.x + k * BLOCK] = ArF64::tw_w(tmp[k]);
+            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[tw_row_slot(threadIdx.x + k * BLOCK)] = ArF64::tw_w(tmp[k]);
         twr.t = twl;
         twr.qinv = ar.qinv;
     } else {
         Tw16 *twl = reinterpret_cast<Tw16 *>(twl_raw);
 #pragma unroll
         for (int k = 0; k < kIter; ++k)
-            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[threadIdx.x + k * BLOCK] = tmp[k];
+            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[tw_row_slot(threadIdx.x + k * BLOCK)] = tmp[k];
         twr.t = twl;
     }
     return twr;
@@ -1457,7 +1483,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
     // interleaved digits -- the earlier shape, kept selectable.)
     __shared__ u64 lds[kWaves][U][kLdsRow];
     __shared__ __attribute__((aligned(16))) u64 stage[STAGE ? kWaves : 1][STAGE ? U : 1][STAGE ? kRowN : 2];
-    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTwSlots * 8 : kRowTwSlots * 16];
     constexpr int kKeyArrays = Ar::kKeyQuotient ? 4 : 2; // key rows of polynomial 0, 1 (+ their quotient rows)
     __shared__ __attribute__((aligned(16))) u64 keybuf[KSHARE ? 2 : 1][KSHARE ? kKeyArrays : 1][KSHARE ? kRowN : 2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2158,7 +2184,7 @@ __global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const Pri
     typedef typename Ar::T T;
     constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
     __shared__ u64 lds[kWaves][kLdsRow];
-    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTwSlots * 8 : kRowTwSlots * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 n1 = 1u << A.logn1;
     const u64 N = (u64)n1 << kRowLog;

@@ -150,9 +150,18 @@ template <class P> HE_HD TwTable<P> tw_table(P base, u32 rowbase)
     return t;
 }
 constexpr int kRowTw = kRowN; // 1023 entries used
+// Where row-local entry i lives in the copy.  The lanes of a wave read the later stages' entries at power-of-two strides (stage 8: four
+// consecutive entries per quad of lanes, quads 16 entries apart; stage 9: eight per quad, 32 apart), which in a dense table is one set
+// of LDS banks for every quad.  HE355_TW_PAD=1 (measured: k_k3<ArF64> 23.67 -> 23.92 ms, not adopted) inserts 4 slots after every 16 entries: quads of a 16-lane group then start 160 / 320 bytes
+// apart and walk the banks (fp64 copy: 8-byte slots, 10 KiB instead of 8; u64 copy: 16-byte slots, 20 KiB instead of 16).
+#ifndef HE355_TW_PAD
+#define HE355_TW_PAD 0
+#endif
+HE_HD u32 tw_row_slot(u32 i) { return HE355_TW_PAD ? i + ((i >> 4) << 2) : i; }
+constexpr int kRowTwSlots = HE355_TW_PAD ? kRowTw + (kRowTw >> 4) * 4 : kRowTw;
 struct TwRow {
     const Tw16 *t;
-    HE_HD Tw16 get(int s, u32 g) const { return t[(1u << s) - 1u + g]; }
+    HE_HD Tw16 get(int s, u32 g) const { return t[tw_row_slot((1u << s) - 1u + g)]; }
 };
 // fp64 engine: the row-local copy keeps only w (8 bytes); its butterflies take the quotient estimate from
 // h * (1/q), so nothing else is needed.
@@ -163,7 +172,7 @@ struct TwRowF64 {
     {
         Tw16 r;
         union { u64 u; double d; } c;
-        c.d = t[(1u << s) - 1u + g];
+        c.d = t[tw_row_slot((1u << s) - 1u + g)];
         r.a = c.u;
         r.b = 0; // the fp64 butterflies do not use the second word
         return r;

@@ -115,11 +115,11 @@ template <class Ar> static void rows_fwd(const Ar &ar, const PrimeTables &pt, in
         const u32 rowbase = (u32)(n1 + a);
         const u64 *src = in + (size_t)a * kRowN;
         // the row-local twiddle copy (what K3 stages in LDS) must be equivalent to the table
-        std::vector<Tw16> rowtw(kRowTw);
-        for (u32 i = 0; i + 1 < (u32)kRowTw; ++i) rowtw[i] = pt.fwd[tw_row_source(rowbase, i)];
+        std::vector<Tw16> rowtw(kRowTwSlots);
+        for (u32 i = 0; i + 1 < (u32)kRowTw; ++i) rowtw[tw_row_slot(i)] = pt.fwd[tw_row_source(rowbase, i)];
         TwRow twr; twr.t = rowtw.data();
-        std::vector<double> roww(kRowTw);
-        for (u32 i = 0; i + 1 < (u32)kRowTw; ++i) std::memcpy(&roww[i], &rowtw[i].a, 8);
+        std::vector<double> roww(kRowTwSlots);
+        for (u32 i = 0; i + 1 < (u32)kRowTw; ++i) std::memcpy(&roww[tw_row_slot(i)], &rowtw[tw_row_slot(i)].a, 8);
         TwRowF64 twf; twf.t = roww.data(); twf.qinv = 1.0 / (double)pt.q;
         const bool f64row = std::is_same<T, double>::value && (a & 2);
         const auto twt = tw_table(pt.fwd.data(), rowbase);

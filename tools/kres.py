@@ -15,7 +15,8 @@ def main(path, flt=""):
         # the device code object sits in the host object's .hip_fatbin section as a clang offload bundle
         fat = os.path.join(td, "fat.bin")
         out = os.path.join(td, "dev.co")
-        subprocess.run([f"{ROCM_LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", path], capture_output=True)
+        # objcopy rewrites its input when no output is named (and with it the mtime make goes by): always write to a scratch copy
+        subprocess.run([f"{ROCM_LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", path, os.path.join(td, "copy.o")], capture_output=True)
         r = subprocess.run([f"{ROCM_LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
                             "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={out}"], capture_output=True, text=True)
         if r.returncode != 0 or not os.path.exists(out) or os.path.getsize(out) == 0:
