@@ -142,6 +142,7 @@ public:
             d.k2_direct = d.k2_lift = 0;
             d.pow32 = (double)((((u64)1) << 32) % pt.q);
             env_.prime_f64[i] = pt.f64 ? 1 : 0;
+            env_.prime_q[i] = pt.q;
         }
         // k_k2n's lift classes per (digit prime j, fp64-engine target prime t) -- the same rule the kernel's general path evaluates
         for (size_t j = 0; j < K; ++j)

@@ -32,6 +32,7 @@ struct KernelEnv {
     int N, logn1, K, Ltop, scheme;
     hipStream_t stream;
     unsigned char prime_f64[kMaxPrimes]; // host copy: 1 if the fp64 engine owns prime i
+    u64 prime_q[kMaxPrimes];             // host copy of the moduli
 };
 
 

@@ -804,6 +804,8 @@ struct K2Args {
     int L, K, ckks, src_is_coeff;
     u64 f64_mask; // bit t: key prime t belongs to the fp64 engine
     int ablate;  // timing experiments (wrong results): 1 = every target's rows land in the slab region of target 0 (no HBM write stream), 2 = no u64-engine targets, 4 = no stores for the fp64 targets
+    int n_dig;   // k_k2n: digits handled by this launch (one instantiation per digit width: each gets its own register allocation)
+    unsigned char dig_list[64];
     int tsplit;  // k_k2n, latency shape: the targets of a (digit, column block) are dealt to tsplit blocks (blockIdx.y)
     int xcd_map; // k_k2n: the four column blocks of one (op, digit) run on the same XCD (blocks b and b + 8 share one)
 };
@@ -1260,11 +1262,18 @@ __device__ __forceinline__ void k2n_targets_u64(const K2Args &A, const PrimeDev 
     }
 }
 
+// WIDE: the launch's digits are 60-bit (integers throughout); else below 2^52 (doubles).  Two instantiations instead of one kernel with
+// both paths: each gets its own register allocation (one kernel at 168 registers spilled 102 through the wide path's live ranges and
+// cost 14.9 ms; at 256 it took 12.4; the pair takes 11.0 + 1.0).  Two or three waves per SIMD make no difference to the narrow
+// instantiation any more (11.04 / 11.18 ms): K2N_WAVES = 2 leaves it without spills.
 #ifndef K2N_WAVES
 #define K2N_WAVES 2
 #endif
-template <int LOGN1>
-__global__ void __launch_bounds__(kBlock, K2N_WAVES) k_k2n(K2Args A, const PrimeDev *primes)
+#ifndef K2N_WAVES_WIDE
+#define K2N_WAVES_WIDE 2
+#endif
+template <int LOGN1, bool WIDE>
+__global__ void __launch_bounds__(kBlock, WIDE ? K2N_WAVES_WIDE : K2N_WAVES) k_k2n(K2Args A, const PrimeDev *primes)
 {
     constexpr int N1 = 1 << LOGN1;
     constexpr u64 N = (u64)N1 << kRowLog;
@@ -1274,19 +1283,19 @@ __global__ void __launch_bounds__(kBlock, K2N_WAVES) k_k2n(K2Args A, const Prime
         const u64 s = blockIdx.x >> 3, xcd = blockIdx.x & 7;
         oj = (s >> 2) * 8 + xcd;
         cb = (u32)(s & 3);
-        if (oj >= A.n_ops * A.L) return; // whole block
+        if (oj >= A.n_ops * A.n_dig) return; // whole block
     }
     const int col = (int)(cb << 8) | threadIdx.x;
     const u32 oj32 = (u32)oj; // n_ops * L < 2^32
-    const int j = (int)__builtin_amdgcn_readfirstlane(oj32 % (u32)A.L);
-    const u64 op = __builtin_amdgcn_readfirstlane(oj32 / (u32)A.L);
+    const int j = A.dig_list[__builtin_amdgcn_readfirstlane(oj32 % (u32)A.n_dig)];
+    const u64 op = __builtin_amdgcn_readfirstlane(oj32 / (u32)A.n_dig);
     const u64 *src = A.c2r + op * A.src_op_stride + (u64)j * N;
     const PrimeDev &Pj = primes[j];
     const bool coeff_in = A.src_is_coeff || LOGN1 == 0; // BFV: coefficient form already; N = 1024: the row pass was the whole inverse
     constexpr bool kTile = kK2Wide && kPackD && N1 >= 8;
     __shared__ __attribute__((aligned(16))) unsigned char tiles[kTile ? kWaves : 1][kTile ? N1 * 384 : 16];
     unsigned char *tile = tiles[kTile ? threadIdx.x >> 6 : 0];
-    if (Pj.q >> 52) { // a 60-bit digit: integers
+    if constexpr (WIDE) { // 60-bit digits: integers
         u64 c[N1];
         if (coeff_in) {
 #pragma unroll
@@ -1302,8 +1311,7 @@ __global__ void __launch_bounds__(kBlock, K2N_WAVES) k_k2n(K2Args A, const Prime
         }
         k2n_targets_f64<LOGN1, false>(A, primes, Pj, j, op, c, col, tile);
         k2n_targets_u64<LOGN1>(A, primes, Pj, j, op, c, col);
-        return;
-    }
+    } else {
     double c[N1];
     if (coeff_in) {
 #pragma unroll
@@ -1329,6 +1337,7 @@ __global__ void __launch_bounds__(kBlock, K2N_WAVES) k_k2n(K2Args A, const Prime
 #pragma unroll
     for (int a = 0; a < N1; ++a) cu[a] = f64_to_u52(c[a]);
     k2n_targets_u64<LOGN1>(A, primes, Pj, j, op, cu, col);
+    }
 }
 
 // K2 split in two (HE355_K2_SPLIT): k_k2a finishes the inverse transform of every digit in place (column pass, canonical
@@ -2900,16 +2909,22 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     A.xcd_map = k2_new && k2_xcd;
     static const int k2_abl = getenv("HE355_K2_ABL") ? atoi(getenv("HE355_K2_ABL")) : 0;
     A.ablate = k2_abl;
-    if (A.xcd_map) g = (unsigned)(((n_ops * L + 7) / 8) * 8 * 4);
     if (k2_new) {
-        const dim3 gd(g, (unsigned)A.tsplit);
-        switch (env.logn1) {
-        case 0: hipLaunchKernelGGL(k_k2n<0>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 1: hipLaunchKernelGGL(k_k2n<1>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 2: hipLaunchKernelGGL(k_k2n<2>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 3: hipLaunchKernelGGL(k_k2n<3>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 4: hipLaunchKernelGGL(k_k2n<4>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 5: hipLaunchKernelGGL(k_k2n<5>, gd, dim3(kBlock), 0, env.stream, A, env.primes); break;
+        for (int wide = 0; wide < 2; ++wide) { // digits below 2^52, then the 60-bit ones
+            A.n_dig = 0;
+            for (int j = 0; j < L; ++j)
+                if ((env.prime_q[j] >> 52 != 0) == (wide != 0)) A.dig_list[A.n_dig++] = (unsigned char)j;
+            if (!A.n_dig) continue;
+            unsigned gw = (unsigned)(n_ops * A.n_dig * 4);
+            if (A.xcd_map) gw = (unsigned)(((n_ops * A.n_dig + 7) / 8) * 8 * 4);
+            const dim3 gd(gw, (unsigned)A.tsplit);
+#define HE355_K2N(L1)                                                                                                         \
+    case L1:                                                                                                                  \
+        if (wide) hipLaunchKernelGGL((k_k2n<L1, true>), gd, dim3(kBlock), 0, env.stream, A, env.primes);                      \
+        else hipLaunchKernelGGL((k_k2n<L1, false>), gd, dim3(kBlock), 0, env.stream, A, env.primes);                          \
+        break;
+            switch (env.logn1) { HE355_K2N(0) HE355_K2N(1) HE355_K2N(2) HE355_K2N(3) HE355_K2N(4) HE355_K2N(5) }
+#undef HE355_K2N
         }
         return;
     }
