@@ -83,7 +83,7 @@ __global__ void k_key_quotients(const u64 *key, u64 *keyq, u64 n_dk, int logN, c
     const u64 dk = poly / n_q;
     ArU64 ar;
     ar.q = primes[t].q; ar.two_q = 2 * ar.q; ar.cr0 = primes[t].cr0; ar.cr1 = primes[t].cr1; ar.ninv = ar.ninv_q = 0;
-    keyq[gid] = ar.shoup_quotient_est(key[((dk * K + t) << logN) + (gid & (((u64)1 << logN) - 1))]);
+    keyq[gid] = ar.shoup_quotient(key[((dk * K + t) << logN) + (gid & (((u64)1 << logN) - 1))]); // exact: k_k3's lazy runs rely on it
 }
 
 } // namespace

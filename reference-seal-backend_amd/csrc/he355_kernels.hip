@@ -135,6 +135,18 @@ constexpr bool kKeyShare = HE355_KSHARE != 0 && kXlT1 && kXlT2;
 #define HE355_KEY_EARLY 1
 #endif
 constexpr bool kKeyEarly = HE355_KEY_EARLY != 0;
+// HE355_ACC_RUN: the u64 engine adds kAccRun key products to an accumulator between two range reductions (ArU64::acc_mac_lazy; needs the
+// exact key quotients k_key_quotients writes) instead of reducing after every product: k_k3<ArU64> 7.69 -> 7.47 ms per step.
+// HE355_KEY_EARLY_U64: polynomial 0's key row and quotient row are requested before the second exchange of the row pass, polynomial
+// 1's before polynomial 0's products -- what HE355_KEY_EARLY does for the fp64 engine; here the 64 extra live registers spill and the
+// kernels get slower (7.69 -> 8.24 ms), so it stays off.
+#ifndef HE355_ACC_RUN
+#define HE355_ACC_RUN 1
+#endif
+#ifndef HE355_KEY_EARLY_U64
+#define HE355_KEY_EARLY_U64 0
+#endif
+constexpr bool kAccRunOn = HE355_ACC_RUN != 0, kKeyEarlyU64 = HE355_KEY_EARLY_U64 != 0;
 // HE355_LAZY_U64: k_k3 transforms the digit rows of the u64-engine key primes over the wide lazy range (one correction per row instead
 // of one per butterfly); key primes are below 2^60 (Params), the key multiply-accumulate takes any 64-bit lazy value
 #ifndef HE355_LAZY_U64
@@ -287,7 +299,7 @@ __device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int 
 {
     typedef typename Ar::T T;
     if (wa_pre) {
-        if constexpr (LAZY) row_fwd_A_lazy<U>(ar, x, wa_pre); else row_fwd_A<U>(ar, x, wa_pre);
+        if constexpr (LAZY) row_fwd_A_lazy<U, true>(ar, x, wa_pre); else row_fwd_A<U>(ar, x, wa_pre);
     } else {
         Tw16 wa[kTwA];
         gather_A(tw, wa);
@@ -1540,6 +1552,30 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         Acc acc0[kRowE], acc1[kRowE];
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) { acc0[r] = 0; acc1[r] = 0; }
+        // u64 engine: products added since the accumulators were last brought under 4q (wave-uniform); acc_flush before anything reads them
+        constexpr int kRun = kAccRunOn ? Ar::kAccRun : 1;
+        int pend = 0;
+        auto acc_flush = [&]() {
+            if constexpr (kRun > 1) {
+                if (pend) {
+#pragma unroll
+                    for (int r = 0; r < kRowE; ++r) { acc0[r] = ar.acc_reduce(acc0[r]); acc1[r] = ar.acc_reduce(acc1[r]); }
+                    pend = 0;
+                }
+            }
+        };
+        auto acc_step = [&]() { // after one product went into every accumulator
+            if constexpr (kRun > 1) {
+                if (++pend == kRun) acc_flush();
+            }
+        };
+        auto mac_row = [&](Acc acc[kRowE], const T x[kRowE], const u64 kv[kRowE], const u64 kq[kRowE]) {
+#pragma unroll
+            for (int r = 0; r < kRowE; ++r) {
+                if constexpr (kRun > 1) ar.acc_mac_lazy(acc[r], x[r], ar.key_in(kv[r]), Ar::kKeyQuotient ? kq[r] : 0);
+                else ar.acc_mac(acc[r], x[r], ar.key_in(kv[r]), Ar::kKeyQuotient ? kq[r] : 0);
+            }
+        };
 #if defined(HE355_ABLATE) && (HE355_ABLATE & 1) // timing experiment (wrong results): every key row is the tile's first one (L1-resident)
         auto key_row = [&](int, int) -> const u64 * { return A.key + (u64)t * N + rowoff; };
         auto keyq_row = [&](int, int) -> const u64 * { return A.keyq + (u64)q_slot * N + rowoff; };
@@ -1551,12 +1587,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             u64 kv[kRowE], kq[kRowE];
             load_rowC(key_row(j, k), lane, kv);
             if constexpr (Ar::kKeyQuotient) load_rowC(keyq_row(j, k), lane, kq);
-#pragma unroll
-            for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc[r], x[r], ar.key_in(kv[r]), Ar::kKeyQuotient ? kq[r] : 0);
+            mac_row(acc, x, kv, kq);
         };
         auto mac_digit = [&](const T x[kRowE], int j) {
             mac_poly(acc0, x, j, 0);
             mac_poly(acc1, x, j, 1);
+            acc_step();
         };
         // KSHARE: this wave's share of the block's key rows of digit j -> keybuf[b] (wave w moves piece w of every array)
         auto key_dma = [&](int j, int b) {
@@ -1585,10 +1621,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 u64 kv[kRowE], kq[kRowE];
                 key_lds(keybuf[KSHARE ? b : 0][KSHARE ? k : 0], kv);
                 if constexpr (Ar::kKeyQuotient) key_lds(keybuf[KSHARE ? b : 0][KSHARE ? 2 + k : 0], kq);
-                Acc *acc = k == 0 ? acc0 : acc1;
-#pragma unroll
-                for (int r = 0; r < kRowE; ++r) ar.acc_mac(acc[r], x[r], ar.key_in(kv[r]), Ar::kKeyQuotient ? kq[r] : 0);
+                mac_row(k == 0 ? acc0 : acc1, x, kv, kq);
             }
+            acc_step();
         };
         // digits that go through the forward row pass: all of them, except (CKKS) the one that lives under this very
         // prime -- that one is the NTT-form target itself and is multiplied in directly
@@ -1693,12 +1728,23 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                             for (int k = 0; k < kMacG / 2; ++k) { acc0[r0 + k] += pr[2 * k]; acc1[r0 + k] += pr[2 * k + 1]; }
                         }
                     }
+                } else if constexpr (kKeyEarlyU64 && !KSHARE && Ar::kKeyQuotient) {
+                    u64 kv0[kRowE], kq0[kRowE], kv1[kRowE], kq1[kRowE];
+                    const int j = digit(i);
+                    auto early = [&]() { load_rowC(key_row(j, 0), lane, kv0); load_rowC(keyq_row(j, 0), lane, kq0); };
+                    wave_rows_fwd_n<1, Ar, decltype(twr), decltype(early), kLazyU64>(ar, twr, lane, lds[wave], x, early, wa_pre);
+                    load_rowC(key_row(j, 1), lane, kv1);
+                    load_rowC(keyq_row(j, 1), lane, kq1);
+                    mac_row(acc0, x[0], kv0, kq0);
+                    mac_row(acc1, x[0], kv1, kq1);
+                    acc_step();
                 } else {
                     wave_rows_fwd_n<1, Ar, decltype(twr), NoHook, kLazyU64>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
                     if constexpr (KSHARE) mac_digit_lds(x[0], i & 1);
                     else mac_digit(x[0], digit(i));
                 }
             }
+            acc_flush();
             // correction rows: transform + floor step(s)
 #pragma unroll 1
             for (int i = nd; i < n_rows; ++i) {
@@ -1768,6 +1814,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
 #pragma unroll
                     for (int r = 0; r < kRowE; ++r) x[U - 1][r] = 0;
                 }
+                if constexpr (kKeyEarlyU64 && !KSHARE && Ar::kKeyQuotient && U == 1) {
+                    u64 kv0[kRowE], kq0[kRowE], kv1[kRowE], kq1[kRowE]; // as in the fused loop above
+                    const int j = digit(i);
+                    auto early = [&]() { load_rowC(key_row(j, 0), lane, kv0); load_rowC(keyq_row(j, 0), lane, kq0); };
+                    wave_rows_fwd_n<U, Ar, decltype(twr), decltype(early), kLazyU64>(ar, twr, lane, lds[wave], x, early, wa_pre);
+                    load_rowC(key_row(j, 1), lane, kv1);
+                    load_rowC(keyq_row(j, 1), lane, kq1);
+                    mac_row(acc0, x[0], kv0, kq0);
+                    mac_row(acc1, x[0], kv1, kq1);
+                    acc_step();
+                } else {
                 wave_rows_fwd_n<U, Ar, decltype(twr), NoHook, kLazyU64>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
                 if constexpr (KSHARE) {
                     mac_digit_lds(x[0], i & 1);
@@ -1776,7 +1833,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                     for (int u = 0; u < U; ++u)
                         if (u < cnt) mac_digit(x[u], digit(i + u));
                 }
+                }
             }
+            acc_flush();
             // Epilogue: canonical sums, NTT form, layout C.  Data primes -> t; special prime -> tp.  Where the next step is the
             // inverse transform of these very rows (the special prime always; every prime for BFV, whose key switch returns to
             // coefficient form) the wave runs the inverse row pass right here and writes the raw rows (special prime -> tpr).

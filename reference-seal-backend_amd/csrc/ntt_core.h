@@ -137,6 +137,11 @@ HE_HD Tw16 tw_load(ctw_t p, u32 i)
     return t;
 }
 #endif
+// entries read through ctw_t are wave-uniform by contract (scalar loads): the u64 engine's butterflies keep them in scalar registers
+template <class TW> struct TwIsUniform { static constexpr bool value = false; };
+#if defined(__HIP__)
+template <> struct TwIsUniform<ctw_t> { static constexpr bool value = true; };
+#endif
 template <class P> struct TwTable {
     P base;
     u32 rowbase;
@@ -228,7 +233,7 @@ template <class TW> HE_HD void gather_C(const TW &tw, int lane, Tw16 w[kTwC])
 #define HE355_BFLY_GROUP 2
 #endif
 constexpr int kBflyGroup = HE355_BFLY_GROUP;
-template <int U, int BIT, bool LAZY, class Ar, class WIdx> HE_HD void row_fwd_stage_x(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 *w, WIdx widx)
+template <int U, int BIT, bool LAZY, bool SW = false, class Ar, class WIdx> HE_HD void row_fwd_stage_x(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 *w, WIdx widx)
 {
     constexpr int kTotal = 8 * U, G = kBflyGroup < kTotal ? kBflyGroup : kTotal;
     static_assert(kTotal % G == 0, "group size must divide the butterflies of a stage");
@@ -242,7 +247,7 @@ template <int U, int BIT, bool LAZY, class Ar, class WIdx> HE_HD void row_fwd_st
             const int r = ((b >> BIT) << (BIT + 1)) | (b & ((1 << BIT) - 1));    // b with a 0 inserted at BIT
             X[k] = x[u][r]; Y[k] = x[u][r | (1 << BIT)]; W[k] = w[widx(r)];
         }
-        if constexpr (LAZY) ar.template bfly_fwd_lazy_g<G>(X, Y, W);
+        if constexpr (LAZY) ar.template bfly_fwd_lazy_g<G, SW>(X, Y, W);
         else ar.template bfly_fwd_g<G>(X, Y, W);
 #pragma unroll
         for (int k = 0; k < G; ++k) {
@@ -277,12 +282,13 @@ template <int U, class Ar> HE_HD void row_fwd_C(const Ar &ar, typename Ar::T (*x
 }
 // The same three phases over the wide lazy range of the u64 engine (ArU64::bfly_fwd_lazy; q < 2^60): in below 4q, A to 12q, B runs two
 // stages (16q), comes back under 4q, runs two more (8q), C to 12q.  The fp64 engine's instantiations are the plain phases.
-template <int U, class Ar> HE_HD void row_fwd_A_lazy(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwA])
+// SW: w[] is wave-uniform (a caller that keeps phase A's twiddles in scalar registers)
+template <int U, bool SW = false, class Ar> HE_HD void row_fwd_A_lazy(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwA])
 {
-    row_fwd_stage_x<U, 3, true>(ar, x, w, [](int r) { return 0 + (r >> 4); });
-    row_fwd_stage_x<U, 2, true>(ar, x, w, [](int r) { return 1 + (r >> 3); });
-    row_fwd_stage_x<U, 1, true>(ar, x, w, [](int r) { return 3 + (r >> 2); });
-    row_fwd_stage_x<U, 0, true>(ar, x, w, [](int r) { return 7 + (r >> 1); });
+    row_fwd_stage_x<U, 3, true, SW>(ar, x, w, [](int r) { return 0 + (r >> 4); });
+    row_fwd_stage_x<U, 2, true, SW>(ar, x, w, [](int r) { return 1 + (r >> 3); });
+    row_fwd_stage_x<U, 1, true, SW>(ar, x, w, [](int r) { return 3 + (r >> 2); });
+    row_fwd_stage_x<U, 0, true, SW>(ar, x, w, [](int r) { return 7 + (r >> 1); });
 }
 template <int U, class Ar> HE_HD void row_fwd_B_lazy(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwB])
 {
@@ -398,7 +404,7 @@ template <class Ar, int LOGN1, class TW> HE_HD void col_fwd(const Ar &ar, typena
         for (int a = 0; a < N1; ++a) {
             if (a & gap) continue;
             const Tw16 w = tw_load(tw, (u32)((1 << s) + (a / (2 * gap))));
-            ar.bfly_fwd(x[a], x[a + gap], w);
+            ar.template bfly_fwd<TwIsUniform<TW>::value>(x[a], x[a + gap], w);
         }
     }
 }
@@ -453,10 +459,10 @@ template <class Ar, int LOGN1, class TW> HE_HD void col_inv(const Ar &ar, typena
         for (int a = 0; a < N1; ++a) {
             if (a & gap) continue;
             if (s == 0) {
-                ar.bfly_inv_last(x[a], x[a + gap], w0_scaled);
+                ar.template bfly_inv_last<TwIsUniform<TW>::value>(x[a], x[a + gap], w0_scaled);
             } else {
                 const Tw16 w = tw_load(itw, (u32)((1 << s) + (a / (2 * gap))));
-                ar.bfly_inv(x[a], x[a + gap], w);
+                ar.template bfly_inv<TwIsUniform<TW>::value>(x[a], x[a + gap], w);
             }
         }
     }

@@ -176,6 +176,23 @@ template <class Ar> static void rows_fwd(const Ar &ar, const PrimeTables &pt, in
                     }
                 }
                 if (he355_sim_overflow) throw std::runtime_error("wide-lazy row pass: a sum left 64 bits");
+                // k_k3's lazy accumulation runs: kAccRun products of the largest operands on an accumulator just below 4q fit 64 bits, with
+                // the exact key quotient (shoup_quotient) and for any 64-bit x
+                const u64 xs[4] = {~(u64)0, 12 * pt.q - 1, pt.q - 1, 0x9e3779b97f4a7c15ull};
+                const u64 ks[3] = {pt.q - 1, pt.q / 2 + 1, 1};
+                for (u64 xv : xs)
+                    for (u64 kv : ks) {
+                        const u64 kq = ar.shoup_quotient(kv);
+                        if ((u128)kq * pt.q > ((u128)kv << 64) || (u128)(kq + 1) * pt.q <= ((u128)kv << 64)) throw std::runtime_error("shoup_quotient is not floor(w * 2^64 / q)");
+                        u64 acc = 4 * pt.q - 1, want = (u64)(((u128)(4 * pt.q - 1)) % pt.q);
+                        for (int k = 0; k < ArU64::kAccRun; ++k) {
+                            ar.acc_mac_lazy(acc, xv, kv, kq);
+                            want = (u64)((want + (u128)(xv % pt.q) * kv) % pt.q);
+                        }
+                        if (he355_sim_overflow) throw std::runtime_error("lazy accumulation run: a sum left 64 bits");
+                        acc = ar.acc_reduce(acc);
+                        if (acc >= 4 * pt.q || ar.acc_canon(acc) != want) throw std::runtime_error("lazy accumulation run: wrong residue");
+                    }
             }
         }
         for (int mode = 0; mode < 4; ++mode) {
