@@ -109,6 +109,8 @@ public:
         HIPCHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
         HIPCHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&ev_side_fork_, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&ev_side_join_, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
         HIPCHECK(hipEventCreate(&ev0_));
         HIPCHECK(hipEventCreate(&ev1_));
@@ -204,6 +206,8 @@ public:
         (void)hipFree(client_scratch_);
         for (auto &kv : d_gather_) (void)hipFree(kv.second);
         (void)hipEventDestroy(ev_fork_);
+        (void)hipEventDestroy(ev_side_fork_);
+        (void)hipEventDestroy(ev_side_join_);
         (void)hipEventDestroy(ev_join_);
         (void)hipStreamDestroy(stream2_);
         (void)hipEventDestroy(ev0_);
@@ -480,6 +484,22 @@ public:
     // 2.5x as long), blocks per column for the targets of k_k2n / k_floor_colsn
     static constexpr int kLatSplit = 4, kLatSplitU64 = 8, kLatTargets = 8;
     bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
+    // the kernel environment of a batch of nc ciphertexts on stream `which`.  HE355_LAT_SIDE=1: in the latency shape the other stream
+    // takes the second engine's launches (KernelEnv::side).  Off by default: measured at batch 1 the two engines' kernels each fill
+    // the chip already and only stretch each other (k_k3 50 + 26 us in line, 65 and 59 us side by side; 0.331 -> 0.356 ms per call);
+    // at batch 8 it is 0.952 -> 0.937 ms.
+    KernelEnv batch_env(u64 nc, int which = 0) const
+    {
+        static const bool side_on = getenv("HE355_LAT_SIDE") && getenv("HE355_LAT_SIDE")[0] == '1';
+        KernelEnv env = env_;
+        env.stream = which ? stream2_ : stream_;
+        if (side_on && latency_shape(nc)) {
+            env.side = which ? stream_ : stream2_;
+            env.ev_side_fork = ev_side_fork_;
+            env.ev_side_join = ev_side_join_;
+        }
+        return env;
+    }
     u64 *latency_partials(size_t elems, int which) // one buffer per stream: chunks of the two streams are in flight together
     {
         if (elems * 8 > lat_part_bytes_[which]) {
@@ -525,8 +545,7 @@ public:
         for (u64 off = 0; off < n; off += chunk_, ++ci) {
             const u64 nc = std::min<u64>(chunk_, n - off);
             const int which = dual ? (int)(ci & 1) : 0;
-            KernelEnv env = env_;
-            env.stream = which ? stream2_ : stream_;
+            const KernelEnv env = batch_env(nc, which);
             Scratch S = scratch(std::min<u64>(chunk_, n), L, which);
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
@@ -572,10 +591,11 @@ public:
             Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
-            launch_k1(env_, L, K1_CT3, nc, off, ct3, nullptr, ix, nullptr, B);
+            const KernelEnv env = batch_env(nc);
+            launch_k1(env, L, K1_CT3, nc, off, ct3, nullptr, ix, nullptr, B);
             u64 *ro = rescale ? out + off * 2 * (size_t)(L - 1) * N : nullptr;
-            const bool done = key_switch_tail(env_, L, nc, S, B, d_relin_, rescale, nullptr, ro);
-            if (rescale && !done) rescale_tail(env_, L, 2, nc, S, B.c01, 2 * LN, ro);
+            const bool done = key_switch_tail(env, L, nc, S, B, d_relin_, rescale, nullptr, ro);
+            if (rescale && !done) rescale_tail(env, L, 2, nc, S, B.c01, 2 * LN, ro);
         }
         HIPCHECK(hipGetLastError());
     }
@@ -667,8 +687,9 @@ public:
             Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
             KsBuffers B = S.ks;
             B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
-            launch_k1(env_, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend);
-            key_switch_tail(env_, L, nc, S, B, key, false);
+            const KernelEnv env = batch_env(nc);
+            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend);
+            key_switch_tail(env, L, nc, S, B, key, false);
         }
         HIPCHECK(hipGetLastError());
     }
@@ -1322,6 +1343,7 @@ private:
     size_t scratch_bytes_ = 0, scratch2_bytes_ = 0;
     hipStream_t stream2_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    hipEvent_t ev_side_fork_ = nullptr, ev_side_join_ = nullptr; // KernelEnv::side (latency shape)
     bool dual_stream_ = true;
     u64 *rot_tmp_ = nullptr;
     size_t rot_tmp_bytes_ = 0;

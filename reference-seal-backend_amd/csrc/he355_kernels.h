@@ -31,6 +31,10 @@ struct KernelEnv {
     const FloorConst *floor_consts; // device array [K*K], entry [s*K + i]
     int N, logn1, K, Ltop, scheme;
     hipStream_t stream;
+    // Latency shape (few ciphertexts per call): launchers that issue one kernel per arithmetic engine put the second one on `side`, so
+    // the two run beside each other instead of one after the other (each fills a fraction of the chip).  Null: everything on `stream`.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
     unsigned char prime_f64[kMaxPrimes]; // host copy: 1 if the fp64 engine owns prime i
     u64 prime_q[kMaxPrimes];             // host copy of the moduli
 };

@@ -2898,10 +2898,39 @@ void launch_mul3(const KernelEnv &env, int L, u64 n_results, const u64 *a, const
     hipLaunchKernelGGL(k_mul3, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, a, b, out, ix, env.primes, L, logN, n_results);
 }
 
+// KernelEnv::side: the stream of a launcher's pass (0: env.stream; later passes: env.side once forked) and the join that makes
+// env.stream wait for what went to the side stream.  Every launch that follows on env.stream depends on both.
+namespace {
+struct SideFork {
+    const KernelEnv &env;
+    bool forked = false;
+    explicit SideFork(const KernelEnv &e) : env(e)
+    {
+        if (env.side) { // the fork point is in front of the first pass: the side stream's kernel does not wait for it
+            (void)hipEventRecord(env.ev_side_fork, env.stream);
+        }
+    }
+    hipStream_t stream(int pass)
+    {
+        if (!env.side || pass == 0) return env.stream;
+        if (!forked) { (void)hipStreamWaitEvent(env.side, env.ev_side_fork, 0); forked = true; }
+        return env.side;
+    }
+    ~SideFork()
+    {
+        if (forked) {
+            (void)hipEventRecord(env.ev_side_join, env.side);
+            (void)hipStreamWaitEvent(env.stream, env.ev_side_join, 0);
+        }
+    }
+};
+} // namespace
+
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
                const KsBuffers &buf, const u64 *addend)
 {
     if (!n_ops) return;
+    SideFork sf(env);
     K1Args A;
     A.a = a; A.b = b; A.ix = ix; A.perm = perm; A.addend = addend;
     A.c01 = buf.c01; A.c01_item_stride = buf.c01_item_stride; A.c2n = buf.c2n; A.c2r = buf.c2r;
@@ -2913,14 +2942,15 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
         if (!A.n_i) continue;
         const u64 jobs = (n_ops * A.n_i) << env.logn1;
         const dim3 grid(grid_for(jobs, kWaves));
+        const hipStream_t st = sf.stream(pass);
         if (pass == 0) {
-            if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArF64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
-            else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArF64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
-            else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArF64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
+            if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
+            else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
+            else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
         } else {
-            if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArU64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
-            else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArU64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
-            else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArU64>), grid, dim3(kBlock), 0, env.stream, A, env.primes);
+            if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
+            else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
+            else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
         }
     }
 }
@@ -2969,6 +2999,8 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     static const int k2_abl = getenv("HE355_K2_ABL") ? atoi(getenv("HE355_K2_ABL")) : 0;
     A.ablate = k2_abl;
     if (k2_new) {
+        SideFork sf(env);
+        int launched = 0;
         for (int wide = 0; wide < 2; ++wide) { // digits below 2^52, then the 60-bit ones
             A.n_dig = 0;
             for (int j = 0; j < L; ++j)
@@ -2977,10 +3009,11 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             unsigned gw = (unsigned)(n_ops * A.n_dig * 4);
             if (A.xcd_map) gw = (unsigned)(((n_ops * A.n_dig + 7) / 8) * 8 * 4);
             const dim3 gd(gw, (unsigned)A.tsplit);
+            const hipStream_t st = sf.stream(launched++);
 #define HE355_K2N(L1)                                                                                                         \
     case L1:                                                                                                                  \
-        if (wide) hipLaunchKernelGGL((k_k2n<L1, true>), gd, dim3(kBlock), 0, env.stream, A, env.primes);                      \
-        else hipLaunchKernelGGL((k_k2n<L1, false>), gd, dim3(kBlock), 0, env.stream, A, env.primes);                          \
+        if (wide) hipLaunchKernelGGL((k_k2n<L1, true>), gd, dim3(kBlock), 0, st, A, env.primes);                              \
+        else hipLaunchKernelGGL((k_k2n<L1, false>), gd, dim3(kBlock), 0, st, A, env.primes);                                  \
         break;
             switch (env.logn1) { HE355_K2N(0) HE355_K2N(1) HE355_K2N(2) HE355_K2N(3) HE355_K2N(4) HE355_K2N(5) }
 #undef HE355_K2N
@@ -3015,6 +3048,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     const unsigned char *prime_f64 = env.prime_f64;
     if (!n_ops) return;
     if (fuse && (part != K3_DATA_ONLY || !k3_can_fuse(env))) throw std::runtime_error("fused mod-down: data-prime tiles of the default shapes only");
+    SideFork sf(env);
     for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine primes, pass 1: u64-engine primes
         K3Args A;
         A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tp = buf.tp; A.tpr = buf.tpr;
@@ -3071,8 +3105,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         const bool staged = stage_env != 0 || shape / 10 != 1;
         if (shape == 11) {
             const dim3 gd(g, (unsigned)A.n_split);
-            if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 1, 1, true>), gd, dim3(64), 0, env.stream, A, env.primes);
-            else hipLaunchKernelGGL((k_k3<ArU64, 1, 1, true>), gd, dim3(64), 0, env.stream, A, env.primes);
+            if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 1, 1, true>), gd, dim3(64), 0, sf.stream(0), A, env.primes);
+            else hipLaunchKernelGGL((k_k3<ArU64, 1, 1, true>), gd, dim3(64), 0, sf.stream(1), A, env.primes);
         } else if (pass == 0) {
             switch (shape) {
             case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
@@ -3164,6 +3198,7 @@ void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &arg
     // per block: up to 8 jobs per wave, fewer when that would leave CUs without blocks
     u32 jpb = 8 * kWaves;
     while (jpb > (u32)kWaves && (((u64)args.n_tgt << env.logn1) * ((n_jobs + jpb - 1) / jpb) < 256u * 8 || jpb / 2 >= n_jobs)) jpb >>= 1;
+    SideFork sf(env);
     for (int pass = 0; pass < 4; ++pass) { // (engine, tail) combinations; the tail prime gets its own launch
         const bool f64 = pass < 2, tail = pass & 1;
         FloorRowsDev A;
@@ -3174,10 +3209,11 @@ void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &arg
             if ((prime_f64[i] != 0) == f64 && (i == args.tail_prime) == tail) A.i_list[A.n_i++] = (unsigned char)i;
         if (!A.n_i) continue;
         const unsigned g = (unsigned)((((u64)A.n_i) << env.logn1) * ((n_jobs + jpb - 1) / jpb));
-        if (f64 && !tail) hipLaunchKernelGGL((k_floor_rows<ArF64, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
-        else if (f64) hipLaunchKernelGGL((k_floor_rows<ArF64, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
-        else if (!tail) hipLaunchKernelGGL((k_floor_rows<ArU64, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
-        else hipLaunchKernelGGL((k_floor_rows<ArU64, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+        const hipStream_t st = sf.stream(f64 ? 0 : 1);
+        if (f64 && !tail) hipLaunchKernelGGL((k_floor_rows<ArF64, false>), dim3(g), dim3(kBlock), 0, st, A, env.primes);
+        else if (f64) hipLaunchKernelGGL((k_floor_rows<ArF64, true>), dim3(g), dim3(kBlock), 0, st, A, env.primes);
+        else if (!tail) hipLaunchKernelGGL((k_floor_rows<ArU64, false>), dim3(g), dim3(kBlock), 0, st, A, env.primes);
+        else hipLaunchKernelGGL((k_floor_rows<ArU64, true>), dim3(g), dim3(kBlock), 0, st, A, env.primes);
     }
 }
 
