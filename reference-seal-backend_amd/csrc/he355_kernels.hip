@@ -313,12 +313,14 @@ __device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int 
         for (int u = 0; u < U; ++u) xl_T1(xl, x[u]);
     } else {
         __builtin_amdgcn_sched_barrier(0);
+#if !(defined(HE355_ABLATE) && (HE355_ABLATE & 4)) // timing experiment (wrong results): the row pass without its two LDS exchanges
 #pragma unroll
         for (int u = 0; u < U; ++u) lds_store_A(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
         HE_WAVE_SYNC();
 #pragma unroll
         for (int u = 0; u < U; ++u) lds_load_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
         HE_WAVE_SYNC();
+#endif
     }
     if constexpr (LAZY) row_fwd_B_lazy<U>(ar, x, wb); else row_fwd_B<U>(ar, x, wb);
     Tw16 wc[kTwC];
@@ -329,12 +331,14 @@ __device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int 
         for (int u = 0; u < U; ++u) xl_T2(xl, x[u]);
     } else {
         __builtin_amdgcn_sched_barrier(0);
+#if !(defined(HE355_ABLATE) && (HE355_ABLATE & 4))
 #pragma unroll
         for (int u = 0; u < U; ++u) lds_store_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
         HE_WAVE_SYNC();
 #pragma unroll
         for (int u = 0; u < U; ++u) lds_load_C(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
         HE_WAVE_SYNC();
+#endif
     }
     if constexpr (LAZY) row_fwd_C_lazy<U>(ar, x, wc); else row_fwd_C<U>(ar, x, wc);
 }
@@ -1690,6 +1694,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 T x[1][kRowE];
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's row (and this wave's share of its key rows) has landed in LDS
                 if constexpr (KSHARE) __syncthreads();            // ... and so has every other wave's share; all waves are past the previous step's MAC
+#if defined(HE355_K3_SYNC) && HE355_K3_SYNC
+                else if ((i % HE355_K3_SYNC) == 0) __syncthreads(); // experiment: the block's eight waves on the same digit, so that one L1 fill of its key rows serves all
+#endif
                 if constexpr (kPacked) {
                     lds_rowA48(stage[wave][0], lane, x[0]);
                 } else {
@@ -1711,7 +1718,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                     // two L2 round trips per step (poly 0, then poly 1)
                     u64 kv0[kRowE], kv1[kRowE];
                     const int j = digit(i);
+                    // HE355_KEY_EARLY = 1: both rows in the hook; 2: both before the row pass; 3: polynomial 0's before the row pass, 1's in the hook
+                    if constexpr (HE355_KEY_EARLY == 2) {
+                        load_rowC(key_row(j, 0), lane, kv0); load_rowC(key_row(j, 1), lane, kv1);
+                        wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
+                    } else if constexpr (HE355_KEY_EARLY == 3) {
+                        load_rowC(key_row(j, 0), lane, kv0);
+                        wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, [&]() { load_rowC(key_row(j, 1), lane, kv1); }, wa_pre);
+                    } else {
                     wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, [&]() { load_rowC(key_row(j, 0), lane, kv0); load_rowC(key_row(j, 1), lane, kv1); }, wa_pre);
+                    }
                     // the 32 products, kMacG at a time (interleaved chains: at two waves per SIMD a serial chain issues at 3/4 of the
                     // pipe's rate)
                     if constexpr (kF64) {

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the HIP path against the CPU oracle (test tool, GPU box): random ring sizes, prime chains (mixed
+fp64-/u64-engine primes, forced-u64 contexts), levels, batch sizes on both sides of the latency-shape boundary, chunk sizes with
+ragged tails; multiply -> relinearize (-> rescale), relinearize of size-3 ciphertexts, rescale, rotations and rotate_add -- every
+result compared bit for bit.  usage: tools/fuzz_parity.py <seconds> [seed]   (prints one line per case; exit 1 on the first mismatch)"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    be = importlib.import_module("reference-seal-backend_amd")
+    import oracle  # noqa: E402  (the checker; test infrastructure)
+    oracle.build()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    case = 0
+    while time.time() < t_end:
+        case += 1
+        N = int(rng.choice([1024, 2048, 4096, 8192, 16384], p=[0.3, 0.25, 0.2, 0.15, 0.1]))
+        n_data = int(rng.integers(1, 6 if N <= 4096 else 4))
+        bits = [int(rng.choice([36, 40, 44, 45, 46, 47, 50, 52, 55, 60])) for _ in range(n_data)]
+        bits.append(int(rng.choice([45, 47, 50, 58, 60])))  # the special prime
+        force = bool(rng.random() < 0.15)
+        if force:
+            os.environ["HE355_FORCE_U64"] = "1"
+        try:
+            try:
+                g = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, sec128=False, device=0)
+            except be.HE355Error as e:  # e.g. not enough primes of a size for this N
+                print(f"case {case}: N={N} bits={bits} skipped ({str(e)[:60]})", flush=True)
+                continue
+        finally:
+            os.environ.pop("HE355_FORCE_U64", None)
+        o = oracle.Context(oracle.SCHEME_CKKS, N, bit_sizes=bits, sec128=False)
+        assert g.moduli == o.moduli
+        L = int(rng.integers(1, g.L + 1))
+        n = int(rng.choice([1, 2, 3, 5, 8, 9, 13]))
+        g.set_chunk(int(rng.choice([2, 4, 32, 256])))
+        g.set_latency_max(int(rng.choice([0, 4, 8])))
+        rk = o.random_kswitch_key(rng)
+        g.set_relin_key(rk)
+        a = np.stack([o.random_poly(rng, L, 2) for _ in range(n)])
+        b = np.stack([o.random_poly(rng, L, 2) for _ in range(n)])
+        da, db = g.to_device(a), g.to_device(b)
+        what = []
+        # multiply -> relinearize (-> rescale)
+        out = g.alloc(n * 2 * L * N)
+        g.multiply_relin(L, n, da, db, be.Context.pairwise(), out)
+        got = out.download((n, 2, L, N))
+        want = [o.relinearize(o.multiply_ntt(a[r], b[r]), rk) for r in range(n)]
+        ok = all(np.array_equal(got[r], want[r]) for r in range(n))
+        what.append("mul_relin")
+        if ok and L >= 2:
+            out2 = g.alloc(n * 2 * (L - 1) * N)
+            g.multiply_relin(L, n, da, db, be.Context.pairwise(), out2, rescale=True)
+            got2 = out2.download((n, 2, L - 1, N))
+            ok = all(np.array_equal(got2[r], o.rescale(want[r])) for r in range(n))
+            what.append("rescale")
+        # relinearize of size-3 ciphertexts
+        if ok:
+            m = min(n, 3)
+            ct3 = np.stack([o.random_poly(rng, L, 3) for _ in range(m)])
+            o3 = g.alloc(m * 2 * L * N)
+            g.relinearize(L, m, g.to_device(ct3), o3)
+            g3 = o3.download((m, 2, L, N))
+            ok = all(np.array_equal(g3[r], o.relinearize(ct3[r], rk)) for r in range(m))
+            what.append("relin3")
+        # a rotation with its own key, and rotate_add
+        if ok:
+            step = int(rng.choice([1, -1, 2, 4, -8, 16]))
+            e = o.galois_elt(step)
+            gk = o.random_kswitch_key(rng)
+            g.set_galois_key(e, gk)
+            orot = g.alloc(n * 2 * L * N)
+            g.rotate(L, n, da, step, orot)
+            gr = orot.download((n, 2, L, N))
+            wr = [o.apply_galois(a[r], e, gk) for r in range(n)]
+            ok = all(np.array_equal(gr[r], wr[r]) for r in range(n))
+            what.append(f"rot{step}")
+            if ok:
+                g.rotate_add(L, n, da, step, db, orot)
+                gr = orot.download((n, 2, L, N))
+                ok = all(np.array_equal(gr[r], o.add(b[r], wr[r])) for r in range(n))
+                what.append("rot_add")
+        print(f"case {case}: N={N} bits={bits} force_u64={int(force)} L={L} n={n} {'+'.join(what)} {'ok' if ok else 'MISMATCH'}", flush=True)
+        g.close()
+        if not ok:
+            return 1
+    print(f"{case} cases, all equal")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
