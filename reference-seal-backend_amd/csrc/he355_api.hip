@@ -355,10 +355,29 @@ public:
         u64 *f;   // [C][3][L][N]
     };
     // layout of the scratch arena (one per stream) for `c` ops at level L
+    size_t scratch_words_per_op(int L) const
+    {
+        const size_t N = P.N, LN = (size_t)L * N;
+        return 2 * LN + LN + LN + (size_t)(L + 1) * LN + 2 * LN + 2 * N + 2 * N + 2 * LN + 3 * N + 3 * LN;
+    }
+    // Ciphertexts per chunk for a batch of n at level L: chunk_ (default 1024, HE355_CHUNK / he355_set_chunk), halved while the scratch
+    // arena(s) it needs -- two when the batch is cut and the chunks alternate between the streams -- would not fit in the device memory
+    // that is free now (plus the arenas this context already holds, which a larger request replaces).
+    size_t chunk_ops(u64 n, int L, bool may_dual)
+    {
+        size_t c = std::min<u64>(chunk_, n ? n : 1);
+        const size_t per_op = scratch_words_per_op(L) * 8;
+        size_t free_b = 0, total_b = 0;
+        if (per_op * c * (may_dual && n > c ? 2 : 1) <= scratch_bytes_ + scratch2_bytes_) return c; // (cheap path: no query)
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return c;
+        const size_t avail = (size_t)((double)(free_b + scratch_bytes_ + scratch2_bytes_) * 0.9);
+        while (c > 32 && per_op * c * (may_dual && n > c ? 2 : 1) > avail) c = (c + 1) / 2;
+        return c;
+    }
     Scratch scratch(size_t c, int L, int which = 0)
     {
         const size_t N = P.N, LN = (size_t)L * N;
-        const size_t per_op = 2 * LN + LN + LN + (size_t)(L + 1) * LN + 2 * LN + 2 * N + 2 * N + 2 * LN + 3 * N + 3 * LN;
+        const size_t per_op = scratch_words_per_op(L);
         const size_t need = per_op * c * 8;
         u64 *&arena = which ? scratch2_ : scratch_;
         size_t &arena_bytes = which ? scratch2_bytes_ : scratch_bytes_;
@@ -528,6 +547,7 @@ public:
         const size_t N = P.N, LN = (size_t)L * N;
         // Alternate chunks between two streams, each with its own scratch arena: the ALU-bound key-product kernel
         // of one chunk overlaps the HBM-bound multiply / digit-lift / floor kernels of the other.
+        const size_t chunk_ = chunk_ops(n, L, dual_stream_); // (shadows the member: this call's chunk size)
         const bool dual = dual_stream_ && n > chunk_;
         // The second stream starts half a pipeline late (after the first chunk's K1+K2 on the first stream): from then on
         // one stream's ALU-bound kernels (K3, floor column pass) run beside the other's HBM-bound ones (K1, K2, floor row pass)
@@ -571,6 +591,7 @@ public:
         const size_t N = P.N, LN = (size_t)L * N;
         if (P.scheme == kSchemeBFV) {
             if (rescale) throw std::invalid_argument("rescale is a CKKS operation");
+            const size_t chunk_ = chunk_ops(n, L, false); // this call's chunk size (shadows the member)
             for (u64 off = 0; off < n; off += chunk_) {
                 const u64 nc = std::min<u64>(chunk_, n - off);
                 Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
@@ -586,6 +607,7 @@ public:
         }
         if (rescale && L < 2) throw std::invalid_argument("cannot rescale at the last level");
         Indexer ix{};
+        const size_t chunk_ = chunk_ops(n, L, false); // this call's chunk size (shadows the member)
         for (u64 off = 0; off < n; off += chunk_) {
             const u64 nc = std::min<u64>(chunk_, n - off);
             Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
@@ -645,6 +667,7 @@ public:
         if (L < 2) throw std::invalid_argument("cannot rescale at the last level");
         if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
         const size_t N = P.N, LN = (size_t)L * N;
+        const size_t chunk_ = chunk_ops(n, L, false); // this call's chunk size (shadows the member)
         for (u64 off = 0; off < n; off += chunk_) {
             const u64 nc = std::min<u64>(chunk_, n - off);
             Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
@@ -668,6 +691,7 @@ public:
         if (P.scheme == kSchemeBFV) {
             const uint32_t *gt = gather(elt);
             const size_t LN = (size_t)L * P.N;
+            const size_t chunk_ = chunk_ops(n, L, false); // this call's chunk size (shadows the member)
             for (u64 off = 0; off < n; off += chunk_) {
                 const u64 nc = std::min<u64>(chunk_, n - off);
                 Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
@@ -682,6 +706,7 @@ public:
         const uint32_t *pm = perm(elt);
         const size_t N = P.N, LN = (size_t)L * N;
         Indexer ix{};
+        const size_t chunk_ = chunk_ops(n, L, false); // this call's chunk size (shadows the member)
         for (u64 off = 0; off < n; off += chunk_) {
             const u64 nc = std::min<u64>(chunk_, n - off);
             Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
@@ -1351,7 +1376,7 @@ private:
     size_t bfv_bytes_ = 0;
     std::map<int, BehzDev> behz_;
     std::map<uint32_t, uint32_t *> d_gather_;
-    size_t chunk_ = 256;
+    size_t chunk_ = 1024;
 };
 
 } // namespace he355

@@ -3100,7 +3100,9 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         const u64 tiles = (u64)A.n_tt << env.logn1;
         // enough blocks to keep every CU busy for several rounds, few enough that start-up costs are amortised
         static const u32 og_env = getenv("HE355_K3_OG") ? (u32)atoi(getenv("HE355_K3_OG")) : 0;
-        u32 ogpb = og_env ? og_env : (waves == 8 ? 2 : 4);
+        // (8-wave shape: 4 op-groups per block once a tile has 128 of them -- chunks of 1024 ciphertexts: 50.3 vs 50.9 ms per step
+        // with 2 -- and 2 below that, where 4 measured slower; profiles/r03_chunk_sweep.txt)
+        u32 ogpb = og_env ? og_env : (waves == 8 ? (n_og >= 128 ? 4 : 2) : 4);
         while (ogpb > 1 && tiles * ((n_og + ogpb - 1) / ogpb) < 256u * 6) ogpb >>= 1;
         A.og_per_block = ogpb;
         const u64 n_ogb = (n_og + ogpb - 1) / ogpb;
