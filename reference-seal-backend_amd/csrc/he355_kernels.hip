@@ -2503,8 +2503,20 @@ __global__ void __launch_bounds__(kBlock) k_bfv_tail_sp(const u64 *tpr, u64 *rp,
     for (int a = 0; a < N1; ++a) rp[poly * N + (a << kRowLog) + col] = addmod(c[a], half, Ps.q);
 }
 
+// k_bfv_tail_fin is memory-bound and latency-hidden by occupancy alone: at 101 registers five waves fit a SIMD, and the 6144 waves of
+// BASELINE configs[4]'s calls (64 ciphertexts x 2 x 3 polynomials) ran as one full round plus a fifth of one.  Held to six waves per SIMD
+// (80 registers, 32 spilled) the call is one round: 109 -> 95 us, the matrix product 67.1 -> 65.3 ms.
+#ifndef HE355_TAILFIN_WAVES
+#define HE355_TAILFIN_WAVES 6
+#endif
 template <int LOGN1>
-__global__ void __launch_bounds__(kBlock) k_bfv_tail_fin(const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride, const PrimeDev *primes,
+__global__ void
+#if HE355_TAILFIN_WAVES
+__launch_bounds__(kBlock, HE355_TAILFIN_WAVES)
+#else
+__launch_bounds__(kBlock)
+#endif
+k_bfv_tail_fin(const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride, const PrimeDev *primes,
                                                          const FloorConst *fcs, int L, int K)
 {
     constexpr int N1 = 1 << LOGN1;
