@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential run of the HIP path against the CPU oracle (test tool, GPU box): random ring sizes, prime chains (mixed
 fp64-/u64-engine primes, forced-u64 contexts), levels, batch sizes on both sides of the latency-shape boundary, chunk sizes with
-ragged tails; multiply -> relinearize (-> rescale), relinearize of size-3 ciphertexts, rescale, rotations and rotate_add -- every
-result compared bit for bit.  usage: tools/fuzz_parity.py <seconds> [seed]   (prints one line per case; exit 1 on the first mismatch)"""
+ragged tails; CKKS multiply -> relinearize (-> rescale), relinearize of size-3 ciphertexts, rotations and rotate_add; BFV (30 % of the
+cases) BEHZ multiply, relinearize and a row or column rotation -- every result compared bit for bit.  usage: tools/fuzz_parity.py <seconds> [seed]   (prints one line per case; exit 1 on the first mismatch)"""
 import importlib
 import os
 import sys
@@ -25,6 +25,47 @@ def main():
     case = 0
     while time.time() < t_end:
         case += 1
+        if rng.random() < 0.3:  # BFV: BEHZ multiply, relinearize, a row / column rotation (also added to another ciphertext)
+            N = int(rng.choice([1024, 2048, 4096, 8192]))
+            K = int(rng.integers(2, 6))
+            bits = [int(x) for x in rng.integers(35, 61, K)]
+            pb = int(rng.integers(16, 23))
+            try:
+                g = be.Context(be.SCHEME_BFV, N, bit_sizes=bits, plain_bits=pb, sec128=False, device=0)
+            except be.HE355Error as e:
+                print(f"case {case}: BFV N={N} bits={bits} skipped ({str(e)[:60]})", flush=True)
+                continue
+            o = oracle.Context(oracle.SCHEME_BFV, N, bit_sizes=bits, plain_bits=pb, sec128=False)
+            assert g.moduli == o.moduli and g.t == o.t
+            L, n = g.L, int(rng.choice([1, 2, 3, 5, 9]))
+            g.set_chunk(int(rng.choice([2, 4, 256])))
+            a = np.stack([o.random_poly(rng, L, 2) for _ in range(n)])
+            b = np.stack([o.random_poly(rng, L, 2) for _ in range(n)])
+            da, db = g.to_device(a), g.to_device(b)
+            c3 = g.alloc(n * 3 * L * N)
+            g.bfv_multiply(L, n, da, db, be.Context.pairwise(), c3)
+            got3 = c3.download((n, 3, L, N))
+            ok = all(np.array_equal(got3[r], o.bfv_multiply(a[r], b[r])) for r in range(n))
+            if ok:
+                rk = o.random_kswitch_key(rng)
+                g.set_relin_key(rk)
+                out = g.alloc(n * 2 * L * N)
+                g.relinearize(L, n, c3, out)
+                got = out.download((n, 2, L, N))
+                ok = all(np.array_equal(got[r], o.relinearize(got3[r], rk)) for r in range(n))
+            if ok:
+                elt = 2 * N - 1 if rng.random() < 0.3 else g.galois_elt(int(rng.choice([1, 2, -1, 4])))
+                gk = o.random_kswitch_key(rng)
+                g.set_galois_key(elt, gk)
+                rot = g.alloc(n * 2 * L * N)
+                g.apply_galois(L, n, da, elt, rot)
+                gotr = rot.download((n, 2, L, N))
+                ok = all(np.array_equal(gotr[r], o.apply_galois(a[r], elt, gk)) for r in range(n))
+            print(f"case {case}: BFV N={N} bits={bits} t_bits={pb} L={L} n={n} multiply+relin+galois {'ok' if ok else 'MISMATCH'}", flush=True)
+            g.close()
+            if not ok:
+                return 1
+            continue
         N = int(rng.choice([1024, 2048, 4096, 8192, 16384], p=[0.3, 0.25, 0.2, 0.15, 0.1]))
         n_data = int(rng.integers(1, 6 if N <= 4096 else 4))
         bits = [int(rng.choice([36, 40, 44, 45, 46, 47, 50, 52, 55, 60])) for _ in range(n_data)]
