@@ -205,7 +205,10 @@ int he355_set_dual_stream(he355_ctx *ctx, int on); /* chunks alternate between t
  * Latency category is batch 1: src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:138-141).  Default 8 (HE355_LATENCY_MAX); 0: never.
  * Results are bit-identical either way. */
 int he355_set_latency_max(he355_ctx *ctx, uint64_t n);
-int he355_set_chunk(he355_ctx *ctx, uint64_t ops_per_chunk); /* ops processed per kernel sequence, default 256 (scratch ~ 117 MiB/op at N=2^15, L=16) */
+/* ops processed per kernel sequence: default 1024 (HE355_CHUNK), i.e. BASELINE configs[2]'s batch in one piece (scratch ~ 117 MiB/op at
+ * N=2^15, L=16).  The size actually used is halved until the scratch arena(s) fit in the device memory that is free at the call. */
+int he355_set_chunk(he355_ctx *ctx, uint64_t ops_per_chunk);
+int he355_mem_info(he355_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes); /* hipMemGetInfo of the context's device */
 
 #ifdef __cplusplus
 }

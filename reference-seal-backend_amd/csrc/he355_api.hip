@@ -1489,6 +1489,16 @@ int he355_device_init(he355_ctx *c, int device)
         c->dev.reset(new DeviceContext(*c->params, device));
     });
 }
+int he355_mem_info(he355_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    return guarded([&] {
+        dev(c).use();
+        size_t f = 0, t = 0;
+        HIPCHECK(hipMemGetInfo(&f, &t));
+        if (free_bytes) *free_bytes = f;
+        if (total_bytes) *total_bytes = t;
+    });
+}
 int he355_malloc(he355_ctx *c, uint64_t bytes, void **d_ptr)
 {
     return guarded([&] {

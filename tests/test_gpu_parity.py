@@ -884,3 +884,39 @@ def test_shards_hold_the_global_batch_and_replicated_keys_agree(be):
             assert np.array_equal(so.download_head((sh.n_results, 2, L - 1, N)), r_all[sh.first_result:sh.first_result + sh.n_results]), (world, rank)
             g.close()
     whole.close()
+
+
+def test_chunk_shrinks_until_the_scratch_arenas_fit(be, oracle):
+    """The default chunk is the whole batch up to 1024 ciphertexts (scratch 117 MiB per op at N=2^15, L=16): when the device memory that is
+    free at the call cannot hold the arenas, the chunk is halved until they fit (DeviceContext::chunk_ops) and the results do not change."""
+    N, bits = 32768, [60, 45, 45, 45, 60]
+    g = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, sec128=False, device=0)
+    o = oracle.Context(oracle.SCHEME_CKKS, N, bit_sizes=bits, sec128=False)
+    rng = np.random.default_rng(20261004)
+    L, n = g.L, 200
+    rk = o.random_kswitch_key(rng)
+    g.set_relin_key(rk)
+    base = rand_cts(o, rng, 4, L)
+    a = np.concatenate([base[:2]] * (n // 2))  # few distinct rows, many ops
+    b = np.concatenate([base[2:]] * (n // 2))
+    da, db = g.to_device(a), g.to_device(b)
+    out = g.alloc(n * 2 * (L - 1) * N)
+    g.multiply_relin(L, n, da, db, be.Context.pairwise(), out, rescale=True)  # one chunk of 200: ~3.7 GB of scratch
+    ref = out.download((n, 2, L - 1, N))
+    for r in range(2):
+        assert np.array_equal(ref[r], o.rescale(o.relinearize(o.multiply_ntt(a[r], b[r]), rk))), r
+    g2 = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, sec128=False, device=0)  # a fresh context: no arena yet
+    g2.set_relin_key(rk)
+    da2, db2 = g2.to_device(a), g2.to_device(b)
+    out2 = g2.alloc(n * 2 * (L - 1) * N)
+    free, total = g2.mem_info()
+    keep = 3 << 29  # leave 1.5 GiB: the arena of 200 ops (3.7 GB) does not fit, the two of 25 ops each (0.93 GB) do
+    hog = g2.alloc((free - keep) // 8) if free > 2 * keep else None
+    assert hog is not None
+    free2, _ = g2.mem_info()
+    assert free2 < 2 * keep
+    g2.multiply_relin(L, n, da2, db2, be.Context.pairwise(), out2, rescale=True)
+    got = out2.download((n, 2, L - 1, N))
+    assert np.array_equal(got, ref)
+    g2.close()
+    g.close()
