@@ -172,6 +172,7 @@ public:
                 f.inv_d = (double)inv;
                 f.inv_i = (double)inv / (double)qi;
                 f.half_mod = (qs >> 1) % qi;
+                f.src_mod = qs % qi;
             }
         HIPCHECK(hipMalloc(&d_floor_, K * K * sizeof(FloorConst)));
         HIPCHECK(hipMemcpy(d_floor_, fc.data(), K * K * sizeof(FloorConst), hipMemcpyHostToDevice));
@@ -408,9 +409,25 @@ public:
     // K2, K3, mod-down; result added into B.c01.  with_tail: also start the rescale (tail of prime L-1)
     // rescale_out != null (size-2 result wanted at level L-1): when the fused path applies, the rescale is finished here too
     // and the function returns true (the caller skips rescale_tail).
-    bool key_switch_tail(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail,
-                         hipEvent_t after_k2 = nullptr, u64 *rescale_out = nullptr)
+    // operands of a ct x ct multiply whose c0, c1 k_k1 did not write (tensor_in_k3): the fused k_k3 computes them where it adds them in
+    struct TensorOperands {
+        const u64 *a = nullptr, *b = nullptr;
+        Indexer ix{};
+        u64 op_offset = 0;
+    };
+    // true when key_switch_tail will take a fused path for this batch, i.e. when k_k3's epilogue is where c0, c1 are consumed
+    bool tensor_in_k3(const KernelEnv &env_, int L, u64 nc, const KsBuffers &B) const
     {
+        static const bool on = !(getenv("HE355_C01_RECOMPUTE") && getenv("HE355_C01_RECOMPUTE")[0] == '0');
+        return on && !latency_shape(nc) && k3_can_fuse(env_) && B.c01_item_stride == 2 * (size_t)L * P.N;
+    }
+    bool key_switch_tail(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail,
+                         hipEvent_t after_k2 = nullptr, u64 *rescale_out = nullptr, const TensorOperands *ten = nullptr)
+    {
+        auto with_operands = [&](K3Fuse f) {
+            if (ten) { f.ta = ten->a; f.tb = ten->b; f.tix = ten->ix; f.t_op_offset = ten->op_offset; }
+            return f;
+        };
         const size_t N = P.N, LN = (size_t)L * N;
         const int SP = (int)P.K - 1;
         if (latency_shape(nc)) {
@@ -440,11 +457,11 @@ public:
                 // special prime's sums and the divided-out prime's tail) -- 16 column passes per polynomial instead of 31, and the
                 // mod-down correction slab is neither written for those primes nor read back.
                 launch_floor_cols(env_, SP, 1, nc * 2, B.tpr, B.e, nullptr, 0, 0, /*tgt_first*/ L - 1, /*dst_ntgt*/ L);
-                K3Fuse last{B.e, B.c01, B.c01_item_stride, L - 1, L, nullptr, nullptr};
+                const K3Fuse last = with_operands(K3Fuse{B.e, B.c01, B.c01_item_stride, L - 1, L, nullptr, nullptr});
                 launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &last);
                 launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
                 launch_floor_cols(env_, L - 1, L - 1, nc * 2, S.rlr, S.f, nullptr, 0, 0, 0, L - 1, /*src2*/ B.tpr, SP);
-                K3Fuse rest{B.e, B.c01, B.c01_item_stride, 0, L - 1, S.f, rescale_out};
+                const K3Fuse rest = with_operands(K3Fuse{B.e, B.c01, B.c01_item_stride, 0, L - 1, S.f, rescale_out});
                 launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &rest);
                 return true;
             }
@@ -452,19 +469,20 @@ public:
             if (rescale_out && L >= 2) {
                 // ... and the rescale too: the last data prime's tiles first (mod-down only), their inverse transform and the
                 // second correction slab, then all other primes with BOTH floor steps finished in the epilogue -> rescale_out
-                K3Fuse last{B.e, B.c01, B.c01_item_stride, L - 1, L, nullptr, nullptr};
+                const K3Fuse last = with_operands(K3Fuse{B.e, B.c01, B.c01_item_stride, L - 1, L, nullptr, nullptr});
                 launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &last);
                 launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
                 launch_floor_cols(env_, L - 1, L - 1, nc * 2, S.rlr, S.f, B.e, SP, L); // combined correction: delta2 + P^-1 * delta1
-                K3Fuse rest{B.e, B.c01, B.c01_item_stride, 0, L - 1, S.f, rescale_out};
+                const K3Fuse rest = with_operands(K3Fuse{B.e, B.c01, B.c01_item_stride, 0, L - 1, S.f, rescale_out});
                 launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &rest);
                 return true;
             }
-            K3Fuse fuse{B.e, B.c01, B.c01_item_stride, 0, L, nullptr, nullptr};
+            const K3Fuse fuse = with_operands(K3Fuse{B.e, B.c01, B.c01_item_stride, 0, L, nullptr, nullptr});
             launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &fuse);
             if (with_tail) launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
             return false;
         }
+        if (ten) throw std::logic_error("key_switch_tail: c0, c1 were left to a fused k_k3 that is not running");
         launch_k3(env_, L, nc, B, key);
         launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
         return key_switch_floor_rows(env_, L, nc, S, B, with_tail);
@@ -561,6 +579,15 @@ public:
                 HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
             }
         }
+        // k_k3 reads the operand rows while it writes results: only when `out` is a slab of its own (it always was meant to be)
+        bool out_overlaps_operands = false;
+        if (n) {
+            auto overlap = [](const u64 *p, size_t np, const u64 *q, size_t nq) { return p < q + nq && q < p + np; };
+            const size_t out_words = n * 2 * (size_t)(rescale ? L - 1 : L) * N;
+            const u64 a_lo = idx_a(ix, 0), a_hi = idx_a(ix, n - 1), b_lo = ix.pairwise ? ix.b_base : ix.b_base, b_hi = ix.pairwise ? ix.b_base + n - 1 : ix.b_base + std::min<u64>(n, ix.b1) - 1;
+            out_overlaps_operands = overlap(out, out_words, a + a_lo * 2 * LN, (size_t)(a_hi - a_lo + 1) * 2 * LN) ||
+                                    overlap(out, out_words, b + b_lo * 2 * LN, (size_t)(b_hi - b_lo + 1) * 2 * LN);
+        }
         u64 ci = 0;
         for (u64 off = 0; off < n; off += chunk_, ++ci) {
             const u64 nc = std::min<u64>(chunk_, n - off);
@@ -569,10 +596,15 @@ public:
             Scratch S = scratch(std::min<u64>(chunk_, n), L, which);
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
-            launch_k1(env, L, K1_MUL, nc, off, a, b, ix, nullptr, B);
+            // c0, c1 of the tensor product: written by k_k1, or (fused key switch) computed by k_k3 where it adds them in -- k_k1 is
+            // HBM-bound and then reads half and writes a third of what it did, k_k3 is not and reads the operand rows instead of c01
+            const bool in_k3 = tensor_in_k3(env, L, nc, B) && !out_overlaps_operands;
+            TensorOperands ten;
+            ten.a = a; ten.b = b; ten.ix = ix; ten.op_offset = off;
+            launch_k1(env, L, K1_MUL, nc, off, a, b, ix, nullptr, B, nullptr, in_k3);
             const bool fork_here = dual && stagger && ci == 0;
             u64 *ro = rescale ? out + off * 2 * (size_t)(L - 1) * N : nullptr;
-            const bool done = key_switch_tail(env, L, nc, S, B, d_relin_, rescale, fork_here ? ev_fork_ : nullptr, ro);
+            const bool done = key_switch_tail(env, L, nc, S, B, d_relin_, rescale, fork_here ? ev_fork_ : nullptr, ro, in_k3 ? &ten : nullptr);
             if (fork_here) HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
             if (rescale && !done) rescale_tail(env, L, 2, nc, S, B.c01, 2 * LN, ro);
         }

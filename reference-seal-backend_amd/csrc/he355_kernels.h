@@ -13,7 +13,7 @@ struct FloorConst {
     u64 inv, inv_shoup;   // s^-1 mod q_i (+ Shoup quotient)
     double inv_d, inv_i;  // same for the fp64 engine: value and fl(value/q_i)
     u64 half_mod;         // floor(s/2) mod q_i
-    u64 pad_;
+    u64 src_mod;          // s mod q_i
 };
 
 // Optional HIP-event probe around the launches of the dominant kernel (k_k3, fp64 engine): bench.py reports that
@@ -75,7 +75,8 @@ enum K1Mode { K1_MUL = 0, K1_CT3 = 1, K1_GALOIS = 2 };
 // GALOIS: `a` is [n][2][L][N], perm = device permutation table (NTT-form gather); optional addend [n][2][L][N] (indexed like `a`):
 // the rotated ciphertext starts from it, i.e. the pipeline computes addend + rotate(a).
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix,
-               const uint32_t *perm, const KsBuffers &buf, const u64 *addend = nullptr);
+               const uint32_t *perm, const KsBuffers &buf, const u64 *addend = nullptr, bool no_c01 = false);
+// (no_c01, K1_MUL only: just the key-switch target c2 = a1 b1 is produced; c0, c1 are computed where they are consumed, K3Fuse::ta)
 // K2: finish iNTT of each digit, lift to every key prime, forward column pass -> d
 // src_is_coeff (BFV): `src` already holds coefficient-form digits [op][L][N] (op stride src_op_stride) and every
 // (prime, digit) pair is lifted, including the digit's own prime
@@ -97,6 +98,12 @@ struct K3Fuse {
     // delta2 + P^-1 * delta1; out [n_ops][2][L-1][N].  Null: mod-down only (correction from cols).
     const u64 *cols2;
     u64 *out;
+    // ct x ct multiply (he355_multiply_relin): the addend of the floor step -- c0 = a0 b0, c1 = a0 b1 + a1 b0 -- is computed here from the
+    // operand rows instead of being written by k_k1 and read back (k_k1 is HBM-bound, this kernel is not).  Null: the addend is read
+    // from c01.  ta / tb: the operand slabs [.][2][L][N], tix / t_op_offset: result r = t_op_offset + op multiplies a[ia(r)] by b[ib(r)].
+    const u64 *ta = nullptr, *tb = nullptr;
+    Indexer tix{};
+    u64 t_op_offset = 0;
 };
 bool k3_can_fuse(const KernelEnv &env);
 // n_split > 1 (latency shape, unfused only): the digits of every tile are cut into n_split groups, one single-wave block per (tile, op,

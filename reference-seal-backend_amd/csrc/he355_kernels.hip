@@ -135,6 +135,9 @@ constexpr bool kKeyShare = HE355_KSHARE != 0 && kXlT1 && kXlT2;
 #define HE355_KEY_EARLY 1
 #endif
 constexpr bool kKeyEarly = HE355_KEY_EARLY != 0;
+#ifndef HE355_TENSOR_INIT_EARLY
+#define HE355_TENSOR_INIT_EARLY 0 // 1: the ct x ct multiply's operand rows are fetched before the first digit row's DMA is issued, 0: after
+#endif
 // HE355_ACC_RUN: the u64 engine adds kAccRun key products to an accumulator between two range reductions (ArU64::acc_mac_lazy; needs the
 // exact key quotients k_key_quotients writes) instead of reducing after every product: k_k3<ArU64> 7.69 -> 7.47 ms per step.
 // HE355_KEY_EARLY_U64: polynomial 0's key row and quotient row are requested before the second exchange of the row pass, polynomial
@@ -713,6 +716,7 @@ __global__ void __launch_bounds__(kBlock) k_mul3_acc(const u64 *a, const u64 *b,
 // =======================================================================================================
 // K1: (multiply | take ct3 | Galois-permute) + inverse row pass of the key-switch target
 // =======================================================================================================
+constexpr int K1_MUL_C2 = 3; // k_k1 instantiation of K1_MUL with no_c01 (its own register allocation: the full tensor keeps three waves per SIMD)
 struct K1Args {
     const u64 *addend; // GALOIS mode, optional: [n][2][L][N] added to the rotated ciphertext (c0' + addend0, addend1); null: (c0', 0)
     const u64 *a, *b;
@@ -740,13 +744,23 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
     u64 *c2rp = A.c2r + op * P1 + roff;
     T x[kRowE];
     u64 v0[kRowE], v1[kRowE];
-    if (MODE == K1_MUL) {
+    if (MODE == K1_MUL || MODE == K1_MUL_C2) {
         const u64 r = A.op_offset + op;
         const u64 *pa = A.a + idx_a(A.ix, r) * 2 * P1 + roff, *pb = A.b + idx_b(A.ix, r) * 2 * P1 + roff;
         u64 a0[kRowE], a1[kRowE], b0[kRowE], b1[kRowE];
+        u64 v2[kRowE];
+        if (MODE == K1_MUL_C2) { // only c2 = a1 b1 (c0, c1 are computed by the fused k_k3 from the operands): half the reads, a third of the writes
+            load_rowC(pa + P1, lane, a1);
+            load_rowC(pb + P1, lane, b1);
+#pragma unroll
+            for (int r2 = 0; r2 < kRowE; ++r2) {
+                v2[r2] = ar.dy_out(ar.dy_mul(ar.dy_in(a1[r2]), ar.dy_in(b1[r2])));
+                x[r2] = ar.from_canon(v2[r2]);
+            }
+            if (valid) store_rowC(c2np, lane, v2);
+        } else {
         load_rowC(pa, lane, a0); load_rowC(pa + P1, lane, a1);
         load_rowC(pb, lane, b0); load_rowC(pb + P1, lane, b1);
-        u64 v2[kRowE];
 #pragma unroll
         for (int r2 = 0; r2 < kRowE; ++r2) {
             const T x0 = ar.dy_in(a0[r2]), x1 = ar.dy_in(a1[r2]), y0 = ar.dy_in(b0[r2]), y1 = ar.dy_in(b1[r2]);
@@ -756,6 +770,7 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
             x[r2] = ar.from_canon(v2[r2]);
         }
         if (valid) { store_rowC(c0p, lane, v0); store_rowC(c1p, lane, v1); store_rowC(c2np, lane, v2); }
+        }
     } else if (MODE == K1_CT3) {
         const u64 *pa = A.a + (A.op_offset + op) * 3 * P1 + roff;
         u64 v2[kRowE];
@@ -1464,6 +1479,7 @@ struct K3Args {
     u64 *c01; u64 c01_item_stride; // FUSE: polys that receive (T - NTT(cols)) * P^-1
     const FloorConst *fc;          // FUSE: floor constants [K][K]
     const u64 *cols2; u64 *out2;   // FUSE + rescale: second correction slab [n_ops*2][L-1][N] and the final output [n_ops][2][L-1][N]
+    const u64 *ta, *tb; Indexer tix; u64 t_op_offset; // FUSE, ct x ct multiply: the floor step's addend is a0 b0 / a0 b1 + a1 b0 of these operands (K3Fuse::ta); ta null: read from c01
     const u64 *keyq;   // Shoup quotients of the key residues under the u64-engine primes: [L_top][2][n_q][N]
     int n_q;           // u64-engine primes in the key chain
     unsigned char q_slot[64]; // tt_list[k] -> its index among them
@@ -1493,9 +1509,12 @@ struct K3Args {
 // chunk-swizzled (kswz) so that the layout-C reads (a quad of lanes = 128 consecutive bytes, quads 512 bytes apart) are
 // conflict-free ds_read_b128.  Needs the exchange buffers' LDS, i.e. the cross-lane transposes (HE355_XCHG = 3).
 __device__ __forceinline__ u32 kswz(u32 quad) { return (quad & 1u) | ((quad & 2u) << 2); } // XOR mask on the 16-byte chunk index: 0, 1, 8, 9
-template <class Ar, int U, int WAVES, bool STAGE, bool FUSE = false, bool KSHARE = false>
+// TENSOR (FUSE only): the launch belongs to a ct x ct multiply whose c0, c1 this kernel computes from the operand rows (K3Args::ta); an
+// instantiation of its own, so that the other users of the fused kernel keep their register allocation.
+template <class Ar, int U, int WAVES, bool STAGE, bool FUSE = false, bool KSHARE = false, bool TENSOR = false>
 __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *primes)
 {
+    static_assert(!TENSOR || FUSE, "the operand rows enter through the fused epilogue's sums");
     static_assert(!KSHARE || (U == 1 && STAGE && WAVES == 8), "shared key staging is written for the 8-wave staged shape");
     constexpr int kWaves = WAVES, kBlock = WAVES * 64; // this kernel's own block shape (shadows the file-wide one)
     typedef typename Ar::T T;
@@ -1556,6 +1575,31 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         Acc acc0[kRowE], acc1[kRowE];
 #pragma unroll
         for (int r = 0; r < kRowE; ++r) { acc0[r] = 0; acc1[r] = 0; }
+        auto tensor_init = [&]() {
+            if constexpr (TENSOR) {
+                // ct x ct multiply: c0 = a0 b0 and c1 = a0 b1 + a1 b0 are not read back from k_k1's c01 rows, they start the sums.  The floor
+                // step computes (sums - x) * P^-1 + addend (mod-down) or ((sums * P^-1 + addend) - x) * q_last^-1 (with the rescale): adding
+                // addend * P to the sums gives the same residue with a zero addend, and here no other row is live yet (the first digit row
+                // is on its way into LDS meanwhile).  (The identity is exact modular arithmetic: the canonical result is the same integer.)
+                const u64 tr = A.t_op_offset + op;
+                const u64 LNt = (u64)A.L * N;
+                const u64 *pa = A.ta + idx_a(A.tix, tr) * 2 * LNt + (u64)tt * N + rowoff;
+                const u64 *pb = A.tb + idx_b(A.tix, tr) * 2 * LNt + (u64)tt * N + rowoff;
+                u64 a0[kRowE], a1[kRowE], b0[kRowE], b1[kRowE];
+                load_rowC(pa, lane, a0); load_rowC(pb, lane, b0);
+                load_rowC(pa + LNt, lane, a1); load_rowC(pb + LNt, lane, b1);
+                const T pq = ar.dy_in(A.fc[(A.K - 1) * A.K + t].src_mod); // P mod q_t
+#pragma unroll
+                for (int r = 0; r < kRowE; ++r) {
+                    const T x0 = ar.dy_in(a0[r]), x1 = ar.dy_in(a1[r]), y0 = ar.dy_in(b0[r]), y1 = ar.dy_in(b1[r]);
+                    acc0[r] = ar.acc_from_lazy(ar.dy_mul(ar.dy_mul(x0, y0), pq));
+                    acc1[r] = ar.acc_from_lazy(ar.dy_mul(ar.dy_add(ar.dy_mul(x0, y1), ar.dy_mul(x1, y0)), pq));
+                }
+            }
+        };
+#if HE355_TENSOR_INIT_EARLY
+        tensor_init();
+#endif
         // u64 engine: products added since the accumulators were last brought under 4q (wave-uniform); acc_flush before anything reads them
         constexpr int kRun = kAccRunOn ? Ar::kAccRun : 1;
         int pend = 0;
@@ -1647,6 +1691,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             for (int u = 0; u < U; ++u)
                 if (i_begin + u < i_end) dma_row_to_lds<kDigitPieces>(src_row(digit(i_begin + u)), stage[wave][u], lane);
         }
+#if !HE355_TENSOR_INIT_EARLY
+        tensor_init();
+#endif
         if constexpr (KSHARE) {
             __syncthreads(); // every wave is done with the key buffers of the previous op-group
             if (nd > 0) key_dma(digit(0), 0);
@@ -1774,7 +1821,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 if (i + 1 < n_rows) dma_row_to_lds(row_ptr(i + 1), stage[wave][0], lane);
                 const int k = i - nd;
                 u64 *c01_row = A.c01 + op * A.c01_item_stride + k * LN + (u64)tt * N + rowoff;
-                load_rowC(c01_row, lane, av); // the addend, in flight during the transform
+                // the addend, in flight during the transform -- or nothing: for a ct x ct multiply (A.ta) it entered the accumulators before the digits
+                if constexpr (TENSOR) {
+#pragma unroll
+                    for (int r = 0; r < kRowE; ++r) av[r] = 0;
+                } else {
+                    load_rowC(c01_row, lane, av);
+                }
                 wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
                 const Acc *acc = k == 0 ? acc0 : acc1;
                 if (!resc) {
@@ -2955,9 +3008,10 @@ struct SideFork {
 } // namespace
 
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
-               const KsBuffers &buf, const u64 *addend)
+               const KsBuffers &buf, const u64 *addend, bool no_c01)
 {
     if (!n_ops) return;
+    if (no_c01 && mode != K1_MUL) throw std::runtime_error("no_c01: the ct x ct multiply only");
     SideFork sf(env);
     K1Args A;
     A.a = a; A.b = b; A.ix = ix; A.perm = perm; A.addend = addend;
@@ -2972,11 +3026,13 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
         const dim3 grid(grid_for(jobs, kWaves));
         const hipStream_t st = sf.stream(pass);
         if (pass == 0) {
-            if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
+            if (mode == K1_MUL && no_c01) hipLaunchKernelGGL((k_k1<K1_MUL_C2, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
+            else if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
             else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
             else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
         } else {
-            if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
+            if (mode == K1_MUL && no_c01) hipLaunchKernelGGL((k_k1<K1_MUL_C2, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
+            else if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
             else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
             else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
         }
@@ -3083,6 +3139,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.n_ops = n_ops; A.L = L; A.K = env.K; A.logn1 = env.logn1; A.ckks = env.scheme == 2;
         A.cols = fuse ? fuse->cols : nullptr; A.c01 = fuse ? fuse->c01 : nullptr; A.c01_item_stride = fuse ? fuse->c01_item_stride : 0;
         A.cols2 = fuse ? fuse->cols2 : nullptr; A.out2 = fuse ? fuse->out : nullptr;
+        A.ta = fuse ? fuse->ta : nullptr; A.tb = fuse ? fuse->tb : nullptr; A.tix = fuse ? fuse->tix : Indexer{}; A.t_op_offset = fuse ? fuse->t_op_offset : 0;
         if (fuse && fuse->cols2 && fuse->tt_hi > L - 1) throw std::runtime_error("fused rescale: only primes below the one divided out");
         A.fc = env.floor_consts;
         A.n_split = n_split > 1 ? (pass == 0 ? n_split : n_split_u64) : 1; A.part = split_part;
@@ -3141,7 +3198,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             switch (shape) {
             case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
             case 18:
-                if (fuse) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true, kKeyShare, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                else if (fuse) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 else if (staged) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, false, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 else hipLaunchKernelGGL((k_k3<ArF64, 1, 8, false>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 break;
@@ -3151,7 +3209,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             switch (shape) {
             case 14: hipLaunchKernelGGL((k_k3<ArU64, 1, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
             case 18:
-                if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true, kKeyShare, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                else if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 else if (staged) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, false, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 else hipLaunchKernelGGL((k_k3<ArU64, 1, 8, false>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
                 break;
