@@ -749,7 +749,7 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
         const u64 *pa = A.a + idx_a(A.ix, r) * 2 * P1 + roff, *pb = A.b + idx_b(A.ix, r) * 2 * P1 + roff;
         u64 a0[kRowE], a1[kRowE], b0[kRowE], b1[kRowE];
         u64 v2[kRowE];
-        if (MODE == K1_MUL_C2) { // only c2 = a1 b1 (c0, c1 are computed by the fused k_k3 from the operands): half the reads, a third of the writes
+        if (MODE == K1_MUL_C2) { // only the key-switch target c2 = a1 b1, through the inverse row pass (c0, c1 are computed by the fused k_k3 from the operands): half the reads, a quarter of the writes
             load_rowC(pa + P1, lane, a1);
             load_rowC(pb + P1, lane, b1);
 #pragma unroll
@@ -757,7 +757,7 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
                 v2[r2] = ar.dy_out(ar.dy_mul(ar.dy_in(a1[r2]), ar.dy_in(b1[r2])));
                 x[r2] = ar.from_canon(v2[r2]);
             }
-            if (valid) store_rowC(c2np, lane, v2);
+            // (no c2n row either: the fused k_k3 of a ct x ct multiply forms a1 b1 itself, from the rows it reads for c0, c1)
         } else {
         load_rowC(pa, lane, a0); load_rowC(pa + P1, lane, a1);
         load_rowC(pb, lane, b0); load_rowC(pb + P1, lane, b1);
@@ -1708,12 +1708,26 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             }
         }
         if (has_own && grp == 0) {
-            T x[kRowE];
-            u64 v[kRowE];
-            load_rowC(A.c2n + (op * A.L + tt) * N + rowoff, lane, v);
+            if constexpr (TENSOR) {
+                // the digit that lives under this prime is c2 = a1 b1 in NTT form: formed here (k_k1 writes no c2n row for a ct x ct
+                // multiply) from the two operand rows tensor_init has just pulled through the caches
+                const u64 tr = A.t_op_offset + op;
+                const u64 LNt = (u64)A.L * N;
+                u64 a1[kRowE], b1[kRowE];
+                load_rowC(A.ta + (idx_a(A.tix, tr) * 2 + 1) * LNt + (u64)tt * N + rowoff, lane, a1);
+                load_rowC(A.tb + (idx_b(A.tix, tr) * 2 + 1) * LNt + (u64)tt * N + rowoff, lane, b1);
+                T x[kRowE];
 #pragma unroll
-            for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
-            mac_digit(x, tt);
+                for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(ar.dy_out(ar.dy_mul(ar.dy_in(a1[r]), ar.dy_in(b1[r])))); // as the c2n row would read
+                mac_digit(x, tt);
+            } else {
+                T x[kRowE];
+                u64 v[kRowE];
+                load_rowC(A.c2n + (op * A.L + tt) * N + rowoff, lane, v);
+#pragma unroll
+                for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
+                mac_digit(x, tt);
+            }
         }
         if constexpr (FUSE) {
             // One digit per wave, mod-down (and rescale) finished here.  The correction rows ride the same pipeline as the digit
