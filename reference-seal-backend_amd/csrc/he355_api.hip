@@ -414,6 +414,10 @@ public:
         const u64 *a = nullptr, *b = nullptr;
         Indexer ix{};
         u64 op_offset = 0;
+        // rotations (a, b null): polynomial 1 of the ciphertext k_k1 prepares is zero (1) or the addend's (2, c1_src = the addend rows of
+        // this chunk) and is taken from there by the fused k_k3 instead of being written into c01 by k_k1
+        int c1_mode = 0;
+        const u64 *c1_src = nullptr;
     };
     // true when key_switch_tail will take a fused path for this batch, i.e. when k_k3's epilogue is where c0, c1 are consumed
     bool tensor_in_k3(const KernelEnv &env_, int L, u64 nc, const KsBuffers &B) const
@@ -425,7 +429,7 @@ public:
                          hipEvent_t after_k2 = nullptr, u64 *rescale_out = nullptr, const TensorOperands *ten = nullptr)
     {
         auto with_operands = [&](K3Fuse f) {
-            if (ten) { f.ta = ten->a; f.tb = ten->b; f.tix = ten->ix; f.t_op_offset = ten->op_offset; }
+            if (ten) { f.ta = ten->a; f.tb = ten->b; f.tix = ten->ix; f.t_op_offset = ten->op_offset; f.c1_mode = ten->c1_mode; f.c1_src = ten->c1_src; }
             return f;
         };
         const size_t N = P.N, LN = (size_t)L * N;
@@ -745,8 +749,14 @@ public:
             KsBuffers B = S.ks;
             B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
             const KernelEnv env = batch_env(nc);
-            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend);
-            key_switch_tail(env, L, nc, S, B, key, false);
+            // polynomial 1 of the rotated ciphertext is zero (or the addend's): on the fused path k_k1 does not write it and k_k3 takes it
+            // from where it is (the addend may be `out`: the wave that reads a row is the one that writes it, afterwards)
+            const bool c1_in_k3 = tensor_in_k3(env, L, nc, B);
+            TensorOperands ten;
+            ten.c1_mode = addend ? 2 : 1;
+            ten.c1_src = addend ? addend + off * 2 * LN : nullptr;
+            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend, false, c1_in_k3);
+            key_switch_tail(env, L, nc, S, B, key, false, nullptr, nullptr, c1_in_k3 ? &ten : nullptr);
         }
         HIPCHECK(hipGetLastError());
     }

@@ -75,8 +75,9 @@ enum K1Mode { K1_MUL = 0, K1_CT3 = 1, K1_GALOIS = 2 };
 // GALOIS: `a` is [n][2][L][N], perm = device permutation table (NTT-form gather); optional addend [n][2][L][N] (indexed like `a`):
 // the rotated ciphertext starts from it, i.e. the pipeline computes addend + rotate(a).
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix,
-               const uint32_t *perm, const KsBuffers &buf, const u64 *addend = nullptr, bool no_c01 = false);
-// (no_c01, K1_MUL only: just the key-switch target c2 = a1 b1 is produced; c0, c1 are computed where they are consumed, K3Fuse::ta)
+               const uint32_t *perm, const KsBuffers &buf, const u64 *addend = nullptr, bool no_c01 = false, bool no_c1 = false);
+// (no_c01, K1_MUL only: just the key-switch target c2 = a1 b1 is produced; c0, c1 are computed where they are consumed, K3Fuse::ta.
+//  no_c1, K1_GALOIS only: polynomial 1 of c01 -- zeros, or the addend's -- is not written; the fused k_k3 takes it from K3Fuse::c1_mode)
 // K2: finish iNTT of each digit, lift to every key prime, forward column pass -> d
 // src_is_coeff (BFV): `src` already holds coefficient-form digits [op][L][N] (op stride src_op_stride) and every
 // (prime, digit) pair is lifted, including the digit's own prime
@@ -104,6 +105,10 @@ struct K3Fuse {
     const u64 *ta = nullptr, *tb = nullptr;
     Indexer tix{};
     u64 t_op_offset = 0;
+    // rotations: polynomial 1 of the ciphertext the switched key part is added into is zero, or polynomial 1 of the rotation's addend --
+    // k_k1 neither writes nor copies it.  c1_mode 0: read from c01 (as polynomial 0 always is); 1: zero; 2: row of c1_src [n_ops][2][L][N]
+    int c1_mode = 0;
+    const u64 *c1_src = nullptr;
 };
 bool k3_can_fuse(const KernelEnv &env);
 // n_split > 1 (latency shape, unfused only): the digits of every tile are cut into n_split groups, one single-wave block per (tile, op,

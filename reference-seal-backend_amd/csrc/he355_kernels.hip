@@ -726,6 +726,7 @@ struct K1Args {
     u64 *c2n, *c2r;
     u64 n_ops, op_offset;
     int L, logn1, mode;
+    int no_c1;                 // K1_GALOIS: polynomial 1 of c01 (zeros / the addend's) is left to the fused k_k3 (K3Fuse::c1_mode)
     int n_i;                   // residues handled by this launch (one arithmetic engine per launch)
     unsigned char i_list[64];
 };
@@ -794,11 +795,15 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
             const u64 *ad = A.addend + (A.op_offset + op) * 2 * P1 + roff;
             u64 a0[kRowE];
             load_rowC(ad, lane, a0);
-            load_rowC(ad + P1, lane, v1);
+            if (!A.no_c1) load_rowC(ad + P1, lane, v1);
 #pragma unroll
             for (int r2 = 0; r2 < kRowE; ++r2) v0[r2] = addmod(v0[r2], a0[r2], P.q);
         }
-        if (valid) { store_rowC(c0p, lane, v0); store_rowC(c1p, lane, v1); store_rowC(c2np, lane, v2); }
+        if (valid) {
+            store_rowC(c0p, lane, v0);
+            if (!A.no_c1) store_rowC(c1p, lane, v1);
+            store_rowC(c2np, lane, v2);
+        }
     }
     const bool last = A.logn1 == 0;
     wave_rows_inv(ar, P, last, n1 + a_row, lane, lds, x);
@@ -1479,6 +1484,7 @@ struct K3Args {
     u64 *c01; u64 c01_item_stride; // FUSE: polys that receive (T - NTT(cols)) * P^-1
     const FloorConst *fc;          // FUSE: floor constants [K][K]
     const u64 *cols2; u64 *out2;   // FUSE + rescale: second correction slab [n_ops*2][L-1][N] and the final output [n_ops][2][L-1][N]
+    int c1_mode; const u64 *c1_src; // FUSE, rotations: the floor step's addend of polynomial 1 is zero (1) / a row of c1_src (2) instead of a c01 row (0)
     const u64 *ta, *tb; Indexer tix; u64 t_op_offset; // FUSE, ct x ct multiply: the floor step's addend is a0 b0 / a0 b1 + a1 b0 of these operands (K3Fuse::ta); ta null: read from c01
     const u64 *keyq;   // Shoup quotients of the key residues under the u64-engine primes: [L_top][2][n_q][N]
     int n_q;           // u64-engine primes in the key chain
@@ -1839,8 +1845,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 if constexpr (TENSOR) {
 #pragma unroll
                     for (int r = 0; r < kRowE; ++r) av[r] = 0;
-                } else {
-                    load_rowC(c01_row, lane, av);
+                } else if (k == 1 && A.c1_mode == 1) { // a rotation without addend: polynomial 1 starts from zero (k_k1 wrote no row of zeros)
+#pragma unroll
+                    for (int r = 0; r < kRowE; ++r) av[r] = 0;
+                } else { // ... with addend: its polynomial 1, read where it lies
+                    load_rowC(k == 1 && A.c1_mode == 2 ? A.c1_src + (op * 2 + 1) * LN + (u64)tt * N + rowoff : c01_row, lane, av);
                 }
                 wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
                 const Acc *acc = k == 0 ? acc0 : acc1;
@@ -3022,12 +3031,14 @@ struct SideFork {
 } // namespace
 
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
-               const KsBuffers &buf, const u64 *addend, bool no_c01)
+               const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1)
 {
     if (!n_ops) return;
     if (no_c01 && mode != K1_MUL) throw std::runtime_error("no_c01: the ct x ct multiply only");
+    if (no_c1 && mode != K1_GALOIS) throw std::runtime_error("no_c1: rotations only");
     SideFork sf(env);
     K1Args A;
+    A.no_c1 = no_c1 ? 1 : 0;
     A.a = a; A.b = b; A.ix = ix; A.perm = perm; A.addend = addend;
     A.c01 = buf.c01; A.c01_item_stride = buf.c01_item_stride; A.c2n = buf.c2n; A.c2r = buf.c2r;
     A.n_ops = n_ops; A.op_offset = op_offset; A.L = L; A.logn1 = env.logn1; A.mode = (int)mode;
@@ -3153,6 +3164,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.n_ops = n_ops; A.L = L; A.K = env.K; A.logn1 = env.logn1; A.ckks = env.scheme == 2;
         A.cols = fuse ? fuse->cols : nullptr; A.c01 = fuse ? fuse->c01 : nullptr; A.c01_item_stride = fuse ? fuse->c01_item_stride : 0;
         A.cols2 = fuse ? fuse->cols2 : nullptr; A.out2 = fuse ? fuse->out : nullptr;
+        A.c1_mode = fuse ? fuse->c1_mode : 0; A.c1_src = fuse ? fuse->c1_src : nullptr;
         A.ta = fuse ? fuse->ta : nullptr; A.tb = fuse ? fuse->tb : nullptr; A.tix = fuse ? fuse->tix : Indexer{}; A.t_op_offset = fuse ? fuse->t_op_offset : 0;
         if (fuse && fuse->cols2 && fuse->tt_hi > L - 1) throw std::runtime_error("fused rescale: only primes below the one divided out");
         A.fc = env.floor_consts;
