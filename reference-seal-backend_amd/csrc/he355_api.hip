@@ -569,15 +569,15 @@ public:
         const size_t N = P.N, LN = (size_t)L * N;
         // Alternate chunks between two streams, each with its own scratch arena: the ALU-bound key-product kernel
         // of one chunk overlaps the HBM-bound multiply / digit-lift / floor kernels of the other.
-        const size_t chunk_ = chunk_ops(n, L, dual_stream_); // (shadows the member: this call's chunk size)
-        const bool dual = dual_stream_ && n > chunk_;
+        const size_t chunk = chunk_ops(n, L, dual_stream_); // this call's chunk size
+        const bool dual = dual_stream_ && n > chunk;
         // The second stream starts half a pipeline late (after the first chunk's K1+K2 on the first stream): from then on
         // one stream's ALU-bound kernels (K3, floor column pass) run beside the other's HBM-bound ones (K1, K2, floor row pass)
         // instead of beside their own kind.
         static const bool stagger = !(getenv("HE355_STAGGER") && getenv("HE355_STAGGER")[0] == '0');
         if (dual) {
-            (void)scratch(std::min<u64>(chunk_, n), L, 0);
-            (void)scratch(std::min<u64>(chunk_, n), L, 1);
+            (void)scratch(std::min<u64>(chunk, n), L, 0);
+            (void)scratch(std::min<u64>(chunk, n), L, 1);
             if (!stagger) {
                 HIPCHECK(hipEventRecord(ev_fork_, stream_));
                 HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
@@ -593,11 +593,11 @@ public:
                                     overlap(out, out_words, b + b_lo * 2 * LN, (size_t)(b_hi - b_lo + 1) * 2 * LN);
         }
         u64 ci = 0;
-        for (u64 off = 0; off < n; off += chunk_, ++ci) {
-            const u64 nc = std::min<u64>(chunk_, n - off);
+        for (u64 off = 0; off < n; off += chunk, ++ci) {
+            const u64 nc = std::min<u64>(chunk, n - off);
             const int which = dual ? (int)(ci & 1) : 0;
             const KernelEnv env = batch_env(nc, which);
-            Scratch S = scratch(std::min<u64>(chunk_, n), L, which);
+            Scratch S = scratch(std::min<u64>(chunk, n), L, which);
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
             // c0, c1 of the tensor product: written by k_k1, or (fused key switch) computed by k_k3 where it adds them in -- k_k1 is
@@ -627,10 +627,10 @@ public:
         const size_t N = P.N, LN = (size_t)L * N;
         if (P.scheme == kSchemeBFV) {
             if (rescale) throw std::invalid_argument("rescale is a CKKS operation");
-            const size_t chunk_ = chunk_ops(n, L, false); // this call's chunk size (shadows the member)
-            for (u64 off = 0; off < n; off += chunk_) {
-                const u64 nc = std::min<u64>(chunk_, n - off);
-                Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
+            const size_t chunk = chunk_ops(n, L, false); // this call's chunk size
+            for (u64 off = 0; off < n; off += chunk) {
+                const u64 nc = std::min<u64>(chunk, n - off);
+                Scratch S = scratch(std::min<u64>(chunk, n), L); // arena sized for the batch actually processed
                 KsBuffers B = S.ks;
                 B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
                 const u64 *src = ct3 + off * 3 * LN;
@@ -643,10 +643,10 @@ public:
         }
         if (rescale && L < 2) throw std::invalid_argument("cannot rescale at the last level");
         Indexer ix{};
-        const size_t chunk_ = chunk_ops(n, L, false); // this call's chunk size (shadows the member)
-        for (u64 off = 0; off < n; off += chunk_) {
-            const u64 nc = std::min<u64>(chunk_, n - off);
-            Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
+        const size_t chunk = chunk_ops(n, L, false); // this call's chunk size
+        for (u64 off = 0; off < n; off += chunk) {
+            const u64 nc = std::min<u64>(chunk, n - off);
+            Scratch S = scratch(std::min<u64>(chunk, n), L); // arena sized for the batch actually processed
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
             const KernelEnv env = batch_env(nc);
@@ -703,10 +703,10 @@ public:
         if (L < 2) throw std::invalid_argument("cannot rescale at the last level");
         if (size < 1 || size > 3) throw std::invalid_argument("ciphertext size must be 1..3");
         const size_t N = P.N, LN = (size_t)L * N;
-        const size_t chunk_ = chunk_ops(n, L, false); // this call's chunk size (shadows the member)
-        for (u64 off = 0; off < n; off += chunk_) {
-            const u64 nc = std::min<u64>(chunk_, n - off);
-            Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
+        const size_t chunk = chunk_ops(n, L, false); // this call's chunk size
+        for (u64 off = 0; off < n; off += chunk) {
+            const u64 nc = std::min<u64>(chunk, n - off);
+            Scratch S = scratch(std::min<u64>(chunk, n), L); // arena sized for the batch actually processed
             const u64 *src = in + off * size * LN;
             launch_rows_inv_select(env_, L - 1, nc * size, src + (size_t)(L - 1) * N, LN, S.rlr);
             rescale_tail(env_, L, size, nc, S, src, (u64)size * LN, out + off * size * (size_t)(L - 1) * N);
@@ -727,10 +727,10 @@ public:
         if (P.scheme == kSchemeBFV) {
             const uint32_t *gt = gather(elt);
             const size_t LN = (size_t)L * P.N;
-            const size_t chunk_ = chunk_ops(n, L, false); // this call's chunk size (shadows the member)
-            for (u64 off = 0; off < n; off += chunk_) {
-                const u64 nc = std::min<u64>(chunk_, n - off);
-                Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
+            const size_t chunk = chunk_ops(n, L, false); // this call's chunk size
+            for (u64 off = 0; off < n; off += chunk) {
+                const u64 nc = std::min<u64>(chunk, n - off);
+                Scratch S = scratch(std::min<u64>(chunk, n), L); // arena sized for the batch actually processed
                 KsBuffers B = S.ks;
                 B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
                 launch_bfv_galois(env_, L, nc, in + off * 2 * LN, gt, B.c01, B.c01_item_stride, B.c2n, addend ? addend + off * 2 * LN : nullptr);
@@ -742,10 +742,10 @@ public:
         const uint32_t *pm = perm(elt);
         const size_t N = P.N, LN = (size_t)L * N;
         Indexer ix{};
-        const size_t chunk_ = chunk_ops(n, L, false); // this call's chunk size (shadows the member)
-        for (u64 off = 0; off < n; off += chunk_) {
-            const u64 nc = std::min<u64>(chunk_, n - off);
-            Scratch S = scratch(std::min<u64>(chunk_, n), L); // arena sized for the batch actually processed
+        const size_t chunk = chunk_ops(n, L, false); // this call's chunk size
+        for (u64 off = 0; off < n; off += chunk) {
+            const u64 nc = std::min<u64>(chunk, n - off);
+            Scratch S = scratch(std::min<u64>(chunk, n), L); // arena sized for the batch actually processed
             KsBuffers B = S.ks;
             B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
             const KernelEnv env = batch_env(nc);
@@ -1042,7 +1042,14 @@ public:
         const BehzDev &Z = behz(L);
         const size_t N = P.N, S = (size_t)L + 1;
         const size_t per_op = (4 * L + 4 * S + 3 * L + 3 * S) * N;
-        const size_t c = std::min<size_t>(chunk_, (size_t)n ? (size_t)n : 1);
+        size_t c = std::min<size_t>(chunk_, (size_t)n ? (size_t)n : 1);
+        if (per_op * c * 8 > bfv_bytes_) { // as chunk_ops: halved until the arena fits in the memory that is free now
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t avail = (size_t)((double)(free_b + bfv_bytes_) * 0.9);
+                while (c > 32 && per_op * c * 8 > avail) c = (c + 1) / 2;
+            }
+        }
         if (per_op * c * 8 > bfv_bytes_) {
             HIPCHECK(hipStreamSynchronize(stream_));
             if (bfv_scratch_) HIPCHECK(hipFree(bfv_scratch_));
