@@ -920,3 +920,20 @@ def test_chunk_shrinks_until_the_scratch_arenas_fit(be, oracle):
     assert np.array_equal(got, ref)
     g2.close()
     g.close()
+
+
+def test_multiply_relin_into_an_operand_slab(be, oracle):
+    """he355_multiply_relin with `out` = the slab of operand 0 (pairwise, no rescale: same shape): the fused k_k3 reads the operand rows
+    while it writes results, so this call takes the path on which k_k1 forms the tensor first -- and still equals the oracle."""
+    g, o = make_pair(be, oracle, "n8192_default")
+    rng = np.random.default_rng(77)
+    L, n = g.L, 12  # throughput shape
+    rk = o.random_kswitch_key(rng)
+    g.set_relin_key(rk)
+    a, b = rand_cts(o, rng, n, L), rand_cts(o, rng, n, L)
+    da, db = g.to_device(a), g.to_device(b)
+    g.multiply_relin(L, n, da, db, be.Context.pairwise(), da)
+    got = da.download((n, 2, L, g.N))
+    for r in range(n):
+        assert np.array_equal(got[r], o.relinearize(o.multiply_ntt(a[r], b[r]), rk)), r
+    g.close()
