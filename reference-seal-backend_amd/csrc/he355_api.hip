@@ -73,6 +73,32 @@ __global__ void k_key_to_engine(u64 *key, u64 n_polys, int logN, const PrimeDev 
     }
 }
 
+// A finished key (k_key_to_engine's format) with the residues under the data primes multiplied by P^-1 (P = the special prime; the
+// special prime's own residues are copied): what k_k3<TENSOR> multiplies the lifted digits by, so that its sums are sums * P^-1.
+__global__ void k_key_scaled_copy(const u64 *key, u64 *out, u64 n_polys, int logN, const PrimeDev *primes, const FloorConst *fcs, int K)
+{
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 poly = gid >> logN;
+    if (poly >= n_polys) return;
+    const int t = (int)(poly % K);
+    u64 v = key[gid];
+    if (t != K - 1) {
+        const PrimeDev &P = primes[t];
+        const FloorConst fc = fcs[(K - 1) * K + t];
+        if (P.f64) {
+            ArF64 ar;
+            ar.q = (double)P.q; ar.qinv = 1.0 / (double)P.q;
+            union { u64 u; double d; } c;
+            c.u = v;
+            c.d = ar.canon2(ar.mulmod_c(c.d, fc.inv_d, fc.inv_i));
+            v = c.u;
+        } else {
+            v = mul_shoup(v, fc.inv, fc.inv_shoup, P.q);
+        }
+    }
+    out[gid] = v;
+}
+
 // Shoup quotients of the key residues under the u64-engine primes, appended to the key: [L_top][2][n_q][N]
 __global__ void k_key_quotients(const u64 *key, u64 *keyq, u64 n_dk, int logN, const PrimeDev *primes, int K, int n_q, PrimeMap qmap)
 {
@@ -195,6 +221,7 @@ public:
         (void)hipFree(d_primes_);
         (void)hipFree(d_floor_);
         (void)hipFree(d_relin_);
+        (void)hipFree(d_relin_scaled_);
         for (auto &kv : d_galois_) (void)hipFree(kv.second);
         for (auto &kv : d_perm_) (void)hipFree(kv.second);
         (void)hipStreamSynchronize(stream2_);
@@ -266,6 +293,14 @@ public:
     void key_finish(u64 *d_key)
     {
         const u64 n_polys = P.Ltop * 2 * P.K, total = n_polys * P.N;
+        if (d_key == d_relin_) d_relin_scaled_ok_ = false; // the scaled copy follows the key
+        key_quotients(d_key);
+        hipLaunchKernelGGL(k_key_to_engine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, d_key, n_polys, P.logn, d_primes_, (int)P.K);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(stream_));
+    }
+    void key_quotients(u64 *d_key) // Shoup quotients of the residues under the u64-engine primes (integers in either key format)
+    {
         const int n_q = (int)n_q_primes();
         if (n_q) { // before the fp64 conversion below rewrites the other residues; these stay integers
             PrimeMap qm;
@@ -277,13 +312,25 @@ public:
             hipLaunchKernelGGL(k_key_quotients, dim3((unsigned)((tq + 255) / 256)), dim3(256), 0, stream_, d_key, d_key + key_elems(), n_dk, P.logn, d_primes_,
                                (int)P.K, n_q, qm);
         }
-        hipLaunchKernelGGL(k_key_to_engine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, d_key, n_polys, P.logn, d_primes_, (int)P.K);
-        HIPCHECK(hipGetLastError());
-        HIPCHECK(hipStreamSynchronize(stream_));
     }
     u64 **relin_slot() { return &d_relin_; }
     u64 **galois_slot(uint32_t elt) { return &d_galois_[elt]; }
     const u64 *relin_key() const { return d_relin_; }
+    // the relinearization key with its data-prime residues times P^-1 (k_key_scaled_copy), built on first use after every change of the key
+    const u64 *relin_scaled()
+    {
+        if (!d_relin_scaled_ok_) {
+            if (!d_relin_scaled_) HIPCHECK(hipMalloc(&d_relin_scaled_, key_alloc_elems() * 8));
+            const u64 n_polys = P.Ltop * 2 * P.K, total = n_polys * P.N;
+            hipLaunchKernelGGL(k_key_scaled_copy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, d_relin_, d_relin_scaled_, n_polys, P.logn, d_primes_,
+                               d_floor_, (int)P.K);
+            key_quotients(d_relin_scaled_);
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipStreamSynchronize(stream_));
+            d_relin_scaled_ok_ = true;
+        }
+        return d_relin_scaled_;
+    }
     const u64 *galois_key(uint32_t elt) const
     {
         auto it = d_galois_.find(elt);
@@ -608,7 +655,7 @@ public:
             launch_k1(env, L, K1_MUL, nc, off, a, b, ix, nullptr, B, nullptr, in_k3);
             const bool fork_here = dual && stagger && ci == 0;
             u64 *ro = rescale ? out + off * 2 * (size_t)(L - 1) * N : nullptr;
-            const bool done = key_switch_tail(env, L, nc, S, B, d_relin_, rescale, fork_here ? ev_fork_ : nullptr, ro, in_k3 ? &ten : nullptr);
+            const bool done = key_switch_tail(env, L, nc, S, B, in_k3 ? relin_scaled() : d_relin_, rescale, fork_here ? ev_fork_ : nullptr, ro, in_k3 ? &ten : nullptr);
             if (fork_here) HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
             if (rescale && !done) rescale_tail(env, L, 2, nc, S, B.c01, 2 * LN, ro);
         }
@@ -1402,6 +1449,8 @@ private:
     FloorConst *d_floor_ = nullptr;
     std::vector<void *> owned_;
     u64 *d_relin_ = nullptr;
+    u64 *d_relin_scaled_ = nullptr; // relin_scaled()
+    bool d_relin_scaled_ok_ = false;
     PrimeTables plain_tables_; // BFV: NTT tables mod t
     int t_index_ = -1;         // index of t in the device prime array (-1: none)
     EncTablesDev enc_{nullptr, nullptr, nullptr};

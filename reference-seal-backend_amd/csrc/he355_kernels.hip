@@ -1583,10 +1583,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         for (int r = 0; r < kRowE; ++r) { acc0[r] = 0; acc1[r] = 0; }
         auto tensor_init = [&]() {
             if constexpr (TENSOR) {
-                // ct x ct multiply: c0 = a0 b0 and c1 = a0 b1 + a1 b0 are not read back from k_k1's c01 rows, they start the sums.  The floor
-                // step computes (sums - x) * P^-1 + addend (mod-down) or ((sums * P^-1 + addend) - x) * q_last^-1 (with the rescale): adding
-                // addend * P to the sums gives the same residue with a zero addend, and here no other row is live yet (the first digit row
-                // is on its way into LDS meanwhile).  (The identity is exact modular arithmetic: the canonical result is the same integer.)
+                // ct x ct multiply: c0 = a0 b0 and c1 = a0 b1 + a1 b0 are not read back from k_k1's c01 rows, they start the sums -- here,
+                // where no other row is live yet (the first digit row is on its way into LDS meanwhile).  The floor step computes
+                // (sums - x) * P^-1 + addend (mod-down) or ((sums * P^-1 + addend) - x) * q_last^-1 (with the rescale); this instantiation is
+                // handed key residues that carry the factor P^-1 already (DeviceContext::relin_scaled), so its sums ARE sums * P^-1 and the
+                // addend joins them as it is: the results are sums' - x * P^-1 and (sums' - x) * q_last^-1 (floor_fin_s / floor_fin2_s), the
+                // same residues exactly (modular identities), with two products per element fewer at this end and one fewer at that.
                 const u64 tr = A.t_op_offset + op;
                 const u64 LNt = (u64)A.L * N;
                 const u64 *pa = A.ta + idx_a(A.tix, tr) * 2 * LNt + (u64)tt * N + rowoff;
@@ -1594,12 +1596,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 u64 a0[kRowE], a1[kRowE], b0[kRowE], b1[kRowE];
                 load_rowC(pa, lane, a0); load_rowC(pb, lane, b0);
                 load_rowC(pa + LNt, lane, a1); load_rowC(pb + LNt, lane, b1);
-                const T pq = ar.dy_in(A.fc[(A.K - 1) * A.K + t].src_mod); // P mod q_t
 #pragma unroll
                 for (int r = 0; r < kRowE; ++r) {
                     const T x0 = ar.dy_in(a0[r]), x1 = ar.dy_in(a1[r]), y0 = ar.dy_in(b0[r]), y1 = ar.dy_in(b1[r]);
-                    acc0[r] = ar.acc_from_lazy(ar.dy_mul(ar.dy_mul(x0, y0), pq));
-                    acc1[r] = ar.acc_from_lazy(ar.dy_mul(ar.dy_add(ar.dy_mul(x0, y1), ar.dy_mul(x1, y0)), pq));
+                    acc0[r] = ar.acc_from_lazy(ar.dy_mul(x0, y0));
+                    acc1[r] = ar.acc_from_lazy(ar.dy_add(ar.dy_mul(x0, y1), ar.dy_mul(x1, y0)));
                 }
             }
         };
@@ -1843,8 +1844,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 u64 *c01_row = A.c01 + op * A.c01_item_stride + k * LN + (u64)tt * N + rowoff;
                 // the addend, in flight during the transform -- or nothing: for a ct x ct multiply (A.ta) it entered the accumulators before the digits
                 if constexpr (TENSOR) {
-#pragma unroll
-                    for (int r = 0; r < kRowE; ++r) av[r] = 0;
+                    // (no addend row: it entered the sums before the digits)
                 } else if (k == 1 && A.c1_mode == 1) { // a rotation without addend: polynomial 1 starts from zero (k_k1 wrote no row of zeros)
 #pragma unroll
                     for (int r = 0; r < kRowE; ++r) av[r] = 0;
@@ -1853,7 +1853,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 }
                 wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
                 const Acc *acc = k == 0 ? acc0 : acc1;
-                if (!resc) {
+                if constexpr (TENSOR) { // sums formed with scaled key residues, addend inside them
+                    if (!resc) {
+#pragma unroll
+                        for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin_s(ar.acc_canon(acc[r]), x[0][r], fc.inv, fc.inv_shoup, fc.inv_d, fc.inv_i);
+                        if (valid) store_rowC(c01_row, lane, v);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin2_s(ar.acc_canon(acc[r]), x[0][r], fc2);
+                        if (valid) store_rowC(A.out2 + (op * 2 + k) * L1N + (u64)tt * N + rowoff, lane, v);
+                    }
+                } else if (!resc) {
 #pragma unroll
                     for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin(ar.acc_canon(acc[r]), x[0][r], fc.inv, fc.inv_shoup, fc.inv_d, fc.inv_i, av[r]);
                     if (valid) store_rowC(c01_row, lane, v);
