@@ -581,7 +581,10 @@ public:
         static const bool side_on = getenv("HE355_LAT_SIDE") && getenv("HE355_LAT_SIDE")[0] == '1';
         KernelEnv env = env_;
         env.stream = which ? stream2_ : stream_;
-        if (side_on && latency_shape(nc)) {
+        // HE355_SIDE_ALL=1: in the throughput shape too (the u64 engine's k_k1 / k_k2n / k_k3 / k_floor_rows beside the fp64 engine's: they fill
+        // each other's tails; 47.82 -> 47.65 ms per step, 0.35 %: not worth the dominant kernel's clean single-stream timing, off)
+        static const bool side_all = getenv("HE355_SIDE_ALL") && getenv("HE355_SIDE_ALL")[0] == '1';
+        if ((side_on && latency_shape(nc)) || side_all) {
             env.side = which ? stream_ : stream2_;
             env.ev_side_fork = ev_side_fork_;
             env.ev_side_join = ev_side_join_;

@@ -3226,29 +3226,30 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         }
         static const int stage_env = getenv("HE355_K3_STAGE") ? atoi(getenv("HE355_K3_STAGE")) : HE355_K3_STAGE_DEFAULT;
         const bool staged = stage_env != 0 || shape / 10 != 1;
+        const hipStream_t st3 = sf.stream(pass); // (env.side: the u64 engine's launch beside the fp64 engine's)
         if (shape == 11) {
             const dim3 gd(g, (unsigned)A.n_split);
             if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 1, 1, true>), gd, dim3(64), 0, sf.stream(0), A, env.primes);
             else hipLaunchKernelGGL((k_k3<ArU64, 1, 1, true>), gd, dim3(64), 0, sf.stream(1), A, env.primes);
         } else if (pass == 0) {
             switch (shape) {
-            case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
+            case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4, true>), dim3(g), dim3(256), 0, st3, A, env.primes); break;
             case 18:
-                if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true, kKeyShare, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
-                else if (fuse) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
-                else if (staged) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, false, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
-                else hipLaunchKernelGGL((k_k3<ArF64, 1, 8, false>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true, kKeyShare, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+                else if (fuse) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, st3, A, env.primes);
+                else if (staged) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, false, kKeyShare>), dim3(g), dim3(512), 0, st3, A, env.primes);
+                else hipLaunchKernelGGL((k_k3<ArF64, 1, 8, false>), dim3(g), dim3(512), 0, st3, A, env.primes);
                 break;
             default: throw std::runtime_error("unsupported K3 fp64 shape");
             }
         } else {
             switch (shape) {
-            case 14: hipLaunchKernelGGL((k_k3<ArU64, 1, 4, true>), dim3(g), dim3(256), 0, env.stream, A, env.primes); break;
+            case 14: hipLaunchKernelGGL((k_k3<ArU64, 1, 4, true>), dim3(g), dim3(256), 0, st3, A, env.primes); break;
             case 18:
-                if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true, kKeyShare, true>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
-                else if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
-                else if (staged) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, false, kKeyShare>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
-                else hipLaunchKernelGGL((k_k3<ArU64, 1, 8, false>), dim3(g), dim3(512), 0, env.stream, A, env.primes);
+                if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true, kKeyShare, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+                else if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, st3, A, env.primes);
+                else if (staged) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, false, kKeyShare>), dim3(g), dim3(512), 0, st3, A, env.primes);
+                else hipLaunchKernelGGL((k_k3<ArU64, 1, 8, false>), dim3(g), dim3(512), 0, st3, A, env.primes);
                 break;
             default: throw std::runtime_error("unsupported K3 u64 shape");
             }

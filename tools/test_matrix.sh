@@ -7,7 +7,7 @@
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 rc=0
-for cfg in "HE355_NONE=1" "HE355_K3_FUSE=0" "HE355_K3_SHAPE=2414" "HE355_K3_STAGE=0" "HE355_DEVICE_CLIENT=0" "HE355_DUAL_STREAM=0 HE355_CHUNK=3" "HE355_K2_SPLIT=1" "HE355_FC_MERGE=0" "HE355_K2_NEW=0" "HE355_FC_NEW=0" "HE355_K2_XCD=1" "HE355_LATENCY_MAX=0" "HE355_LATENCY_MAX=64" "HE355_LATENCY_MAX=64 HE355_LAT_SIDE=1" "HE355_C01_RECOMPUTE=0" "HE355_CHUNK=256" "HE355_NUM_DEVICES=2 HE355_LOGICAL_DEVICES=2"; do
+for cfg in "HE355_NONE=1" "HE355_K3_FUSE=0" "HE355_K3_SHAPE=2414" "HE355_K3_STAGE=0" "HE355_DEVICE_CLIENT=0" "HE355_DUAL_STREAM=0 HE355_CHUNK=3" "HE355_K2_SPLIT=1" "HE355_FC_MERGE=0" "HE355_K2_NEW=0" "HE355_FC_NEW=0" "HE355_K2_XCD=1" "HE355_LATENCY_MAX=0" "HE355_LATENCY_MAX=64" "HE355_LATENCY_MAX=64 HE355_LAT_SIDE=1" "HE355_C01_RECOMPUTE=0" "HE355_SIDE_ALL=1" "HE355_CHUNK=256" "HE355_NUM_DEVICES=2 HE355_LOGICAL_DEVICES=2"; do
   echo "== $cfg"
   env $cfg timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -1 || rc=1
 done
