@@ -3205,10 +3205,24 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         const u64 tiles = (u64)A.n_tt << env.logn1;
         // enough blocks to keep every CU busy for several rounds, few enough that start-up costs are amortised
         static const u32 og_env = getenv("HE355_K3_OG") ? (u32)atoi(getenv("HE355_K3_OG")) : 0;
-        // (8-wave shape: 4 op-groups per block once a tile has 128 of them -- chunks of 1024 ciphertexts: 50.3 vs 50.9 ms per step
-        // with 2 -- and 2 below that, where 4 measured slower; profiles/r03_chunk_sweep.txt)
-        u32 ogpb = og_env ? og_env : (waves == 8 ? (n_og >= 128 ? 4 : 2) : 4);
-        while (ogpb > 1 && tiles * ((n_og + ogpb - 1) / ogpb) < 256u * 6) ogpb >>= 1;
+        // Op-groups per block: more of them amortise the block's start-up (twiddle staging, ~4 us) over more work, fewer of them give the
+        // dispatcher more blocks to fill the 256 CUs with.  What counts for small grids is the number of ROUNDS of blocks: 64 tiles x 8
+        // op-groups (BFV, 64 ciphertexts, L = 3) are two rounds of 256 one-group blocks or ONE round of two-group blocks, the same work
+        // with half the start-ups (configs[4]: 65.3 -> 63.4 ms).  So: the candidate sizes from the shape's maximum down, each priced as
+        // rounds x (groups x work per group + start-up), ties to the larger.  (Maximum for the 8-wave shape: 4 once a tile has 128
+        // op-groups -- chunks of 1024 ciphertexts: 50.3 vs 50.9 ms per step with 2 -- and 2 below that, where 4 measured slower;
+        // profiles/r03_chunk_sweep.txt.)  HE355_K3_OG=<n> fixes the size.
+        const u32 og_max = waves == 8 ? (n_og >= 128 ? 4 : 2) : 4;
+        u32 ogpb = og_env ? og_env : og_max;
+        if (!og_env) {
+            const double work = (pass == 0 ? 7.0 : 14.0) * (L + 2), startup = 4.0; // us per op-group (one row step per digit + epilogue), per block
+            double best = 0;
+            for (u32 c = og_max; c >= 1; c >>= 1) {
+                const u64 blocks = tiles * ((n_og + c - 1) / c);
+                const double cost = (double)((blocks + 255) / 256) * (c * work + startup);
+                if (c == og_max || cost < best * 0.999) { best = cost; ogpb = c; }
+            }
+        }
         A.og_per_block = ogpb;
         const u64 n_ogb = (n_og + ogpb - 1) / ogpb;
         const unsigned g = (unsigned)(((tiles + 7) / 8) * 8 * n_ogb);
