@@ -3127,6 +3127,23 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             if (!A.n_dig) continue;
             unsigned gw = (unsigned)(n_ops * A.n_dig * 4);
             if (A.xcd_map) gw = (unsigned)(((n_ops * A.n_dig + 7) / 8) * 8 * 4);
+            // Small grids: the targets of a (digit, column block) dealt to 2 or 4 blocks (blockIdx.y, as the latency shape does) when
+            // that fills the rounds of blocks better -- 512 blocks run at a time (two per CU); a block pays the digit's inverse column
+            // pass once and a forward column pass + stores per target.  64 BFV ciphertexts at L = 3: 768 blocks = 1.5 rounds of all four
+            // targets, or 3 full rounds of two targets each.  Only taken for a modelled gain of 5 % or more (the headline's 61440 blocks
+            // stay whole); HE355_K2_TSPLIT=<n> fixes it.
+            static const int ts_env = getenv("HE355_K2_TSPLIT") ? atoi(getenv("HE355_K2_TSPLIT")) : 0;
+            int ts = tsplit > 1 ? tsplit : 1;
+            if (tsplit <= 1 && ts_env > 0) ts = ts_env;
+            else if (tsplit <= 1) {
+                const int n_tgt = L + 1 - (A.ckks ? 1 : 0);
+                auto cost = [&](int c) { return (double)(((u64)gw * c + 511) / 512) * (1.0 + 1.2 * ((n_tgt + c - 1) / c)); };
+                const double c1 = cost(1);
+                double best = c1;
+                for (int c = 2; c <= 4; c <<= 1)
+                    if (cost(c) < best * 0.95 && cost(c) < c1 * 0.95) { best = cost(c); ts = c; }
+            }
+            A.tsplit = ts;
             const dim3 gd(gw, (unsigned)A.tsplit);
             const hipStream_t st = sf.stream(launched++);
 #define HE355_K2N(L1)                                                                                                         \
