@@ -488,7 +488,7 @@ public:
             // digits of a tile over kLatSplit (u64 engine: kLatSplitU64) single-wave blocks whose partial sums k_k3_combine adds (k_k3).
             launch_k2(env_, L, nc, B, nullptr, 0, kLatTargets);
             if (after_k2) HIPCHECK(hipEventRecord(after_k2, env_.stream));
-            u64 *part = latency_partials((size_t)kLatSplitU64 * nc * 2 * (L + 1) * N, env_.stream == stream2_ ? 1 : 0);
+            u64 *part = latency_partials((size_t)std::max(kLatSplit, kLatSplitU64) * nc * 2 * (L + 1) * N, env_.stream == stream2_ ? 1 : 0);
             launch_k3(env_, L, nc, B, key, K3_ALL, nullptr, kLatSplit, part, kLatSplitU64);
             launch_k3_combine(env_, L, nc, B, kLatSplit, part, kLatSplitU64);
             launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e, nullptr, 0, 0, 0, 0, nullptr, 0, kLatTargets);
@@ -570,7 +570,12 @@ public:
     // latency shape of the key switch (key_switch_tail): batches of at most lat_max_ ciphertexts, CKKS pipeline
     // digit groups per fp64-engine tile (480 tiles x 4 single-wave blocks fill the chip once at batch 1), per u64-engine tile (64 tiles, rows
     // 2.5x as long), blocks per column for the targets of k_k2n / k_floor_colsn
-    static constexpr int kLatSplit = 4, kLatSplitU64 = 8, kLatTargets = 8;
+    static constexpr int kLatTargets = 8;
+    // Digit groups per tile of the latency shape (HE355_LAT_SPLIT / HE355_LAT_SPLIT_U64; n_split > 1 is what selects the shape).  fp64-engine
+    // tiles: 480 x 2 single-wave blocks are ONE round of the chip's 1024 one-wave slots, 480 x 4 were two rounds of half the work each with
+    // twice the start-ups and partial sums (batch 1: 0.326 -> 0.312 ms, batch 8: 0.98 -> 0.91 ms; 3 and 8 groups measured slower).
+    const int kLatSplit = getenv("HE355_LAT_SPLIT") && atoi(getenv("HE355_LAT_SPLIT")) > 1 ? atoi(getenv("HE355_LAT_SPLIT")) : 2;
+    const int kLatSplitU64 = getenv("HE355_LAT_SPLIT_U64") && atoi(getenv("HE355_LAT_SPLIT_U64")) > 1 ? atoi(getenv("HE355_LAT_SPLIT_U64")) : 8;
     bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
     // the kernel environment of a batch of nc ciphertexts on stream `which`.  HE355_LAT_SIDE=1: in the latency shape the other stream
     // takes the second engine's launches (KernelEnv::side).  Off by default: measured at batch 1 the two engines' kernels each fill
