@@ -115,7 +115,9 @@ int he355_multiply(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const
 /* BFV multiply (BEHZ, coefficient form): [.][2][L][N] x [.][2][L][N] -> [n][3][L][N]
  * (evaluator()->multiply, src/benchmarks/bfv/seal_bfv_element_wise_benchmark.cpp:325, seal_bfv_dot_product_benchmark.cpp:311) */
 int he355_bfv_multiply(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, uint64_t *d_out);
-/* multiply -> relinearize (-> rescale): out [n][2][L][N] or [n][2][L-1][N] */
+/* multiply -> relinearize (-> rescale): out [n][2][L][N] or [n][2][L-1][N].  Give d_out a slab of its own: then the tensor product's
+ * c0, c1 never travel through HBM (the key-switch kernel forms them from the operand rows); a d_out that overlaps an operand is
+ * detected and served by the slower path that materialises them first. */
 int he355_multiply_relin(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, int rescale,
                          uint64_t *d_out);
 int he355_relinearize(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_ct3, uint64_t *d_out);            /* [n][3][L][N] -> [n][2][L][N] */
