@@ -705,9 +705,16 @@ public:
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
             const KernelEnv env = batch_env(nc);
-            launch_k1(env, L, K1_CT3, nc, off, ct3, nullptr, ix, nullptr, B);
+            // on the fused path k_k3 reads c0, c1 and the NTT-form c2 from the size-3 input where it lies (k_k1 copies nothing: it only
+            // sends c2 through the inverse row pass); `out` must then be a slab of its own
+            auto overlap = [](const u64 *p, size_t np, const u64 *q, size_t nq) { return p < q + nq && q < p + np; };
+            const bool in_k3 = tensor_in_k3(env, L, nc, B) && !overlap(out, n * 2 * (size_t)(rescale ? L - 1 : L) * N, ct3, n * 3 * LN);
+            TensorOperands ten;
+            ten.c1_mode = 3;
+            ten.c1_src = ct3 + off * 3 * LN;
+            launch_k1(env, L, K1_CT3, nc, off, ct3, nullptr, ix, nullptr, B, nullptr, false, in_k3);
             u64 *ro = rescale ? out + off * 2 * (size_t)(L - 1) * N : nullptr;
-            const bool done = key_switch_tail(env, L, nc, S, B, d_relin_, rescale, nullptr, ro);
+            const bool done = key_switch_tail(env, L, nc, S, B, d_relin_, rescale, nullptr, ro, in_k3 ? &ten : nullptr);
             if (rescale && !done) rescale_tail(env, L, 2, nc, S, B.c01, 2 * LN, ro);
         }
         HIPCHECK(hipGetLastError());

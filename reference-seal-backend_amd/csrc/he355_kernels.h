@@ -106,7 +106,8 @@ struct K3Fuse {
     Indexer tix{};
     u64 t_op_offset = 0;
     // rotations: polynomial 1 of the ciphertext the switched key part is added into is zero, or polynomial 1 of the rotation's addend --
-    // k_k1 neither writes nor copies it.  c1_mode 0: read from c01 (as polynomial 0 always is); 1: zero; 2: row of c1_src [n_ops][2][L][N]
+    // k_k1 neither writes nor copies it.  c1_mode 0: read from c01 (as polynomial 0 always is); 1: zero; 2: row of c1_src [n_ops][2][L][N];
+    // 3 (relinearize of size-3 ciphertexts): polynomials 0 AND 1, and the NTT-form own digit, are rows of c1_src [n_ops][3][L][N], the input
     int c1_mode = 0;
     const u64 *c1_src = nullptr;
 };

@@ -775,10 +775,13 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
     } else if (MODE == K1_CT3) {
         const u64 *pa = A.a + (A.op_offset + op) * 3 * P1 + roff;
         u64 v2[kRowE];
-        load_rowC(pa, lane, v0); load_rowC(pa + P1, lane, v1); load_rowC(pa + 2 * P1, lane, v2);
+        load_rowC(pa + 2 * P1, lane, v2);
 #pragma unroll
         for (int r2 = 0; r2 < kRowE; ++r2) x[r2] = ar.from_canon(v2[r2]);
-        if (valid) { store_rowC(c0p, lane, v0); store_rowC(c1p, lane, v1); store_rowC(c2np, lane, v2); }
+        if (!A.no_c1) { // (no_c1: the fused k_k3 reads c0, c1 and the NTT-form c2 from the size-3 ciphertext itself, K3Fuse::c1_mode 3)
+            load_rowC(pa, lane, v0); load_rowC(pa + P1, lane, v1);
+            if (valid) { store_rowC(c0p, lane, v0); store_rowC(c1p, lane, v1); store_rowC(c2np, lane, v2); }
+        }
     } else { // K1_GALOIS: out[idx] = in[perm[idx]] on both polys; c1 := 0; key-switch target = permuted c1
         const u64 *p0 = A.a + (A.op_offset + op) * 2 * P1 + (u64)i * N;
         const uint32_t *pm = A.perm + ((u64)a_row << kRowLog);
@@ -1730,7 +1733,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             } else {
                 T x[kRowE];
                 u64 v[kRowE];
-                load_rowC(A.c2n + (op * A.L + tt) * N + rowoff, lane, v);
+                load_rowC(FUSE && A.c1_mode == 3 ? A.c1_src + (op * 3 + 2) * ((u64)A.L * N) + (u64)tt * N + rowoff : A.c2n + (op * A.L + tt) * N + rowoff, lane, v);
 #pragma unroll
                 for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
                 mac_digit(x, tt);
@@ -1848,6 +1851,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 } else if (k == 1 && A.c1_mode == 1) { // a rotation without addend: polynomial 1 starts from zero (k_k1 wrote no row of zeros)
 #pragma unroll
                     for (int r = 0; r < kRowE; ++r) av[r] = 0;
+                } else if (A.c1_mode == 3) { // relinearize of a size-3 ciphertext: c0, c1 read from the input itself (k_k1 copied nothing)
+                    load_rowC(A.c1_src + (op * 3 + k) * LN + (u64)tt * N + rowoff, lane, av);
                 } else { // ... with addend: its polynomial 1, read where it lies
                     load_rowC(k == 1 && A.c1_mode == 2 ? A.c1_src + (op * 2 + 1) * LN + (u64)tt * N + rowoff : c01_row, lane, av);
                 }
@@ -3045,7 +3050,7 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
 {
     if (!n_ops) return;
     if (no_c01 && mode != K1_MUL) throw std::runtime_error("no_c01: the ct x ct multiply only");
-    if (no_c1 && mode != K1_GALOIS) throw std::runtime_error("no_c1: rotations only");
+    if (no_c1 && mode != K1_GALOIS && mode != K1_CT3) throw std::runtime_error("no_c1: rotations and size-3 inputs only");
     SideFork sf(env);
     K1Args A;
     A.no_c1 = no_c1 ? 1 : 0;
