@@ -93,18 +93,29 @@ def main():
         b = np.stack([o.random_poly(rng, L, 2) for _ in range(n)])
         da, db = g.to_device(a), g.to_device(b)
         what = []
-        # multiply -> relinearize (-> rescale)
-        out = g.alloc(n * 2 * L * N)
-        g.multiply_relin(L, n, da, db, be.Context.pairwise(), out)
-        got = out.download((n, 2, L, N))
-        want = [o.relinearize(o.multiply_ntt(a[r], b[r]), rk) for r in range(n)]
-        ok = all(np.array_equal(got[r], want[r]) for r in range(n))
+        # multiply -> relinearize (-> rescale): pairwise, or HEBench's outer product (result r = i * b1 + x) with operand bases > 0
+        b1 = int(rng.choice([0, 0, 1, 2, 3]))  # 0: pairwise
+        if b1 and n >= b1 + 2:
+            a_base, b_base = 1, int(rng.integers(0, n - b1 + 1))
+            nres = ((n - 1) // b1) * b1 if (n - 1) // b1 else b1
+            nres = min(nres, (n - 1) * b1)
+            ix = be.Context.outer(a_base, nres // b1, b_base, b1)
+            pick = [(a_base + r // b1, b_base + r % b1) for r in range(nres)]
+            what.append(f"outer{b1}")
+        else:
+            nres, ix = n, be.Context.pairwise()
+            pick = [(r, r) for r in range(n)]
+        out = g.alloc(nres * 2 * L * N)
+        g.multiply_relin(L, nres, da, db, ix, out)
+        got = out.download((nres, 2, L, N))
+        want = [o.relinearize(o.multiply_ntt(a[i], b[x]), rk) for i, x in pick]
+        ok = all(np.array_equal(got[r], want[r]) for r in range(nres))
         what.append("mul_relin")
         if ok and L >= 2:
-            out2 = g.alloc(n * 2 * (L - 1) * N)
-            g.multiply_relin(L, n, da, db, be.Context.pairwise(), out2, rescale=True)
-            got2 = out2.download((n, 2, L - 1, N))
-            ok = all(np.array_equal(got2[r], o.rescale(want[r])) for r in range(n))
+            out2 = g.alloc(nres * 2 * (L - 1) * N)
+            g.multiply_relin(L, nres, da, db, ix, out2, rescale=True)
+            got2 = out2.download((nres, 2, L - 1, N))
+            ok = all(np.array_equal(got2[r], o.rescale(want[r])) for r in range(nres))
             what.append("rescale")
         # relinearize of size-3 ciphertexts
         if ok:
