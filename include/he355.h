@@ -80,8 +80,22 @@ uint64_t he355_galois_elts_all(const he355_ctx *ctx, uint32_t *out, uint64_t cap
 /* ---- device ---- */
 int he355_device_count(int *count);
 int he355_device_init(he355_ctx *ctx, int device_ordinal); /* uploads tables; creates the stream */
+/* Device memory comes from the context's pool (csrc/device_pool.h): size-class free lists over hipMalloc'd blocks, the counterpart
+ * of the MemoryPoolHandle::ThreadLocal() the reference hands to the evaluator inside operate()
+ * (src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:343).  he355_free returns the block to its list: no HIP call and no
+ * synchronisation (a re-issued block is only touched by work queued later on the context's streams), so a steady-state operate()
+ * performs no hipMalloc / hipFree.  he355_alloc_stats counts every raw hipMalloc / hipFree the context has made since
+ * he355_device_init (its tables, keys and scratch arenas included); he355_pool_trim drains the streams and hipFree()s the cached
+ * blocks (also done by itself when the device runs out of memory). */
 int he355_malloc(he355_ctx *ctx, uint64_t bytes, void **d_ptr);
 int he355_free(he355_ctx *ctx, void *d_ptr);
+typedef struct {
+    uint64_t raw_mallocs, raw_frees; /* hipMalloc / hipFree calls            */
+    uint64_t pool_hits, pool_misses;  /* he355_malloc served from a list / by a new block */
+    uint64_t cached_bytes, live_bytes;
+} he355_alloc_stats_t;
+int he355_alloc_stats(he355_ctx *ctx, he355_alloc_stats_t *out); /* ctx == NULL: totals over every context of the process (byte fields 0) */
+int he355_pool_trim(he355_ctx *ctx, uint64_t *released_bytes);
 int he355_upload(he355_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int he355_download(he355_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
 int he355_copy(he355_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes); /* device to device, on the context's stream */

@@ -34,6 +34,11 @@ class Indexer(C.Structure):
                 ("pairwise", C.c_int32), ("reserved", C.c_int32)]
 
 
+class AllocStats(C.Structure):
+    _fields_ = [("raw_mallocs", C.c_uint64), ("raw_frees", C.c_uint64), ("pool_hits", C.c_uint64), ("pool_misses", C.c_uint64),
+                ("cached_bytes", C.c_uint64), ("live_bytes", C.c_uint64)]
+
+
 def build(force: bool = False) -> str:
     """Compile the backend for gfx950 with hipcc (csrc/Makefile)."""
     csrc = os.path.join(_HERE, "csrc")
@@ -116,6 +121,8 @@ def lib():
             "he355_set_chunk": (i32, [vp, u64]),
             "he355_set_latency_max": (i32, [vp, u64]),
             "he355_mem_info": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+            "he355_alloc_stats": (i32, [vp, C.POINTER(AllocStats)]),
+            "he355_pool_trim": (i32, [vp, C.POINTER(C.c_uint64)]),
             "he355_bridge_abi": (u64, [C.c_char_p, u64]),
             "he355_bridge_group_load_bytes": (u64, [i32, i32]),
         }
@@ -136,7 +143,7 @@ C_ABI_SYMBOLS = [
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",
     "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_keygen_relin", "he355_keygen_galois", "he355_ckks_encode", "he355_ckks_decode",
     "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_rotate_each", "he355_rotate_sum", "he355_accumulate", "he355_encrypt_zero", "he355_set_zero_stream",
-    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk", "he355_set_latency_max", "he355_mem_info", "he355_bridge_abi", "he355_bridge_group_load_bytes",
+    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk", "he355_set_latency_max", "he355_mem_info", "he355_alloc_stats", "he355_pool_trim", "he355_bridge_abi", "he355_bridge_group_load_bytes",
 ]
 
 
@@ -377,6 +384,17 @@ class Context:
         _check(lib().he355_mem_info(self.h, C.byref(f), C.byref(t)))
         return f.value, t.value
 
+    def alloc_stats(self) -> dict:
+        """raw hipMalloc / hipFree calls and pool hits / misses of this context since device_init"""
+        st = AllocStats()
+        _check(lib().he355_alloc_stats(self.h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in AllocStats._fields_}
+
+    def pool_trim(self) -> int:
+        b = C.c_uint64()
+        _check(lib().he355_pool_trim(self.h, C.byref(b)))
+        return int(b.value)
+
     def rotate_sum(self, L, n, inp, steps, out):
         """out = inp + sum_j rotate(inp, steps[j]) with shared NAF prefixes; returns the Galois key switches issued per ciphertext"""
         arr = (C.c_int32 * len(steps))(*[int(v) for v in steps])
@@ -409,6 +427,13 @@ class Context:
         ms = C.c_float()
         _check(lib().he355_timer_end(self.h, C.byref(ms)))
         return float(ms.value)
+
+
+def process_alloc_stats() -> dict:
+    """totals over every context of this process (the benchmark objects behind API-Bridge handles own theirs)"""
+    st = AllocStats()
+    _check(lib().he355_alloc_stats(None, C.byref(st)))
+    return {k: int(getattr(st, k)) for k, _ in AllocStats._fields_}
 
 
 def device_count() -> int:

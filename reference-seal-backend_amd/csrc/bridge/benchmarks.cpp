@@ -326,11 +326,10 @@ std::shared_ptr<DeviceCiphers> VectorBenchmark::operateOn(he355_ctx *ctx, Device
             std::shared_ptr<DeviceCiphers> c3 = alloc(n, 3, 1.0);
             HeContextWrapper::check(he355_bfv_multiply(ctx, L, n, p0.d, p1.d, ix, c3->d), "multiply");
             HeContextWrapper::check(he355_relinearize(ctx, L, n, c3->d, out), "relinearize");
-            HeContextWrapper::check(he355_sync(ctx), "synchronise");
+            // c3 goes back to the pool here: whatever reuses it is queued behind the relinearization on the same stream
         }
         std::shared_ptr<DeviceCiphers> tmp = alloc(n, 2, result->scale);
         HeContextWrapper::check(he355_accumulate(ctx, L, n, out, m_w_params.n(), tmp->d), "accumulate");
-        HeContextWrapper::check(he355_sync(ctx), "synchronise");
         break;
     }
     default:

@@ -309,7 +309,7 @@ AB::Handle LogRegHornerBenchmark::operate(AB::Handle h_remote_packed, const AB::
         std::shared_ptr<DeviceCiphers> ck = cw.allocResult(1, 1, lvl - 1, scale);
         chk(he355_mod_switch_drop(ctx, in.coeff->L, lvl - 1, 1, in.coeff->d + k * coeffN, ck->d), "mod_switch_to");
         chk(he355_add_plain(ctx, lvl - 1, 2, 1, nxt->d, ck->d, pairwise, nxt->d), "add_plain");
-        chk(he355_sync(ctx), "synchronise"); // temporaries of this step are released below
+        // the temporaries of this step go back to the pool: reuse is stream-ordered, no synchronisation needed
         acc = nxt;
     }
     chk(he355_sync(ctx), "synchronise");

@@ -327,7 +327,6 @@ std::shared_ptr<DeviceCiphers> MatMultRowLatencyBenchmark::rowsOn(he355_ctx *ctx
         std::shared_ptr<DeviceCiphers> c3 = alloc(3, 1.0);
         HeContextWrapper::check(he355_bfv_multiply(ctx, L, nA, A.d, B.d, ix, c3->d), "multiply");                     // :515
         HeContextWrapper::check(he355_relinearize(ctx, L, nA, c3->d, base->d), "relinearize");                       // :516
-        HeContextWrapper::check(he355_sync(ctx), "synchronise");
     }
     // result[i] = base (:519), then result[i] += rotate_rows(base, j * spacers), j = 1 .. dim2-1 (:520-531): all rotations start from
     // `base`, so the ones whose NAF term sequences share a prefix share that prefix's ciphertext (he355_rotate_sum) -- bit-identical

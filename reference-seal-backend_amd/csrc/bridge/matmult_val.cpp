@@ -228,7 +228,6 @@ AB::Handle MatMultValBenchmark::operate(AB::Handle h_remote_packed, const AB::Pa
         result = m_p_ctx_wrapper->allocResult(n, 2, L, 1.0);
         HeContextWrapper::check(he355_bfv_multiply(ctx, L, n, in.m[0]->d, in.m[1]->d, ix, c3->d), "multiply");
         HeContextWrapper::check(he355_relinearize(ctx, L, n, c3->d, result->d), "relinearize");
-        HeContextWrapper::check(he355_sync(ctx), "synchronise");
     }
     std::shared_ptr<DeviceCiphers> tmp = m_p_ctx_wrapper->allocResult(n, 2, result->L, result->scale);
     HeContextWrapper::check(he355_accumulate(ctx, result->L, n, result->d, cols_M0(), tmp->d), "accumulate"); // :256 / bfv :255

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/he355.h"
+#include "device_pool.h"
 #include "he355_internal.h"
 #include "he355_kernels.h"
 #include "he_params.h"
@@ -23,9 +24,6 @@
 
 namespace he355 {
 
-struct DeviceError : std::runtime_error {
-    using std::runtime_error::runtime_error;
-};
 #define HIPCHECK(expr)                                                                                             \
     do {                                                                                                           \
         hipError_t e__ = (expr);                                                                                   \
@@ -150,9 +148,9 @@ public:
         for (size_t i = 0; i < n_all; ++i) {
             const PrimeTables &pt = i < K ? P.primes[i] : i < K + P.aux.size() ? P.aux[i - K] : plain_tables_;
             Tw16 *dfwd = nullptr, *dinv = nullptr;
-            HIPCHECK(hipMalloc(&dfwd, N * sizeof(Tw16)));
+            dmalloc(dfwd, N * sizeof(Tw16));
             owned_.push_back(dfwd);
-            HIPCHECK(hipMalloc(&dinv, N * sizeof(Tw16)));
+            dmalloc(dinv, N * sizeof(Tw16));
             owned_.push_back(dinv);
             HIPCHECK(hipMemcpy(dfwd, pt.fwd.data(), N * sizeof(Tw16), hipMemcpyHostToDevice));
             HIPCHECK(hipMemcpy(dinv, pt.inv.data(), N * sizeof(Tw16), hipMemcpyHostToDevice));
@@ -183,7 +181,7 @@ public:
                 if (!(m * 1.0000001 < 140737488355328.0)) continue;
                 (direct ? pd[j].k2_direct : pd[j].k2_lift) |= (u64)1 << t;
             }
-        HIPCHECK(hipMalloc(&d_primes_, n_all * sizeof(PrimeDev)));
+        dmalloc(d_primes_, n_all * sizeof(PrimeDev));
         HIPCHECK(hipMemcpy(d_primes_, pd.data(), n_all * sizeof(PrimeDev), hipMemcpyHostToDevice));
         std::vector<FloorConst> fc(K * K);
         for (size_t s = 0; s < K; ++s)
@@ -200,7 +198,7 @@ public:
                 f.half_mod = (qs >> 1) % qi;
                 f.src_mod = qs % qi;
             }
-        HIPCHECK(hipMalloc(&d_floor_, K * K * sizeof(FloorConst)));
+        dmalloc(d_floor_, K * K * sizeof(FloorConst));
         HIPCHECK(hipMemcpy(d_floor_, fc.data(), K * K * sizeof(FloorConst), hipMemcpyHostToDevice));
         env_.primes = d_primes_;
         env_.floor_consts = d_floor_;
@@ -217,22 +215,23 @@ public:
     {
         (void)hipSetDevice(device_);
         (void)hipStreamSynchronize(stream_);
-        for (void *p : owned_) (void)hipFree(p);
-        (void)hipFree(d_primes_);
-        (void)hipFree(d_floor_);
-        (void)hipFree(d_relin_);
-        (void)hipFree(d_relin_scaled_);
-        for (auto &kv : d_galois_) (void)hipFree(kv.second);
-        for (auto &kv : d_perm_) (void)hipFree(kv.second);
+        for (void *p : owned_) pool_.raw_free(p);
+        pool_.raw_free(d_primes_);
+        pool_.raw_free(d_floor_);
+        pool_.raw_free(d_relin_);
+        pool_.raw_free(d_relin_scaled_);
+        for (auto &kv : d_galois_) pool_.raw_free(kv.second);
+        for (auto &kv : d_perm_) pool_.raw_free(kv.second);
         (void)hipStreamSynchronize(stream2_);
-        (void)hipFree(scratch_);
-        (void)hipFree(scratch2_);
-        (void)hipFree(rot_tmp_);
-        (void)hipFree(lat_part_[0]);
-        (void)hipFree(lat_part_[1]);
-        (void)hipFree(bfv_scratch_);
-        (void)hipFree(client_scratch_);
-        for (auto &kv : d_gather_) (void)hipFree(kv.second);
+        pool_.raw_free(scratch_);
+        pool_.raw_free(scratch2_);
+        pool_.raw_free(rot_tmp_);
+        pool_.raw_free(lat_part_[0]);
+        pool_.raw_free(lat_part_[1]);
+        pool_.raw_free(bfv_scratch_);
+        pool_.raw_free(client_scratch_);
+        for (auto &kv : d_gather_) pool_.raw_free(kv.second);
+        pool_.destroy();
         (void)hipEventDestroy(ev_fork_);
         (void)hipEventDestroy(ev_side_fork_);
         (void)hipEventDestroy(ev_side_join_);
@@ -244,6 +243,25 @@ public:
     }
 
     void use() { HIPCHECK(hipSetDevice(device_)); }
+    // ---- device memory (device_pool.h): slabs handed to callers come from the pool, the context's own tables / keys / arenas
+    // are raw allocations; both are counted
+    template <class T> void dmalloc(T *&p, size_t bytes) { p = static_cast<T *>(pool_.raw_malloc(bytes)); }
+    // HE355_POOL=0: every he355_malloc / he355_free is a hipMalloc / drain + hipFree again (the pre-pool behaviour, kept for A/B timing:
+    // tools/bench_bridge.py, profiles/r04_bridge_phases.jsonl)
+    void *pool_alloc(size_t bytes)
+    {
+        use();
+        return pool_on_ ? pool_.alloc(bytes) : pool_.raw_malloc(bytes ? bytes : 8);
+    }
+    void pool_free(void *p)
+    {
+        if (pool_on_ && pool_.release(p)) return;
+        // not one of the pool's blocks (a pointer the caller made some other way): the old contract, drain and free
+        sync();
+        pool_.raw_free(p);
+    }
+    DevicePool::Stats alloc_stats() const { return pool_.stats(); }
+    size_t pool_trim() { sync(); return pool_.trim(); }
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
     const KernelEnv &env() const { return env_; }
@@ -262,14 +280,14 @@ public:
     void key_from_host(u64 **slot, const u64 *h_key)
     {
         use();
-        if (!*slot) HIPCHECK(hipMalloc(slot, key_alloc_elems() * 8));
+        if (!*slot) dmalloc(*slot, key_alloc_elems() * 8);
         HIPCHECK(hipMemcpyAsync(*slot, h_key, key_elems() * 8, hipMemcpyHostToDevice, stream_));
         key_finish(*slot);
     }
     void key_synthetic(u64 **slot, u64 seed)
     {
         use();
-        if (!*slot) HIPCHECK(hipMalloc(slot, key_alloc_elems() * 8));
+        if (!*slot) dmalloc(*slot, key_alloc_elems() * 8);
         PrimeMap pm;
         pm.period = (u32)P.K;
         for (size_t i = 0; i < P.K; ++i) pm.prime_of[i] = (unsigned char)i;
@@ -284,7 +302,7 @@ public:
         use();
         require_keyswitch();
         if (!d_sk_) throw std::invalid_argument("secret key not set");
-        if (!*slot) HIPCHECK(hipMalloc(slot, key_alloc_elems() * 8));
+        if (!*slot) dmalloc(*slot, key_alloc_elems() * 8);
         const uint32_t *perm_tab = galois_elt ? perm(galois_elt) : nullptr;
         u64 *scr = client_scratch((P.Ltop * P.K + P.K) * P.N);
         launch_keygen_kswitch(env_, *slot, scr, scr + P.Ltop * P.K * P.N, d_sk_, perm_tab, seed, galois_elt ? 2 + (u64)galois_elt : 1);
@@ -320,7 +338,7 @@ public:
     const u64 *relin_scaled()
     {
         if (!d_relin_scaled_ok_) {
-            if (!d_relin_scaled_) HIPCHECK(hipMalloc(&d_relin_scaled_, key_alloc_elems() * 8));
+            if (!d_relin_scaled_) dmalloc(d_relin_scaled_, key_alloc_elems() * 8);
             const u64 n_polys = P.Ltop * 2 * P.K, total = n_polys * P.N;
             hipLaunchKernelGGL(k_key_scaled_copy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream_, d_relin_, d_relin_scaled_, n_polys, P.logn, d_primes_,
                                d_floor_, (int)P.K);
@@ -342,7 +360,7 @@ public:
         if (it != d_perm_.end()) return it->second;
         const std::vector<uint32_t> h = P.galois_perm_ntt(elt);
         uint32_t *d = nullptr;
-        HIPCHECK(hipMalloc(&d, P.N * 4));
+        dmalloc(d, P.N * 4);
         HIPCHECK(hipMemcpy(d, h.data(), P.N * 4, hipMemcpyHostToDevice));
         d_perm_[elt] = d;
         return d;
@@ -354,7 +372,7 @@ public:
         if (it != d_gather_.end()) return it->second;
         const std::vector<uint32_t> h = P.galois_gather_coeff(elt);
         uint32_t *d = nullptr;
-        HIPCHECK(hipMalloc(&d, P.N * 4));
+        dmalloc(d, P.N * 4);
         HIPCHECK(hipMemcpy(d, h.data(), P.N * 4, hipMemcpyHostToDevice));
         d_gather_[elt] = d;
         return d;
@@ -408,36 +426,61 @@ public:
         const size_t N = P.N, LN = (size_t)L * N;
         return 2 * LN + LN + LN + (size_t)(L + 1) * LN + 2 * LN + 2 * N + 2 * N + 2 * LN + 3 * N + 3 * LN;
     }
-    // Ciphertexts per chunk for a batch of n at level L: chunk_ (default 1024, HE355_CHUNK / he355_set_chunk), halved while the scratch
-    // arena(s) it needs -- two when the batch is cut and the chunks alternate between the streams -- would not fit in the device memory
-    // that is free now (plus the arenas this context already holds, which a larger request replaces).
+    // Ciphertexts per chunk for a batch of n at level L: chunk_ (default 1024, HE355_CHUNK / he355_set_chunk), halved until the scratch
+    // arena(s) it needs -- two when the batch is cut and the chunks alternate between the streams -- are RESERVED: each arena is checked by
+    // itself (growing one frees only that one), against 0.9 of the memory that is free now plus what this context can give back (the
+    // arena being replaced, the pool's cached blocks); a hipMalloc that fails all the same (another context or process took the memory
+    // between the query and the call) halves the chunk again instead of failing the operation.  On return scratch(c, L, which) does not
+    // allocate.
     size_t chunk_ops(u64 n, int L, bool may_dual)
     {
         size_t c = std::min<u64>(chunk_, n ? n : 1);
         const size_t per_op = scratch_words_per_op(L) * 8;
-        size_t free_b = 0, total_b = 0;
-        if (per_op * c * (may_dual && n > c ? 2 : 1) <= scratch_bytes_ + scratch2_bytes_) return c; // (cheap path: no query)
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return c;
-        const size_t avail = (size_t)((double)(free_b + scratch_bytes_ + scratch2_bytes_) * 0.9);
-        while (c > 32 && per_op * c * (may_dual && n > c ? 2 : 1) > avail) c = (c + 1) / 2;
-        return c;
+        for (;;) {
+            const int arenas = (may_dual && n > c) ? 2 : 1;
+            const size_t need = per_op * c;
+            size_t grow = 0, reclaim = pool_.cached_bytes();
+            for (int a = 0; a < arenas; ++a) {
+                const size_t have = a ? scratch2_bytes_ : scratch_bytes_;
+                if (need > have) { grow += need; reclaim += have; }
+            }
+            bool fits = grow == 0;
+            if (!fits) {
+                size_t free_b = 0, total_b = 0;
+                fits = hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)grow <= 0.9 * (double)(free_b + reclaim);
+            }
+            if (fits) {
+                try {
+                    for (int a = 0; a < arenas; ++a) reserve_arena(a, need);
+                    return c;
+                } catch (const OutOfDeviceMemory &) {
+                    if (c == 1) throw;
+                }
+            } else if (c == 1) {
+                throw OutOfDeviceMemory("HIP error: out of device memory: the key-switch scratch of one ciphertext (" + std::to_string(per_op) + " bytes) does not fit");
+            }
+            c = (c + 1) / 2;
+        }
+    }
+    void reserve_arena(int which, size_t need)
+    {
+        u64 *&arena = which ? scratch2_ : scratch_;
+        size_t &arena_bytes = which ? scratch2_bytes_ : scratch_bytes_;
+        if (need <= arena_bytes) return;
+        HIPCHECK(hipStreamSynchronize(stream_));
+        HIPCHECK(hipStreamSynchronize(stream2_));
+        pool_.raw_free(arena);
+        arena = nullptr;
+        arena_bytes = 0;
+        dmalloc(arena, need);
+        arena_bytes = need;
     }
     Scratch scratch(size_t c, int L, int which = 0)
     {
         const size_t N = P.N, LN = (size_t)L * N;
         const size_t per_op = scratch_words_per_op(L);
-        const size_t need = per_op * c * 8;
-        u64 *&arena = which ? scratch2_ : scratch_;
-        size_t &arena_bytes = which ? scratch2_bytes_ : scratch_bytes_;
-        if (need > arena_bytes) {
-            HIPCHECK(hipStreamSynchronize(stream_));
-            HIPCHECK(hipStreamSynchronize(stream2_));
-            if (arena) HIPCHECK(hipFree(arena));
-            arena = nullptr;
-            arena_bytes = 0;
-            HIPCHECK(hipMalloc(&arena, need));
-            arena_bytes = need;
-        }
+        reserve_arena(which, per_op * c * 8);
+        u64 *arena = which ? scratch2_ : scratch_;
         Scratch s;
         u64 *p = arena;
         s.ks.c01 = p; p += c * 2 * LN; s.ks.c01_item_stride = 2 * LN;
@@ -601,9 +644,9 @@ public:
         if (elems * 8 > lat_part_bytes_[which]) {
             HIPCHECK(hipStreamSynchronize(stream_));
             HIPCHECK(hipStreamSynchronize(stream2_));
-            if (lat_part_[which]) HIPCHECK(hipFree(lat_part_[which]));
+            pool_.raw_free(lat_part_[which]);
             lat_part_[which] = nullptr; lat_part_bytes_[which] = 0;
-            HIPCHECK(hipMalloc(&lat_part_[which], elems * 8));
+            dmalloc(lat_part_[which], elems * 8);
             lat_part_bytes_[which] = elems * 8;
         }
         return lat_part_[which];
@@ -857,9 +900,9 @@ public:
         if (addend == out && steps.size() > 1) throw std::invalid_argument("rotate_add through several Galois steps cannot add in place");
         if (steps.size() > 1 && bytes > rot_tmp_bytes_) {
             HIPCHECK(hipStreamSynchronize(stream_));
-            if (rot_tmp_) HIPCHECK(hipFree(rot_tmp_));
+            pool_.raw_free(rot_tmp_);
             rot_tmp_ = nullptr; rot_tmp_bytes_ = 0;
-            HIPCHECK(hipMalloc(&rot_tmp_, bytes));
+            dmalloc(rot_tmp_, bytes);
             rot_tmp_bytes_ = bytes;
         }
         // ping-pong between out and the temporary so that the last rotation lands in out
@@ -949,9 +992,9 @@ public:
         const size_t levels = depth;
         if (levels * bytes > rot_tmp_bytes_) {
             HIPCHECK(hipStreamSynchronize(stream_));
-            if (rot_tmp_) HIPCHECK(hipFree(rot_tmp_));
+            pool_.raw_free(rot_tmp_);
             rot_tmp_ = nullptr; rot_tmp_bytes_ = 0;
-            HIPCHECK(hipMalloc(&rot_tmp_, levels * bytes));
+            dmalloc(rot_tmp_, levels * bytes);
             rot_tmp_bytes_ = levels * bytes;
         }
         u64 switches = 0;
@@ -998,9 +1041,9 @@ public:
         require_keyswitch();
         if (2 * bytes > rot_tmp_bytes_) {
             HIPCHECK(hipStreamSynchronize(stream_));
-            if (rot_tmp_) HIPCHECK(hipFree(rot_tmp_));
+            pool_.raw_free(rot_tmp_);
             rot_tmp_ = nullptr; rot_tmp_bytes_ = 0;
-            HIPCHECK(hipMalloc(&rot_tmp_, 2 * bytes));
+            dmalloc(rot_tmp_, 2 * bytes);
             rot_tmp_bytes_ = 2 * bytes;
         }
         u64 *ga = rot_tmp_, *gb = rot_tmp_ + n * per;
@@ -1083,7 +1126,7 @@ public:
                      o_imb = push(T.inv_mt_bsk), o_iqb = push(T.inv_q_bsk), o_tq = push(T.t_mod_q), o_tb = push(T.t_mod_bsk), o_ipB = push(T.inv_punct_B),
                      o_B2q = push(T.B2q), o_B2m = push(T.B2msk), o_Bq = push(T.B_mod_q);
         u64 *d = nullptr;
-        HIPCHECK(hipMalloc(&d, blob.size() * 8));
+        dmalloc(d, blob.size() * 8);
         owned_.push_back(d);
         HIPCHECK(hipMemcpy(d, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
         BehzDev Z{};
@@ -1105,19 +1148,25 @@ public:
         const size_t N = P.N, S = (size_t)L + 1;
         const size_t per_op = (4 * L + 4 * S + 3 * L + 3 * S) * N;
         size_t c = std::min<size_t>(chunk_, (size_t)n ? (size_t)n : 1);
-        if (per_op * c * 8 > bfv_bytes_) { // as chunk_ops: halved until the arena fits in the memory that is free now
+        while (per_op * c * 8 > bfv_bytes_) { // as chunk_ops: halved until the arena is reserved
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const size_t avail = (size_t)((double)(free_b + bfv_bytes_) * 0.9);
-                while (c > 32 && per_op * c * 8 > avail) c = (c + 1) / 2;
+            const bool fits = hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+                              (double)(per_op * c * 8) <= 0.9 * (double)(free_b + bfv_bytes_ + pool_.cached_bytes());
+            if (fits) {
+                try {
+                    HIPCHECK(hipStreamSynchronize(stream_));
+                    pool_.raw_free(bfv_scratch_);
+                    bfv_scratch_ = nullptr; bfv_bytes_ = 0;
+                    dmalloc(bfv_scratch_, per_op * c * 8);
+                    bfv_bytes_ = per_op * c * 8;
+                    break;
+                } catch (const OutOfDeviceMemory &) {
+                    if (c == 1) throw;
+                }
+            } else if (c == 1) {
+                throw OutOfDeviceMemory("HIP error: out of device memory: the BFV multiply scratch of one ciphertext does not fit");
             }
-        }
-        if (per_op * c * 8 > bfv_bytes_) {
-            HIPCHECK(hipStreamSynchronize(stream_));
-            if (bfv_scratch_) HIPCHECK(hipFree(bfv_scratch_));
-            bfv_scratch_ = nullptr; bfv_bytes_ = 0;
-            HIPCHECK(hipMalloc(&bfv_scratch_, per_op * c * 8));
-            bfv_bytes_ = per_op * c * 8;
+            c = (c + 1) / 2;
         }
         u64 *xq = bfv_scratch_, *xb = xq + c * 4 * L * N, *dq = xb + c * 4 * S * N, *ds = dq + c * 3 * L * N;
         PolyView vq{}, vb{};
@@ -1152,23 +1201,23 @@ public:
     {
         use();
         const size_t bytes = 2 * P.K * P.N * 8;
-        if (!d_pk_) { HIPCHECK(hipMalloc(&d_pk_, bytes)); owned_.push_back(d_pk_); }
+        if (!d_pk_) { dmalloc(d_pk_, bytes); owned_.push_back(d_pk_); }
         HIPCHECK(hipMemcpy(d_pk_, h_pk, bytes, hipMemcpyHostToDevice));
     }
     void set_secret_key(const u64 *h_sk) // [K][N], NTT form
     {
         use();
         const size_t bytes = P.K * P.N * 8;
-        if (!d_sk_) { HIPCHECK(hipMalloc(&d_sk_, bytes)); owned_.push_back(d_sk_); }
+        if (!d_sk_) { dmalloc(d_sk_, bytes); owned_.push_back(d_sk_); }
         HIPCHECK(hipMemcpy(d_sk_, h_sk, bytes, hipMemcpyHostToDevice));
     }
     u64 *client_scratch(size_t elems)
     {
         if (elems > client_scratch_elems_) {
             HIPCHECK(hipStreamSynchronize(stream_));
-            if (client_scratch_) HIPCHECK(hipFree(client_scratch_));
+            pool_.raw_free(client_scratch_);
             client_scratch_ = nullptr;
-            HIPCHECK(hipMalloc(&client_scratch_, elems * 8));
+            dmalloc(client_scratch_, elems * 8);
             client_scratch_elems_ = elems;
         }
         return client_scratch_;
@@ -1265,7 +1314,7 @@ public:
         }
         u64 *d = nullptr;
         const size_t tot = (size_t)words * 2 + (size_t)L * words + L;
-        HIPCHECK(hipMalloc(&d, tot * 8));
+        dmalloc(d, tot * 8);
         owned_.push_back(d);
         HIPCHECK(hipMemcpy(d, Q.data(), words * 8, hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(d + words, halfQ.data(), words * 8, hipMemcpyHostToDevice));
@@ -1311,7 +1360,7 @@ public:
         std::vector<uint32_t> si;
         client::build_slot_index(P.N, si);
         uint32_t *dsi = nullptr;
-        HIPCHECK(hipMalloc(&dsi, P.N * 4));
+        dmalloc(dsi, P.N * 4);
         owned_.push_back(dsi);
         HIPCHECK(hipMemcpy(dsi, si.data(), P.N * 4, hipMemcpyHostToDevice));
         enc_.slot_index = dsi;
@@ -1319,13 +1368,13 @@ public:
             std::vector<client::Cplx> W, Z;
             client::build_ckks_tables(P.N, W, Z);
             client::Cplx *dw = nullptr;
-            HIPCHECK(hipMalloc(&dw, 2 * P.N * sizeof(client::Cplx)));
+            dmalloc(dw, 2 * P.N * sizeof(client::Cplx));
             owned_.push_back(dw);
             HIPCHECK(hipMemcpy(dw, W.data(), P.N * sizeof(client::Cplx), hipMemcpyHostToDevice));
             HIPCHECK(hipMemcpy(dw + P.N, Z.data(), P.N * sizeof(client::Cplx), hipMemcpyHostToDevice));
             enc_.W = dw; enc_.Z = dw + P.N;
         }
-        if (!d_err_) { HIPCHECK(hipMalloc(&d_err_, sizeof(int))); owned_.push_back(d_err_); }
+        if (!d_err_) { dmalloc(d_err_, sizeof(int)); owned_.push_back(d_err_); }
         return enc_;
     }
     // CKKSEncoder::encode: values [n][count] (count <= N/2) at `scale` -> [n][Ltop][N] NTT-form plaintexts
@@ -1490,6 +1539,8 @@ private:
     std::map<int, BehzDev> behz_;
     std::map<uint32_t, uint32_t *> d_gather_;
     size_t chunk_ = 1024;
+    DevicePool pool_;
+    const bool pool_on_ = !(getenv("HE355_POOL") && getenv("HE355_POOL")[0] == '0');
 };
 
 } // namespace he355
@@ -1615,16 +1666,37 @@ int he355_mem_info(he355_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes)
 int he355_malloc(he355_ctx *c, uint64_t bytes, void **d_ptr)
 {
     return guarded([&] {
-        dev(c).use();
         if (!d_ptr) throw std::invalid_argument("null pointer");
-        HIPCHECK(hipMalloc(d_ptr, bytes ? bytes : 8));
+        *d_ptr = dev(c).pool_alloc(bytes);
     });
 }
 int he355_free(he355_ctx *c, void *d_ptr)
 {
     return guarded([&] {
-        dev(c).sync();
-        HIPCHECK(hipFree(d_ptr));
+        dev(c).pool_free(d_ptr);
+    });
+}
+int he355_alloc_stats(he355_ctx *c, he355_alloc_stats_t *out)
+{
+    return guarded([&] {
+        if (!out) throw std::invalid_argument("null pointer");
+        if (!c) { // process-wide totals (every context's pool)
+            out->raw_mallocs = g_pool_totals.raw_mallocs; out->raw_frees = g_pool_totals.raw_frees;
+            out->pool_hits = g_pool_totals.pool_hits; out->pool_misses = g_pool_totals.pool_misses;
+            out->cached_bytes = out->live_bytes = 0;
+            return;
+        }
+        const DevicePool::Stats st = dev(c).alloc_stats();
+        out->raw_mallocs = st.raw_mallocs; out->raw_frees = st.raw_frees;
+        out->pool_hits = st.pool_hits; out->pool_misses = st.pool_misses;
+        out->cached_bytes = st.cached_bytes; out->live_bytes = st.live_bytes;
+    });
+}
+int he355_pool_trim(he355_ctx *c, uint64_t *released_bytes)
+{
+    return guarded([&] {
+        const size_t b = dev(c).pool_trim();
+        if (released_bytes) *released_bytes = b;
     });
 }
 int he355_upload(he355_ctx *c, void *d_dst, const void *h_src, uint64_t bytes)
