@@ -14,7 +14,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libhe_oracle.so")
+# HE_ORACLE_LIB_PATH: another build of the same oracle (the ASan/UBSan build of `make -C oracle asan`, tools/asan_oracle.sh)
+_LIB_PATH = os.environ.get("HE_ORACLE_LIB_PATH") or os.path.join(_HERE, "_build", "libhe_oracle.so")
 
 SCHEME_BFV = 1
 SCHEME_CKKS = 2
@@ -57,6 +58,7 @@ def lib():
             "ho_ctx_create": (vp, [i32, sz, C.POINTER(C.c_int), sz, i32, i32, C.c_char_p, sz]),
             "ho_ctx_create_primes": (vp, [i32, sz, _u64p, sz, u64, C.c_char_p, sz]),
             "ho_ctx_destroy": (None, [vp]),
+            "ho_scratch_release": (None, []), "ho_scratch_release_all": (None, []),
             "ho_N": (sz, [vp]), "ho_key_mod_count": (sz, [vp]), "ho_data_mod_count": (sz, [vp]),
             "ho_modulus": (u64, [vp, sz]), "ho_plain_modulus": (u64, [vp]), "ho_root": (u64, [vp, sz]),
             "ho_root_powers": (None, [vp, sz, _u64p]),

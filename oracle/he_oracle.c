@@ -22,6 +22,60 @@ typedef unsigned __int128 u128;
 typedef uint64_t u64;
 
 /* ------------------------------------------------------------------------------------------------ */
+/* Per-thread scratch.  The reference's operate() loop hands SEAL a thread-local memory pool          */
+/* (MemoryPoolHandle::ThreadLocal(), src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:343), so */
+/* its evaluator takes no system allocation per ciphertext.  The temporaries of the evaluator         */
+/* functions below come from the same kind of cache: a block is malloc'ed once per thread and size    */
+/* and handed out again by scr_alloc() after scr_free().  (With malloc/free per op, the 27 MiB of    */
+/* key-switch temporaries at N = 2^15 are an mmap + page faults + munmap per ciphertext per thread:   */
+/* 128 threads serialise on the address-space lock and the timed CPU baseline drops to 14 % parallel  */
+/* efficiency.)                                                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+#define SCR_SLOTS 32
+#define SCR_HDR 64
+typedef struct { void *blk[SCR_SLOTS]; size_t cap[SCR_SLOTS]; int n; } scr_cache;
+static _Thread_local scr_cache g_scr;
+static void *scr_alloc(size_t bytes)
+{
+    scr_cache *c = &g_scr;
+    int best = -1;
+    for (int i = 0; i < c->n; ++i)
+        if (c->cap[i] >= bytes && (best < 0 || c->cap[i] < c->cap[best])) best = i;
+    if (best >= 0 && c->cap[best] <= 2 * bytes + 4096) {
+        void *b = c->blk[best];
+        c->blk[best] = c->blk[--c->n];
+        c->cap[best] = c->cap[c->n];
+        return (char *)b + SCR_HDR;
+    }
+    const size_t cap = (bytes + 63) & ~(size_t)63;
+    char *b = (char *)aligned_alloc(64, cap + SCR_HDR);
+    if (!b) { fprintf(stderr, "he_oracle: out of memory (%zu bytes)\n", bytes); abort(); }
+    *(size_t *)b = cap;
+    return b + SCR_HDR;
+}
+static void scr_free(void *p)
+{
+    if (!p) return;
+    char *b = (char *)p - SCR_HDR;
+    scr_cache *c = &g_scr;
+    if (c->n < SCR_SLOTS) { c->blk[c->n] = b; c->cap[c->n] = *(size_t *)b; ++c->n; }
+    else free(b);
+}
+/* give the calling thread's cached blocks back (ho_scratch_release_all: every thread of the OpenMP team) */
+void ho_scratch_release(void)
+{
+    scr_cache *c = &g_scr;
+    for (int i = 0; i < c->n; ++i) free(c->blk[i]);
+    c->n = 0;
+}
+void ho_scratch_release_all(void)
+{
+#pragma omp parallel
+    ho_scratch_release();
+    ho_scratch_release();
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* Modulus with Barrett constant  (seal/modulus.h: Modulus::const_ratio = floor(2^128/q))            */
 /* ------------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -453,10 +507,10 @@ void ho_switch_key(const ho_ctx *c, size_t L, const u64 *target, const u64 *key,
 {
     const size_t N = c->N, K = c->K, SP = K - 1; /* SP: index of the special prime */
     const int ckks = (c->scheme == HO_SCHEME_CKKS);
-    u64 *coef = (u64 *)malloc(L * N * 8);   /* target in coefficient form */
-    u64 *tmp = (u64 *)malloc(N * 8);
-    u64 *prod = (u64 *)malloc(2 * (L + 1) * N * 8); /* [k][i'] i' = 0..L-1 data, L = special */
-    u128 *acc = (u128 *)malloc(2 * N * sizeof(u128));
+    u64 *coef = (u64 *)scr_alloc(L * N * 8);   /* target in coefficient form */
+    u64 *tmp = (u64 *)scr_alloc(N * 8);
+    u64 *prod = (u64 *)scr_alloc(2 * (L + 1) * N * 8); /* [k][i'] i' = 0..L-1 data, L = special */
+    u128 *acc = (u128 *)scr_alloc(2 * N * sizeof(u128));
     memcpy(coef, target, L * N * 8);
     if (ckks)
         for (size_t j = 0; j < L; ++j) ntt_inverse(&c->t[j], N, coef + j * N);
@@ -510,7 +564,7 @@ void ho_switch_key(const ho_ctx *c, size_t L, const u64 *target, const u64 *key,
             }
         }
     }
-    free(coef); free(tmp); free(prod); free(acc);
+    scr_free(coef); scr_free(tmp); scr_free(prod); scr_free(acc);
 }
 
 /* evaluator.cpp Evaluator::relinearize_internal (size 3 -> 2): switch_key(c2, relin_keys[0]) */
@@ -526,7 +580,7 @@ void ho_rescale(const ho_ctx *c, size_t L, size_t size, const u64 *in, u64 *out)
     const size_t N = c->N, last = L - 1;
     const ho_mod *ml = &c->t[last].m;
     const u64 half = ml->q >> 1;
-    u64 *r = (u64 *)malloc(N * 8), *tmp = (u64 *)malloc(N * 8);
+    u64 *r = (u64 *)scr_alloc(N * 8), *tmp = (u64 *)scr_alloc(N * 8);
     for (size_t k = 0; k < size; ++k) {
         memcpy(r, in + (k * L + last) * N, N * 8);
         ntt_inverse(&c->t[last], N, r);
@@ -542,7 +596,7 @@ void ho_rescale(const ho_ctx *c, size_t L, size_t size, const u64 *in, u64 *out)
             for (size_t n = 0; n < N; ++n) dst[n] = mulmod(submod(src[n], tmp[n], qi), inv, m);
         }
     }
-    free(r); free(tmp);
+    scr_free(r); scr_free(tmp);
 }
 
 /* util/rns.cpp RNSTool::divide_and_round_q_last_inplace (coefficient form): BFV mod_switch_to_next and
@@ -552,7 +606,7 @@ void ho_mod_switch_coeff(const ho_ctx *c, size_t L, size_t size, const u64 *in, 
     const size_t N = c->N, last = L - 1;
     const ho_mod *ml = &c->t[last].m;
     const u64 half = ml->q >> 1;
-    u64 *r = (u64 *)malloc(N * 8);
+    u64 *r = (u64 *)scr_alloc(N * 8);
     for (size_t k = 0; k < size; ++k) {
         const u64 *lp = in + (k * L + last) * N;
         for (size_t n = 0; n < N; ++n) r[n] = addmod(lp[n], half, ml->q);
@@ -568,7 +622,7 @@ void ho_mod_switch_coeff(const ho_ctx *c, size_t L, size_t size, const u64 *in, 
             }
         }
     }
-    free(r);
+    scr_free(r);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -632,14 +686,14 @@ void ho_apply_galois(const ho_ctx *c, size_t L, uint32_t elt, const u64 *gkey, c
 {
     const size_t N = c->N;
     const int ntt_form = (c->scheme == HO_SCHEME_CKKS);
-    u64 *t1 = (u64 *)malloc(L * N * 8);
+    u64 *t1 = (u64 *)scr_alloc(L * N * 8);
     for (size_t i = 0; i < L; ++i) {
         ho_apply_galois_poly(c, i, elt, ntt_form, in + i * N, out + i * N);
         ho_apply_galois_poly(c, i, elt, ntt_form, in + (L + i) * N, t1 + i * N);
     }
     memset(out + L * N, 0, L * N * 8);
     ho_switch_key(c, L, t1, gkey, out);
-    free(t1);
+    scr_free(t1);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -677,12 +731,12 @@ void ho_batch_op(const ho_ctx *c, int op, size_t L, size_t n_results, const u64 
         } else if (op == HO_OP_MUL) {
             ho_multiply_ntt(c, L, pa, pb, po);
         } else {
-            u64 *t3 = (u64 *)malloc(3 * L * N * 8);
+            u64 *t3 = (u64 *)scr_alloc(3 * L * N * 8);
             ho_multiply_ntt(c, L, pa, pb, t3);
             ho_relinearize(c, L, t3, relin_key);
             if (op == HO_OP_MUL_RELIN) memcpy(po, t3, ct * 8);
             else ho_rescale(c, L, 2, t3, po);
-            free(t3);
+            scr_free(t3);
         }
     }
 }

@@ -50,6 +50,10 @@ ho_ctx *ho_ctx_create(int scheme, size_t N, const int *bit_sizes, size_t n_bits,
 ho_ctx *ho_ctx_create_primes(int scheme, size_t N, const uint64_t *primes, size_t n_primes, uint64_t plain_modulus,
                              char *err, size_t errlen);
 void ho_ctx_destroy(ho_ctx *c);
+/* The evaluator functions keep their temporaries in a per-thread cache (the role of SEAL's MemoryPoolHandle::ThreadLocal() in the
+ * reference's operate() loop, ckks eltwise .cpp:343).  These give the cache of the calling thread / of every OpenMP thread back. */
+void ho_scratch_release(void);
+void ho_scratch_release_all(void);
 size_t ho_N(const ho_ctx *c);
 size_t ho_key_mod_count(const ho_ctx *c);  /* K: all primes, special prime last            */
 size_t ho_data_mod_count(const ho_ctx *c); /* L at the first data level (K-1, or 1 if K==1) */
