@@ -22,14 +22,96 @@ SCHEME_CKKS = 2
 OP_ADD, OP_MUL, OP_MUL_RELIN, OP_MUL_RELIN_RESCALE, OP_DOT = 0, 1, 2, 3, 4
 
 
+def _host_signature() -> str:
+    """what `-march=native` depends on: the CPU model and its feature flags"""
+    model, flags = "", ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and not model:
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("flags") and not flags:
+                    flags = " ".join(sorted(line.split(":", 1)[1].split()))
+                if model and flags:
+                    break
+    except OSError:
+        pass
+    import hashlib
+    return model + " " + hashlib.sha256(flags.encode()).hexdigest()[:16]
+
+
 def build(force: bool = False) -> str:
-    """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("he_oracle.c", "he_oracle_bfv.inc", "he_oracle_pipelines.inc", "he_oracle.h")]
-    stale = force or not os.path.exists(_LIB_PATH) or any(
-        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
-    if stale:
-        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it.
+    The library is built `-march=native`, so it belongs to the host that built it: `_build/host.sig` records that host's CPU
+    model + flags and a different host (the GPU box receives the build container's `_build/`) rebuilds before the first use -- the
+    timed CPU baseline then runs code tuned for the cores it is timed on, and never code the host cannot execute.  A file lock
+    serialises concurrent builders (N bench ranks, parallel test workers)."""
+    if os.environ.get("HE_ORACLE_LIB_PATH"):
+        return _LIB_PATH
+    import fcntl
+    srcs = [os.path.join(_HERE, f) for f in ("he_oracle.c", "he_oracle_bfv.inc", "he_oracle_pipelines.inc", "he_oracle.h", "Makefile")]
+    sig_path = os.path.join(_HERE, "_build", "host.sig")
+    sig = _host_signature()
+
+    def stale():
+        if force or not os.path.exists(_LIB_PATH):
+            return True
+        if any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
+            return True
+        try:
+            return open(sig_path).read().strip() != sig
+        except OSError:
+            return True
+
+    if stale():
+        os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+        with open(os.path.join(_HERE, "_build", ".lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if stale():  # somebody else may have built it while we waited
+                    try:
+                        subprocess.run(["make", "-C", _HERE, "-s", "-B"], check=True)
+                        with open(sig_path, "w") as f:
+                            f.write(sig + "\n")
+                    except (subprocess.CalledProcessError, OSError):
+                        if not os.path.exists(_LIB_PATH):
+                            raise
+                        import sys
+                        print("oracle: rebuild for this host failed, using the library that travelled with the tree", file=sys.stderr)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH
+
+
+def effective_cpus() -> dict:
+    """The CPU share this process really has: the affinity mask, and the cgroup quota when one is set (a container limited to 16
+    CPUs still shows every core of the host in os.cpu_count() and in omp_get_max_threads())."""
+    info = {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cgroup_cpu_max": None,
+            "quota_cpus": None}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().strip()
+        except OSError:
+            continue
+        info["cgroup_cpu_max"] = txt
+        try:
+            if path.endswith("cpu.max"):
+                q, per = txt.split()
+                if q != "max":
+                    info["quota_cpus"] = float(q) / float(per)
+            else:
+                q = float(txt)
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    info["quota_cpus"] = q / per
+        except (ValueError, OSError):
+            pass
+        break
+    eff = info["affinity"] or info["nproc"] or 1
+    if info["quota_cpus"]:
+        eff = max(1, min(eff, int(info["quota_cpus"] + 0.5)))
+    info["effective"] = eff
+    return info
 
 
 _lib = None
@@ -50,8 +132,7 @@ def _p32(a: np.ndarray):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        build()  # no-op when the library is present, newer than its sources and was built on this host
         L = C.CDLL(_LIB_PATH)
         vp, sz, u64, i32, u32 = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int, C.c_uint32
         sig = {

@@ -97,10 +97,10 @@ def _bench(*argv, env=None, timeout=180):
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with no torch.distributed.run around it (how the driver runs N=1): the process starts its own two
     ranks, they rendezvous (gloo), every rank computes its shard of the global batch, rank 0 prints one JSON line."""
-    for scaling, batch, b0 in (("strong", 7, 7), ("weak", 5, 10)):
-        p, doc = _bench("--gpus", "2", "--dry-run", "--scaling", scaling, "--batch", str(batch), env={"HE355_BENCH_BACKEND": "gloo"})
+    for config, scaling, batch, b0 in (("mul_relin_rescale", "strong", 7, 7), ("mul_relin_rescale", "weak", 5, 10), ("dot", "strong", 9, 9), ("dot", "weak", 4, 8)):
+        p, doc = _bench("--gpus", "2", "--dry-run", "--config", config, "--scaling", scaling, "--batch", str(batch), env={"HE355_BENCH_BACKEND": "gloo"})
         assert p.returncode == 0, p.stderr[-2000:]
-        assert doc["dry_run"] and doc["n_gpus"] == 2 and doc["global_b0"] == b0
+        assert doc["dry_run"] and doc["n_gpus"] == 2 and doc["global_b0"] == b0 and doc["config"] == config
         want = [_load_sharding().shard_outer_product(b0, 1, 2, r) for r in range(2)]
         assert [(s["rank"], s["a_base"], s["a_count"], s["n_results"]) for s in doc["shards"]] == [(w.rank, w.a_base, w.a_count, w.n_results) for w in want]
         assert sum(s["a_count"] for s in doc["shards"]) == b0  # the shards tile the global batch
@@ -129,3 +129,25 @@ def test_bench_two_ranks_share_the_gpu_through_the_self_launch_path():
     assert p.returncode == 0, p.stderr[-2000:]
     assert doc["n_gpus"] == 2 and doc["config"]["global_batch"] == 6
     assert doc["parity"]["checked_in_run"] is True and [r["ok"] for r in doc["parity"]["per_rank"]] == [True, True]
+
+
+def test_oracle_build_is_locked_and_host_stamped(tmp_path):
+    """oracle.build(): N fresh ranks may call it at once (bench.py on a box whose `_build/` did not travel) -- a file lock lets exactly
+    one run make; the library carries the signature of the host it was built on (`-march=native`) and is rebuilt on another host."""
+    import subprocess
+    import sys
+    import oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sig = os.path.join(root, "oracle", "_build", "host.sig")
+    oracle.build()
+    assert open(sig).read().strip() == oracle._host_signature()
+    # a stale signature (the tree came from another host) triggers exactly one rebuild however many processes ask at once
+    open(sig, "w").write("some other host\n")
+    code = "import oracle, os; oracle.lib(); print(os.path.getmtime(oracle._LIB_PATH))"
+    procs = [subprocess.Popen([sys.executable, "-c", code], cwd=root, stdout=subprocess.PIPE, text=True) for _ in range(3)]
+    outs = [p.communicate(timeout=300)[0].strip() for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    assert len(set(outs)) == 1, outs                       # all three loaded the same, single rebuild
+    assert open(sig).read().strip() == oracle._host_signature()
+    cpus = oracle.effective_cpus()
+    assert 1 <= cpus["effective"] <= (cpus["nproc"] or 1)
