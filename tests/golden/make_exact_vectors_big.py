@@ -5,6 +5,8 @@
     multiply -> relinearize -> rescale, and one rotation (Galois element of step 1) -- the kernel instances the headline uses
     (k_k2n<5>, k_k3<.., fused>, k_floor_colsn<5, merged>) are then held to the model with no oracle involved;
   * N = 2^14, key chain {60, 45 x 7, 60} (configs[1]): multiply.
+  * BFV, N = 2^15, key chain {60, 40, 40, 60}, t = 786433 (configs[4]): BEHZ multiply, -> relinearize, -> rotate_rows(1), and
+    rotate_columns of an input -- the kernel instances of the MatMultRow product (k_behz_*, the BFV key-switch tail, k_bfv_galois).
 
 Same model, same seeded input functions as make_exact_vectors.py; the inputs are produced by their numpy twins
 (exact_inputs.*_np, checked here against the pure-Python functions on samples) because a key is 18 M residues.
@@ -35,7 +37,8 @@ def run_case(case):
     N, bits, seed = case["N"], case["bits"], case["seed"]
     primes = coeff_modulus_create(N, bits)
     K, Ltop = len(primes), len(primes) - 1
-    M = Model(N, primes, ntt_form=True)
+    bfv = case["scheme"] == "bfv"
+    M = Model(N, primes, ntt_form=not bfv)
     # the recursive transform against its definition at a few evaluation points per prime (the full check is O(N^2))
     for i in range(K):
         c = xi.uniform_poly(seed, 999 + i, primes[i], N)
@@ -52,14 +55,31 @@ def run_case(case):
     assert xi.uniform_poly_np(seed, 1000, primes[0], N)[:64].tolist() == xi.uniform_poly(seed, 1000, primes[0], 64 if False else N)[:64]
     a = to_lists(xi.ciphertext_np(seed, 1, primes, Ltop, 2, N))
     b = to_lists(xi.ciphertext_np(seed, 2, primes, Ltop, 2, N))
-    out = {"N": N, "bits": bits, "scheme": "ckks", "seed": seed, "primes": [hex(p) for p in primes], "psi": [hex(p) for p in M.R.psi],
-           "galois_elts": {"1": galois_elt(1, N)}, "expected": {}}
+    out = {"N": N, "bits": bits, "scheme": case["scheme"], "seed": seed, "primes": [hex(p) for p in primes], "psi": [hex(p) for p in M.R.psi],
+           "galois_elts": {"1": galois_elt(1, N), "conj": 2 * N - 1}, "expected": {}}
     exp = out["expected"]
 
     def put(name, ct):
         exp[name] = {"sha256": digest(ct), "shape": [len(ct), len(ct[0]), N], "head": head(ct)}
         log(case["name"], name, "done")
 
+    if bfv:
+        # the chain of bfv row .cpp:515-531 on the exact model: BEHZ multiply (integer statement, no auxiliary base), relinearize,
+        # rotate_rows by one step; plus rotate_columns of an input (accumulateBFV's column swap, seal_context.cpp:308)
+        t = case["plain_modulus"]
+        out["plain_modulus"] = t
+        m3 = M.bfv_multiply(a, b, t)
+        put("bfv_multiply", m3)
+        rk = to_lists(xi.kswitch_key_np(seed, 3, primes, Ltop, N))
+        rl = M.relinearize(m3, rk)
+        del rk
+        put("bfv_multiply_relin", rl)
+        gk = to_lists(xi.kswitch_key_np(seed, 10, primes, Ltop, N))
+        put("bfv_multiply_relin_rotate_rows_1", M.apply_galois(rl, galois_elt(1, N), gk))
+        del gk
+        gc = to_lists(xi.kswitch_key_np(seed, 13, primes, Ltop, N))
+        put("rotate_columns", M.apply_galois(a, 2 * N - 1, gc))
+        return out
     c3 = M.multiply_ckks(a, b)
     put("multiply", c3)
     if "multiply_relin" in case["ops"]:

@@ -112,9 +112,13 @@ def big_case_inputs(name):
     d = dict(primes=primes, N=N, Ltop=Ltop, a=xi.ciphertext_np(seed, 1, primes, Ltop, 2, N), b=xi.ciphertext_np(seed, 2, primes, Ltop, 2, N))
     if "multiply_relin" in f["expected"]:
         d["rk"] = xi.kswitch_key_np(seed, 3, primes, Ltop, N)
-    if "rotate_1" in f["expected"]:
+    if "rotate_1" in f["expected"] or f["scheme"] == "bfv":
         d["g1"] = f["galois_elts"]["1"]
         d["gk1"] = xi.kswitch_key_np(seed, 10, primes, Ltop, N)
+    if f["scheme"] == "bfv":
+        d["rk"] = xi.kswitch_key_np(seed, 3, primes, Ltop, N)
+        d["gconj"] = f["galois_elts"]["conj"]
+        d["gkc"] = xi.kswitch_key_np(seed, 13, primes, Ltop, N)
     return f, d
 
 
@@ -127,7 +131,25 @@ def test_numpy_input_twins_agree_with_the_scalar_functions():
     assert xi.kswitch_key_np(5, 3, primes, 2, 16).tolist() == xi.kswitch_key(5, 3, primes, 2, 16)
 
 
-@pytest.mark.parametrize("name", [c["name"] for c in xi.BIG_CASES])
+@pytest.mark.parametrize("name", [c["name"] for c in xi.BIG_CASES if c["scheme"] == "bfv"])
+def test_oracle_reproduces_the_exact_model_at_bench_sizes_bfv(oracle, name):
+    """BASELINE configs[4]'s parameters (N = 2^15, {60, 40, 40, 60}, t = 786433): BEHZ multiply -> relinearize -> rotate_rows(1), the
+    chain of bfv row .cpp:515-531, and rotate_columns -- the oracle against the exact model's integer statement, bit for bit."""
+    if name not in BIG:
+        pytest.skip("fixture case not generated (tests/golden/make_exact_vectors_big.py)")
+    f, d = big_case_inputs(name)
+    o = oracle.Context(oracle.SCHEME_BFV, f["N"], bit_sizes=f["bits"], plain_bits=20)
+    assert [int(q) for q in o.moduli] == d["primes"] and int(o.t) == f["plain_modulus"]
+    assert o.galois_elt(1) == d["g1"]
+    m3 = o.bfv_multiply(d["a"], d["b"])
+    check(f, "bfv_multiply", m3)
+    rl = o.relinearize(m3, d["rk"])
+    check(f, "bfv_multiply_relin", rl)
+    check(f, "bfv_multiply_relin_rotate_rows_1", o.apply_galois(rl, d["g1"], d["gk1"]))
+    check(f, "rotate_columns", o.apply_galois(d["a"], d["gconj"], d["gkc"]))
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in xi.BIG_CASES if c["scheme"] == "ckks"])
 def test_oracle_reproduces_the_exact_model_at_bench_sizes(oracle, name):
     """N = 2^15 with the headline chain {60, 45 x 15, 60} (multiply, multiply -> relinearize, -> rescale, one rotation) and N = 2^14,
     {60, 45 x 7, 60} (multiply): the oracle on the exact model's ciphertexts, bit for bit."""

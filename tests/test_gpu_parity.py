@@ -848,6 +848,54 @@ def test_exact_model_big_fixture_gpu(be, name):
     g.close()
 
 
+def test_exact_model_big_fixture_gpu_bfv(be):
+    """BASELINE configs[4]'s kernel instances against the exact big-integer model, no oracle involved: N = 2^15, {60, 40, 40, 60},
+    t = 786433 -- he355_bfv_multiply (k_behz_extend, k_tensor4, k_behz_floor_sk), he355_relinearize (the BFV key switch and its
+    coefficient-form tail), he355_apply_galois for rotate_rows(1) and rotate_columns (k_bfv_galois), and the rotation with the
+    add_inplace folded in (he355_rotate_add), at batch 1 and inside a batch of 3.  Reference chain: bfv row .cpp:515-531."""
+    import test_exact_model as tem
+    name = "bfv_n32768_60_40_40_60"
+    if name not in tem.BIG:
+        pytest.skip("fixture case not generated (tests/golden/make_exact_vectors_big.py)")
+    f, d = tem.big_case_inputs(name)
+    N, L = f["N"], d["Ltop"]
+    g = be.Context(be.SCHEME_BFV, N, bit_sizes=f["bits"], plain_bits=20, device=0)
+    assert [int(q) for q in g.moduli] == d["primes"] and int(g.t) == f["plain_modulus"]
+    pw = be.Context.pairwise()
+    g.set_relin_key(d["rk"])
+    g.set_galois_key(d["g1"], d["gk1"])
+    g.set_galois_key(d["gconj"], d["gkc"])
+    for n in (1, 3):
+        da, db = g.to_device(np.repeat(d["a"][None], n, axis=0)), g.to_device(np.repeat(d["b"][None], n, axis=0))
+        m3, rl, rot = g.alloc(n * 3 * L * N), g.alloc(n * 2 * L * N), g.alloc(n * 2 * L * N)
+        g.bfv_multiply(L, n, da, db, pw, m3)
+        got = m3.download((n, 3, L, N))
+        for r in range(n):
+            tem.check(f, "bfv_multiply", got[r])
+        g.relinearize(L, n, m3, rl)
+        got = rl.download((n, 2, L, N))
+        for r in range(n):
+            tem.check(f, "bfv_multiply_relin", got[r])
+        g.apply_galois(L, n, rl, d["g1"], rot)
+        got = rot.download((n, 2, L, N))
+        for r in range(n):
+            tem.check(f, "bfv_multiply_relin_rotate_rows_1", got[r])
+        g.rotate(L, n, rl, 1, rot)  # the same through Evaluator::rotate_rows' step -> element mapping
+        assert tem.sha(rot.download((n, 2, L, N))[0]) == f["expected"]["bfv_multiply_relin_rotate_rows_1"]["sha256"]
+        g.apply_galois(L, n, da, d["gconj"], rot)
+        got = rot.download((n, 2, L, N))
+        for r in range(n):
+            tem.check(f, "rotate_columns", got[r])
+        # rotate + add_inplace as one pipeline: (rl + rotate_rows(rl, 1)) == the model's rotation plus rl, added on the host
+        acc = g.alloc(n * 2 * L * N)
+        g.rotate_add(L, n, rl, 1, rl, acc)
+        want = np.array(f["expected"]["bfv_multiply_relin_rotate_rows_1"]["head"], dtype=np.uint64)  # heads only: the sum is checked on the first coefficients
+        rlh = rl.download((n, 2, L, N))[0][:, :, :3]
+        q = np.array(d["primes"][:L], dtype=np.uint64)[None, :, None]
+        assert np.array_equal(acc.download((n, 2, L, N))[0][:, :, :3], (want + rlh) % q)
+    g.close()
+
+
 def test_shards_hold_the_global_batch_and_replicated_keys_agree(be):
     """Multi-GPU bench path (bench.py, sharding.shard_outer_product): a rank's shard, filled with its offset into the global operand
     array (he355_fill_uniform_at), holds exactly the rows the whole array holds there; two contexts that build their synthetic
