@@ -133,8 +133,6 @@ public:
         HIPCHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         HIPCHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
         HIPCHECK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        HIPCHECK(hipEventCreateWithFlags(&ev_side_fork_, hipEventDisableTiming));
-        HIPCHECK(hipEventCreateWithFlags(&ev_side_join_, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
         HIPCHECK(hipEventCreate(&ev0_));
         HIPCHECK(hipEventCreate(&ev1_));
@@ -233,8 +231,6 @@ public:
         for (auto &kv : d_gather_) pool_.raw_free(kv.second);
         pool_.destroy();
         (void)hipEventDestroy(ev_fork_);
-        (void)hipEventDestroy(ev_side_fork_);
-        (void)hipEventDestroy(ev_side_join_);
         (void)hipEventDestroy(ev_join_);
         (void)hipStreamDestroy(stream2_);
         (void)hipEventDestroy(ev0_);
@@ -534,7 +530,7 @@ public:
             u64 *part = latency_partials((size_t)std::max(kLatSplit, kLatSplitU64) * nc * 2 * (L + 1) * N, env_.stream == stream2_ ? 1 : 0);
             launch_k3(env_, L, nc, B, key, K3_ALL, nullptr, kLatSplit, part, kLatSplitU64);
             launch_k3_combine(env_, L, nc, B, kLatSplit, part, kLatSplitU64);
-            launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e, nullptr, 0, 0, 0, 0, nullptr, 0, kLatTargets);
+            launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e, 0, 0, nullptr, 0, kLatTargets);
             return key_switch_floor_rows(env_, L, nc, S, B, with_tail);
         }
         launch_k2(env_, L, nc, B);
@@ -543,34 +539,22 @@ public:
             // special prime first, its correction through the column pass, then the data primes with the mod-down finished
             // inside K3 (the sums never go to HBM)
             launch_k3(env_, L, nc, B, key, K3_SPECIAL_ONLY);
-            static const bool fc_merge = !(getenv("HE355_FC_MERGE") && getenv("HE355_FC_MERGE")[0] == '0');
-            if (rescale_out && L >= 2 && fc_merge) {
-                // Mod-down + rescale with ONE column pass per target as well: only the prime the rescale divides out needs the
-                // mod-down correction by itself (its tiles run first, mod-down only); for every other prime the two corrections are
-                // combined in coefficient form, delta2 + P^-1 * delta1, inside one k_floor_cols launch that reads both sources (the
+            if (rescale_out && L >= 2) {
+                // Mod-down + rescale with ONE column pass and ONE row transform per target: only the prime the rescale divides out needs
+                // the mod-down correction by itself (its tiles run first, mod-down only); for every other prime the two corrections are
+                // combined in coefficient form, delta2 + P^-1 * delta1, inside one k_floor_colsn launch that reads both sources (the
                 // special prime's sums and the divided-out prime's tail) -- 16 column passes per polynomial instead of 31, and the
                 // mod-down correction slab is neither written for those primes nor read back.
-                launch_floor_cols(env_, SP, 1, nc * 2, B.tpr, B.e, nullptr, 0, 0, /*tgt_first*/ L - 1, /*dst_ntgt*/ L);
+                launch_floor_cols(env_, SP, 1, nc * 2, B.tpr, B.e, /*tgt_first*/ L - 1, /*dst_ntgt*/ L);
                 const K3Fuse last = with_operands(K3Fuse{B.e, B.c01, B.c01_item_stride, L - 1, L, nullptr, nullptr});
                 launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &last);
                 launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
-                launch_floor_cols(env_, L - 1, L - 1, nc * 2, S.rlr, S.f, nullptr, 0, 0, 0, L - 1, /*src2*/ B.tpr, SP);
+                launch_floor_cols(env_, L - 1, L - 1, nc * 2, S.rlr, S.f, 0, L - 1, /*src2*/ B.tpr, SP);
                 const K3Fuse rest = with_operands(K3Fuse{B.e, B.c01, B.c01_item_stride, 0, L - 1, S.f, rescale_out});
                 launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &rest);
                 return true;
             }
             launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
-            if (rescale_out && L >= 2) {
-                // ... and the rescale too: the last data prime's tiles first (mod-down only), their inverse transform and the
-                // second correction slab, then all other primes with BOTH floor steps finished in the epilogue -> rescale_out
-                const K3Fuse last = with_operands(K3Fuse{B.e, B.c01, B.c01_item_stride, L - 1, L, nullptr, nullptr});
-                launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &last);
-                launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
-                launch_floor_cols(env_, L - 1, L - 1, nc * 2, S.rlr, S.f, B.e, SP, L); // combined correction: delta2 + P^-1 * delta1
-                const K3Fuse rest = with_operands(K3Fuse{B.e, B.c01, B.c01_item_stride, 0, L - 1, S.f, rescale_out});
-                launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &rest);
-                return true;
-            }
             const K3Fuse fuse = with_operands(K3Fuse{B.e, B.c01, B.c01_item_stride, 0, L, nullptr, nullptr});
             launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &fuse);
             if (with_tail) launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
@@ -600,7 +584,7 @@ public:
     void rescale_tail(const KernelEnv &env_, int L, int size, u64 nc, const Scratch &S, const u64 *src, u64 src_op_stride, u64 *out)
     {
         const size_t N = P.N, LN = (size_t)L * N, L1N = (size_t)(L - 1) * N;
-        launch_floor_cols(env_, L - 1, L - 1, nc * size, S.rlr, S.f, nullptr, 0, 0, 0, 0, nullptr, 0, latency_shape(nc) ? kLatTargets : 1);
+        launch_floor_cols(env_, L - 1, L - 1, nc * size, S.rlr, S.f, 0, 0, nullptr, 0, latency_shape(nc) ? kLatTargets : 1);
         FloorRowsArgs fr;
         fr.src_prime = L - 1; fr.n_tgt = L - 1; fr.n_src = size;
         fr.cols = S.f;
@@ -620,23 +604,11 @@ public:
     const int kLatSplit = getenv("HE355_LAT_SPLIT") && atoi(getenv("HE355_LAT_SPLIT")) > 1 ? atoi(getenv("HE355_LAT_SPLIT")) : 2;
     const int kLatSplitU64 = getenv("HE355_LAT_SPLIT_U64") && atoi(getenv("HE355_LAT_SPLIT_U64")) > 1 ? atoi(getenv("HE355_LAT_SPLIT_U64")) : 8;
     bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
-    // the kernel environment of a batch of nc ciphertexts on stream `which`.  HE355_LAT_SIDE=1: in the latency shape the other stream
-    // takes the second engine's launches (KernelEnv::side).  Off by default: measured at batch 1 the two engines' kernels each fill
-    // the chip already and only stretch each other (k_k3 50 + 26 us in line, 65 and 59 us side by side; 0.331 -> 0.356 ms per call);
-    // at batch 8 it is 0.952 -> 0.937 ms.
-    KernelEnv batch_env(u64 nc, int which = 0) const
+    // the kernel environment of a batch on stream `which`
+    KernelEnv batch_env(u64 /*nc*/, int which = 0) const
     {
-        static const bool side_on = getenv("HE355_LAT_SIDE") && getenv("HE355_LAT_SIDE")[0] == '1';
         KernelEnv env = env_;
         env.stream = which ? stream2_ : stream_;
-        // HE355_SIDE_ALL=1: in the throughput shape too (the u64 engine's k_k1 / k_k2n / k_k3 / k_floor_rows beside the fp64 engine's: they fill
-        // each other's tails; 47.82 -> 47.65 ms per step, 0.35 %: not worth the dominant kernel's clean single-stream timing, off)
-        static const bool side_all = getenv("HE355_SIDE_ALL") && getenv("HE355_SIDE_ALL")[0] == '1';
-        if ((side_on && latency_shape(nc)) || side_all) {
-            env.side = which ? stream_ : stream2_;
-            env.ev_side_fork = ev_side_fork_;
-            env.ev_side_join = ev_side_join_;
-        }
         return env;
     }
     u64 *latency_partials(size_t elems, int which) // one buffer per stream: chunks of the two streams are in flight together
@@ -1530,7 +1502,6 @@ private:
     size_t scratch_bytes_ = 0, scratch2_bytes_ = 0;
     hipStream_t stream2_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
-    hipEvent_t ev_side_fork_ = nullptr, ev_side_join_ = nullptr; // KernelEnv::side (latency shape)
     bool dual_stream_ = true;
     u64 *rot_tmp_ = nullptr;
     size_t rot_tmp_bytes_ = 0;

@@ -31,10 +31,6 @@ struct KernelEnv {
     const FloorConst *floor_consts; // device array [K*K], entry [s*K + i]
     int N, logn1, K, Ltop, scheme;
     hipStream_t stream;
-    // Latency shape (few ciphertexts per call): launchers that issue one kernel per arithmetic engine put the second one on `side`, so
-    // the two run beside each other instead of one after the other (each fills a fraction of the chip).  Null: everything on `stream`.
-    hipStream_t side = nullptr;
-    hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
     unsigned char prime_f64[kMaxPrimes]; // host copy: 1 if the fp64 engine owns prime i
     u64 prime_q[kMaxPrimes];             // host copy of the moduli
 };
@@ -85,8 +81,8 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
 void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *src = nullptr, u64 src_op_stride = 0, int tsplit = 1);
 // K3: forward row pass of every (tt, j) + multiply-accumulate with the key -> t (data primes) / tpr (special)
 // BFV (env.scheme == 1): the products of ALL primes continue into the inverse row pass (t then holds raw rows)
-// `part`: all tiles, only the special prime's, or only the data primes'.  With `fuse` (data-prime tiles, CKKS, default block
-// shapes: k3_can_fuse) the mod-down is finished inside the kernel: c01 += (sums - NTT(cols)) * P^-1, no t slab, no k_floor_rows.
+// `part`: all tiles, only the special prime's, or only the data primes'.  With `fuse` (data-prime tiles, CKKS: k3_can_fuse)
+// the mod-down is finished inside the kernel: c01 += (sums - NTT(cols)) * P^-1, no t slab, no k_floor_rows.
 enum K3Part { K3_ALL = 0, K3_SPECIAL_ONLY = 1, K3_DATA_ONLY = 2 };
 struct K3Fuse {
     const u64 *cols;     // [n_ops*2][L][N] output of launch_floor_cols(special prime -> L targets)
@@ -95,7 +91,7 @@ struct K3Fuse {
     // data-prime range of this launch [tt_lo, tt_hi) (K3_DATA_ONLY)
     int tt_lo, tt_hi;
     // second floor step (CKKS rescale by prime L-1) finished in the same epilogue, for primes < L-1: cols2 is the output of
-    // launch_floor_cols(prime L-1 -> L-1 targets, addin = cols) [n_ops*2][L-1][N], i.e. the COMBINED correction
+    // launch_floor_cols(prime L-1 -> L-1 targets, src2 = the special prime's sums) [n_ops*2][L-1][N], i.e. the COMBINED correction
     // delta2 + P^-1 * delta1; out [n_ops][2][L-1][N].  Null: mod-down only (correction from cols).
     const u64 *cols2;
     u64 *out;
@@ -118,12 +114,11 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
                int n_split = 1, u64 *split_part = nullptr, int n_split_u64 = 0); // n_split_u64: groups of the u64-engine tiles (0: as n_split)
 void launch_k3_combine(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, int n_split, const u64 *split_part, int n_split_u64 = 0);
 // floor step, column half: src [n_ops*n_src][N] raw of prime s -> r = (x + floor(s/2)) mod s ->
-// (r mod q_i - floor(s/2) mod q_i) for i < n_tgt -> forward column pass -> dst [n_ops*n_src][n_tgt][N]
-// addin (optional): the column-passed correction of an earlier floor step [n_polys][addin_ntgt][N], folded in scaled by
-// addin_src^-1 mod q_i (mod-down + rescale then share one row transform per residue)
-void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst, const u64 *addin = nullptr,
-                       int addin_src = 0, int addin_ntgt = 0, int tgt_first = 0, int dst_ntgt = 0, const u64 *src2 = nullptr, int src2_prime = 0,
-                       int tsplit = 1);
+// (r mod q_i - floor(s/2) mod q_i) for i in [tgt_first, tgt_first + n_tgt) -> forward column pass -> dst [n_ops*n_src][dst_ntgt][N]
+// src2 (optional): the SOURCE of an earlier floor step ([n_polys][N] after its inverse row pass, prime src2_prime): its correction is
+// folded in before the column pass, delta2 + src2^-1 * delta1 (mod-down + rescale share one column pass and one row transform)
+void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst, int tgt_first = 0, int dst_ntgt = 0,
+                       const u64 *src2 = nullptr, int src2_prime = 0, int tsplit = 1);
 // floor step, row half: out[(op,k,i)] = (tsrc[(op,k,i)] - NTT(dst_cols[(op,k,i)])) * s^-1 (+ addend) mod q_i.
 // Strides are in u64 elements.  If tail_prime >= 0 the rows of that prime additionally go through the
 // inverse row pass into tail[(op,k)] (next floor step's source).

@@ -3,9 +3,9 @@
 //
 // Work decomposition (one residue polynomial = N = N1 x 1024 coefficients):
 //   * row kernels   : one 64-lane WAVE owns one 1024-element row, 16 elements per lane in VGPRs, the ten
-//                     stages run 4+4+2 in registers with two register/lane transposes between them (ntt_core.h):
-//                     LDS exchanges by default, cross-lane swap steps (permlane / DPP) selectable (HE355_XCHG);
-//                     a workgroup is four such waves (four rows of the same residue) and 34 KiB of LDS.
+//                     stages run 4+4+2 in registers with two register/lane transposes between them (ntt_core.h),
+//                     each an exchange through the wave's own LDS region; a workgroup is four such waves (four
+//                     rows of the same residue) and 34 KiB of LDS.
 //   * column kernels: one LANE owns one stride-1024 column (N1 <= 32 values in VGPRs); twiddles of a column
 //                     pass are wave-uniform, so they come through scalar loads.
 // Global accesses are coalesced: layout A reads/writes 512 contiguous bytes per wave instruction, layout C
@@ -29,19 +29,7 @@
 namespace he355 {
 namespace {
 
-#ifndef HE355_K3_F64_SHAPE
-#define HE355_K3_F64_SHAPE 18
-#endif
-#ifndef HE355_K3_U64_SHAPE
-#define HE355_K3_U64_SHAPE 18
-#endif
-#ifndef HE355_K3_STAGE_DEFAULT
-#define HE355_K3_STAGE_DEFAULT 1
-#endif
 constexpr int kBlock = 256;
-#ifndef K2_WAVES
-#define K2_WAVES 2
-#endif
 constexpr int kWaves = 4;
 
 // Each wave exchanges data only inside its own LDS region: LDS instructions of one wave execute in
@@ -117,114 +105,31 @@ __device__ __forceinline__ void store_rowC(u64 *row, int lane, const u64 v[kRowE
     }
 }
 
-// ---- cross-lane swap steps (ntt_core.h xl_T1 / xl_T2): the device side ------------------------------------
-// HE355_XCHG selects how the two register/lane transposes of a row pass run: bit 0: B <-> C by DPP quad permutes (xl_T2),
-// bit 1: A <-> B by v_permlane32_swap / v_permlane16_swap / DPP row shifts (xl_T1); a clear bit = exchange through LDS.
-#ifndef HE355_XCHG
-#define HE355_XCHG 0
-#endif
-constexpr bool kXlT1 = (HE355_XCHG & 2) != 0, kXlT2 = (HE355_XCHG & 1) != 0;
-// HE355_KSHARE: K3's blocks stage the key rows of a digit step in LDS once for their eight waves (k_k3, KSHARE).  The LDS for it
-// is what the exchange buffers would take, so it needs both transposes on the cross-lane path.
-#ifndef HE355_KSHARE
-#define HE355_KSHARE 0
-#endif
-constexpr bool kKeyShare = HE355_KSHARE != 0 && kXlT1 && kXlT2;
-// HE355_KEY_EARLY: the fused fp64 K3 requests a digit's two key rows before the second exchange of its row transform
-#ifndef HE355_KEY_EARLY
-#define HE355_KEY_EARLY 1
-#endif
-constexpr bool kKeyEarly = HE355_KEY_EARLY != 0;
-#ifndef HE355_TENSOR_INIT_EARLY
-#define HE355_TENSOR_INIT_EARLY 0 // 1: the ct x ct multiply's operand rows are fetched before the first digit row's DMA is issued, 0: after
-#endif
-// HE355_ACC_RUN: the u64 engine adds kAccRun key products to an accumulator between two range reductions (ArU64::acc_mac_lazy; needs the
-// exact key quotients k_key_quotients writes) instead of reducing after every product: k_k3<ArU64> 7.69 -> 7.47 ms per step.
-// HE355_KEY_EARLY_U64: polynomial 0's key row and quotient row are requested before the second exchange of the row pass, polynomial
-// 1's before polynomial 0's products -- what HE355_KEY_EARLY does for the fp64 engine; here the 64 extra live registers spill and the
-// kernels get slower (7.69 -> 8.24 ms), so it stays off.
-#ifndef HE355_ACC_RUN
-#define HE355_ACC_RUN 1
-#endif
-#ifndef HE355_KEY_EARLY_U64
-#define HE355_KEY_EARLY_U64 0
-#endif
-constexpr bool kAccRunOn = HE355_ACC_RUN != 0, kKeyEarlyU64 = HE355_KEY_EARLY_U64 != 0;
-// HE355_LAZY_U64: k_k3 transforms the digit rows of the u64-engine key primes over the wide lazy range (one correction per row instead
-// of one per butterfly); key primes are below 2^60 (Params), the key multiply-accumulate takes any 64-bit lazy value
-#ifndef HE355_LAZY_U64
-#define HE355_LAZY_U64 1
-#endif
-constexpr bool kLazyU64 = HE355_LAZY_U64 != 0;
+// Key products issued together in the fused fp64 k_k3 (2 polynomials x kMacG / 2 elements): interleaved chains, at two waves per
+// SIMD a serial chain issues at 3/4 of the pipe's rate.
 #ifndef HE355_MAC_G
 #define HE355_MAC_G 4
 #endif
-constexpr int kMacG = HE355_MAC_G; // key products issued together (2 polynomials x kMacG / 2 elements)
-struct XLaneHw {
-    int lane;
-    template <int LB> __device__ __forceinline__ void step32(u32 &a, u32 &b) const
-    {
-        if constexpr (LB == 5) {
-            const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); // lanes 32..63 of a <-> lanes 0..31 of b
-            a = r[0]; b = r[1];
-        } else if constexpr (LB == 4) {
-            const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); // odd 16-lane rows of a <-> even rows of b
-            a = r[0]; b = r[1];
-        } else if constexpr (LB == 3 || LB == 2) {
-            // bank = 4 lanes of a 16-lane row: the lanes with bit LB clear read from lane + D (row_shl), the others from lane - D
-            constexpr int D = 1 << LB;
-            constexpr int lo_banks = LB == 3 ? 0x3 : 0x5, hi_banks = LB == 3 ? 0xC : 0xA;
-            const u32 nb = __builtin_amdgcn_update_dpp(b, a, 0x100 + D, 0xF, lo_banks, false);
-            const u32 na = __builtin_amdgcn_update_dpp(a, b, 0x110 + D, 0xF, hi_banks, false);
-            a = na; b = nb;
-        } else {
-            constexpr int ctrl = LB == 0 ? 0xB1 : 0x4E; // quad_perm [1,0,3,2] / [2,3,0,1]
-            const u32 pa = __builtin_amdgcn_update_dpp(0u, a, ctrl, 0xF, 0xF, true);
-            const u32 pb = __builtin_amdgcn_update_dpp(0u, b, ctrl, 0xF, 0xF, true);
-            const bool hi = (lane >> LB) & 1;
-            b = hi ? b : pa;
-            a = hi ? pb : a;
-        }
-    }
-    template <int LB, class T> __device__ __forceinline__ void step(T &a, T &b) const
-    {
-        static_assert(sizeof(T) == 8, "64-bit lane values");
-        union { T t; u32 w[2]; } ua, ub;
-        ua.t = a; ub.t = b;
-        step32<LB>(ua.w[0], ub.w[0]);
-        step32<LB>(ua.w[1], ub.w[1]);
-        a = ua.t; b = ub.t;
-    }
-};
+constexpr int kMacG = HE355_MAC_G;
 
 // ---- LDS-DMA: one 8 KiB row, HBM -> this wave's LDS staging buffer, no VGPRs, asynchronous -------------
 // Each global_load_lds_dwordx4 moves 64 x 16 B; the LDS image is the row in natural element order.
 // Completion is covered by the issuing wave's vmcnt (s_waitcnt vmcnt(0) before the first ds_read).
 typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
-// HE355_DMA_ASM (default): the instruction is issued from inline assembly, i.e. hidden from the compiler's wait-count insertion.
-// Through the builtin, every ds_read that follows a DMA in program order gets an s_waitcnt vmcnt(0) in front of it whenever the
+// The instruction is issued from inline assembly, i.e. hidden from the compiler's wait-count insertion.
+// Through the builtin (__builtin_amdgcn_global_load_lds), every ds_read that follows a DMA in program order gets an s_waitcnt vmcnt(0) in front of it whenever the
 // compiler cannot rule out that it reads the landing buffer -- in k_k3 that is the first LDS exchange of the row transform, a third
 // of the way into the step the DMA was meant to hide behind (ISA of round 2's kernel).  The kernels wait for a landing buffer
 // themselves (asm volatile s_waitcnt vmcnt(0) before they read it); vector-memory results return in issue order, so the waits the
 // compiler places for its own, younger loads stay sufficient.  M0 (LDS base of the DMA) is used by nothing else in these kernels.
-#ifndef HE355_DMA_ASM
-#define HE355_DMA_ASM 1
-#endif
 template <int PIECES = 8> // 1 KiB pieces of the row slot that hold data (8: a row of 64-bit words; 6: a 48-bit packed digit row)
 __device__ __forceinline__ void dma_row_to_lds(const u64 *grow, u64 *lds_row, int lane)
 {
-#if HE355_DMA_ASM
     const u32 lbase = __builtin_amdgcn_readfirstlane((u32)(unsigned long long)(lds_void_t *)lds_row);
     const u64 *g = grow + (lane << 1);
 #pragma unroll
     for (int k = 0; k < PIECES; ++k)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lbase + (u32)(k << 10)), "v"(g + (k << 7)) : "memory");
-#else
-#pragma unroll
-    for (int k = 0; k < PIECES; ++k)
-        __builtin_amdgcn_global_load_lds((glb_void_t *)(grow + (k << 7) + (lane << 1)), (lds_void_t *)(lds_row + (k << 7)), 16, 0, 0);
-#endif
 }
 __device__ __forceinline__ void lds_rowA(const u64 *lds_row, int lane, u64 v[kRowE])
 {
@@ -237,10 +142,6 @@ __device__ __forceinline__ void lds_rowA(const u64 *lds_row, int lane, u64 v[kRo
 // read/write bandwidth bounds the sequence, so a digit row of an fp64-engine prime is stored in 6 of the 8 KiB of its slot:
 // a plane of 1024 low 32-bit words, then a plane of 1024 high 16-bit words, of the bit pattern of (x + kPackBias), x an
 // integer with |x| < 2^47.  The pattern's top 16 bits are then always 0x4338, so 48 bits carry the value exactly.
-#ifndef HE355_PACK_D
-#define HE355_PACK_D 1
-#endif
-constexpr bool kPackD = HE355_PACK_D != 0;
 constexpr double kPackBias = 4503599627370496.0 + 2251799813685248.0 + 140737488355328.0; // 2^52 + 2^51 + 2^47
 constexpr int kPackHiOff = 4096;                                                          // byte offset of the high plane in the slot
 __device__ __forceinline__ double unpack48(u32 lo, u32 hi16)
@@ -249,24 +150,6 @@ __device__ __forceinline__ double unpack48(u32 lo, u32 hi16)
     c.u = ((u64)(0x43380000u | hi16) << 32) | lo;
     return c.d - kPackBias;
 }
-// HE355_K2_ABLATE (timing experiments, wrong results): 1 = no stores at all (the values are folded into one store per target so that
-// the arithmetic stays), 2 = no high-plane stores, 4 = stores of a constant (no arithmetic feeds them)
-#ifndef HE355_K2_ABLATE
-#define HE355_K2_ABLATE 0
-#endif
-__device__ __forceinline__ void store48(u64 *row, int e, double x) // element e of a packed row
-{
-    union { u64 u; double d; } c;
-    c.d = x + kPackBias;
-#if HE355_K2_ABLATE & 1
-    if (c.u == 0x1234567ull) reinterpret_cast<u32 *>(row)[e] = (u32)c.u; // never true for real data: keeps the arithmetic, drops the store
-#else
-    reinterpret_cast<u32 *>(row)[e] = (u32)c.u;
-#if !(HE355_K2_ABLATE & 2)
-    reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(row) + kPackHiOff)[e] = (unsigned short)(c.u >> 32);
-#endif
-#endif
-}
 __device__ __forceinline__ void lds_rowA48(const u64 *lds_row, int lane, double x[kRowE])
 {
     const u32 *lo = reinterpret_cast<const u32 *>(lds_row);
@@ -274,81 +157,46 @@ __device__ __forceinline__ void lds_rowA48(const u64 *lds_row, int lane, double 
 #pragma unroll
     for (int r = 0; r < kRowE; ++r) x[r] = unpack48(lo[(r << 6) | lane], hi[(r << 6) | lane]);
 }
-struct Row48 { u32 lo[kRowE]; unsigned short hi[kRowE]; }; // a packed row in flight in registers (layout A)
-__device__ __forceinline__ void load_rowA48(const u64 *row, int lane, Row48 &v)
-{
-    const u32 *lo = reinterpret_cast<const u32 *>(row);
-    const unsigned short *hi = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(row) + kPackHiOff);
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r) { v.lo[r] = lo[(r << 6) | lane]; v.hi[r] = hi[(r << 6) | lane]; }
-}
-
 // ---- wave-level row transforms (x in: layout A for forward, layout C for inverse) ---------------------
-// U rows of the same tile at once (shared twiddles, interleaved butterfly chains); lds_w: U exchange buffers.
-// The twiddles of phase B / C are gathered BEFORE the exchange that precedes the phase and pinned there with a
-// scheduling barrier, so their loads are in flight while the exchange round-trips through LDS.
+// lds_w: the wave's exchange buffer.  The twiddles of phase B / C are gathered BEFORE the exchange that precedes the phase and
+// pinned there with a scheduling barrier, so their loads are in flight while the exchange round-trips through LDS.
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 // `before_c` runs after phase B's math and before the second exchange: a caller uses it to put global loads in flight
 // that it needs right after the transform (they then land during the exchange and phase C).
-// `wa_pre`: phase A's 15 twiddles, already gathered by the caller (they are the same for every lane, so a caller that
-// transforms many rows of one (prime, row) tile keeps them in scalar registers); null: gather them here.
 // LAZY (u64 engine, q < 2^60, rows entering below 4q): the wide lazy range of ntt_core.h's row_fwd_*_lazy -- results below 12q, for
 // consumers that take any 64-bit lazy value (k_k3's key multiply-accumulate); ignored by the fp64 engine.
-template <int U, class Ar, class TW, class Hook = NoHook, bool LAZY = false>
-__device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int lane, u64 (*lds_w)[kLdsRow], typename Ar::T (*x)[kRowE],
-                                                Hook before_c = Hook(), const Tw16 *wa_pre = nullptr)
+template <class Ar, class TW, class Hook = NoHook, bool LAZY = false>
+__device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int lane, u64 *lds_w, typename Ar::T (*x)[kRowE], Hook before_c = Hook())
 {
     typedef typename Ar::T T;
-    if (wa_pre) {
-        if constexpr (LAZY) row_fwd_A_lazy<U, true>(ar, x, wa_pre); else row_fwd_A<U>(ar, x, wa_pre);
-    } else {
-        Tw16 wa[kTwA];
-        gather_A(tw, wa);
-        if constexpr (LAZY) row_fwd_A_lazy<U>(ar, x, wa); else row_fwd_A<U>(ar, x, wa);
-    }
+    T *lds = reinterpret_cast<T *>(lds_w);
+    Tw16 wa[kTwA];
+    gather_A(tw, wa);
+    if constexpr (LAZY) row_fwd_A_lazy<1>(ar, x, wa); else row_fwd_A<1>(ar, x, wa);
     Tw16 wb[kTwB];
     gather_B(tw, lane, wb);
-    XLaneHw xl{lane};
-    if constexpr (kXlT1) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) xl_T1(xl, x[u]);
-    } else {
-        __builtin_amdgcn_sched_barrier(0);
-#if !(defined(HE355_ABLATE) && (HE355_ABLATE & 4)) // timing experiment (wrong results): the row pass without its two LDS exchanges
-#pragma unroll
-        for (int u = 0; u < U; ++u) lds_store_A(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
-        HE_WAVE_SYNC();
-#pragma unroll
-        for (int u = 0; u < U; ++u) lds_load_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
-        HE_WAVE_SYNC();
-#endif
-    }
-    if constexpr (LAZY) row_fwd_B_lazy<U>(ar, x, wb); else row_fwd_B<U>(ar, x, wb);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_store_A(lds, lane, x[0]);
+    HE_WAVE_SYNC();
+    lds_load_B(lds, lane, x[0]);
+    HE_WAVE_SYNC();
+    if constexpr (LAZY) row_fwd_B_lazy<1>(ar, x, wb); else row_fwd_B<1>(ar, x, wb);
     Tw16 wc[kTwC];
     gather_C(tw, lane, wc);
     before_c();
-    if constexpr (kXlT2) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) xl_T2(xl, x[u]);
-    } else {
-        __builtin_amdgcn_sched_barrier(0);
-#if !(defined(HE355_ABLATE) && (HE355_ABLATE & 4))
-#pragma unroll
-        for (int u = 0; u < U; ++u) lds_store_B(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
-        HE_WAVE_SYNC();
-#pragma unroll
-        for (int u = 0; u < U; ++u) lds_load_C(reinterpret_cast<T *>(lds_w[u]), lane, x[u]);
-        HE_WAVE_SYNC();
-#endif
-    }
-    if constexpr (LAZY) row_fwd_C_lazy<U>(ar, x, wc); else row_fwd_C<U>(ar, x, wc);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_store_B(lds, lane, x[0]);
+    HE_WAVE_SYNC();
+    lds_load_C(lds, lane, x[0]);
+    HE_WAVE_SYNC();
+    if constexpr (LAZY) row_fwd_C_lazy<1>(ar, x, wc); else row_fwd_C<1>(ar, x, wc);
 }
 template <class Ar, class TW>
 __device__ __forceinline__ void wave_rows_fwd(const Ar &ar, const TW &tw, int lane, u64 *lds_w, typename Ar::T x[kRowE])
 {
-    wave_rows_fwd_n<1>(ar, tw, lane, reinterpret_cast<u64(*)[kLdsRow]>(lds_w), reinterpret_cast<typename Ar::T(*)[kRowE]>(x));
+    wave_rows_fwd_n(ar, tw, lane, lds_w, reinterpret_cast<typename Ar::T(*)[kRowE]>(x));
 }
 template <class Ar>
 __device__ __forceinline__ void wave_rows_inv(const Ar &ar, const PrimeDev &P, bool last, u32 rowbase, int lane, u64 *lds_w, typename Ar::T x[kRowE])
@@ -356,25 +204,16 @@ __device__ __forceinline__ void wave_rows_inv(const Ar &ar, const PrimeDev &P, b
     typedef typename Ar::T T;
     T *lds = reinterpret_cast<T *>(lds_w);
     const auto itw = tw_table(gtw(P.inv), rowbase);
-    XLaneHw xl{lane};
     row_inv_C(ar, x, itw, lane);
-    if constexpr (kXlT2) {
-        xl_T2(xl, x);
-    } else {
-        lds_store_C(lds, lane, x);
-        HE_WAVE_SYNC();
-        lds_load_B(lds, lane, x);
-        HE_WAVE_SYNC();
-    }
+    lds_store_C(lds, lane, x);
+    HE_WAVE_SYNC();
+    lds_load_B(lds, lane, x);
+    HE_WAVE_SYNC();
     row_inv_B(ar, x, itw, lane);
-    if constexpr (kXlT1) {
-        xl_T1(xl, x);
-    } else {
-        lds_store_B(lds, lane, x);
-        HE_WAVE_SYNC();
-        lds_load_A(lds, lane, x);
-        HE_WAVE_SYNC();
-    }
+    lds_store_B(lds, lane, x);
+    HE_WAVE_SYNC();
+    lds_load_A(lds, lane, x);
+    HE_WAVE_SYNC();
     if (last) row_inv_A<Ar, true>(ar, x, itw, P.inv_w0_scaled);
     else row_inv_A<Ar, false>(ar, x, itw, P.inv_w0_scaled);
 }
@@ -842,134 +681,20 @@ struct K2Args {
     u64 n_ops;
     int L, K, ckks, src_is_coeff;
     u64 f64_mask; // bit t: key prime t belongs to the fp64 engine
-    int ablate;  // timing experiments (wrong results): 1 = every target's rows land in the slab region of target 0 (no HBM write stream), 2 = no u64-engine targets, 4 = no stores for the fp64 targets
-    int n_dig;   // k_k2n: digits handled by this launch (one instantiation per digit width: each gets its own register allocation)
+    int n_dig;    // digits handled by this launch (one instantiation per digit width: each gets its own register allocation)
     unsigned char dig_list[64];
-    int tsplit;  // k_k2n, latency shape: the targets of a (digit, column block) are dealt to tsplit blocks (blockIdx.y)
-    int xcd_map; // k_k2n: the four column blocks of one (op, digit) run on the same XCD (blocks b and b + 8 share one)
+    int tsplit;   // the targets of a (digit, column block) are dealt to tsplit blocks (blockIdx.y): latency shape, small grids
 };
 
-// The digit slab is written once and read once, much later and by other CUs (a chunk of it is gigabytes): HE355_K2_NT=1
-// builds the stores as non-temporal.
-#if defined(HE355_K2_NT) && HE355_K2_NT
-#define K2_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define K2_STORE(p, v) (*(p) = (v))
-#endif
-// lift canonical c (mod q_j) to a value usable as forward-transform input under prime t
-template <int LOGN1>
-__device__ __forceinline__ void k2_target(const PrimeDev &Pj, const PrimeDev &Pt, const u64 c[1 << LOGN1], u64 *dst, int col)
-{
-    constexpr int N1 = 1 << LOGN1;
-    if (Pt.f64) {
-        const ArF64 ar = make_ar(Pt, (ArF64 *)nullptr);
-        double x[N1];
-        if (Pj.q >> 52) { // digit too wide for an exact double: reduce with integers first
-            const ModU64 mt = make_modu(Pt);
-#pragma unroll
-            for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(barrett64(c[a], mt));
-        } else if (Pj.q > 2 * Pt.q) {
-#pragma unroll
-            for (int a = 0; a < N1; ++a) x[a] = ar.renorm(u52_to_f64(c[a]));
-        } else {
-#pragma unroll
-            for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(c[a]);
-        }
-#if !(HE355_K2_ABLATE & 4)
-        col_fwd<ArF64, LOGN1>(ar, x, ctw(Pt.fwd));
-#endif
-        if constexpr (kPackD) {
-            // 48-bit rows need |x| < 2^47.  The column pass starts from |x| < m0 (the lift above: q_t after an integer reduction,
-            // q_t/2 + 1 after a re-centring, q_j <= 2 q_t otherwise) and a stage takes the bound m to m + q (1/2 + m 2^-51)
-            // (ArF64::bfly_fwd).  For the 40/45-bit primes of the reference's parameter rule the result stays below 2^47
-            // (3.66 q from m0 = q < 2^45); where it does not (wider fp64-engine primes, a digit prime well above the target)
-            // the values are re-centred first.  The test is the same in every lane.
-            double m = (Pj.q >> 52) ? (double)Pt.q : (Pj.q > 2 * Pt.q ? 0.5 * (double)Pt.q + 1.0 : (double)Pj.q);
-#pragma unroll
-            for (int st = 0; st < LOGN1; ++st) m += (double)Pt.q * (0.5 + m * 4.440892098500626e-16); // 2^-51
-            const bool fits = m * 1.0000001 < 140737488355328.0;                                         // 2^47
-            if (fits) {
-#pragma unroll
-                for (int a = 0; a < N1; ++a) store48(dst + (a << kRowLog), col, x[a]);
-            } else {
-#pragma unroll
-                for (int a = 0; a < N1; ++a) store48(dst + (a << kRowLog), col, ar.renorm(x[a]));
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < N1; ++a) K2_STORE(&dst[(a << kRowLog) + col], ar.to_raw(x[a]));
-        }
-    } else {
-        const ArU64 ar = make_ar(Pt, (ArU64 *)nullptr);
-        u64 x[N1];
-        if (Pj.q > Pt.q) {
-            const ModU64 mt = make_modu(Pt);
-#pragma unroll
-            for (int a = 0; a < N1; ++a) x[a] = barrett64(c[a], mt);
-        } else {
-#pragma unroll
-            for (int a = 0; a < N1; ++a) x[a] = c[a];
-        }
-        col_fwd<ArU64, LOGN1>(ar, x, ctw(Pt.fwd));
-#pragma unroll
-        for (int a = 0; a < N1; ++a) K2_STORE(&dst[(a << kRowLog) + col], x[a]);
-    }
-}
-
-template <int LOGN1>
-__global__ void __launch_bounds__(kBlock, K2_WAVES) k_k2(K2Args A, const PrimeDev *primes)
-{
-    constexpr int N1 = 1 << LOGN1;
-    constexpr u64 N = (u64)N1 << kRowLog;
-    const u64 oj = blockIdx.x >> 2;
-    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
-    const int j = (int)(oj % A.L);
-    const u64 op = oj / A.L;
-    const u64 *src = A.c2r + op * A.src_op_stride + (u64)j * N;
-    const PrimeDev &Pj = primes[j];
-    u64 c[N1];
-    if (A.src_is_coeff) {
-#pragma unroll
-        for (int a = 0; a < N1; ++a) c[a] = src[(a << kRowLog) + col]; // BFV: the target is in coefficient form already
-    } else if (LOGN1 == 0) {
-        c[0] = src[col]; // the row pass was the whole inverse transform: already canonical coefficients
-    } else if (Pj.f64) {
-        const ArF64 ar = make_ar(Pj, (ArF64 *)nullptr);
-        double x[N1];
-#pragma unroll
-        for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
-        col_inv<ArF64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
-#pragma unroll
-        for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
-    } else {
-        const ArU64 ar = make_ar(Pj, (ArU64 *)nullptr);
-        u64 x[N1];
-#pragma unroll
-        for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
-        col_inv<ArU64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
-#pragma unroll
-        for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
-    }
-    for (int tt = 0; tt <= A.L; ++tt) {
-        if (A.ckks && tt == j) continue; // CKKS: digit j under its own prime is the NTT-form input itself
-        const int t = (tt == A.L) ? A.K - 1 : tt;
-        u64 *dst = A.d + ((op * (A.L + 1) + tt) * A.L + j) * N;
-        k2_target<LOGN1>(Pj, primes[t], c, dst, col);
-    }
-}
-
-// ---- K2, second form (round 3) --------------------------------------------------------------------------
-// Same job and same slab contents as k_k2; what changed is everything around the butterflies, which in k_k2 cost as many VALU
-// instructions as the butterflies themselves (ISA count per fp64 target and lane: 640 butterfly instructions out of ~1000):
+// What surrounds the butterflies is as lean as the butterflies (round 3; the first form of this kernel spent ~1000 VALU instructions per
+// fp64 target and lane for 640 instructions of butterflies, HISTORY.md):
 //   * the digit column is held in the form the targets consume: canonical doubles when q_j < 2^52 (every target of the fp64
 //     engine then reads it as is; the two u64-engine targets convert back), integers only for a 60-bit digit;
-//   * column twiddles come from PrimeDev::colw (bare doubles): 62 scalar registers per target instead of 124 -- k_k2 spilled 63
-//     SGPRs into VGPR lanes and paid ~106 v_readlane / v_writelane per target for it;
+//   * column twiddles come from PrimeDev::colw (bare doubles): 62 scalar registers per target instead of 124;
 //   * the first stage reads the digit column and writes the target column (no copy of 32 values per target), the last stage
-//     produces the 48-bit patterns directly (col_fwd_w, BIAS);
+//     produces the 48-bit patterns directly (BIAS);
 //   * every store address is (scalar row base) + (one per-lane 32-bit offset computed once per kernel): the slab pointer of the
-//     target is made wave-uniform explicitly, the row bases advance on the scalar unit -- k_k2 spent two 64-bit VALU additions
-//     (and the wait states of their carry chains) per store, ~170 instructions per target.
+//     target is made wave-uniform explicitly, the row bases advance on the scalar unit.
 // canonical v of a prime >= 2^52 as a lazy value of the fp64 engine: hi * 2^32 + lo == hi * pow32 + lo (mod q), |result| < q/2 + 2^32 + 1
 __device__ __forceinline__ double lift_wide(const ArF64 &ar, u64 v, double pow32)
 {
@@ -1009,24 +734,10 @@ template <int N1> __device__ __forceinline__ void store_word_rows(__amdgpu_buffe
         __builtin_amdgcn_raw_buffer_store_b64(v, dst, (int)off8, a * (int)kSlotBytes, 0);
     }
 }
-// HE355_K2_WIDE: the pattern rows of a wave's 64 columns go through a 12 KiB LDS tile (8 KiB of low words, 4 KiB of high half-words,
+// N1 >= 8: the pattern rows of a wave's 64 columns go through a 12 KiB LDS tile (8 KiB of low words, 4 KiB of high half-words,
 // row-major) and leave as 16-byte stores: 8 + 4 buffer_store_dwordx4 of 1 KiB per target instead of 32 + 32 stores of 256 / 128 bytes.
 // Only the issuing wave touches its tile (wavefront-scope hand-off).  lane_lo / lane_hi: the per-lane byte offsets of the 16-byte
 // pieces inside a group of 4 (low plane) / 8 (high plane) rows, wave's column offset included.
-#ifndef HE355_K2_WIDE
-#define HE355_K2_WIDE 1
-#endif
-constexpr bool kK2Wide = HE355_K2_WIDE != 0;
-// HE355_K2_STREAM: the fast path of k_k2n stores a row (dword + half-word per lane) as soon as the last stage has produced it, instead of
-// collecting the 32 rows in the LDS tile and storing them in one burst after the pass
-#ifndef HE355_K2_STREAM
-#define HE355_K2_STREAM 0
-#endif
-constexpr bool kK2Stream = HE355_K2_STREAM != 0;
-#ifndef HE355_K2_LIFTWIDE
-#define HE355_K2_LIFTWIDE 1
-#endif
-constexpr bool kK2LiftWide = HE355_K2_LIFTWIDE != 0;
 typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
 template <int N1>
 __device__ __forceinline__ void store_pattern_rows_wide(__amdgpu_buffer_rsrc_t dst, unsigned char *tile, int lane, u32 lane_lo, u32 lane_hi, const double x[N1])
@@ -1096,9 +807,9 @@ __device__ __forceinline__ d16_t load_colw16(cprime_t cp, int t, int first) { re
 // before the current target's last stage and its stores, the 16 entries of stage 4 at the top of the target, behind stages 0..3 --
 // as the compiler places them (one s_load + s_waitcnt lgkmcnt(0) per stage) each target waited five scalar-load latencies.
 // DIRECT: the column enters as it is; else it is lifted first (re-centred, or reduced with integers from a 60-bit digit: DF false).
-template <int LOGN1, bool DF, bool DIRECT, class Store, class StoreRow>
+template <int LOGN1, bool DF, bool DIRECT, class Store>
 __device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev *primes, int j, u64 op, u64 mask,
-                                                 const typename std::conditional<DF, double, u64>::type (&c)[1 << LOGN1], Store store_rows, StoreRow store_row)
+                                                 const typename std::conditional<DF, double, u64>::type (&c)[1 << LOGN1], Store store_rows)
 {
     constexpr int N1 = 1 << LOGN1;
     constexpr u64 N = (u64)N1 << kRowLog;
@@ -1127,15 +838,10 @@ __device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev
             if constexpr (DF) {
 #pragma unroll
                 for (int a = 0; a < N1; ++a) x[a] = ar.renorm(c[a]);
-            } else if (kK2LiftWide) { // a 60-bit digit: hi * (2^32 mod q_t) + lo, one exact fp64 product (lift_wide) instead of a 64-bit Barrett reduction
+            } else { // a 60-bit digit: hi * (2^32 mod q_t) + lo, one exact fp64 product (lift_wide) instead of a 64-bit Barrett reduction
                 const double pow32 = cp[t].pow32;
 #pragma unroll
                 for (int a = 0; a < N1; ++a) x[a] = lift_wide(ar, c[a], pow32);
-            } else {
-                ModU64 mt;
-                mt.q = cp[t].q; mt.cr0 = cp[t].cr0; mt.cr1 = cp[t].cr1;
-#pragma unroll
-                for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(barrett64(c[a], mt));
             }
         }
 #pragma unroll
@@ -1172,8 +878,7 @@ __device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev
         const double qd_n = cp[tn].qd, qinv_n = cp[tn].qinv;
         __builtin_amdgcn_sched_barrier(0);
         const int tt = t == A.K - 1 ? A.L : t;
-        const __amdgpu_buffer_rsrc_t dst = poly_rsrc(A.d + ((op * (A.L + 1) + ((A.ablate & 1) ? 0 : tt)) * A.L + j) * N, (u32)N1 * kSlotBytes);
-        constexpr bool kStream = kK2Stream && LOGN1 == 5; // rows leave as the last stage finishes them, not as one burst after it
+        const __amdgpu_buffer_rsrc_t dst = poly_rsrc(A.d + ((op * (A.L + 1) + tt) * A.L + j) * N, (u32)N1 * kSlotBytes);
         if constexpr (LOGN1 == 5) {
             constexpr int G = kK2G;
 #pragma unroll
@@ -1186,15 +891,12 @@ __device__ __forceinline__ void k2n_fast_targets(const K2Args &A, const PrimeDev
                 for (int k = 0; k < G; ++k) {
                     const double xb = x[a0 + 2 * k] + kPackBias;
                     x[a0 + 2 * k] = xb + tw[k]; x[a0 + 2 * k + 1] = xb - tw[k];
-                    if constexpr (kStream) { store_row(dst, a0 + 2 * k, x[a0 + 2 * k]); store_row(dst, a0 + 2 * k + 1, x[a0 + 2 * k + 1]); }
                 }
             }
         }
         if constexpr (LOGN1 == 0) x[0] = (DIRECT ? (double)c[0] : x[0]) + kPackBias;
-        if constexpr (!kStream) {
-            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the prefetch had the last stage to land; the tile's LDS traffic then waits by count
-            store_rows(dst, x);
-        }
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the prefetch had the last stage to land; the tile's LDS traffic then waits by count
+        store_rows(dst, x);
         if (!m) break;
         t = tn; wa = wa_n; qd = qd_n; qinv = qinv_n;
     }
@@ -1207,20 +909,13 @@ __device__ __forceinline__ void k2n_targets_f64(const K2Args &A, const PrimeDev 
 {
     constexpr int N1 = 1 << LOGN1;
     constexpr u64 N = (u64)N1 << kRowLog;
-    constexpr bool kWide = kK2Wide && kPackD && N1 >= 8;
-    const u32 off8 = (u32)col << 3, off4 = (u32)col << 2, off2h = ((u32)col << 1) + kPackHiOff;
+    constexpr bool kWide = N1 >= 8;
+    const u32 off4 = (u32)col << 2, off2h = ((u32)col << 1) + kPackHiOff;
     const int lane = col & 63;
     const u32 wc = (u32)col & ~63u; // the wave's first column
     const u32 lane_lo = ((u32)lane >> 4) * kSlotBytes + (wc << 2) + (((u32)lane & 15u) << 4);
     const u32 lane_hi = ((u32)lane >> 3) * kSlotBytes + kPackHiOff + (wc << 1) + (((u32)lane & 7u) << 4);
     auto store_rows = [&](__amdgpu_buffer_rsrc_t dst, const double (&x)[N1]) {
-        if (A.ablate & 4) { // timing experiment: no stores (one lane keeps the values alive)
-            double sum = 0;
-#pragma unroll
-            for (int a = 0; a < N1; ++a) sum += x[a];
-            if (sum == 1.2345) __builtin_amdgcn_raw_buffer_store_b32(1u, dst, 0, 0, 0);
-            return;
-        }
         if constexpr (kWide) store_pattern_rows_wide<N1>(dst, tile, lane, lane_lo, lane_hi, x);
         else store_pattern_rows<N1>(dst, off4, off2h, x);
     };
@@ -1231,17 +926,10 @@ __device__ __forceinline__ void k2n_targets_f64(const K2Args &A, const PrimeDev 
     if (A.ckks) level &= ~((u64)1 << j);
     level = split_mask(level, (int)blockIdx.y, A.tsplit);
     const u64 f64_targets = A.f64_mask & level;
-    u64 direct = 0, lift = 0;
-    if constexpr (kPackD) { direct = cp[j].k2_direct & f64_targets; lift = cp[j].k2_lift & f64_targets; }
-    auto store_row = [&](__amdgpu_buffer_rsrc_t dst, int a, double v) { // one pattern row of this lane's column
-        union { u64 u; double d; } cv;
-        cv.d = v;
-        __builtin_amdgcn_raw_buffer_store_b32((u32)cv.u, dst, (int)off4, a * (int)kSlotBytes, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(cv.u >> 32), dst, (int)off2h, a * (int)kSlotBytes, 0);
-    };
-    if constexpr (DF) k2n_fast_targets<LOGN1, DF, true>(A, primes, j, op, direct, c, store_rows, store_row);
-    k2n_fast_targets<LOGN1, DF, false>(A, primes, j, op, DF ? lift : (lift | direct), c, store_rows, store_row);
-    // the general path: any lift, results re-centred before they are packed (wider fp64-engine primes), or 64-bit rows (HE355_PACK_D=0)
+    const u64 direct = cp[j].k2_direct & f64_targets, lift = cp[j].k2_lift & f64_targets;
+    if constexpr (DF) k2n_fast_targets<LOGN1, DF, true>(A, primes, j, op, direct, c, store_rows);
+    k2n_fast_targets<LOGN1, DF, false>(A, primes, j, op, DF ? lift : (lift | direct), c, store_rows);
+    // the general path: any lift, results re-centred before they are packed (wider fp64-engine primes)
     for (u64 m = f64_targets & ~(direct | lift); m; m &= m - 1) {
         const int t = __builtin_ctzll(m), tt = t == A.K - 1 ? A.L : t;
         const PrimeDev &Pt = primes[t];
@@ -1259,16 +947,9 @@ __device__ __forceinline__ void k2n_targets_f64(const K2Args &A, const PrimeDev 
             for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(barrett64(c[a], mt));
         }
         col_fwd_w<LOGN1, false>(ar, [&](int a) { return x[a]; }, x, cw, 0.0);
-        if constexpr (kPackD) {
 #pragma unroll
-            for (int a = 0; a < N1; ++a) x[a] = ar.renorm(x[a]) + kPackBias;
-            store_rows(dst, x);
-        } else {
-            u64 v[N1];
-#pragma unroll
-            for (int a = 0; a < N1; ++a) v[a] = ar.to_raw(x[a]);
-            store_word_rows<N1>(dst, off8, v);
-        }
+        for (int a = 0; a < N1; ++a) x[a] = ar.renorm(x[a]) + kPackBias;
+        store_rows(dst, x);
     }
 }
 // Targets of the u64 engine, from the digit's canonical coefficients as integers.
@@ -1281,11 +962,10 @@ __device__ __forceinline__ void k2n_targets_u64(const K2Args &A, const PrimeDev 
     u64 level = (A.L >= 64 ? ~(u64)0 : (((u64)1 << A.L) - 1)) | ((u64)1 << (A.K - 1));
     if (A.ckks) level &= ~((u64)1 << j);
     level = split_mask(level, (int)blockIdx.y, A.tsplit);
-    if (A.ablate & 2) level = 0;
     for (u64 m = ~A.f64_mask & level; m; m &= m - 1) {
         const int t = __builtin_ctzll(m), tt = t == A.K - 1 ? A.L : t;
         const PrimeDev &Pt = primes[t];
-        const __amdgpu_buffer_rsrc_t dst = poly_rsrc(A.d + ((op * (A.L + 1) + ((A.ablate & 1) ? 0 : tt)) * A.L + j) * N, (u32)N1 * kSlotBytes);
+        const __amdgpu_buffer_rsrc_t dst = poly_rsrc(A.d + ((op * (A.L + 1) + tt) * A.L + j) * N, (u32)N1 * kSlotBytes);
         const ArU64 ar = make_ar(Pt, (ArU64 *)nullptr);
         u64 x[N1];
         if (Pj.q > Pt.q) {
@@ -1316,14 +996,8 @@ __global__ void __launch_bounds__(kBlock, WIDE ? K2N_WAVES_WIDE : K2N_WAVES) k_k
 {
     constexpr int N1 = 1 << LOGN1;
     constexpr u64 N = (u64)N1 << kRowLog;
-    u64 oj = blockIdx.x >> 2;
-    u32 cb = blockIdx.x & 3;
-    if (A.xcd_map) {
-        const u64 s = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-        oj = (s >> 2) * 8 + xcd;
-        cb = (u32)(s & 3);
-        if (oj >= A.n_ops * A.n_dig) return; // whole block
-    }
+    const u64 oj = blockIdx.x >> 2;
+    const u32 cb = blockIdx.x & 3;
     const int col = (int)(cb << 8) | threadIdx.x;
     const u32 oj32 = (u32)oj; // n_ops * L < 2^32
     const int j = A.dig_list[__builtin_amdgcn_readfirstlane(oj32 % (u32)A.n_dig)];
@@ -1331,7 +1005,7 @@ __global__ void __launch_bounds__(kBlock, WIDE ? K2N_WAVES_WIDE : K2N_WAVES) k_k
     const u64 *src = A.c2r + op * A.src_op_stride + (u64)j * N;
     const PrimeDev &Pj = primes[j];
     const bool coeff_in = A.src_is_coeff || LOGN1 == 0; // BFV: coefficient form already; N = 1024: the row pass was the whole inverse
-    constexpr bool kTile = kK2Wide && kPackD && N1 >= 8;
+    constexpr bool kTile = N1 >= 8;
     __shared__ __attribute__((aligned(16))) unsigned char tiles[kTile ? kWaves : 1][kTile ? N1 * 384 : 16];
     unsigned char *tile = tiles[kTile ? threadIdx.x >> 6 : 0];
     if constexpr (WIDE) { // 60-bit digits: integers
@@ -1379,71 +1053,6 @@ __global__ void __launch_bounds__(kBlock, WIDE ? K2N_WAVES_WIDE : K2N_WAVES) k_k
     }
 }
 
-// K2 split in two (HE355_K2_SPLIT): k_k2a finishes the inverse transform of every digit in place (column pass, canonical
-// coefficients), k_k2b lifts ONE digit to ONE target prime per block.  A k_k2b lane holds one column of one target (32 values)
-// instead of the source column plus a target column, so four waves fit a SIMD where k_k2 fits two; the 17 blocks that read the
-// same 64 KiB source tile are dealt to the same XCD back to back (block index = (group * targets + tt) * 8 + xcd), so the tile
-// comes from that XCD's L2 after its first read.
-#ifndef HE355_K2_SPLIT
-#define HE355_K2_SPLIT 0
-#endif
-#ifndef K2B_WAVES
-#define K2B_WAVES 4
-#endif
-template <int LOGN1>
-__global__ void __launch_bounds__(kBlock) k_k2a(u64 *c2r, u64 op_stride, u64 n_ops, int L, const PrimeDev *primes)
-{
-    constexpr int N1 = 1 << LOGN1;
-    constexpr u64 N = (u64)N1 << kRowLog;
-    const u64 oj = blockIdx.x >> 2;
-    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
-    const int j = (int)(oj % L);
-    const u64 op = oj / L;
-    if (op >= n_ops) return;
-    u64 *src = c2r + op * op_stride + (u64)j * N;
-    const PrimeDev &Pj = primes[j];
-    if (Pj.f64) {
-        const ArF64 ar = make_ar(Pj, (ArF64 *)nullptr);
-        double x[N1];
-#pragma unroll
-        for (int a = 0; a < N1; ++a) x[a] = ar.from_raw(src[(a << kRowLog) + col]);
-        col_inv<ArF64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
-#pragma unroll
-        for (int a = 0; a < N1; ++a) src[(a << kRowLog) + col] = ar.to_canon(x[a]);
-    } else {
-        const ArU64 ar = make_ar(Pj, (ArU64 *)nullptr);
-        u64 x[N1];
-#pragma unroll
-        for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
-        col_inv<ArU64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
-#pragma unroll
-        for (int a = 0; a < N1; ++a) src[(a << kRowLog) + col] = ar.to_canon(x[a]);
-    }
-}
-template <int LOGN1>
-__global__ void __launch_bounds__(kBlock, K2B_WAVES) k_k2b(K2Args A, const PrimeDev *primes)
-{
-    constexpr int N1 = 1 << LOGN1;
-    constexpr u64 N = (u64)N1 << kRowLog;
-    const u32 nt = (u32)A.L + 1;
-    const u64 xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
-    const u64 tile = (s / nt) * 8 + xcd; // (op, digit, column block)
-    const int tt = (int)(s % nt);
-    if (tile >= A.n_ops * A.L * 4) return;
-    const int col = (int)((tile & 3) << 8) | threadIdx.x;
-    const u64 oj = tile >> 2;
-    const int j = (int)(oj % A.L);
-    const u64 op = oj / A.L;
-    if (A.ckks && tt == j) return; // CKKS: digit j under its own prime is the NTT-form input itself
-    const u64 *src = A.c2r + op * A.src_op_stride + (u64)j * N;
-    u64 c[N1];
-#pragma unroll
-    for (int a = 0; a < N1; ++a) c[a] = src[(a << kRowLog) + col]; // canonical coefficients of digit j (k_k2a, or BFV's coefficient-form target)
-    const int t = (tt == A.L) ? A.K - 1 : tt;
-    u64 *dst = A.d + ((op * (A.L + 1) + tt) * A.L + j) * N;
-    k2_target<LOGN1>(primes[j], primes[t], c, dst, col);
-}
-
 // =======================================================================================================
 // K3: per (op, key prime tt, row): sum over digits j of NTT_tt(digit j) * key_j[k][tt]
 // =======================================================================================================
@@ -1468,14 +1077,14 @@ stage_row_twiddles(const PrimeDev &P, const Ar &ar, u32 rowbase, unsigned char *
         double *twl = reinterpret_cast<double *>(twl_raw);
 #pragma unroll
         for (int k = 0; k < kIter; ++k)
-            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[tw_row_slot(threadIdx.x + k * BLOCK)] = ArF64::tw_w(tmp[k]);
+            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[threadIdx.x + k * BLOCK] = ArF64::tw_w(tmp[k]);
         twr.t = twl;
         twr.qinv = ar.qinv;
     } else {
         Tw16 *twl = reinterpret_cast<Tw16 *>(twl_raw);
 #pragma unroll
         for (int k = 0; k < kIter; ++k)
-            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[tw_row_slot(threadIdx.x + k * BLOCK)] = tmp[k];
+            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[threadIdx.x + k * BLOCK] = tmp[k];
         twr.t = twl;
     }
     return twr;
@@ -1504,41 +1113,28 @@ struct K3Args {
     unsigned char tt_list[64];
 };
 
-// STAGE: digit rows reach the wave through an LDS landing buffer filled by LDS-DMA one step ahead (true), or straight
-// into registers by global loads issued one step ahead (false: no LDS traffic for them, 32 more live registers).
+// Digit rows reach the wave through an LDS landing buffer filled by LDS-DMA one step ahead.
 // FUSE: the mod-down of the key switch is finished here instead of in k_floor_rows: the tile's sums never leave the
 // registers — the wave transforms the matching rows of the special-prime correction (forward row pass, same tile twiddles)
 // and writes (T - NTT(delta)) * P^-1 + c01 straight into c01.  Needs the special prime's sums first: the caller launches the
-// special-prime tiles, the inverse transform and k_floor_cols before the data-prime tiles.
-// KSHARE: the key rows of a digit step are the same for all eight waves of the block (eight ops of one (prime, row) tile), and
-// fetched by each wave from L2 right before its multiply-accumulate they cost the kernel 11 % in exposed latency (measured: a
-// build that reads every key row from one L1-resident row, profiles/r02_k3_ablation.txt).  With KSHARE the block stages them in
-// LDS once per step, one step ahead, by LDS-DMA (each wave moves 1 KiB pieces of the 2 or 4 rows: key residues, and their Shoup
-// quotients for the u64 engine) into a double buffer; one workgroup barrier per digit step hands a buffer over.  The image is
-// chunk-swizzled (kswz) so that the layout-C reads (a quad of lanes = 128 consecutive bytes, quads 512 bytes apart) are
-// conflict-free ds_read_b128.  Needs the exchange buffers' LDS, i.e. the cross-lane transposes (HE355_XCHG = 3).
-__device__ __forceinline__ u32 kswz(u32 quad) { return (quad & 1u) | ((quad & 2u) << 2); } // XOR mask on the 16-byte chunk index: 0, 1, 8, 9
+// special-prime tiles, the inverse transform and k_floor_colsn before the data-prime tiles.
 // TENSOR (FUSE only): the launch belongs to a ct x ct multiply whose c0, c1 this kernel computes from the operand rows (K3Args::ta); an
 // instantiation of its own, so that the other users of the fused kernel keep their register allocation.
-template <class Ar, int U, int WAVES, bool STAGE, bool FUSE = false, bool KSHARE = false, bool TENSOR = false>
+// WAVES: 8 (throughput shape: one block per CU, two waves per SIMD, each wave on its own op; LDS: 8 x 8.5 KiB exchange + 8 x 8 KiB
+// DMA landing + the tile's twiddles) or 1 (latency shape: one wave per block, the digits of a tile dealt to n_split blocks).
+template <class Ar, int WAVES, bool FUSE = false, bool TENSOR = false>
 __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *primes)
 {
     static_assert(!TENSOR || FUSE, "the operand rows enter through the fused epilogue's sums");
-    static_assert(!KSHARE || (U == 1 && STAGE && WAVES == 8), "shared key staging is written for the 8-wave staged shape");
     constexpr int kWaves = WAVES, kBlock = WAVES * 64; // this kernel's own block shape (shadows the file-wide one)
     typedef typename Ar::T T;
     typedef typename Ar::Acc Acc;
     constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
-    constexpr bool kPacked = kF64 && kPackD;          // this engine's digit rows are 48-bit packed (k_k2 wrote them so)
+    constexpr bool kPacked = kF64;                    // this engine's digit rows are 48-bit packed (k_k2n wrote them so)
     constexpr int kDigitPieces = kPacked ? 6 : 8;
-    // One block per CU.  Default shape (U = 1, 8 waves): two waves per SIMD, each on its own op, LDS-DMA prefetch of the next
-    // row; LDS: 8 x 8.5 KiB exchange + 8 x 8 KiB DMA landing + the tile's twiddles.  (U = 2, 4 waves: one wave per SIMD with two
-    // interleaved digits -- the earlier shape, kept selectable.)
-    __shared__ u64 lds[kWaves][U][kLdsRow];
-    __shared__ __attribute__((aligned(16))) u64 stage[STAGE ? kWaves : 1][STAGE ? U : 1][STAGE ? kRowN : 2];
-    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTwSlots * 8 : kRowTwSlots * 16];
-    constexpr int kKeyArrays = Ar::kKeyQuotient ? 4 : 2; // key rows of polynomial 0, 1 (+ their quotient rows)
-    __shared__ __attribute__((aligned(16))) u64 keybuf[KSHARE ? 2 : 1][KSHARE ? kKeyArrays : 1][KSHARE ? kRowN : 2];
+    __shared__ u64 lds[kWaves][kLdsRow];
+    __shared__ __attribute__((aligned(16))) u64 stage[kWaves][kRowN];
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 n1 = 1u << A.logn1;
     const u64 N = (u64)n1 << kRowLog;
@@ -1563,18 +1159,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
     // this block's forward twiddles of row (t, a_row), staged once in LDS
     const auto twr = stage_row_twiddles<Ar, kBlock>(P, ar, n1 + a_row, twl_raw);
     __syncthreads();
-    // phase A's twiddles are lane-uniform and the same for every digit and op of the tile: fp64 engine keeps them in SGPRs
-    Tw16 wa_s[kTwA];
-    if constexpr (kF64 && !STAGE) {
-        gather_A(twr, wa_s);
-#pragma unroll
-        for (int k = 0; k < kTwA; ++k) {
-            const u32 lo = __builtin_amdgcn_readfirstlane((u32)wa_s[k].a), hi = __builtin_amdgcn_readfirstlane((u32)(wa_s[k].a >> 32));
-            wa_s[k].a = ((u64)hi << 32) | lo;
-            wa_s[k].b = 0;
-        }
-    }
-    const Tw16 *wa_pre = (kF64 && !STAGE) ? wa_s : nullptr;
     for (u32 g = 0; g < A.og_per_block; ++g) {
         const u64 og = og_first + g;
         if (og >= n_og) break; // block-uniform
@@ -1607,11 +1191,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 }
             }
         };
-#if HE355_TENSOR_INIT_EARLY
-        tensor_init();
-#endif
         // u64 engine: products added since the accumulators were last brought under 4q (wave-uniform); acc_flush before anything reads them
-        constexpr int kRun = kAccRunOn ? Ar::kAccRun : 1;
+        constexpr int kRun = Ar::kAccRun;
         int pend = 0;
         auto acc_flush = [&]() {
             if constexpr (kRun > 1) {
@@ -1634,13 +1215,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 else ar.acc_mac(acc[r], x[r], ar.key_in(kv[r]), Ar::kKeyQuotient ? kq[r] : 0);
             }
         };
-#if defined(HE355_ABLATE) && (HE355_ABLATE & 1) // timing experiment (wrong results): every key row is the tile's first one (L1-resident)
-        auto key_row = [&](int, int) -> const u64 * { return A.key + (u64)t * N + rowoff; };
-        auto keyq_row = [&](int, int) -> const u64 * { return A.keyq + (u64)q_slot * N + rowoff; };
-#else
         auto key_row = [&](int j, int k) -> const u64 * { return A.key + (((u64)j * 2 + k) * A.K + t) * N + rowoff; };
         auto keyq_row = [&](int j, int k) -> const u64 * { return A.keyq + (((u64)j * 2 + k) * A.n_q + q_slot) * N + rowoff; };
-#endif
         auto mac_poly = [&](Acc acc[kRowE], const T x[kRowE], int j, int k) {
             u64 kv[kRowE], kq[kRowE];
             load_rowC(key_row(j, k), lane, kv);
@@ -1652,37 +1228,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             mac_poly(acc1, x, j, 1);
             acc_step();
         };
-        // KSHARE: this wave's share of the block's key rows of digit j -> keybuf[b] (wave w moves piece w of every array)
-        auto key_dma = [&](int j, int b) {
-#pragma unroll
-            for (int arr = 0; arr < kKeyArrays; ++arr) {
-                const u64 *src = arr < 2 ? key_row(j, arr) : keyq_row(j, arr - 2);
-                const u32 slot = 64u * (u32)wave + (u32)lane;     // 16-byte slot of the LDS image this lane fills
-                const u32 chunk = slot ^ kswz((slot >> 5) & 3u);  // the row's chunk that lives there
-                __builtin_amdgcn_global_load_lds((glb_void_t *)(src + 2 * chunk), (lds_void_t *)(keybuf[KSHARE ? b : 0][KSHARE ? arr : 0] + 128 * wave), 16, 0, 0);
-            }
-        };
-        auto key_lds = [&](const u64 *img, u64 kv[kRowE]) { // layout-C registers of a staged row
-            const u32 quad = (u32)lane >> 2, m = (u32)lane & 3u, swz = kswz(quad & 3u);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const u32 slot = quad * 32u + (((u32)c * 8u + m * 2u + (u32)h) ^ swz);
-                    const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(img)[slot];
-                    kv[4 * c + 2 * h] = v.x; kv[4 * c + 2 * h + 1] = v.y;
-                }
-        };
-        auto mac_digit_lds = [&](const T x[kRowE], int b) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                u64 kv[kRowE], kq[kRowE];
-                key_lds(keybuf[KSHARE ? b : 0][KSHARE ? k : 0], kv);
-                if constexpr (Ar::kKeyQuotient) key_lds(keybuf[KSHARE ? b : 0][KSHARE ? 2 + k : 0], kq);
-                mac_row(k == 0 ? acc0 : acc1, x, kv, kq);
-            }
-            acc_step();
-        };
         // digits that go through the forward row pass: all of them, except (CKKS) the one that lives under this very
         // prime -- that one is the NTT-form target itself and is multiplied in directly
         const bool has_own = A.ckks && tt < A.L;
@@ -1691,32 +1236,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
         // this block's share of the transformed digits: all of them, or group blockIdx.y of n_split (unfused instantiations only)
         const int split = FUSE ? 1 : (A.n_split > 1 ? A.n_split : 1), grp = split > 1 ? (int)blockIdx.y : 0;
         const int i_begin = nd * grp / split, i_end = nd * (grp + 1) / split;
-#if defined(HE355_ABLATE) && (HE355_ABLATE & 2) // timing experiment (wrong results): every digit row is the same row (no HBM stream)
-        auto src_row = [&](int) -> const u64 * { return A.d + (u64)wave * N + rowoff; };
-#else
         auto src_row = [&](int j) -> const u64 * { return A.d + ((op * (A.L + 1) + tt) * A.L + j) * N + rowoff; };
-#endif
-        if constexpr (STAGE) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (i_begin + u < i_end) dma_row_to_lds<kDigitPieces>(src_row(digit(i_begin + u)), stage[wave][u], lane);
-        }
-#if !HE355_TENSOR_INIT_EARLY
+        if (i_begin < i_end) dma_row_to_lds<kDigitPieces>(src_row(digit(i_begin)), stage[wave], lane);
         tensor_init();
-#endif
-        if constexpr (KSHARE) {
-            __syncthreads(); // every wave is done with the key buffers of the previous op-group
-            if (nd > 0) key_dma(digit(0), 0);
-        }
-        u64 vn[kRowE]; // !STAGE: the next digit's row, in flight or landed
-        Row48 vn48;
-        if constexpr (!STAGE) {
-            static_assert(STAGE || U == 1, "register prefetch is written for one digit per wave");
-            if (i_begin < i_end) {
-                if constexpr (kPacked) load_rowA48(src_row(digit(i_begin)), lane, vn48);
-                else load_rowA(src_row(digit(i_begin)), lane, vn);
-            }
-        }
         if (has_own && grp == 0) {
             if constexpr (TENSOR) {
                 // the digit that lives under this prime is c2 = a1 b1 in NTT form: formed here (k_k1 writes no c2n row for a ct x ct
@@ -1744,7 +1266,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             // rows: rows [0, nd) are digits (transform + key MAC), rows nd, nd+1 the special-prime correction of polynomial
             // 0 / 1 (transform, then (sums - x) * P^-1 + c01), rows nd+2, nd+3 the rescale correction (transform, then
             // (result - x) * q_last^-1).  Every row is prefetched into the LDS landing buffer behind the previous row's math.
-            static_assert(!FUSE || (U == 1 && STAGE), "the fused floor steps are written for one staged digit per wave");
             // resc: the rescale is finished here too.  Its correction slab already holds delta2 + P^-1 * delta1 (k_floor_cols folded
             // the mod-down correction in), so there are two correction rows per tile either way:
             //   mod-down only: rows nd, nd+1 from cols:   c01 <- (sums - x) * P^-1 + c01
@@ -1759,46 +1280,30 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
             };
             const FloorConst fc = A.fc[(A.K - 1) * A.K + t];
             const FloorConst fc2 = A.fc[(resc ? A.L - 1 : 0) * A.K + t];
-            if (nd == 0) dma_row_to_lds(row_ptr(0), stage[wave][0], lane); // no digit row was primed above
+            if (nd == 0) dma_row_to_lds(row_ptr(0), stage[wave], lane); // no digit row was primed above
             // digit rows: transform + key MAC (the last one prefetches the first correction row)
             for (int i = 0; i < nd; ++i) {
                 T x[1][kRowE];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's row (and this wave's share of its key rows) has landed in LDS
-                if constexpr (KSHARE) __syncthreads();            // ... and so has every other wave's share; all waves are past the previous step's MAC
-#if defined(HE355_K3_SYNC) && HE355_K3_SYNC
-                else if ((i % HE355_K3_SYNC) == 0) __syncthreads(); // experiment: the block's eight waves on the same digit, so that one L1 fill of its key rows serves all
-#endif
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's row has landed in LDS
                 if constexpr (kPacked) {
-                    lds_rowA48(stage[wave][0], lane, x[0]);
+                    lds_rowA48(stage[wave], lane, x[0]);
                 } else {
                     u64 v[kRowE];
-                    lds_rowA(stage[wave][0], lane, v);
+                    lds_rowA(stage[wave], lane, v);
 #pragma unroll
                     for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffer drained into registers
                 // next row, behind this step's math: a digit row (packed for this engine) or the first correction row (64-bit words)
-                if (i + 1 < nd) dma_row_to_lds<kDigitPieces>(row_ptr(i + 1), stage[wave][0], lane);
-                else dma_row_to_lds(row_ptr(i + 1), stage[wave][0], lane);
-                if constexpr (KSHARE) {
-                    if (i + 1 < nd) key_dma(digit(i + 1), (i + 1) & 1); // the buffer the previous step's MAC read
-                }
-                if constexpr (kKeyEarly && !KSHARE && !Ar::kKeyQuotient) {
+                if (i + 1 < nd) dma_row_to_lds<kDigitPieces>(row_ptr(i + 1), stage[wave], lane);
+                else dma_row_to_lds(row_ptr(i + 1), stage[wave], lane);
+                if constexpr (!Ar::kKeyQuotient) {
                     // both key rows of the digit are requested before the second exchange (the hook runs after phase B's math): they
                     // land behind the exchange and phase C instead of in front of the multiply-accumulate, which used to wait out
                     // two L2 round trips per step (poly 0, then poly 1)
                     u64 kv0[kRowE], kv1[kRowE];
                     const int j = digit(i);
-                    // HE355_KEY_EARLY = 1: both rows in the hook; 2: both before the row pass; 3: polynomial 0's before the row pass, 1's in the hook
-                    if constexpr (HE355_KEY_EARLY == 2) {
-                        load_rowC(key_row(j, 0), lane, kv0); load_rowC(key_row(j, 1), lane, kv1);
-                        wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
-                    } else if constexpr (HE355_KEY_EARLY == 3) {
-                        load_rowC(key_row(j, 0), lane, kv0);
-                        wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, [&]() { load_rowC(key_row(j, 1), lane, kv1); }, wa_pre);
-                    } else {
-                    wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, [&]() { load_rowC(key_row(j, 0), lane, kv0); load_rowC(key_row(j, 1), lane, kv1); }, wa_pre);
-                    }
+                    wave_rows_fwd_n(ar, twr, lane, lds[wave], x, [&]() { load_rowC(key_row(j, 0), lane, kv0); load_rowC(key_row(j, 1), lane, kv1); });
                     // the 32 products, kMacG at a time (interleaved chains: at two waves per SIMD a serial chain issues at 3/4 of the
                     // pipe's rate)
                     if constexpr (kF64) {
@@ -1815,20 +1320,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                             for (int k = 0; k < kMacG / 2; ++k) { acc0[r0 + k] += pr[2 * k]; acc1[r0 + k] += pr[2 * k + 1]; }
                         }
                     }
-                } else if constexpr (kKeyEarlyU64 && !KSHARE && Ar::kKeyQuotient) {
-                    u64 kv0[kRowE], kq0[kRowE], kv1[kRowE], kq1[kRowE];
-                    const int j = digit(i);
-                    auto early = [&]() { load_rowC(key_row(j, 0), lane, kv0); load_rowC(keyq_row(j, 0), lane, kq0); };
-                    wave_rows_fwd_n<1, Ar, decltype(twr), decltype(early), kLazyU64>(ar, twr, lane, lds[wave], x, early, wa_pre);
-                    load_rowC(key_row(j, 1), lane, kv1);
-                    load_rowC(keyq_row(j, 1), lane, kq1);
-                    mac_row(acc0, x[0], kv0, kq0);
-                    mac_row(acc1, x[0], kv1, kq1);
-                    acc_step();
-                } else {
-                    wave_rows_fwd_n<1, Ar, decltype(twr), NoHook, kLazyU64>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
-                    if constexpr (KSHARE) mac_digit_lds(x[0], i & 1);
-                    else mac_digit(x[0], digit(i));
+                } else { // u64 engine: the digit rows are transformed over the wide lazy range (one correction per row, not per butterfly)
+                    wave_rows_fwd_n<Ar, decltype(twr), NoHook, true>(ar, twr, lane, lds[wave], x);
+                    mac_digit(x[0], digit(i));
                 }
             }
             acc_flush();
@@ -1838,11 +1332,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 T x[1][kRowE];
                 u64 v[kRowE], av[kRowE];
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                lds_rowA(stage[wave][0], lane, v);
+                lds_rowA(stage[wave], lane, v);
 #pragma unroll
                 for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (i + 1 < n_rows) dma_row_to_lds(row_ptr(i + 1), stage[wave][0], lane);
+                if (i + 1 < n_rows) dma_row_to_lds(row_ptr(i + 1), stage[wave], lane);
                 const int k = i - nd;
                 u64 *c01_row = A.c01 + op * A.c01_item_stride + k * LN + (u64)tt * N + rowoff;
                 // the addend, in flight during the transform -- or nothing: for a ct x ct multiply (A.ta) it entered the accumulators before the digits
@@ -1856,7 +1350,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 } else { // ... with addend: its polynomial 1, read where it lies
                     load_rowC(k == 1 && A.c1_mode == 2 ? A.c1_src + (op * 2 + 1) * LN + (u64)tt * N + rowoff : c01_row, lane, av);
                 }
-                wave_rows_fwd_n<1>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
+                wave_rows_fwd_n(ar, twr, lane, lds[wave], x);
                 const Acc *acc = k == 0 ? acc0 : acc1;
                 if constexpr (TENSOR) { // sums formed with scaled key residues, addend inside them
                     if (!resc) {
@@ -1879,68 +1373,21 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 }
             }
         } else {
-            for (int i = i_begin; i < i_end; i += U) {
-                const int cnt = (i_end - i) < U ? (i_end - i) : U;
-                T x[U][kRowE];
-                if constexpr (STAGE) {
+            for (int i = i_begin; i < i_end; ++i) {
+                T x[1][kRowE];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's row has landed in the staging buffer
+                if constexpr (kPacked) {
+                    lds_rowA48(stage[wave], lane, x[0]);
+                } else {
                     u64 v[kRowE];
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the rows of this step have landed in the staging buffers
-                    if constexpr (KSHARE) __syncthreads();            // and the block's key rows of this step (see the fused loop)
+                    lds_rowA(stage[wave], lane, v);
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        if (u < cnt) {
-                            if constexpr (kPacked) {
-                                lds_rowA48(stage[wave][u], lane, x[u]);
-                            } else {
-                                lds_rowA(stage[wave][u], lane, v);
-#pragma unroll
-                                for (int r = 0; r < kRowE; ++r) x[u][r] = ar.from_raw(v[r]);
-                            }
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffers drained into registers
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        if (i + U + u < i_end) dma_row_to_lds<kDigitPieces>(src_row(digit(i + U + u)), stage[wave][u], lane); // next step's rows, behind this step's math
-                    if constexpr (KSHARE) {
-                        if (i + 1 < nd) key_dma(digit(i + 1), (i + 1) & 1);
-                    }
-                } else {
-                    asm volatile("" ::: "memory"); // keeps the LDS twiddle reads inside the loop (hoisted, they would cost 54 registers)
-                    if constexpr (kPacked) {
-#pragma unroll
-                        for (int r = 0; r < kRowE; ++r) x[0][r] = unpack48(vn48.lo[r], vn48.hi[r]);
-                        if (i + 1 < i_end) load_rowA48(src_row(digit(i + 1)), lane, vn48); // lands behind this step's math
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(vn[r]);
-                        if (i + 1 < i_end) load_rowA(src_row(digit(i + 1)), lane, vn); // lands behind this step's math
-                    }
+                    for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
                 }
-                if (U == 2 && cnt < U) { // odd digit count: the partner row is zeros (its products add nothing)
-#pragma unroll
-                    for (int r = 0; r < kRowE; ++r) x[U - 1][r] = 0;
-                }
-                if constexpr (kKeyEarlyU64 && !KSHARE && Ar::kKeyQuotient && U == 1) {
-                    u64 kv0[kRowE], kq0[kRowE], kv1[kRowE], kq1[kRowE]; // as in the fused loop above
-                    const int j = digit(i);
-                    auto early = [&]() { load_rowC(key_row(j, 0), lane, kv0); load_rowC(keyq_row(j, 0), lane, kq0); };
-                    wave_rows_fwd_n<U, Ar, decltype(twr), decltype(early), kLazyU64>(ar, twr, lane, lds[wave], x, early, wa_pre);
-                    load_rowC(key_row(j, 1), lane, kv1);
-                    load_rowC(keyq_row(j, 1), lane, kq1);
-                    mac_row(acc0, x[0], kv0, kq0);
-                    mac_row(acc1, x[0], kv1, kq1);
-                    acc_step();
-                } else {
-                wave_rows_fwd_n<U, Ar, decltype(twr), NoHook, kLazyU64>(ar, twr, lane, lds[wave], x, NoHook(), wa_pre);
-                if constexpr (KSHARE) {
-                    mac_digit_lds(x[0], i & 1);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        if (u < cnt) mac_digit(x[u], digit(i + u));
-                }
-                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffer drained into registers
+                if (i + 1 < i_end) dma_row_to_lds<kDigitPieces>(src_row(digit(i + 1)), stage[wave], lane); // next step's row, behind this step's math
+                wave_rows_fwd_n<Ar, decltype(twr), NoHook, true>(ar, twr, lane, lds[wave], x);
+                mac_digit(x[0], digit(i));
             }
             acc_flush();
             // Epilogue: canonical sums, NTT form, layout C.  Data primes -> t; special prime -> tp.  Where the next step is the
@@ -1965,7 +1412,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 T x[kRowE];
 #pragma unroll
                 for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
-                wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave][0], x);
+                wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
 #pragma unroll
                 for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
                 u64 *dst = tt < A.L ? A.t + ((op * 2 + k) * A.L + tt) * N + rowoff : A.tpr + (op * 2 + k) * N + rowoff;
@@ -2046,18 +1493,14 @@ struct FloorColsArgs {
     int src_prime, n_tgt, K;
     const FloorConst *fc;
     int tgt_first, dst_ntgt; // targets [tgt_first, tgt_first + n_tgt) of a destination slab laid out for dst_ntgt targets
-    // optional: an earlier floor step's column-passed correction [n_polys][addin_ntgt][N] (raw of the target prime) is folded in,
-    // scaled by addin_src^-1 mod q_i: the two corrections of mod-down + rescale then need ONE row transform (both passes are linear)
-    const u64 *addin;
-    int addin_src, addin_ntgt;
-    // optional (HE355_FC_MERGE): the earlier floor step's SOURCE instead ([n_polys][N], after the inverse row pass, prime src2_prime):
-    // its correction is formed here in coefficient form and folded in BEFORE the column pass, delta = delta2 + src2^-1 * delta1 mod q_i,
-    // so both floor steps share ONE column pass per target as well (the pass is linear) and the earlier correction slab is neither
-    // written for these targets nor read back
+    // optional (MERGE): an earlier floor step's SOURCE ([n_polys][N], after the inverse row pass, prime src2_prime): its correction is
+    // formed here in coefficient form and folded in BEFORE the column pass, delta = delta2 + src2^-1 * delta1 mod q_i, so mod-down and
+    // rescale share ONE column pass and ONE row transform per target (both passes are linear) and the earlier correction slab is
+    // neither written for these targets nor read back
     const u64 *src2;
     int src2_prime;
-    u64 f64_mask; // bit i: key prime i belongs to the fp64 engine (k_floor_colsn)
-    int tsplit;   // k_floor_colsn, latency shape: the targets of a column are dealt to tsplit blocks (blockIdx.y)
+    u64 f64_mask; // bit i: key prime i belongs to the fp64 engine
+    int tsplit;   // latency shape: the targets of a column are dealt to tsplit blocks (blockIdx.y)
 };
 
 // canonical coefficients + floor(s/2) of one column of a source residue after its inverse row pass
@@ -2089,96 +1532,12 @@ __device__ __forceinline__ void floor_source_column(const PrimeDev &Ps, const u6
     for (int a = 0; a < N1; ++a) c[a] = addmod(c[a], half, qs);
 }
 
-template <int LOGN1, bool MERGE>
-__global__ void __launch_bounds__(kBlock, 2) k_floor_cols(FloorColsArgs A, const PrimeDev *primes)
-{
-    constexpr int N1 = 1 << LOGN1;
-    constexpr u64 N = (u64)N1 << kRowLog;
-    const u64 poly = blockIdx.x >> 2;
-    const int col = ((blockIdx.x & 3) << 8) | threadIdx.x;
-    const PrimeDev &Ps = primes[A.src_prime];
-    u64 c[N1];
-    floor_source_column<LOGN1>(Ps, A.src + poly * N, col, c);
-    const u64 qs = Ps.q;
-    // MERGE: the second source's column is parked in LDS (one 8-byte word per (row, thread): conflict-free), not in 64 more
-    // registers -- with both columns in registers the kernel needs 298 and runs at one wave per SIMD, or spills at two
-    __shared__ u64 park[MERGE ? N1 : 1][MERGE ? kBlock : 1];
-    u64 qs2 = 0;
-    if constexpr (MERGE) {
-        u64 c2[N1];
-        floor_source_column<LOGN1>(primes[A.src2_prime], A.src2 + poly * N, col, c2);
-#pragma unroll
-        for (int a = 0; a < N1; ++a) park[a][threadIdx.x] = c2[a];
-        qs2 = primes[A.src2_prime].q;
-        // each thread reads back only what it wrote itself: no barrier needed
-    }
-    for (int i = A.tgt_first; i < A.tgt_first + A.n_tgt; ++i) {
-        const PrimeDev &Pi = primes[i];
-        const u64 qi = Pi.q;
-        const u64 half_i = A.fc[A.src_prime * A.K + i].half_mod;
-        const ModU64 mi = make_modu(Pi);
-        u64 *dst = A.dst + (poly * A.dst_ntgt + i) * N;
-        u64 dl[N1];
-#pragma unroll
-        for (int a = 0; a < N1; ++a) dl[a] = submod(qs > qi ? barrett64(c[a], mi) : c[a], half_i, qi);
-        if (Pi.f64) {
-            const ArF64 ar = make_ar(Pi, (ArF64 *)nullptr);
-            double x[N1];
-#pragma unroll
-            for (int a = 0; a < N1; ++a) x[a] = u52_to_f64(dl[a]);
-            if constexpr (MERGE) { // x = delta2 + src2^-1 * delta1 (centred product: |x| < 1.5 q + 1, the column pass's bound holds)
-                const FloorConst f2 = A.fc[A.src2_prime * A.K + i];
-#pragma unroll
-                for (int a = 0; a < N1; ++a) {
-                    const u64 v2 = park[a][threadIdx.x];
-                    const u64 d1 = submod(qs2 > qi ? barrett64(v2, mi) : v2, f2.half_mod, qi);
-                    x[a] += ar.mulmod_c(u52_to_f64(d1), f2.inv_d, f2.inv_i);
-                }
-            }
-            col_fwd<ArF64, LOGN1>(ar, x, ctw(Pi.fwd));
-            if (A.addin) {
-                const FloorConst fa = A.fc[A.addin_src * A.K + i];
-                const u64 *ad = A.addin + (poly * A.addin_ntgt + i) * N;
-#pragma unroll
-                for (int a = 0; a < N1; ++a) x[a] += ar.mulmod_c(ar.from_raw(ad[(a << kRowLog) + col]), fa.inv_d, fa.inv_i);
-            }
-#pragma unroll
-            for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = ar.to_raw(x[a]);
-        } else {
-            const ArU64 ar = make_ar(Pi, (ArU64 *)nullptr);
-            if constexpr (MERGE) { // [0,q) + [0,q): a valid lazy input of the column pass
-                const FloorConst f2 = A.fc[A.src2_prime * A.K + i];
-#pragma unroll
-                for (int a = 0; a < N1; ++a) {
-                    const u64 v2 = park[a][threadIdx.x];
-                    const u64 d1 = submod(qs2 > qi ? barrett64(v2, mi) : v2, f2.half_mod, qi);
-                    dl[a] += mul_shoup(d1, f2.inv, f2.inv_shoup, qi);
-                }
-            }
-            col_fwd<ArU64, LOGN1>(ar, dl, ctw(Pi.fwd));
-            if (A.addin) {
-                const FloorConst fa = A.fc[A.addin_src * A.K + i];
-                const u64 *ad = A.addin + (poly * A.addin_ntgt + i) * N;
-#pragma unroll
-                for (int a = 0; a < N1; ++a) { // lazy values: [0,4q) + [0,2q), brought back under 4q
-                    const u64 sum = dl[a] + mul_shoup_lazy(ad[(a << kRowLog) + col], fa.inv, fa.inv_shoup, qi);
-                    dl[a] = sum >= 2 * ar.two_q ? sum - 2 * ar.two_q : sum;
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < N1; ++a) dst[(a << kRowLog) + col] = dl[a];
-        }
-    }
-}
-
-// ---- floor step, column half, second form (round 3) ---------------------------------------------------
-// Same outputs up to the lazy representative (consumers read the rows as lazy raw values).  What changed against k_floor_cols:
-//   * the corrections are formed in the target's own engine instead of with 64-bit Barrett reductions: under an fp64-engine target
-//     a source residue below 2^52 enters as the double it is (re-centred only where q_s > 2 q_i), a wider one as
-//     hi * (2^32 mod q_i) + lo, one exact fp64 product (8 instructions instead of ~35 per element for the 60-bit special prime);
-//   * per-target constants sit in a small LDS table filled once per block (wave-uniform ds_reads, no scalar registers), the column
-//     twiddles come from PrimeDev::colw through the same software pipeline as k_k2n's, rows leave through buffer stores whose
-//     addresses cost no VALU instruction.
+// The corrections are formed in the target's own engine (round 3; the first form used 64-bit Barrett reductions, HISTORY.md): under an
+// fp64-engine target a source residue below 2^52 enters as the double it is (re-centred only where q_s > 2 q_i), a wider one as
+// hi * (2^32 mod q_i) + lo, one exact fp64 product (8 instructions instead of ~35 per element for the 60-bit special prime).  Per-target
+// constants sit in a small LDS table filled once per block (wave-uniform ds_reads, no scalar registers), the column twiddles come from
+// PrimeDev::colw through the same software pipeline as k_k2n's, rows leave through buffer stores whose addresses cost no VALU
+// instruction.
 struct FcnConsts { // one per target prime, as the fp64 engine wants them
     double half1, half2;   // floor(s/2) mod q_i for the source / the merged earlier source
     double inv2, inv2_i;   // src2^-1 mod q_i and fl(inv2 / q_i)
@@ -2314,7 +1673,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_floor_colsn(FloorColsArgs A, cons
 #pragma unroll
         for (int a = 0; a < N1; ++a) c[a] = f64_to_u52(cd[a]);
     }
-    // u64-engine targets: integers throughout (as k_floor_cols)
+    // u64-engine targets: integers throughout
     const u32 off8 = (u32)col << 3;
     for (u64 m = tgt & ~A.f64_mask; m; m &= m - 1) {
         const int i = __builtin_ctzll(m);
@@ -2359,7 +1718,7 @@ __global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const Pri
     typedef typename Ar::T T;
     constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
     __shared__ u64 lds[kWaves][kLdsRow];
-    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTwSlots * 8 : kRowTwSlots * 16];
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 n1 = 1u << A.logn1;
     const u64 N = (u64)n1 << kRowLog;
@@ -3017,41 +2376,12 @@ void launch_mul3(const KernelEnv &env, int L, u64 n_results, const u64 *a, const
     hipLaunchKernelGGL(k_mul3, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, a, b, out, ix, env.primes, L, logN, n_results);
 }
 
-// KernelEnv::side: the stream of a launcher's pass (0: env.stream; later passes: env.side once forked) and the join that makes
-// env.stream wait for what went to the side stream.  Every launch that follows on env.stream depends on both.
-namespace {
-struct SideFork {
-    const KernelEnv &env;
-    bool forked = false;
-    explicit SideFork(const KernelEnv &e) : env(e)
-    {
-        if (env.side) { // the fork point is in front of the first pass: the side stream's kernel does not wait for it
-            (void)hipEventRecord(env.ev_side_fork, env.stream);
-        }
-    }
-    hipStream_t stream(int pass)
-    {
-        if (!env.side || pass == 0) return env.stream;
-        if (!forked) { (void)hipStreamWaitEvent(env.side, env.ev_side_fork, 0); forked = true; }
-        return env.side;
-    }
-    ~SideFork()
-    {
-        if (forked) {
-            (void)hipEventRecord(env.ev_side_join, env.side);
-            (void)hipStreamWaitEvent(env.stream, env.ev_side_join, 0);
-        }
-    }
-};
-} // namespace
-
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
                const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1)
 {
     if (!n_ops) return;
     if (no_c01 && mode != K1_MUL) throw std::runtime_error("no_c01: the ct x ct multiply only");
     if (no_c1 && mode != K1_GALOIS && mode != K1_CT3) throw std::runtime_error("no_c1: rotations and size-3 inputs only");
-    SideFork sf(env);
     K1Args A;
     A.no_c1 = no_c1 ? 1 : 0;
     A.a = a; A.b = b; A.ix = ix; A.perm = perm; A.addend = addend;
@@ -3064,7 +2394,7 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
         if (!A.n_i) continue;
         const u64 jobs = (n_ops * A.n_i) << env.logn1;
         const dim3 grid(grid_for(jobs, kWaves));
-        const hipStream_t st = sf.stream(pass);
+        const hipStream_t st = env.stream;
         if (pass == 0) {
             if (mode == K1_MUL && no_c01) hipLaunchKernelGGL((k_k1<K1_MUL_C2, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
             else if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
@@ -3087,98 +2417,46 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     A.src_op_stride = src ? src_op_stride : (u64)L * env.N;
     A.src_is_coeff = src ? 1 : 0;
     A.d = buf.d; A.n_ops = n_ops; A.L = L; A.K = env.K; A.ckks = env.scheme == 2;
-    A.f64_mask = 0; A.ablate = 0; A.xcd_map = 0; A.tsplit = tsplit > 1 ? tsplit : 1;
+    A.f64_mask = 0; A.tsplit = tsplit > 1 ? tsplit : 1;
     for (int t = 0; t < env.K; ++t) A.f64_mask |= (u64)(env.prime_f64[t] != 0) << t;
-    static const int split_env = getenv("HE355_K2_SPLIT") ? atoi(getenv("HE355_K2_SPLIT")) : HE355_K2_SPLIT;
-    if (split_env) {
-        // finish the inverse transform in place (nothing to do when the target is in coefficient form already or the row pass was
-        // the whole transform), then one (digit, target prime, column block) per block
-        const unsigned ga = (unsigned)(n_ops * L * 4);
-        if (!src && env.logn1 > 0) {
-            switch (env.logn1) {
-            case 1: hipLaunchKernelGGL(k_k2a<1>, dim3(ga), dim3(kBlock), 0, env.stream, buf.c2r, A.src_op_stride, n_ops, L, env.primes); break;
-            case 2: hipLaunchKernelGGL(k_k2a<2>, dim3(ga), dim3(kBlock), 0, env.stream, buf.c2r, A.src_op_stride, n_ops, L, env.primes); break;
-            case 3: hipLaunchKernelGGL(k_k2a<3>, dim3(ga), dim3(kBlock), 0, env.stream, buf.c2r, A.src_op_stride, n_ops, L, env.primes); break;
-            case 4: hipLaunchKernelGGL(k_k2a<4>, dim3(ga), dim3(kBlock), 0, env.stream, buf.c2r, A.src_op_stride, n_ops, L, env.primes); break;
-            case 5: hipLaunchKernelGGL(k_k2a<5>, dim3(ga), dim3(kBlock), 0, env.stream, buf.c2r, A.src_op_stride, n_ops, L, env.primes); break;
-            }
+    for (int wide = 0; wide < 2; ++wide) { // digits below 2^52, then the 60-bit ones: one instantiation each
+        A.n_dig = 0;
+        for (int j = 0; j < L; ++j)
+            if ((env.prime_q[j] >> 52 != 0) == (wide != 0)) A.dig_list[A.n_dig++] = (unsigned char)j;
+        if (!A.n_dig) continue;
+        const unsigned gw = (unsigned)(n_ops * A.n_dig * 4);
+        // Small grids: the targets of a (digit, column block) dealt to 2 or 4 blocks (blockIdx.y, as the latency shape does) when
+        // that fills the rounds of blocks better -- 512 blocks run at a time (two per CU); a block pays the digit's inverse column
+        // pass once and a forward column pass + stores per target.  64 BFV ciphertexts at L = 3: 768 blocks = 1.5 rounds of all four
+        // targets, or 3 full rounds of two targets each.  Only taken for a modelled gain of 5 % or more (the headline's 61440 blocks
+        // stay whole); HE355_K2_TSPLIT=<n> fixes it.
+        static const int ts_env = getenv("HE355_K2_TSPLIT") ? atoi(getenv("HE355_K2_TSPLIT")) : 0;
+        int ts = tsplit > 1 ? tsplit : 1;
+        if (tsplit <= 1 && ts_env > 0) ts = ts_env;
+        else if (tsplit <= 1) {
+            const int n_tgt = L + 1 - (A.ckks ? 1 : 0);
+            auto cost = [&](int c) { return (double)(((u64)gw * c + 511) / 512) * (1.0 + 1.2 * ((n_tgt + c - 1) / c)); };
+            const double c1 = cost(1);
+            double best = c1;
+            for (int c = 2; c <= 4; c <<= 1)
+                if (cost(c) < best * 0.95 && cost(c) < c1 * 0.95) { best = cost(c); ts = c; }
         }
-        A.src_is_coeff = 1;
-        const u64 tiles = n_ops * L * 4;
-        const unsigned gb = (unsigned)(((tiles + 7) / 8) * (u64)(L + 1) * 8);
-        switch (env.logn1) {
-        case 0: hipLaunchKernelGGL(k_k2b<0>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 1: hipLaunchKernelGGL(k_k2b<1>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 2: hipLaunchKernelGGL(k_k2b<2>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 3: hipLaunchKernelGGL(k_k2b<3>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 4: hipLaunchKernelGGL(k_k2b<4>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 5: hipLaunchKernelGGL(k_k2b<5>, dim3(gb), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        }
-        return;
-    }
-    unsigned g = (unsigned)(n_ops * L * 4);
-    static const bool k2_new = !(getenv("HE355_K2_NEW") && getenv("HE355_K2_NEW")[0] == '0');
-    static const bool k2_xcd = getenv("HE355_K2_XCD") && getenv("HE355_K2_XCD")[0] == '1';
-    A.xcd_map = k2_new && k2_xcd;
-    static const int k2_abl = getenv("HE355_K2_ABL") ? atoi(getenv("HE355_K2_ABL")) : 0;
-    A.ablate = k2_abl;
-    if (k2_new) {
-        SideFork sf(env);
-        int launched = 0;
-        for (int wide = 0; wide < 2; ++wide) { // digits below 2^52, then the 60-bit ones
-            A.n_dig = 0;
-            for (int j = 0; j < L; ++j)
-                if ((env.prime_q[j] >> 52 != 0) == (wide != 0)) A.dig_list[A.n_dig++] = (unsigned char)j;
-            if (!A.n_dig) continue;
-            unsigned gw = (unsigned)(n_ops * A.n_dig * 4);
-            if (A.xcd_map) gw = (unsigned)(((n_ops * A.n_dig + 7) / 8) * 8 * 4);
-            // Small grids: the targets of a (digit, column block) dealt to 2 or 4 blocks (blockIdx.y, as the latency shape does) when
-            // that fills the rounds of blocks better -- 512 blocks run at a time (two per CU); a block pays the digit's inverse column
-            // pass once and a forward column pass + stores per target.  64 BFV ciphertexts at L = 3: 768 blocks = 1.5 rounds of all four
-            // targets, or 3 full rounds of two targets each.  Only taken for a modelled gain of 5 % or more (the headline's 61440 blocks
-            // stay whole); HE355_K2_TSPLIT=<n> fixes it.
-            static const int ts_env = getenv("HE355_K2_TSPLIT") ? atoi(getenv("HE355_K2_TSPLIT")) : 0;
-            int ts = tsplit > 1 ? tsplit : 1;
-            if (tsplit <= 1 && ts_env > 0) ts = ts_env;
-            else if (tsplit <= 1) {
-                const int n_tgt = L + 1 - (A.ckks ? 1 : 0);
-                auto cost = [&](int c) { return (double)(((u64)gw * c + 511) / 512) * (1.0 + 1.2 * ((n_tgt + c - 1) / c)); };
-                const double c1 = cost(1);
-                double best = c1;
-                for (int c = 2; c <= 4; c <<= 1)
-                    if (cost(c) < best * 0.95 && cost(c) < c1 * 0.95) { best = cost(c); ts = c; }
-            }
-            A.tsplit = ts;
-            const dim3 gd(gw, (unsigned)A.tsplit);
-            const hipStream_t st = sf.stream(launched++);
+        A.tsplit = ts;
+        const dim3 gd(gw, (unsigned)A.tsplit);
 #define HE355_K2N(L1)                                                                                                         \
     case L1:                                                                                                                  \
-        if (wide) hipLaunchKernelGGL((k_k2n<L1, true>), gd, dim3(kBlock), 0, st, A, env.primes);                              \
-        else hipLaunchKernelGGL((k_k2n<L1, false>), gd, dim3(kBlock), 0, st, A, env.primes);                                  \
+        if (wide) hipLaunchKernelGGL((k_k2n<L1, true>), gd, dim3(kBlock), 0, env.stream, A, env.primes);                      \
+        else hipLaunchKernelGGL((k_k2n<L1, false>), gd, dim3(kBlock), 0, env.stream, A, env.primes);                          \
         break;
-            switch (env.logn1) { HE355_K2N(0) HE355_K2N(1) HE355_K2N(2) HE355_K2N(3) HE355_K2N(4) HE355_K2N(5) }
+        switch (env.logn1) { HE355_K2N(0) HE355_K2N(1) HE355_K2N(2) HE355_K2N(3) HE355_K2N(4) HE355_K2N(5) }
 #undef HE355_K2N
-        }
-        return;
-    }
-    A.tsplit = 1;
-    switch (env.logn1) {
-    case 0: hipLaunchKernelGGL(k_k2<0>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 1: hipLaunchKernelGGL(k_k2<1>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 2: hipLaunchKernelGGL(k_k2<2>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 3: hipLaunchKernelGGL(k_k2<3>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 4: hipLaunchKernelGGL(k_k2<4>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 5: hipLaunchKernelGGL(k_k2<5>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
     }
 }
 
 bool k3_can_fuse(const KernelEnv &env)
 {
-    static const bool off = getenv("HE355_K3_FUSE") && getenv("HE355_K3_FUSE")[0] == '0';
-    static const int shape_env = getenv("HE355_K3_SHAPE") ? atoi(getenv("HE355_K3_SHAPE")) : 0;
-    static const int stage_env = getenv("HE355_K3_STAGE") ? atoi(getenv("HE355_K3_STAGE")) : HE355_K3_STAGE_DEFAULT;
-    const int sf = shape_env ? shape_env / 100 : HE355_K3_F64_SHAPE, su = shape_env ? shape_env % 100 : HE355_K3_U64_SHAPE;
-    return !off && env.scheme == 2 && env.K >= 2 && sf == 18 && su == 18 && stage_env != 0; // the fused instantiations exist for the default shapes
+    static const bool off = getenv("HE355_K3_FUSE") && getenv("HE355_K3_FUSE")[0] == '0'; // the unfused sequence (k_floor_rows finishes the mod-down)
+    return !off && env.scheme == 2 && env.K >= 2;
 }
 
 void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part, const K3Fuse *fuse, int n_split, u64 *split_part,
@@ -3188,8 +2466,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     if (n_split > 1 && (fuse || !split_part)) throw std::runtime_error("digit-split K3: unfused launches with a partial-sum buffer only");
     const unsigned char *prime_f64 = env.prime_f64;
     if (!n_ops) return;
-    if (fuse && (part != K3_DATA_ONLY || !k3_can_fuse(env))) throw std::runtime_error("fused mod-down: data-prime tiles of the default shapes only");
-    SideFork sf(env);
+    if (fuse && (part != K3_DATA_ONLY || !k3_can_fuse(env))) throw std::runtime_error("fused mod-down: data-prime tiles only");
     for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine primes, pass 1: u64-engine primes
         K3Args A;
         A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tp = buf.tp; A.tpr = buf.tpr;
@@ -3217,12 +2494,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             }
         }
         if (!A.n_tt) continue;
-        // block shape per engine: (interleaved digits per wave, waves per block).  HE355_K3_SHAPE=<u><w><u><w> overrides
-        // (fp64 pair, then u64 pair), e.g. 2418 = fp64 U=2 x 4 waves, u64 U=1 x 8 waves.
-        static const int shape_env = getenv("HE355_K3_SHAPE") ? atoi(getenv("HE355_K3_SHAPE")) : 0;
-        int shape = pass == 0 ? (shape_env ? shape_env / 100 : HE355_K3_F64_SHAPE) : (shape_env ? shape_env % 100 : HE355_K3_U64_SHAPE);
-        if (A.n_split > 1) shape = 11; // latency shape: one wave per block, one (tile, op, digit group) each
-        const int waves = shape % 10;
+        const int waves = A.n_split > 1 ? 1 : 8; // latency shape: one wave per block, one (tile, op, digit group) each; else the 8-wave shape
         const u64 n_og = (n_ops + waves - 1) / waves;
         const u64 tiles = (u64)A.n_tt << env.logn1;
         // enough blocks to keep every CU busy for several rounds, few enough that start-up costs are amortised
@@ -3260,35 +2532,19 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             pr->ops += n_ops;
             (void)hipEventRecord(pr->start[slot], env.stream);
         }
-        static const int stage_env = getenv("HE355_K3_STAGE") ? atoi(getenv("HE355_K3_STAGE")) : HE355_K3_STAGE_DEFAULT;
-        const bool staged = stage_env != 0 || shape / 10 != 1;
-        const hipStream_t st3 = sf.stream(pass); // (env.side: the u64 engine's launch beside the fp64 engine's)
-        if (shape == 11) {
+        const hipStream_t st3 = env.stream;
+        if (waves == 1) {
             const dim3 gd(g, (unsigned)A.n_split);
-            if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 1, 1, true>), gd, dim3(64), 0, sf.stream(0), A, env.primes);
-            else hipLaunchKernelGGL((k_k3<ArU64, 1, 1, true>), gd, dim3(64), 0, sf.stream(1), A, env.primes);
+            if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 1>), gd, dim3(64), 0, st3, A, env.primes);
+            else hipLaunchKernelGGL((k_k3<ArU64, 1>), gd, dim3(64), 0, st3, A, env.primes);
         } else if (pass == 0) {
-            switch (shape) {
-            case 24: hipLaunchKernelGGL((k_k3<ArF64, 2, 4, true>), dim3(g), dim3(256), 0, st3, A, env.primes); break;
-            case 18:
-                if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true, kKeyShare, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
-                else if (fuse) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, st3, A, env.primes);
-                else if (staged) hipLaunchKernelGGL((k_k3<ArF64, 1, 8, true, false, kKeyShare>), dim3(g), dim3(512), 0, st3, A, env.primes);
-                else hipLaunchKernelGGL((k_k3<ArF64, 1, 8, false>), dim3(g), dim3(512), 0, st3, A, env.primes);
-                break;
-            default: throw std::runtime_error("unsupported K3 fp64 shape");
-            }
+            if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArF64, 8, true, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+            else if (fuse) hipLaunchKernelGGL((k_k3<ArF64, 8, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+            else hipLaunchKernelGGL((k_k3<ArF64, 8>), dim3(g), dim3(512), 0, st3, A, env.primes);
         } else {
-            switch (shape) {
-            case 14: hipLaunchKernelGGL((k_k3<ArU64, 1, 4, true>), dim3(g), dim3(256), 0, st3, A, env.primes); break;
-            case 18:
-                if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true, kKeyShare, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
-                else if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, true, kKeyShare>), dim3(g), dim3(512), 0, st3, A, env.primes);
-                else if (staged) hipLaunchKernelGGL((k_k3<ArU64, 1, 8, true, false, kKeyShare>), dim3(g), dim3(512), 0, st3, A, env.primes);
-                else hipLaunchKernelGGL((k_k3<ArU64, 1, 8, false>), dim3(g), dim3(512), 0, st3, A, env.primes);
-                break;
-            default: throw std::runtime_error("unsupported K3 u64 shape");
-            }
+            if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArU64, 8, true, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+            else if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 8, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+            else hipLaunchKernelGGL((k_k3<ArU64, 8>), dim3(g), dim3(512), 0, st3, A, env.primes);
         }
         if (slot >= 0) (void)hipEventRecord(pr->stop[slot], env.stream);
     }
@@ -3306,50 +2562,25 @@ void launch_k3_combine(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &
     hipLaunchKernelGGL(k_k3_combine, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes);
 }
 
-void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst, const u64 *addin, int addin_src,
-                       int addin_ntgt, int tgt_first, int dst_ntgt, const u64 *src2, int src2_prime, int tsplit)
+void launch_floor_cols(const KernelEnv &env, int src_prime, int n_tgt, u64 n_polys, const u64 *src, u64 *dst, int tgt_first, int dst_ntgt, const u64 *src2,
+                       int src2_prime, int tsplit)
 {
     if (!n_polys || n_tgt <= 0) return;
     FloorColsArgs A;
     A.src = src; A.dst = dst; A.src_prime = src_prime; A.n_tgt = n_tgt; A.K = env.K; A.fc = env.floor_consts;
     A.tgt_first = tgt_first; A.dst_ntgt = dst_ntgt > 0 ? dst_ntgt : n_tgt;
-    A.addin = addin; A.addin_src = addin_src; A.addin_ntgt = addin_ntgt;
     A.src2 = src2; A.src2_prime = src2_prime;
     A.tsplit = tsplit > 1 ? tsplit : 1;
-    const unsigned g = (unsigned)(n_polys * 4);
+    const dim3 g((unsigned)(n_polys * 4), (unsigned)A.tsplit);
     A.f64_mask = 0;
     for (int t = 0; t < env.K; ++t) A.f64_mask |= (u64)(env.prime_f64[t] != 0) << t;
-    static const bool fc_new = !(getenv("HE355_FC_NEW") && getenv("HE355_FC_NEW")[0] == '0');
-    if (fc_new && !addin) {
 #define HE355_FCN(L1)                                                                                                          \
     case L1:                                                                                                                   \
-        if (src2) hipLaunchKernelGGL((k_floor_colsn<L1, true>), dim3(g, (unsigned)A.tsplit), dim3(kBlock), 0, env.stream, A, env.primes);   \
-        else hipLaunchKernelGGL((k_floor_colsn<L1, false>), dim3(g, (unsigned)A.tsplit), dim3(kBlock), 0, env.stream, A, env.primes);       \
+        if (src2) hipLaunchKernelGGL((k_floor_colsn<L1, true>), g, dim3(kBlock), 0, env.stream, A, env.primes);                \
+        else hipLaunchKernelGGL((k_floor_colsn<L1, false>), g, dim3(kBlock), 0, env.stream, A, env.primes);                    \
         break;
-        switch (env.logn1) { HE355_FCN(0) HE355_FCN(1) HE355_FCN(2) HE355_FCN(3) HE355_FCN(4) HE355_FCN(5) }
+    switch (env.logn1) { HE355_FCN(0) HE355_FCN(1) HE355_FCN(2) HE355_FCN(3) HE355_FCN(4) HE355_FCN(5) }
 #undef HE355_FCN
-        return;
-    }
-    A.tsplit = 1;
-    if (src2) {
-        switch (env.logn1) {
-        case 0: hipLaunchKernelGGL((k_floor_cols<0, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 1: hipLaunchKernelGGL((k_floor_cols<1, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 2: hipLaunchKernelGGL((k_floor_cols<2, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 3: hipLaunchKernelGGL((k_floor_cols<3, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 4: hipLaunchKernelGGL((k_floor_cols<4, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        case 5: hipLaunchKernelGGL((k_floor_cols<5, true>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-        }
-        return;
-    }
-    switch (env.logn1) {
-    case 0: hipLaunchKernelGGL((k_floor_cols<0, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 1: hipLaunchKernelGGL((k_floor_cols<1, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 2: hipLaunchKernelGGL((k_floor_cols<2, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 3: hipLaunchKernelGGL((k_floor_cols<3, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 4: hipLaunchKernelGGL((k_floor_cols<4, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    case 5: hipLaunchKernelGGL((k_floor_cols<5, false>), dim3(g), dim3(kBlock), 0, env.stream, A, env.primes); break;
-    }
 }
 
 void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &args)
@@ -3360,7 +2591,6 @@ void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &arg
     // per block: up to 8 jobs per wave, fewer when that would leave CUs without blocks
     u32 jpb = 8 * kWaves;
     while (jpb > (u32)kWaves && (((u64)args.n_tgt << env.logn1) * ((n_jobs + jpb - 1) / jpb) < 256u * 8 || jpb / 2 >= n_jobs)) jpb >>= 1;
-    SideFork sf(env);
     for (int pass = 0; pass < 4; ++pass) { // (engine, tail) combinations; the tail prime gets its own launch
         const bool f64 = pass < 2, tail = pass & 1;
         FloorRowsDev A;
@@ -3371,7 +2601,7 @@ void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &arg
             if ((prime_f64[i] != 0) == f64 && (i == args.tail_prime) == tail) A.i_list[A.n_i++] = (unsigned char)i;
         if (!A.n_i) continue;
         const unsigned g = (unsigned)((((u64)A.n_i) << env.logn1) * ((n_jobs + jpb - 1) / jpb));
-        const hipStream_t st = sf.stream(f64 ? 0 : 1);
+        const hipStream_t st = env.stream;
         if (f64 && !tail) hipLaunchKernelGGL((k_floor_rows<ArF64, false>), dim3(g), dim3(kBlock), 0, st, A, env.primes);
         else if (f64) hipLaunchKernelGGL((k_floor_rows<ArF64, true>), dim3(g), dim3(kBlock), 0, st, A, env.primes);
         else if (!tail) hipLaunchKernelGGL((k_floor_rows<ArU64, false>), dim3(g), dim3(kBlock), 0, st, A, env.primes);

@@ -72,316 +72,10 @@ HE_HD u64 barrett128(u128 x, const ModU64 &m)
 HE_HD u64 mulmod(u64 a, u64 b, const ModU64 &m) { return barrett128((u128)a * b, m); }
 HE_HD u64 addmod(u64 a, u64 b, u64 q) { u64 s = a + b; return s >= q ? s - q : s; }
 HE_HD u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
-// ---- the Shoup product as one v_mad_u64_u32 chain (device code) ------------------------------------------------------------------
-// x + (y * w - floor(y * p / 2^64) * q mod 2^64), p = floor(w * 2^64 / q): the product lands in [0, 2q) for ANY 64-bit y.  The
-// compiler builds the 64-bit products from v_mul_lo_u32 / v_add3_u32 and zero-extends 32-bit halves into register pairs with
-// v_mov_b32: 19 instructions (23 per lazy butterfly).  Written as multiply-add chains -- a 32-bit addend enters as
-// v_mad_u64_u32(addend, 1, acc); the cross terms of which only the low word counts ride one chain; -q instead of a subtraction;
-// the sum every user forms next (X + T, acc + T) is the block's last instruction -- it is 16 (19 per butterfly).  One asm block per
-// product (or per two, interleaved, so that no instruction waits for the one before it): the halves of the intermediate pairs have
-// to be named, hence the fixed temporaries v2..v23 (low registers: they never raise a kernel's register count), and every separate
-// asm statement would cost a wait state (the hazard recognizer assumes the worst of inline assembly on gfx950).
-// q MUST be wave-uniform (it is read through scalar registers): true for every transform kernel, where a wave works on one prime.
-// `_sw`: the twiddle is wave-uniform too.  HE355_MAD_ASM=0 keeps the plain C form; the results are the same integers.
-#ifndef HE355_MAD_ASM
-#define HE355_MAD_ASM 0
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && defined(__gfx950__) && HE355_MAD_ASM
-#define HE355_HAVE_MAD_ASM 1
-// >>> generated by tools/gen_shoup_asm.py
-__device__ inline __attribute__((always_inline)) u64 shoup_mad(u64 ya, u64 wa, u64 pa, u64 q) // ya * wa mod q, in [0, 2q)
-{
-    const u64 nq = 0 - q;
-    u64 oa;
-    asm(
-        "v_mul_hi_u32 v12, %[y0a], %[p0a]\n"
-        "v_mad_u64_u32 v[2:3], vcc, %[y0a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[4:5], vcc, %[y1a], %[p0a], 0\n"
-        "v_mad_u64_u32 v[6:7], vcc, %[y1a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y0a], %[w1a], 0\n"
-        "v_mad_u64_u32 v[8:9], vcc, %[y0a], %[w0a], 0\n"
-        "v_mad_u64_u32 v[2:3], vcc, v12, 1, v[2:3]\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y1a], %[w0a], v[10:11]\n"
-        "v_mad_u64_u32 v[4:5], vcc, v2, 1, v[4:5]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v3, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v5, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v6, %[n1], v[10:11]\n"
-        "v_mad_u64_u32 v[8:9], vcc, v6, %[n0], v[8:9]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v7, %[n0], v[10:11]\n"
-        "v_add_u32 v9, v9, v10\n"
-        "v_lshl_add_u64 %[oa], v[8:9], 0, 0\n"
-        : [oa] "=&v"(oa)
-        : [y0a] "v"((u32)ya), [y1a] "v"((u32)(ya >> 32)), [p0a] "v"((u32)pa), [p1a] "v"((u32)(pa >> 32)), [w0a] "v"((u32)wa), [w1a] "v"((u32)(wa >> 32)),
-          [n0] "s"((u32)nq), [n1] "s"((u32)(nq >> 32))
-        : "vcc", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12");
-    return oa;
-}
-__device__ inline __attribute__((always_inline)) u64 shoup_mad_sw(u64 ya, u64 wa, u64 pa, u64 q) // ya * wa mod q, in [0, 2q)
-{
-    const u64 nq = 0 - q;
-    u64 oa;
-    asm(
-        "v_mul_hi_u32 v12, %[y0a], %[p0a]\n"
-        "v_mad_u64_u32 v[2:3], vcc, %[y0a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[4:5], vcc, %[y1a], %[p0a], 0\n"
-        "v_mad_u64_u32 v[6:7], vcc, %[y1a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y0a], %[w1a], 0\n"
-        "v_mad_u64_u32 v[8:9], vcc, %[y0a], %[w0a], 0\n"
-        "v_mad_u64_u32 v[2:3], vcc, v12, 1, v[2:3]\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y1a], %[w0a], v[10:11]\n"
-        "v_mad_u64_u32 v[4:5], vcc, v2, 1, v[4:5]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v3, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v5, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v6, %[n1], v[10:11]\n"
-        "v_mad_u64_u32 v[8:9], vcc, v6, %[n0], v[8:9]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v7, %[n0], v[10:11]\n"
-        "v_add_u32 v9, v9, v10\n"
-        "v_lshl_add_u64 %[oa], v[8:9], 0, 0\n"
-        : [oa] "=&v"(oa)
-        : [y0a] "v"((u32)ya), [y1a] "v"((u32)(ya >> 32)), [p0a] "s"((u32)pa), [p1a] "s"((u32)(pa >> 32)), [w0a] "s"((u32)wa), [w1a] "s"((u32)(wa >> 32)),
-          [n0] "s"((u32)nq), [n1] "s"((u32)(nq >> 32))
-        : "vcc", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12");
-    return oa;
-}
-__device__ inline __attribute__((always_inline)) u64 shoup_mad_add(u64 xa, u64 ya, u64 wa, u64 pa, u64 q) // xa + (ya * wa mod q, in [0, 2q))
-{
-    const u64 nq = 0 - q;
-    u64 oa;
-    asm(
-        "v_mul_hi_u32 v12, %[y0a], %[p0a]\n"
-        "v_mad_u64_u32 v[2:3], vcc, %[y0a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[4:5], vcc, %[y1a], %[p0a], 0\n"
-        "v_mad_u64_u32 v[6:7], vcc, %[y1a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y0a], %[w1a], 0\n"
-        "v_mad_u64_u32 v[8:9], vcc, %[y0a], %[w0a], 0\n"
-        "v_mad_u64_u32 v[2:3], vcc, v12, 1, v[2:3]\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y1a], %[w0a], v[10:11]\n"
-        "v_mad_u64_u32 v[4:5], vcc, v2, 1, v[4:5]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v3, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v5, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v6, %[n1], v[10:11]\n"
-        "v_mad_u64_u32 v[8:9], vcc, v6, %[n0], v[8:9]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v7, %[n0], v[10:11]\n"
-        "v_add_u32 v9, v9, v10\n"
-        "v_lshl_add_u64 %[oa], v[8:9], 0, %[xa]\n"
-        : [oa] "=&v"(oa)
-        : [xa] "v"(xa), [y0a] "v"((u32)ya), [y1a] "v"((u32)(ya >> 32)), [p0a] "v"((u32)pa), [p1a] "v"((u32)(pa >> 32)), [w0a] "v"((u32)wa), [w1a] "v"((u32)(wa >> 32)),
-          [n0] "s"((u32)nq), [n1] "s"((u32)(nq >> 32))
-        : "vcc", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12");
-    return oa;
-}
-// two multiply-adds at once: oa = xa + ya * wa, ob = xb + yb * wb (mod q, the products in [0, 2q))
-__device__ inline __attribute__((always_inline)) void shoup_mad_add2(u64 &Oa, u64 &Ob, u64 xa, u64 ya, u64 xb, u64 yb, u64 wa, u64 pa, u64 wb, u64 pb, u64 q)
-{
-    const u64 nq = 0 - q;
-    u64 oa, ob;
-    asm(
-        "v_mul_hi_u32 v12, %[y0a], %[p0a]\n"
-        "v_mul_hi_u32 v13, %[y0b], %[p0b]\n"
-        "v_mad_u64_u32 v[2:3], vcc, %[y0a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[14:15], vcc, %[y0b], %[p1b], 0\n"
-        "v_mad_u64_u32 v[4:5], vcc, %[y1a], %[p0a], 0\n"
-        "v_mad_u64_u32 v[16:17], vcc, %[y1b], %[p0b], 0\n"
-        "v_mad_u64_u32 v[6:7], vcc, %[y1a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[18:19], vcc, %[y1b], %[p1b], 0\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y0a], %[w1a], 0\n"
-        "v_mad_u64_u32 v[22:23], vcc, %[y0b], %[w1b], 0\n"
-        "v_mad_u64_u32 v[8:9], vcc, %[y0a], %[w0a], 0\n"
-        "v_mad_u64_u32 v[20:21], vcc, %[y0b], %[w0b], 0\n"
-        "v_mad_u64_u32 v[2:3], vcc, v12, 1, v[2:3]\n"
-        "v_mad_u64_u32 v[14:15], vcc, v13, 1, v[14:15]\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y1a], %[w0a], v[10:11]\n"
-        "v_mad_u64_u32 v[22:23], vcc, %[y1b], %[w0b], v[22:23]\n"
-        "v_mad_u64_u32 v[4:5], vcc, v2, 1, v[4:5]\n"
-        "v_mad_u64_u32 v[16:17], vcc, v14, 1, v[16:17]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v3, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[18:19], vcc, v15, 1, v[18:19]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v5, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[18:19], vcc, v17, 1, v[18:19]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v6, %[n1], v[10:11]\n"
-        "v_mad_u64_u32 v[22:23], vcc, v18, %[n1], v[22:23]\n"
-        "v_mad_u64_u32 v[8:9], vcc, v6, %[n0], v[8:9]\n"
-        "v_mad_u64_u32 v[20:21], vcc, v18, %[n0], v[20:21]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v7, %[n0], v[10:11]\n"
-        "v_mad_u64_u32 v[22:23], vcc, v19, %[n0], v[22:23]\n"
-        "v_add_u32 v9, v9, v10\n"
-        "v_add_u32 v21, v21, v22\n"
-        "v_lshl_add_u64 %[oa], v[8:9], 0, %[xa]\n"
-        "v_lshl_add_u64 %[ob], v[20:21], 0, %[xb]\n"
-        : [oa] "=&v"(oa), [ob] "=&v"(ob)
-        : [xa] "v"(xa), [y0a] "v"((u32)ya), [y1a] "v"((u32)(ya >> 32)), [p0a] "v"((u32)pa), [p1a] "v"((u32)(pa >> 32)), [w0a] "v"((u32)wa), [w1a] "v"((u32)(wa >> 32)),
-          [xb] "v"(xb), [y0b] "v"((u32)yb), [y1b] "v"((u32)(yb >> 32)), [p0b] "v"((u32)pb), [p1b] "v"((u32)(pb >> 32)), [w0b] "v"((u32)wb), [w1b] "v"((u32)(wb >> 32)),
-          [n0] "s"((u32)nq), [n1] "s"((u32)(nq >> 32))
-        : "vcc", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23");
-    Oa = oa; Ob = ob;
-}
-// forward butterfly: X' = xa + T, Y' = xa + 2q - T = (2 xa + 2q) - X' with T = ya * wa mod q in [0, 2q)
-__device__ inline __attribute__((always_inline)) void shoup_bfly(u64 &X, u64 &Y, u64 xa, u64 ya, u64 wa, u64 pa, u64 q, u64 two_q)
-{
-    const u64 nq = 0 - q;
-    u64 oa, za;
-    asm(
-        "v_mul_hi_u32 v12, %[y0a], %[p0a]\n"
-        "v_mad_u64_u32 v[2:3], vcc, %[y0a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[4:5], vcc, %[y1a], %[p0a], 0\n"
-        "v_mad_u64_u32 v[6:7], vcc, %[y1a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y0a], %[w1a], 0\n"
-        "v_mad_u64_u32 v[8:9], vcc, %[y0a], %[w0a], 0\n"
-        "v_mad_u64_u32 v[2:3], vcc, v12, 1, v[2:3]\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y1a], %[w0a], v[10:11]\n"
-        "v_mad_u64_u32 v[4:5], vcc, v2, 1, v[4:5]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v3, 1, v[6:7]\n"
-        "v_lshl_add_u64 %[za], %[xa], 1, %[tq]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v5, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v6, %[n1], v[10:11]\n"
-        "v_mad_u64_u32 v[8:9], vcc, v6, %[n0], v[8:9]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v7, %[n0], v[10:11]\n"
-        "v_add_u32 v9, v9, v10\n"
-        "v_lshl_add_u64 %[oa], v[8:9], 0, %[xa]\n"
-        : [oa] "=&v"(oa), [za] "=&v"(za)
-        : [xa] "v"(xa), [y0a] "v"((u32)ya), [y1a] "v"((u32)(ya >> 32)), [p0a] "v"((u32)pa), [p1a] "v"((u32)(pa >> 32)), [w0a] "v"((u32)wa), [w1a] "v"((u32)(wa >> 32)),
-          [n0] "s"((u32)nq), [n1] "s"((u32)(nq >> 32)), [tq] "s"(two_q)
-        : "vcc", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12");
-    X = oa;
-    Y = za - oa;
-}
-// forward butterfly: X' = xa + T, Y' = xa + 2q - T = (2 xa + 2q) - X' with T = ya * wa mod q in [0, 2q)
-__device__ inline __attribute__((always_inline)) void shoup_bfly_sw(u64 &X, u64 &Y, u64 xa, u64 ya, u64 wa, u64 pa, u64 q, u64 two_q)
-{
-    const u64 nq = 0 - q;
-    u64 oa, za;
-    asm(
-        "v_mul_hi_u32 v12, %[y0a], %[p0a]\n"
-        "v_mad_u64_u32 v[2:3], vcc, %[y0a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[4:5], vcc, %[y1a], %[p0a], 0\n"
-        "v_mad_u64_u32 v[6:7], vcc, %[y1a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y0a], %[w1a], 0\n"
-        "v_mad_u64_u32 v[8:9], vcc, %[y0a], %[w0a], 0\n"
-        "v_mad_u64_u32 v[2:3], vcc, v12, 1, v[2:3]\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y1a], %[w0a], v[10:11]\n"
-        "v_mad_u64_u32 v[4:5], vcc, v2, 1, v[4:5]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v3, 1, v[6:7]\n"
-        "v_lshl_add_u64 %[za], %[xa], 1, %[tq]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v5, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v6, %[n1], v[10:11]\n"
-        "v_mad_u64_u32 v[8:9], vcc, v6, %[n0], v[8:9]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v7, %[n0], v[10:11]\n"
-        "v_add_u32 v9, v9, v10\n"
-        "v_lshl_add_u64 %[oa], v[8:9], 0, %[xa]\n"
-        : [oa] "=&v"(oa), [za] "=&v"(za)
-        : [xa] "v"(xa), [y0a] "v"((u32)ya), [y1a] "v"((u32)(ya >> 32)), [p0a] "s"((u32)pa), [p1a] "s"((u32)(pa >> 32)), [w0a] "s"((u32)wa), [w1a] "s"((u32)(wa >> 32)),
-          [n0] "s"((u32)nq), [n1] "s"((u32)(nq >> 32)), [tq] "s"(two_q)
-        : "vcc", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12");
-    X = oa;
-    Y = za - oa;
-}
-__device__ inline __attribute__((always_inline)) void shoup_bfly2(u64 &Xa, u64 &Ya, u64 &Xb, u64 &Yb, u64 xa, u64 ya, u64 xb, u64 yb, u64 wa, u64 pa, u64 wb, u64 pb, u64 q, u64 two_q)
-{
-    const u64 nq = 0 - q;
-    u64 oa, za, ob, zb;
-    asm(
-        "v_mul_hi_u32 v12, %[y0a], %[p0a]\n"
-        "v_mul_hi_u32 v13, %[y0b], %[p0b]\n"
-        "v_mad_u64_u32 v[2:3], vcc, %[y0a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[14:15], vcc, %[y0b], %[p1b], 0\n"
-        "v_mad_u64_u32 v[4:5], vcc, %[y1a], %[p0a], 0\n"
-        "v_mad_u64_u32 v[16:17], vcc, %[y1b], %[p0b], 0\n"
-        "v_mad_u64_u32 v[6:7], vcc, %[y1a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[18:19], vcc, %[y1b], %[p1b], 0\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y0a], %[w1a], 0\n"
-        "v_mad_u64_u32 v[22:23], vcc, %[y0b], %[w1b], 0\n"
-        "v_mad_u64_u32 v[8:9], vcc, %[y0a], %[w0a], 0\n"
-        "v_mad_u64_u32 v[20:21], vcc, %[y0b], %[w0b], 0\n"
-        "v_mad_u64_u32 v[2:3], vcc, v12, 1, v[2:3]\n"
-        "v_mad_u64_u32 v[14:15], vcc, v13, 1, v[14:15]\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y1a], %[w0a], v[10:11]\n"
-        "v_mad_u64_u32 v[22:23], vcc, %[y1b], %[w0b], v[22:23]\n"
-        "v_mad_u64_u32 v[4:5], vcc, v2, 1, v[4:5]\n"
-        "v_mad_u64_u32 v[16:17], vcc, v14, 1, v[16:17]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v3, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[18:19], vcc, v15, 1, v[18:19]\n"
-        "v_lshl_add_u64 %[za], %[xa], 1, %[tq]\n"
-        "v_lshl_add_u64 %[zb], %[xb], 1, %[tq]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v5, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[18:19], vcc, v17, 1, v[18:19]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v6, %[n1], v[10:11]\n"
-        "v_mad_u64_u32 v[22:23], vcc, v18, %[n1], v[22:23]\n"
-        "v_mad_u64_u32 v[8:9], vcc, v6, %[n0], v[8:9]\n"
-        "v_mad_u64_u32 v[20:21], vcc, v18, %[n0], v[20:21]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v7, %[n0], v[10:11]\n"
-        "v_mad_u64_u32 v[22:23], vcc, v19, %[n0], v[22:23]\n"
-        "v_add_u32 v9, v9, v10\n"
-        "v_add_u32 v21, v21, v22\n"
-        "v_lshl_add_u64 %[oa], v[8:9], 0, %[xa]\n"
-        "v_lshl_add_u64 %[ob], v[20:21], 0, %[xb]\n"
-        : [oa] "=&v"(oa), [za] "=&v"(za), [ob] "=&v"(ob), [zb] "=&v"(zb)
-        : [xa] "v"(xa), [y0a] "v"((u32)ya), [y1a] "v"((u32)(ya >> 32)), [p0a] "v"((u32)pa), [p1a] "v"((u32)(pa >> 32)), [w0a] "v"((u32)wa), [w1a] "v"((u32)(wa >> 32)),
-          [xb] "v"(xb), [y0b] "v"((u32)yb), [y1b] "v"((u32)(yb >> 32)), [p0b] "v"((u32)pb), [p1b] "v"((u32)(pb >> 32)), [w0b] "v"((u32)wb), [w1b] "v"((u32)(wb >> 32)),
-          [n0] "s"((u32)nq), [n1] "s"((u32)(nq >> 32)), [tq] "s"(two_q)
-        : "vcc", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23");
-    Xa = oa; Ya = za - oa;
-    Xb = ob; Yb = zb - ob;
-}
-__device__ inline __attribute__((always_inline)) void shoup_bfly2_sw(u64 &Xa, u64 &Ya, u64 &Xb, u64 &Yb, u64 xa, u64 ya, u64 xb, u64 yb, u64 wa, u64 pa, u64 wb, u64 pb, u64 q, u64 two_q)
-{
-    const u64 nq = 0 - q;
-    u64 oa, za, ob, zb;
-    asm(
-        "v_mul_hi_u32 v12, %[y0a], %[p0a]\n"
-        "v_mul_hi_u32 v13, %[y0b], %[p0b]\n"
-        "v_mad_u64_u32 v[2:3], vcc, %[y0a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[14:15], vcc, %[y0b], %[p1b], 0\n"
-        "v_mad_u64_u32 v[4:5], vcc, %[y1a], %[p0a], 0\n"
-        "v_mad_u64_u32 v[16:17], vcc, %[y1b], %[p0b], 0\n"
-        "v_mad_u64_u32 v[6:7], vcc, %[y1a], %[p1a], 0\n"
-        "v_mad_u64_u32 v[18:19], vcc, %[y1b], %[p1b], 0\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y0a], %[w1a], 0\n"
-        "v_mad_u64_u32 v[22:23], vcc, %[y0b], %[w1b], 0\n"
-        "v_mad_u64_u32 v[8:9], vcc, %[y0a], %[w0a], 0\n"
-        "v_mad_u64_u32 v[20:21], vcc, %[y0b], %[w0b], 0\n"
-        "v_mad_u64_u32 v[2:3], vcc, v12, 1, v[2:3]\n"
-        "v_mad_u64_u32 v[14:15], vcc, v13, 1, v[14:15]\n"
-        "v_mad_u64_u32 v[10:11], vcc, %[y1a], %[w0a], v[10:11]\n"
-        "v_mad_u64_u32 v[22:23], vcc, %[y1b], %[w0b], v[22:23]\n"
-        "v_mad_u64_u32 v[4:5], vcc, v2, 1, v[4:5]\n"
-        "v_mad_u64_u32 v[16:17], vcc, v14, 1, v[16:17]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v3, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[18:19], vcc, v15, 1, v[18:19]\n"
-        "v_lshl_add_u64 %[za], %[xa], 1, %[tq]\n"
-        "v_lshl_add_u64 %[zb], %[xb], 1, %[tq]\n"
-        "v_mad_u64_u32 v[6:7], vcc, v5, 1, v[6:7]\n"
-        "v_mad_u64_u32 v[18:19], vcc, v17, 1, v[18:19]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v6, %[n1], v[10:11]\n"
-        "v_mad_u64_u32 v[22:23], vcc, v18, %[n1], v[22:23]\n"
-        "v_mad_u64_u32 v[8:9], vcc, v6, %[n0], v[8:9]\n"
-        "v_mad_u64_u32 v[20:21], vcc, v18, %[n0], v[20:21]\n"
-        "v_mad_u64_u32 v[10:11], vcc, v7, %[n0], v[10:11]\n"
-        "v_mad_u64_u32 v[22:23], vcc, v19, %[n0], v[22:23]\n"
-        "v_add_u32 v9, v9, v10\n"
-        "v_add_u32 v21, v21, v22\n"
-        "v_lshl_add_u64 %[oa], v[8:9], 0, %[xa]\n"
-        "v_lshl_add_u64 %[ob], v[20:21], 0, %[xb]\n"
-        : [oa] "=&v"(oa), [za] "=&v"(za), [ob] "=&v"(ob), [zb] "=&v"(zb)
-        : [xa] "v"(xa), [y0a] "v"((u32)ya), [y1a] "v"((u32)(ya >> 32)), [p0a] "s"((u32)pa), [p1a] "s"((u32)(pa >> 32)), [w0a] "s"((u32)wa), [w1a] "s"((u32)(wa >> 32)),
-          [xb] "v"(xb), [y0b] "v"((u32)yb), [y1b] "v"((u32)(yb >> 32)), [p0b] "s"((u32)pb), [p1b] "s"((u32)(pb >> 32)), [w0b] "s"((u32)wb), [w1b] "s"((u32)(wb >> 32)),
-          [n0] "s"((u32)nq), [n1] "s"((u32)(nq >> 32)), [tq] "s"(two_q)
-        : "vcc", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23");
-    Xa = oa; Ya = za - oa;
-    Xb = ob; Yb = zb - ob;
-}
-// <<< generated by tools/gen_shoup_asm.py
-#endif
 // x * w mod q with Shoup quotient wq = floor(w*2^64/q); result in [0,2q)
 HE_HD u64 mul_shoup_lazy(u64 x, u64 w, u64 wq, u64 q) { return w * x - mulhi64(x, wq) * q; }
-// the same for a wave-uniform q (device code: the multiply-add chain above)
-HE_HD u64 mul_shoup_lazy_uq(u64 x, u64 w, u64 wq, u64 q)
-{
-#if defined(HE355_HAVE_MAD_ASM)
-    return shoup_mad(x, w, wq, q);
-#else
-    return w * x - mulhi64(x, wq) * q;
-#endif
-}
+// the same for a wave-uniform q (a hand-written v_mad_u64_u32 chain was tried here and lost: HISTORY.md, tools/gen_shoup_asm.py)
+HE_HD u64 mul_shoup_lazy_uq(u64 x, u64 w, u64 wq, u64 q) { return w * x - mulhi64(x, wq) * q; }
 HE_HD u64 mul_shoup(u64 x, u64 w, u64 wq, u64 q)
 {
     u64 r = mul_shoup_lazy(x, w, wq, q);
@@ -415,11 +109,7 @@ struct ArU64 {
     static constexpr bool kKeyQuotient = true;
     HE_HD void acc_mac(Acc &acc, T x, T key, u64 keyq) const
     {
-#if defined(HE355_HAVE_MAD_ASM)
-        const u64 s = shoup_mad_add(acc, x, key, keyq, q);
-#else
         const u64 s = acc + mul_shoup_lazy_uq(x, key, keyq, q);
-#endif
         acc = s >= 2 * two_q ? s - 2 * two_q : s;
     }
     // The same without the conditional subtraction, for runs of products between two acc_reduce calls.  With the EXACT quotient
@@ -429,15 +119,11 @@ struct ArU64 {
     static constexpr int kAccRun = 6;
     HE_HD void acc_mac_lazy(Acc &acc, T x, T key, u64 keyq) const
     {
-#if defined(HE355_HAVE_MAD_ASM)
-        acc = shoup_mad_add(acc, x, key, keyq, q);
-#else
         const u64 v = mul_shoup_lazy_uq(x, key, keyq, q);
 #if defined(HE355_LANE_SIM)
         if (acc > ~(u64)0 - v) he355_sim_overflow = 1;
 #endif
         acc += v;
-#endif
     }
     HE_HD Acc acc_reduce(Acc acc) const { return reduce16_to_4q(acc); }
     HE_HD u64 acc_canon(Acc acc) const { return to_canon(acc); }
@@ -487,29 +173,14 @@ struct ArU64 {
     template <bool SW = false> HE_HD void bfly_fwd(T &X, T &Y, const Tw16 &w) const
     {
         u64 u = X >= two_q ? X - two_q : X;
-#if defined(HE355_HAVE_MAD_ASM)
-        if constexpr (SW) shoup_bfly_sw(X, Y, u, Y, w.a, w.b, q, two_q);
-        else shoup_bfly(X, Y, u, Y, w.a, w.b, q, two_q);
-#else
         u64 v = mul_shoup_lazy_uq(Y, w.a, w.b, q);
         X = u + v;
         Y = u + two_q - v;
-#endif
     }
     // inverse (Gentleman-Sande): X,Y in [0,2q) -> [0,2q)
     // G independent butterflies (same meaning as G calls of bfly_fwd)
     template <int G> HE_HD void bfly_fwd_g(T (&X)[G], T (&Y)[G], const Tw16 (&w)[G]) const
     {
-#if defined(HE355_HAVE_MAD_ASM)
-        if constexpr (G % 2 == 0) {
-#pragma unroll
-            for (int k = 0; k < G; k += 2) {
-                const u64 ua = X[k] >= two_q ? X[k] - two_q : X[k], ub = X[k + 1] >= two_q ? X[k + 1] - two_q : X[k + 1];
-                shoup_bfly2(X[k], Y[k], X[k + 1], Y[k + 1], ua, Y[k], ub, Y[k + 1], w[k].a, w[k].b, w[k + 1].a, w[k + 1].b, q, two_q);
-            }
-            return;
-        }
-#endif
 #pragma unroll
         for (int k = 0; k < G; ++k) bfly_fwd(X[k], Y[k], w[k]);
     }
@@ -521,10 +192,6 @@ struct ArU64 {
     // x).  Per 1024-point row and lane: 80 x 4 instructions saved, 16 x 8 spent.
     HE_HD void bfly_fwd_lazy(T &X, T &Y, const Tw16 &w) const
     {
-#if defined(HE355_HAVE_MAD_ASM)
-        shoup_bfly(X, Y, X, Y, w.a, w.b, q, two_q);
-        return;
-#endif
         const u64 v = mul_shoup_lazy_uq(Y, w.a, w.b, q);
 #if defined(HE355_LANE_SIM)
         if (X > ~(u64)0 - v || X + two_q < v) he355_sim_overflow = 1;
@@ -536,16 +203,6 @@ struct ArU64 {
     // SW: the twiddles are wave-uniform (they may stay in scalar registers)
     template <int G, bool SW = false> HE_HD void bfly_fwd_lazy_g(T (&X)[G], T (&Y)[G], const Tw16 (&w)[G]) const
     {
-#if defined(HE355_HAVE_MAD_ASM)
-        if constexpr (G % 2 == 0) {
-#pragma unroll
-            for (int k = 0; k < G; k += 2) {
-                if constexpr (SW) shoup_bfly2_sw(X[k], Y[k], X[k + 1], Y[k + 1], X[k], Y[k], X[k + 1], Y[k + 1], w[k].a, w[k].b, w[k + 1].a, w[k + 1].b, q, two_q);
-                else shoup_bfly2(X[k], Y[k], X[k + 1], Y[k + 1], X[k], Y[k], X[k + 1], Y[k + 1], w[k].a, w[k].b, w[k + 1].a, w[k + 1].b, q, two_q);
-            }
-            return;
-        }
-#endif
 #pragma unroll
         for (int k = 0; k < G; ++k) bfly_fwd_lazy(X[k], Y[k], w[k]);
     }
@@ -561,9 +218,6 @@ struct ArU64 {
     HE_HD u64 to_canon16(T x) const { return to_canon(reduce16_to_4q(x)); }
     template <bool SW = false> HE_HD u64 mul_tw(u64 x, u64 w, u64 wq) const
     {
-#if defined(HE355_HAVE_MAD_ASM)
-        if constexpr (SW) return shoup_mad_sw(x, w, wq, q);
-#endif
         return mul_shoup_lazy_uq(x, w, wq, q);
     }
     template <bool SW = false> HE_HD void bfly_inv(T &X, T &Y, const Tw16 &w) const

@@ -5,10 +5,9 @@
 //                   registers; its twiddles are the same for every column (wave-uniform -> SGPRs).
 //   * row pass    : 1024-point transforms over contiguous rows; ONE 64-lane wave owns one row, 16
 //                   elements per lane; the 10 stages run as 4 + 4 + 2 register-resident stages with two
-//                   register/lane transposes between them (layouts A -> B -> C below).  A transpose is either an
-//                   exchange through LDS (padded against bank conflicts) or a sequence of cross-lane swap steps
-//                   (v_permlane32_swap / v_permlane16_swap / DPP row shifts / DPP quad permutes) that never
-//                   touches LDS: xl_T1 (A <-> B) and xl_T2 (B <-> C).
+//                   register/lane transposes between them (layouts A -> B -> C below), each an exchange through the
+//                   wave's own LDS region (padded against bank conflicts).  (Cross-lane swap steps -- permlane / DPP --
+//                   were built and measured slower: HISTORY.md.)
 // Forward (Cooley-Tukey, natural -> bit-reversed) = column pass then row pass; inverse (Gentleman-Sande)
 // = row pass then column pass with N^-1 folded into the last stage.  The ordering of the NTT form
 // (bit-reversed evaluations, twiddle table w[bitrev(i)] = psi^i) is the one SEAL uses, so device slabs are
@@ -73,37 +72,6 @@ template <class T> HE_HD void lds_load_C(const T *lds, int lane, T x[kRowE])
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Register/lane transposes without LDS.  A swap step (LB, RB) exchanges lane bit LB with register bit RB of the element
-// index map: for every register pair (a = x[r], b = x[r | 1 << RB], bit RB of r clear)
-//     lanes with bit LB clear keep a and take the partner lane's a into b,
-//     lanes with bit LB set   keep b and take the partner lane's b into a        (partner = lane ^ (1 << LB)).
-// XL::step<LB>(a, b) is that exchange for one pair: v_permlane32_swap (LB 5), v_permlane16_swap (LB 4), two bank-masked
-// DPP row shifts (LB 3, 2), DPP quad permutes + selects (LB 1, 0) on the device (XLaneHw, he355_kernels.hip); the lane
-// simulator passes a recorder and replays the recorded steps over all 64 lanes (tests/csim).  Steps on disjoint bit
-// pairs commute and every step is an involution, so the same sequence runs the transpose in either direction.
-//   xl_T1: A <-> B  (register bits 3..0 <-> lane bits 5..2)
-//   xl_T2: B <-> C  (register bits 1..0 <-> lane bits 1..0)
-// ---------------------------------------------------------------------------------------------------
-template <int LB, int RB, class XL, class T> HE_HD void xl_swap_bits(XL &xl, T *x)
-{
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r)
-        if (!(r & (1 << RB))) xl.template step<LB>(x[r], x[r | (1 << RB)]);
-}
-template <class XL, class T> HE_HD void xl_T1(XL &xl, T *x)
-{
-    xl_swap_bits<5, 3>(xl, x);
-    xl_swap_bits<4, 2>(xl, x);
-    xl_swap_bits<3, 1>(xl, x);
-    xl_swap_bits<2, 0>(xl, x);
-}
-template <class XL, class T> HE_HD void xl_T2(XL &xl, T *x)
-{
-    xl_swap_bits<0, 0>(xl, x);
-    xl_swap_bits<1, 1>(xl, x);
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Twiddle accessors for the row pass.  Stage s' (0..9) of row a needs entry (rowbase << s') + g of the prime's
 // table, g = e >> (10-s') in [0, 2^s'), rowbase = N1 + a.
 //   TwTable : straight from the table (any pointer type, e.g. an address_space(1) pointer)
@@ -155,18 +123,9 @@ template <class P> HE_HD TwTable<P> tw_table(P base, u32 rowbase)
     return t;
 }
 constexpr int kRowTw = kRowN; // 1023 entries used
-// Where row-local entry i lives in the copy.  The lanes of a wave read the later stages' entries at power-of-two strides (stage 8: four
-// consecutive entries per quad of lanes, quads 16 entries apart; stage 9: eight per quad, 32 apart), which in a dense table is one set
-// of LDS banks for every quad.  HE355_TW_PAD=1 (measured: k_k3<ArF64> 23.67 -> 23.92 ms, not adopted) inserts 4 slots after every 16 entries: quads of a 16-lane group then start 160 / 320 bytes
-// apart and walk the banks (fp64 copy: 8-byte slots, 10 KiB instead of 8; u64 copy: 16-byte slots, 20 KiB instead of 16).
-#ifndef HE355_TW_PAD
-#define HE355_TW_PAD 0
-#endif
-HE_HD u32 tw_row_slot(u32 i) { return HE355_TW_PAD ? i + ((i >> 4) << 2) : i; }
-constexpr int kRowTwSlots = HE355_TW_PAD ? kRowTw + (kRowTw >> 4) * 4 : kRowTw;
 struct TwRow {
     const Tw16 *t;
-    HE_HD Tw16 get(int s, u32 g) const { return t[tw_row_slot((1u << s) - 1u + g)]; }
+    HE_HD Tw16 get(int s, u32 g) const { return t[(1u << s) - 1u + g]; }
 };
 // fp64 engine: the row-local copy keeps only w (8 bytes); its butterflies take the quotient estimate from
 // h * (1/q), so nothing else is needed.
@@ -177,7 +136,7 @@ struct TwRowF64 {
     {
         Tw16 r;
         union { u64 u; double d; } c;
-        c.d = t[tw_row_slot((1u << s) - 1u + g)];
+        c.d = t[(1u << s) - 1u + g];
         r.a = c.u;
         r.b = 0; // the fp64 butterflies do not use the second word
         return r;

@@ -25,52 +25,9 @@ template <> void track<double>(const double *x, int n)
     for (int i = 0; i < n; ++i) g_maxmag = std::max(g_maxmag, std::fabs(x[i]));
 }
 
-// ---- cross-lane transposes (ntt_core.h xl_T1 / xl_T2) on the simulated wave ----------------------------------------
-// The product's transpose templates run once over register handles with a recording XL; the recorded swap steps are then
-// replayed over all 64 lanes with the step's definition (ntt_core.h): lanes with bit LB clear keep a and take the
-// partner's a into b, lanes with bit LB set keep b and take the partner's b into a.
-struct RegRef { int idx; };
-struct XLaneRec {
-    struct Op { int lb, ra, rb; };
-    std::vector<Op> ops;
-    template <int LB> void step(RegRef &a, RegRef &b) { ops.push_back(Op{LB, a.idx, b.idx}); }
-};
-template <class T> static void replay(const XLaneRec &rec, T (*regs)[kRowE])
+// exchange A -> B / B -> C (forward) and C -> B / B -> A (inverse) through the simulated LDS
+template <class T> static void xchg(int from, int to, std::vector<T> &lds, T (*regs)[kRowE])
 {
-    for (const auto &op : rec.ops) {
-        T na[64], nb[64];
-        for (int lane = 0; lane < 64; ++lane) {
-            const int partner = lane ^ (1 << op.lb);
-            if (!((lane >> op.lb) & 1)) { na[lane] = regs[lane][op.ra]; nb[lane] = regs[partner][op.ra]; }
-            else { na[lane] = regs[partner][op.rb]; nb[lane] = regs[lane][op.rb]; }
-        }
-        for (int lane = 0; lane < 64; ++lane) { regs[lane][op.ra] = na[lane]; regs[lane][op.rb] = nb[lane]; }
-    }
-}
-template <class T> static void wave_T1(T (*regs)[kRowE])
-{
-    RegRef h[kRowE];
-    for (int r = 0; r < kRowE; ++r) h[r].idx = r;
-    XLaneRec rec;
-    xl_T1(rec, h);
-    replay(rec, regs);
-}
-template <class T> static void wave_T2(T (*regs)[kRowE])
-{
-    RegRef h[kRowE];
-    for (int r = 0; r < kRowE; ++r) h[r].idx = r;
-    XLaneRec rec;
-    xl_T2(rec, h);
-    replay(rec, regs);
-}
-// exchange A -> B / B -> C (forward) and C -> B / B -> A (inverse): through the simulated LDS or by the cross-lane steps
-template <class T> static void xchg(int from, int to, bool xl, std::vector<T> &lds, T (*regs)[kRowE])
-{
-    if (xl) {
-        if ((from == 0 && to == 1) || (from == 1 && to == 0)) wave_T1(regs);
-        else wave_T2(regs);
-        return;
-    }
     for (int lane = 0; lane < 64; ++lane) {
         if (from == 0) lds_store_A(lds.data(), lane, regs[lane]);
         else if (from == 1) lds_store_B(lds.data(), lane, regs[lane]);
@@ -115,37 +72,20 @@ template <class Ar> static void rows_fwd(const Ar &ar, const PrimeTables &pt, in
         const u32 rowbase = (u32)(n1 + a);
         const u64 *src = in + (size_t)a * kRowN;
         // the row-local twiddle copy (what K3 stages in LDS) must be equivalent to the table
-        std::vector<Tw16> rowtw(kRowTwSlots);
-        for (u32 i = 0; i + 1 < (u32)kRowTw; ++i) rowtw[tw_row_slot(i)] = pt.fwd[tw_row_source(rowbase, i)];
+        std::vector<Tw16> rowtw(kRowTw);
+        for (u32 i = 0; i + 1 < (u32)kRowTw; ++i) rowtw[i] = pt.fwd[tw_row_source(rowbase, i)];
         TwRow twr; twr.t = rowtw.data();
-        std::vector<double> roww(kRowTwSlots);
-        for (u32 i = 0; i + 1 < (u32)kRowTw; ++i) std::memcpy(&roww[tw_row_slot(i)], &rowtw[tw_row_slot(i)].a, 8);
+        std::vector<double> roww(kRowTw);
+        for (u32 i = 0; i + 1 < (u32)kRowTw; ++i) std::memcpy(&roww[i], &rowtw[i].a, 8);
         TwRowF64 twf; twf.t = roww.data(); twf.qinv = 1.0 / (double)pt.q;
         const bool f64row = std::is_same<T, double>::value && (a & 2);
         const auto twt = tw_table(pt.fwd.data(), rowbase);
         const bool use_row = (a & 1) != 0;
-        // U=2 path (two rows sharing twiddles, as K3 runs it): second copy starts from the element-reversed row
-        static T regs2[64][2][kRowE];
-        std::vector<T> lds2(kLdsRow);
-        const bool pair = (a % 3) == 1;
         for (int lane = 0; lane < 64; ++lane) {
             T *x = regs[lane];
             for (int r = 0; r < kRowE; ++r) x[r] = in_raw ? ar.from_raw(src[elemA(lane, r)]) : ar.from_canon(src[elemA(lane, r)]);
-            if (pair) {
-                for (int r = 0; r < kRowE; ++r) { regs2[lane][0][r] = x[r]; regs2[lane][1][r] = in_raw ? ar.from_raw(src[kRowN - 1 - elemA(lane, r)]) : ar.from_canon(src[kRowN - 1 - elemA(lane, r)]); }
-                { Tw16 w[kTwA]; gather_A(twt, w); row_fwd_A<2>(ar, regs2[lane], w); }
-            }
             if (f64row) row_fwd_A(ar, x, twf); else if (use_row) row_fwd_A(ar, x, twr); else row_fwd_A(ar, x, twt);
             track(x, kRowE);
-        }
-        if (pair) {
-            std::vector<T> ldsa(kLdsRow), ldsb(kLdsRow);
-            for (int lane = 0; lane < 64; ++lane) { lds_store_A(ldsa.data(), lane, regs2[lane][0]); lds_store_A(ldsb.data(), lane, regs2[lane][1]); }
-            for (int lane = 0; lane < 64; ++lane) { lds_load_B(ldsa.data(), lane, regs2[lane][0]); lds_load_B(ldsb.data(), lane, regs2[lane][1]); }
-            for (int lane = 0; lane < 64; ++lane) { Tw16 w[kTwB]; gather_B(twt, lane, w); row_fwd_B<2>(ar, regs2[lane], w); }
-            for (int lane = 0; lane < 64; ++lane) { lds_store_B(ldsa.data(), lane, regs2[lane][0]); lds_store_B(ldsb.data(), lane, regs2[lane][1]); }
-            for (int lane = 0; lane < 64; ++lane) { lds_load_C(ldsa.data(), lane, regs2[lane][0]); lds_load_C(ldsb.data(), lane, regs2[lane][1]); }
-            for (int lane = 0; lane < 64; ++lane) { Tw16 w[kTwC]; gather_C(twt, lane, w); row_fwd_C<2>(ar, regs2[lane], w); }
         }
         // the two transposes run through LDS or through the cross-lane steps: all four combinations must agree
         static T saved[64][kRowE];
@@ -195,25 +135,17 @@ template <class Ar> static void rows_fwd(const Ar &ar, const PrimeTables &pt, in
                     }
             }
         }
-        for (int mode = 0; mode < 4; ++mode) {
-            std::memcpy(regs, saved, sizeof(saved));
-            xchg(0, 1, (mode & 2) != 0, lds, regs);
-            for (int lane = 0; lane < 64; ++lane) { if (f64row) row_fwd_B(ar, regs[lane], twf, lane); else if (use_row) row_fwd_B(ar, regs[lane], twr, lane); else row_fwd_B(ar, regs[lane], twt, lane); track(regs[lane], kRowE); }
-            xchg(1, 2, (mode & 1) != 0, lds, regs);
-            for (int lane = 0; lane < 64; ++lane) {
-                T *x = regs[lane];
-                if (f64row) row_fwd_C(ar, x, twf, lane); else if (use_row) row_fwd_C(ar, x, twr, lane); else row_fwd_C(ar, x, twt, lane);
-                track(x, kRowE);
-                for (int r = 0; r < kRowE; ++r) {
-                    const u64 v = ar.to_canon(x[r]);
-                    if (mode == 0) ref[elemC(lane, r)] = v;
-                    else if (ref[elemC(lane, r)] != v) throw std::runtime_error("cross-lane transposes differ from the LDS exchanges (forward)");
-                    if (mode == 0 && !lazy_ref.empty() && lazy_ref[elemC(lane, r)] != v) throw std::runtime_error("wide-lazy row pass differs from the Harvey row pass");
-                    out[(size_t)a * kRowN + elemC(lane, r)] = v;
-                }
-                if (pair && mode == 0) // the U=2 path's first row must agree with the single-row path
-                    for (int r = 0; r < kRowE; ++r)
-                        if (ar.to_canon(regs2[lane][0][r]) != ar.to_canon(x[r])) throw std::runtime_error("U=2 row transform differs from U=1");
+        xchg(0, 1, lds, regs);
+        for (int lane = 0; lane < 64; ++lane) { if (f64row) row_fwd_B(ar, regs[lane], twf, lane); else if (use_row) row_fwd_B(ar, regs[lane], twr, lane); else row_fwd_B(ar, regs[lane], twt, lane); track(regs[lane], kRowE); }
+        xchg(1, 2, lds, regs);
+        for (int lane = 0; lane < 64; ++lane) {
+            T *x = regs[lane];
+            if (f64row) row_fwd_C(ar, x, twf, lane); else if (use_row) row_fwd_C(ar, x, twr, lane); else row_fwd_C(ar, x, twt, lane);
+            track(x, kRowE);
+            for (int r = 0; r < kRowE; ++r) {
+                const u64 v = ar.to_canon(x[r]);
+                if (!lazy_ref.empty() && lazy_ref[elemC(lane, r)] != v) throw std::runtime_error("wide-lazy row pass differs from the Harvey row pass");
+                out[(size_t)a * kRowN + elemC(lane, r)] = v;
             }
         }
     }
@@ -232,26 +164,15 @@ template <class Ar> static void rows_inv(const Ar &ar, const PrimeTables &pt, in
             row_inv_C(ar, x, itw, lane);
             track(x, kRowE);
         }
-        static T saved[64][kRowE];
-        std::memcpy(saved, regs, sizeof(saved));
-        std::vector<u64> ref(kRowN);
-        for (int mode = 0; mode < 4; ++mode) {
-            std::memcpy(regs, saved, sizeof(saved));
-            xchg(2, 1, (mode & 1) != 0, lds, regs);
-            for (int lane = 0; lane < 64; ++lane) { row_inv_B(ar, regs[lane], itw, lane); track(regs[lane], kRowE); }
-            xchg(1, 0, (mode & 2) != 0, lds, regs);
-            for (int lane = 0; lane < 64; ++lane) {
-                T *x = regs[lane];
-                if (n1 == 1) row_inv_A<Ar, true>(ar, x, itw, pt.inv_w0_scaled);
-                else row_inv_A<Ar, false>(ar, x, itw, pt.inv_w0_scaled);
-                track(x, kRowE);
-                for (int r = 0; r < kRowE; ++r) {
-                    const u64 v = (n1 == 1) ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
-                    if (mode == 0) ref[elemA(lane, r)] = v;
-                    else if (ref[elemA(lane, r)] != v) throw std::runtime_error("cross-lane transposes differ from the LDS exchanges (inverse)");
-                    out[(size_t)a * kRowN + elemA(lane, r)] = v;
-                }
-            }
+        xchg(2, 1, lds, regs);
+        for (int lane = 0; lane < 64; ++lane) { row_inv_B(ar, regs[lane], itw, lane); track(regs[lane], kRowE); }
+        xchg(1, 0, lds, regs);
+        for (int lane = 0; lane < 64; ++lane) {
+            T *x = regs[lane];
+            if (n1 == 1) row_inv_A<Ar, true>(ar, x, itw, pt.inv_w0_scaled);
+            else row_inv_A<Ar, false>(ar, x, itw, pt.inv_w0_scaled);
+            track(x, kRowE);
+            for (int r = 0; r < kRowE; ++r) out[(size_t)a * kRowN + elemA(lane, r)] = (n1 == 1) ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
         }
     }
 }
