@@ -391,6 +391,8 @@ public:
     }
 
     // ---- per-op sequences ------------------------------------------------------------------------------
+    // do the u64 ranges [p, p + np) and [q, q + nq) share an element?
+    static bool ranges_overlap(const u64 *p, size_t np, const u64 *q, size_t nq) { return np && nq && p < q + nq && q < p + np; }
     void check_level(int L) const
     {
         if (L < 1 || (size_t)L > P.Ltop) throw std::invalid_argument("level out of range");
@@ -697,6 +699,7 @@ public:
         const size_t N = P.N, LN = (size_t)L * N;
         if (P.scheme == kSchemeBFV) {
             if (rescale) throw std::invalid_argument("rescale is a CKKS operation");
+            if (ranges_overlap(out, n * 2 * LN, ct3, n * 3 * LN)) throw std::invalid_argument("relinearize: `out` overlaps the size-3 input");
             const size_t chunk = chunk_ops(n, L, false); // this call's chunk size
             for (u64 off = 0; off < n; off += chunk) {
                 const u64 nc = std::min<u64>(chunk, n - off);
@@ -800,7 +803,8 @@ public:
         if (!(elt & 1) || elt >= 2 * P.N) throw std::invalid_argument("Galois element is not valid");
         const u64 *key = galois_key(elt);
         if (!key) throw std::invalid_argument("Galois key not present");
-        if (in == out) throw std::invalid_argument("apply_galois cannot run in place");
+        // every kernel of the pipeline reads `in` while later ones already write `out`: any overlap (not just in == out) corrupts the input
+        if (ranges_overlap(in, n * 2 * (size_t)L * P.N, out, n * 2 * (size_t)L * P.N)) throw std::invalid_argument("apply_galois cannot run in place: `out` overlaps `in`");
         if (P.scheme == kSchemeBFV) {
             const uint32_t *gt = gather(elt);
             const size_t LN = (size_t)L * P.N;
@@ -864,7 +868,7 @@ public:
             }
         }
         if (naf.size() == 1) throw std::invalid_argument("Galois key not present");
-        if (in == out) throw std::invalid_argument("rotate cannot run in place");
+        if (ranges_overlap(in, bytes / 8, out, bytes / 8)) throw std::invalid_argument("rotate cannot run in place: `out` overlaps `in`");
         std::vector<int> steps;
         for (int s : naf)
             if ((size_t)(s < 0 ? -s : s) != P.N / 2) steps.push_back(s); // a term of N/2 is no rotation
@@ -928,8 +932,8 @@ public:
     {
         use();
         check_level(L);
-        if (in == out) throw std::invalid_argument("rotate_sum cannot run in place");
         const size_t per = 2 * (size_t)L * P.N, bytes = n * per * 8;
+        if (ranges_overlap(in, n * per, out, n * per)) throw std::invalid_argument("rotate_sum cannot run in place: `out` overlaps `in`");
         struct Node { uint32_t elt; int parent; u64 ends; std::vector<int> kids; }; // elt: the Galois element of the node's term (steps that
                                                                                    // differ by the row length are the same rotation, same key)
         std::vector<Node> trie(1, Node{0, -1, 0, {}}); // node 0: the input itself
@@ -1000,8 +1004,8 @@ public:
         use();
         check_level(L);
         if (!n) return;
-        if (in == out) throw std::invalid_argument("rotate_each cannot run in place");
         const size_t per = 2 * (size_t)L * P.N, bytes = n * per * 8;
+        if (ranges_overlap(in, n * per, out, n * per)) throw std::invalid_argument("rotate_each cannot run in place: `out` overlaps `in`");
         std::vector<std::vector<int>> terms(n);
         size_t depth = 0;
         for (u64 i = 0; i < n; ++i) {

@@ -638,6 +638,35 @@ def test_rotate_sum_shares_naf_prefixes(pair, be):
         g.rotate_sum(L, 2, da, steps, da)  # not in place
 
 
+def test_partially_overlapping_outputs_are_rejected(pair, be):
+    """The rotation pipelines read `in` in kernels that run after others have started writing `out` (the fused k_k3 takes polynomial 1
+    of the addend from where it lies; the BFV tail reads polynomial 0 of the input through the Galois map), so ANY overlap of the two
+    ranges would corrupt the input silently -- not only in == out.  apply_galois, rotate, rotate_each, rotate_sum and the BFV
+    relinearize reject a shifted view of the input as output with an invalid-argument error."""
+    import ctypes as C
+
+    class View:  # a slab that starts `off` words into another one
+        def __init__(self, buf, off):
+            self.ptr = C.c_void_p(buf.ptr.value + off * 8)
+
+    g, o, rng = pair
+    L, N = g.L, g.N
+    per = 2 * L * N
+    e = o.galois_elt(1)
+    g.set_galois_key(e, o.random_kswitch_key(rng))
+    big = g.alloc(4 * per)
+    g.fill_uniform(big, 4 * 2 * L, list(range(L)), 3)
+    shifted = View(big, per)  # out = in + one ciphertext
+    for call in (lambda: g.apply_galois(L, 2, big, e, shifted), lambda: g.rotate(L, 2, big, 1, shifted), lambda: g.rotate_each(L, 2, big, [1, 1], shifted),
+                 lambda: g.rotate_sum(L, 2, big, [1], shifted), lambda: g.apply_galois(L, 2, shifted, e, big)):
+        with pytest.raises(be.HE355Error) as ei:
+            call()
+        assert ei.value.code == be.E_INVALID_ARGS
+    far = View(big, 2 * per)  # disjoint ranges inside one allocation are fine
+    g.apply_galois(L, 2, big, e, far)
+    g.sync()
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 5])
 def test_latency_shape_equals_throughput_shape(pair, be, n):
     """Key switches over few ciphertexts take the latency shape (he355_set_latency_max: targets of a column and digits of a tile dealt
