@@ -224,6 +224,7 @@ public:
         pool_.raw_free(scratch_);
         pool_.raw_free(scratch2_);
         pool_.raw_free(rot_tmp_);
+        pool_.raw_free(d_groups_);
         pool_.raw_free(lat_part_[0]);
         pool_.raw_free(lat_part_[1]);
         pool_.raw_free(bfv_scratch_);
@@ -511,18 +512,22 @@ public:
     bool tensor_in_k3(const KernelEnv &env_, int L, u64 nc, const KsBuffers &B) const
     {
         static const bool on = !(getenv("HE355_C01_RECOMPUTE") && getenv("HE355_C01_RECOMPUTE")[0] == '0');
-        return on && !latency_shape(nc) && k3_can_fuse(env_) && B.c01_item_stride == 2 * (size_t)L * P.N;
+        return on && !latency_shape_env(env_, nc) && k3_can_fuse(env_) && B.c01_item_stride == 2 * (size_t)L * P.N;
     }
+    // groups (grouped rotations, fused path only): per-group keys; g_off: index of the chunk's first op in the grouped batch
     bool key_switch_tail(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail,
-                         hipEvent_t after_k2 = nullptr, u64 *rescale_out = nullptr, const TensorOperands *ten = nullptr)
+                         hipEvent_t after_k2 = nullptr, u64 *rescale_out = nullptr, const TensorOperands *ten = nullptr, const KsGroups *groups = nullptr,
+                         u64 g_off = 0)
     {
+        if (groups && (rescale_out || with_tail || latency_shape_env(env_, nc) || !(k3_can_fuse(env_) && B.c01_item_stride == 2 * (size_t)L * P.N)))
+            throw std::logic_error("key_switch_tail: grouped keys need the fused mod-down path");
         auto with_operands = [&](K3Fuse f) {
             if (ten) { f.ta = ten->a; f.tb = ten->b; f.tix = ten->ix; f.t_op_offset = ten->op_offset; f.c1_mode = ten->c1_mode; f.c1_src = ten->c1_src; }
             return f;
         };
         const size_t N = P.N, LN = (size_t)L * N;
         const int SP = (int)P.K - 1;
-        if (latency_shape(nc)) {
+        if (latency_shape_env(env_, nc)) {
             // Few ciphertexts (HEBench's Latency category is batch 1: ckks eltwise .cpp:138-141): the throughput shape would leave one
             // wave walking all digits of a tile and one lane walking all targets of a column while the chip idles.  Same kernels,
             // unfused, with the serial loops dealt to more blocks: targets of a column over kLatTargets blocks (k_k2n, k_floor_colsn),
@@ -540,7 +545,7 @@ public:
         if (k3_can_fuse(env_) && B.c01_item_stride == 2 * LN) {
             // special prime first, its correction through the column pass, then the data primes with the mod-down finished
             // inside K3 (the sums never go to HBM)
-            launch_k3(env_, L, nc, B, key, K3_SPECIAL_ONLY);
+            launch_k3(env_, L, nc, B, key, K3_SPECIAL_ONLY, nullptr, 1, nullptr, 0, groups, g_off);
             if (rescale_out && L >= 2) {
                 // Mod-down + rescale with ONE column pass and ONE row transform per target: only the prime the rescale divides out needs
                 // the mod-down correction by itself (its tiles run first, mod-down only); for every other prime the two corrections are
@@ -558,7 +563,7 @@ public:
             }
             launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
             const K3Fuse fuse = with_operands(K3Fuse{B.e, B.c01, B.c01_item_stride, 0, L, nullptr, nullptr});
-            launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &fuse);
+            launch_k3(env_, L, nc, B, key, K3_DATA_ONLY, &fuse, 1, nullptr, 0, groups, g_off);
             if (with_tail) launch_rows_inv_select(env_, L - 1, nc * 2, B.c01 + (size_t)(L - 1) * N, (u64)LN, S.rlr);
             return false;
         }
@@ -606,6 +611,8 @@ public:
     const int kLatSplit = getenv("HE355_LAT_SPLIT") && atoi(getenv("HE355_LAT_SPLIT")) > 1 ? atoi(getenv("HE355_LAT_SPLIT")) : 2;
     const int kLatSplitU64 = getenv("HE355_LAT_SPLIT_U64") && atoi(getenv("HE355_LAT_SPLIT_U64")) > 1 ? atoi(getenv("HE355_LAT_SPLIT_U64")) : 8;
     bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
+    // ... for a given kernel environment (a BFV context runs its rotation chains in the NTT domain on the CKKS pipeline: ntt_env)
+    bool latency_shape_env(const KernelEnv &e, u64 nc) const { return e.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
     // the kernel environment of a batch on stream `which`
     KernelEnv batch_env(u64 /*nc*/, int which = 0) const
     {
@@ -927,28 +934,32 @@ public:
     // ciphertext, and added to the running sum as often as steps end there (modular additions commute, so the order of the adds is
     // free).  For steps j * 2^k, j = 1 .. 2^m - 1, every prefix of a NAF sequence is the NAF sequence of a smaller j: 127 key
     // switches instead of 313 for the 128-column products of BASELINE configs[4].
+    //
+    // Round 4: the trie is walked LEVEL BY LEVEL, all nodes of a level in ONE kernel sequence (grouped key switches: every node's n
+    // ciphertexts are a group with its own Galois element and key, KsGroups).  A node-by-node walk issues 127 sequences over 64
+    // ciphertexts each at configs[4] -- the small-grid regime, 7.0-7.7 us per ciphertext and key switch; a level is 13-50 nodes, i.e.
+    // 800-3200 ciphertexts per sequence: 4.8 us (tools/ks_probe.py, profiles/r04_bfv_gather_fold_negative.txt).  The walk runs in the
+    // NTT domain on the fused CKKS pipeline for BOTH schemes: a BFV ciphertext is transformed once on the way in and the sum once on the
+    // way out; in between every operation (Galois permutation, the key switch's digit lifts, key products and mod-down, modular
+    // additions) is the same exact map on residues in either representation, since the NTT is a bijection that commutes with all of
+    // them -- (t - delta) P^-1 in coefficient form and (NTT(t) - NTT(delta)) P^-1 in NTT form are the same polynomial.
     // Returns the number of key switches issued.  Not in place.
-    u64 rotate_sum(int L, u64 n, const u64 *in, const int *steps, u64 n_steps, u64 *out)
+    struct RotNode { uint32_t elt; int parent; u64 ends; std::vector<int> kids; int level, pos; };
+    std::vector<RotNode> rotation_trie(const int *steps, u64 n_steps, size_t &depth)
     {
-        use();
-        check_level(L);
-        const size_t per = 2 * (size_t)L * P.N, bytes = n * per * 8;
-        if (ranges_overlap(in, n * per, out, n * per)) throw std::invalid_argument("rotate_sum cannot run in place: `out` overlaps `in`");
-        struct Node { uint32_t elt; int parent; u64 ends; std::vector<int> kids; }; // elt: the Galois element of the node's term (steps that
-                                                                                   // differ by the row length are the same rotation, same key)
-        std::vector<Node> trie(1, Node{0, -1, 0, {}}); // node 0: the input itself
-        size_t depth = 0;
+        std::vector<RotNode> trie(1, RotNode{0, -1, 0, {}, 0, 0}); // node 0: the input itself
+        depth = 0;
         for (u64 j = 0; j < n_steps; ++j) {
             const std::vector<int> terms = rotation_terms(steps[j]);
             int at = 0;
             for (int t : terms) {
-                const uint32_t te = P.galois_elt_from_step(t);
+                const uint32_t te = P.galois_elt_from_step(t); // steps that differ by the row length are the same rotation, same key
                 int next = -1;
                 for (int k : trie[(size_t)at].kids)
                     if (trie[(size_t)k].elt == te) { next = k; break; }
                 if (next < 0) {
                     next = (int)trie.size();
-                    trie.push_back(Node{te, at, 0, {}});
+                    trie.push_back(RotNode{te, at, 0, {}, trie[(size_t)at].level + 1, 0});
                     trie[(size_t)at].kids.push_back(next);
                 }
                 at = next;
@@ -956,7 +967,138 @@ public:
             ++trie[(size_t)at].ends;
             depth = std::max(depth, terms.size());
         }
+        return trie;
+    }
+    // device copy of a level's group tables: [perm pointers | key pointers | src_block | mult], grown as needed
+    struct GroupTables { KsGroups g; const u32 *d_mult; };
+    GroupTables upload_groups(const std::vector<const uint32_t *> &perms, const std::vector<const u64 *> &keys, const std::vector<u32> &src_block,
+                              const std::vector<u32> &mult, u32 group_size)
+    {
+        const size_t G = perms.size(), bytes = G * (8 + 8 + 4 + 4);
+        if (bytes > groups_bytes_) {
+            HIPCHECK(hipStreamSynchronize(stream_));
+            pool_.raw_free(d_groups_);
+            d_groups_ = nullptr; groups_bytes_ = 0;
+            dmalloc(d_groups_, bytes * 2);
+            groups_bytes_ = bytes * 2;
+        }
+        std::vector<unsigned char> h(bytes);
+        std::memcpy(h.data(), perms.data(), G * 8);
+        std::memcpy(h.data() + G * 8, keys.data(), G * 8);
+        std::memcpy(h.data() + G * 16, src_block.data(), G * 4);
+        std::memcpy(h.data() + G * 20, mult.data(), G * 4);
+        // the previous level's kernels may still be reading the table: the copy is stream-ordered behind them, and the host buffer is
+        // consumed before hipMemcpyAsync returns (pageable memory is staged)
+        HIPCHECK(hipMemcpyAsync(d_groups_, h.data(), bytes, hipMemcpyHostToDevice, stream_));
+        GroupTables t;
+        t.g.perm = reinterpret_cast<const uint32_t *const *>(d_groups_);
+        t.g.key = reinterpret_cast<const u64 *const *>(d_groups_ + G * 8);
+        t.g.src_block = reinterpret_cast<const u32 *>(d_groups_ + G * 16);
+        t.g.group_size = group_size;
+        t.d_mult = reinterpret_cast<const u32 *>(d_groups_ + G * 20);
+        return t;
+    }
+    // the kernel environment of the NTT-domain pipeline (a BFV context's tables are the same primes; only the data representation differs)
+    KernelEnv ntt_env() const
+    {
+        KernelEnv e = env_;
+        e.scheme = kSchemeCKKS;
+        return e;
+    }
+    // NTT-form ciphertexts: out[g * gs + c] = apply_galois(in[src_block[g] * gs + c], element / key of group g), c < gs, g < G
+    void apply_galois_grouped(int L, u64 G, u64 gs, const u64 *in, const KsGroups &groups, u64 *out)
+    {
+        const KernelEnv env = ntt_env();
+        const size_t N = P.N, LN = (size_t)L * N;
+        const u64 n = G * gs;
+        Indexer ix{};
+        const size_t chunk = chunk_ops(n, L, false);
+        for (u64 off = 0; off < n; off += chunk) {
+            const u64 nc = std::min<u64>(chunk, n - off);
+            Scratch S = scratch(std::min<u64>(chunk, n), L);
+            KsBuffers B = S.ks;
+            B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
+            TensorOperands ten;
+            ten.c1_mode = 1; // polynomial 1 of the rotated ciphertext is zero: the fused k_k3 starts it from there
+            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, nullptr, B, nullptr, false, true, &groups);
+            key_switch_tail(env, L, nc, S, B, nullptr, false, nullptr, nullptr, &ten, &groups, off);
+        }
+    }
+    u64 rotate_sum(int L, u64 n, const u64 *in, const int *steps, u64 n_steps, u64 *out)
+    {
+        use();
+        check_level(L);
+        const size_t per = 2 * (size_t)L * P.N, bytes = n * per * 8;
+        if (ranges_overlap(in, n * per, out, n * per)) throw std::invalid_argument("rotate_sum cannot run in place: `out` overlaps `in`");
+        size_t depth = 0;
+        std::vector<RotNode> trie = rotation_trie(steps, n_steps, depth);
         if (!n) return 0;
+        static const bool bfs_on = !(getenv("HE355_ROTSUM_BFS") && getenv("HE355_ROTSUM_BFS")[0] == '0');
+        const KernelEnv nenv = ntt_env();
+        if (!bfs_on || trie.size() == 1 || !k3_can_fuse(nenv) || latency_shape_env(nenv, n) || n > 0xFFFFFFFFull / trie.size())
+            return rotate_sum_by_node(L, n, in, trie, depth, out);
+        require_keyswitch();
+        const bool bfv = P.scheme == kSchemeBFV;
+        // levels of the trie; a node's position inside its level is its group index
+        std::vector<std::vector<int>> levels(depth + 1);
+        for (size_t id = 0; id < trie.size(); ++id) {
+            trie[id].pos = (int)levels[(size_t)trie[id].level].size();
+            levels[(size_t)trie[id].level].push_back((int)id);
+        }
+        PolyView pv{};
+        pv.polys_per_item = 2 * L; pv.item_stride = per;
+        for (int p2 = 0; p2 < 2 * L; ++p2) pv.prime_of[p2] = (unsigned char)(p2 % L);
+        // level 0: the input in NTT form (BFV: a transformed copy), the running sum starts as (1 + steps of 0) x input
+        const u64 *src = in;
+        u64 *owned_src = nullptr;
+        if (bfv) {
+            owned_src = static_cast<u64 *>(pool_.alloc(bytes));
+            HIPCHECK(hipMemcpyAsync(owned_src, in, bytes, hipMemcpyDeviceToDevice, stream_));
+            pv.base = owned_src;
+            launch_ntt_forward(env_, pv, (u32)n);
+            src = owned_src;
+        }
+        HIPCHECK(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToDevice, stream_));
+        Indexer ixp{};
+        ixp.pairwise = 1;
+        for (u64 r = 0; r < trie[0].ends; ++r) addsub(L, 2, n, out, src, ixp, out, false);
+        u64 switches = 0;
+        for (size_t lv = 1; lv <= depth; ++lv) {
+            const std::vector<int> &nodes = levels[lv];
+            const size_t G = nodes.size();
+            if (!G) break;
+            std::vector<const uint32_t *> perms(G);
+            std::vector<const u64 *> keys(G);
+            std::vector<u32> src_block(G), mult(G);
+            for (size_t g = 0; g < G; ++g) {
+                const RotNode &nd = trie[(size_t)nodes[g]];
+                perms[g] = perm(nd.elt);
+                keys[g] = galois_key(nd.elt);
+                if (!keys[g]) throw std::invalid_argument("Galois key not present");
+                src_block[g] = (u32)trie[(size_t)nd.parent].pos;
+                mult[g] = (u32)nd.ends;
+            }
+            const GroupTables gt = upload_groups(perms, keys, src_block, mult, (u32)n);
+            u64 *cur = static_cast<u64 *>(pool_.alloc(G * bytes));
+            apply_galois_grouped(L, G, n, src, gt.g, cur);
+            launch_sum_groups(env_, L, n, (u32)G, cur, gt.d_mult, out);
+            if (owned_src) pool_.release(owned_src); // (stream-ordered reuse: whatever takes the block next is queued behind these kernels)
+            owned_src = cur;
+            src = cur;
+            switches += G;
+        }
+        if (owned_src) pool_.release(owned_src);
+        if (bfv) {
+            pv.base = out;
+            launch_ntt_inverse(env_, pv, (u32)n);
+        }
+        HIPCHECK(hipGetLastError());
+        return switches;
+    }
+    // the node-by-node walk (depth first, one key-switch sequence per node): the latency shape, the unfused sequence
+    u64 rotate_sum_by_node(int L, u64 n, const u64 *in, const std::vector<RotNode> &trie, size_t depth, u64 *out)
+    {
+        const size_t per = 2 * (size_t)L * P.N, bytes = n * per * 8;
         HIPCHECK(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, stream_));
         Indexer ixp{};
         ixp.pairwise = 1;
@@ -980,7 +1122,7 @@ public:
         while (!stack.empty()) {
             const auto [id, lvl] = stack.back();
             stack.pop_back();
-            const Node &nd = trie[(size_t)id];
+            const RotNode &nd = trie[(size_t)id];
             const u64 *src = lvl == 1 ? in : rot_tmp_ + (lvl - 2) * n * per;
             const uint32_t e = nd.elt;
             if (nd.kids.empty() && nd.ends == 1) {
@@ -1509,6 +1651,8 @@ private:
     bool dual_stream_ = true;
     u64 *rot_tmp_ = nullptr;
     size_t rot_tmp_bytes_ = 0;
+    unsigned char *d_groups_ = nullptr; // group tables of the grouped key switches (upload_groups)
+    size_t groups_bytes_ = 0;
     u64 *bfv_scratch_ = nullptr;
     size_t bfv_bytes_ = 0;
     std::map<int, BehzDev> behz_;

@@ -63,6 +63,18 @@ struct KsBuffers {
     u64 *tpr;   // [C][2][N]      the same after the inverse row pass (raw)
     u64 *e;     // [C][2][L][N]   mod-down corrections after the forward column pass (raw of prime i)
 };
+// Grouped key switches (he355_rotate_sum: all nodes of a trie level in one kernel sequence): the ops of a launch come in groups of
+// group_size consecutive ops; group g rotates the ciphertexts of source block src_block[g] (block = group_size consecutive
+// ciphertexts of the launch's input slab) by the Galois element whose NTT-domain permutation table is perm[g], with key key[g].
+// All three are device arrays of n_groups entries.  group_size == 0: not a grouped launch.
+struct KsGroups {
+    const uint32_t *const *perm = nullptr;
+    const u64 *const *key = nullptr;
+    const u32 *src_block = nullptr;
+    u32 group_size = 0;
+};
+// out[c] += sum_g mult[g] * in[g * n_cts + c] over size-2 ciphertexts at level L (d_mult: device array [n_groups])
+void launch_sum_groups(const KernelEnv &env, int L, u64 n_cts, u32 n_groups, const u64 *in, const u32 *d_mult, u64 *out);
 constexpr int kMoveListCap = 64;
 // whole ciphertexts by index list (host array): gather dst[g] = src[idx[g]], scatter dst[idx[g]] = src[g], g < n
 void launch_move_cts(const KernelEnv &env, u64 *dst, const u64 *src, const uint32_t *idx, u64 n, u64 elems_per_ct, bool scatter);
@@ -71,7 +83,8 @@ enum K1Mode { K1_MUL = 0, K1_CT3 = 1, K1_GALOIS = 2 };
 // GALOIS: `a` is [n][2][L][N], perm = device permutation table (NTT-form gather); optional addend [n][2][L][N] (indexed like `a`):
 // the rotated ciphertext starts from it, i.e. the pipeline computes addend + rotate(a).
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix,
-               const uint32_t *perm, const KsBuffers &buf, const u64 *addend = nullptr, bool no_c01 = false, bool no_c1 = false);
+               const uint32_t *perm, const KsBuffers &buf, const u64 *addend = nullptr, bool no_c01 = false, bool no_c1 = false,
+               const KsGroups *groups = nullptr);
 // (no_c01, K1_MUL only: just the key-switch target c2 = a1 b1 is produced; c0, c1 are computed where they are consumed, K3Fuse::ta.
 //  no_c1, K1_GALOIS only: polynomial 1 of c01 -- zeros, or the addend's -- is not written; the fused k_k3 takes it from K3Fuse::c1_mode)
 // K2: finish iNTT of each digit, lift to every key prime, forward column pass -> d
@@ -111,7 +124,8 @@ bool k3_can_fuse(const KernelEnv &env);
 // n_split > 1 (latency shape, unfused only): the digits of every tile are cut into n_split groups, one single-wave block per (tile, op,
 // group), canonical partial sums -> split_part [n_split][n_ops * 2][L + 1][N]; launch_k3_combine then leaves t / tpr as the unsplit launch
 void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part = K3_ALL, const K3Fuse *fuse = nullptr,
-               int n_split = 1, u64 *split_part = nullptr, int n_split_u64 = 0); // n_split_u64: groups of the u64-engine tiles (0: as n_split)
+               int n_split = 1, u64 *split_part = nullptr, int n_split_u64 = 0, // n_split_u64: groups of the u64-engine tiles (0: as n_split)
+               const KsGroups *groups = nullptr, u64 g_op_offset = 0);         // groups: per-group keys (`key` unused), op 0 of the launch is op g_op_offset of the grouped batch
 void launch_k3_combine(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, int n_split, const u64 *split_part, int n_split_u64 = 0);
 // floor step, column half: src [n_ops*n_src][N] raw of prime s -> r = (x + floor(s/2)) mod s ->
 // (r mod q_i - floor(s/2) mod q_i) for i in [tgt_first, tgt_first + n_tgt) -> forward column pass -> dst [n_ops*n_src][dst_ntgt][N]

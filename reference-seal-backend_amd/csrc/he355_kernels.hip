@@ -457,6 +457,29 @@ __global__ void __launch_bounds__(kBlock) k_sum_cts(const u64 *in, u64 *out, con
     reinterpret_cast<ulonglong2 *>(out + (p << logN))[e2] = s;
 }
 
+// Sum over the groups of a grouped launch: out[c] (+)= sum_g mult[g] * in[g * n_cts + c] (mult: how many rotation steps end at trie node g;
+// he355_rotate_sum).  One thread = 2 coefficients of one residue polynomial of one result ciphertext; it walks the groups.
+__global__ void __launch_bounds__(kBlock) k_sum_groups(const u64 *in, u64 *out, const u32 *mult, const PrimeDev *primes, int L, int polys, int logN, u64 n_cts,
+                                                       u32 n_groups)
+{
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 cp = gid >> (logN - 1), e2 = gid & (((u64)1 << (logN - 1)) - 1);
+    const u64 c = cp / polys;
+    if (c >= n_cts) return;
+    const int p = (int)(cp % polys);
+    const u64 q = primes[p % L].q;
+    const u64 ctn = (u64)polys << logN;
+    ulonglong2 *po = reinterpret_cast<ulonglong2 *>(out + c * ctn + ((u64)p << logN)) + e2;
+    ulonglong2 s = *po;
+    for (u32 g = 0; g < n_groups; ++g) {
+        const u32 m = mult[g];
+        if (!m) continue;
+        const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(in + ((u64)g * n_cts + c) * ctn + ((u64)p << logN))[e2];
+        for (u32 r = 0; r < m; ++r) { s.x = addmod(s.x, x.x, q); s.y = addmod(s.y, x.y, q); }
+    }
+    *po = s;
+}
+
 // Gather / scatter of whole ciphertexts by an index list held in the kernel arguments (rotate_each groups the ciphertexts
 // that need the same Galois element): gather: dst[g] = src[idx[g]]; scatter: dst[idx[g]] = src[g].  16 B per lane.
 struct MoveList {
@@ -568,6 +591,7 @@ struct K1Args {
     int no_c1;                 // K1_GALOIS: polynomial 1 of c01 (zeros / the addend's) is left to the fused k_k3 (K3Fuse::c1_mode)
     int n_i;                   // residues handled by this launch (one arithmetic engine per launch)
     unsigned char i_list[64];
+    KsGroups groups;           // K1_GALOIS, grouped launch (group_size > 0): op's source ciphertext and permutation table come from its group
 };
 
 template <class Ar, int MODE>
@@ -622,8 +646,15 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
             if (valid) { store_rowC(c0p, lane, v0); store_rowC(c1p, lane, v1); store_rowC(c2np, lane, v2); }
         }
     } else { // K1_GALOIS: out[idx] = in[perm[idx]] on both polys; c1 := 0; key-switch target = permuted c1
-        const u64 *p0 = A.a + (A.op_offset + op) * 2 * P1 + (u64)i * N;
-        const uint32_t *pm = A.perm + ((u64)a_row << kRowLog);
+        u64 src_ct = A.op_offset + op;
+        const uint32_t *perm = A.perm;
+        if (A.groups.group_size) { // (wave-uniform) the op's group names its source block and its Galois element
+            const u32 gop = (u32)(A.op_offset + op), grp = gop / A.groups.group_size;
+            src_ct = (u64)A.groups.src_block[grp] * A.groups.group_size + gop % A.groups.group_size;
+            perm = A.groups.perm[grp];
+        }
+        const u64 *p0 = A.a + src_ct * 2 * P1 + (u64)i * N;
+        const uint32_t *pm = perm + ((u64)a_row << kRowLog);
         u64 v2[kRowE];
 #pragma unroll
         for (int r2 = 0; r2 < kRowE; ++r2) {
@@ -1098,6 +1129,7 @@ struct K3Args {
     const u64 *cols2; u64 *out2;   // FUSE + rescale: second correction slab [n_ops*2][L-1][N] and the final output [n_ops][2][L-1][N]
     int c1_mode; const u64 *c1_src; // FUSE, rotations: the floor step's addend of polynomial 1 is zero (1) / a row of c1_src (2) instead of a c01 row (0)
     const u64 *ta, *tb; Indexer tix; u64 t_op_offset; // FUSE, ct x ct multiply: the floor step's addend is a0 b0 / a0 b1 + a1 b0 of these operands (K3Fuse::ta); ta null: read from c01
+    KsGroups groups; u64 g_op_offset; u64 keyq_offset; // GROUPED: op (g_op_offset + op) takes its key from groups.key[group]; its quotients follow at keyq_offset
     const u64 *keyq;   // Shoup quotients of the key residues under the u64-engine primes: [L_top][2][n_q][N]
     int n_q;           // u64-engine primes in the key chain
     unsigned char q_slot[64]; // tt_list[k] -> its index among them
@@ -1122,10 +1154,13 @@ struct K3Args {
 // instantiation of its own, so that the other users of the fused kernel keep their register allocation.
 // WAVES: 8 (throughput shape: one block per CU, two waves per SIMD, each wave on its own op; LDS: 8 x 8.5 KiB exchange + 8 x 8 KiB
 // DMA landing + the tile's twiddles) or 1 (latency shape: one wave per block, the digits of a tile dealt to n_split blocks).
-template <class Ar, int WAVES, bool FUSE = false, bool TENSOR = false>
+// GROUPED: every group of ops has its own key (he355_rotate_sum: all nodes of a trie level in one launch); ops of a group are consecutive,
+// so the waves of a block still share their key rows through L1 / L2 for a group's worth of ops.  Instantiations of its own.
+template <class Ar, int WAVES, bool FUSE = false, bool TENSOR = false, bool GROUPED = false>
 __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *primes)
 {
     static_assert(!TENSOR || FUSE, "the operand rows enter through the fused epilogue's sums");
+    static_assert(!GROUPED || !TENSOR, "grouped keys are for rotations");
     constexpr int kWaves = WAVES, kBlock = WAVES * 64; // this kernel's own block shape (shadows the file-wide one)
     typedef typename Ar::T T;
     typedef typename Ar::Acc Acc;
@@ -1215,8 +1250,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
                 else ar.acc_mac(acc[r], x[r], ar.key_in(kv[r]), Ar::kKeyQuotient ? kq[r] : 0);
             }
         };
-        auto key_row = [&](int j, int k) -> const u64 * { return A.key + (((u64)j * 2 + k) * A.K + t) * N + rowoff; };
-        auto keyq_row = [&](int j, int k) -> const u64 * { return A.keyq + (((u64)j * 2 + k) * A.n_q + q_slot) * N + rowoff; };
+        const u64 *kbase = A.key, *kqbase = A.keyq;
+        if constexpr (GROUPED) { // this wave's op names its key (one scalar load per op)
+            typedef const __attribute__((address_space(4))) unsigned long long *ckeys_t;
+            const u32 grp = __builtin_amdgcn_readfirstlane((u32)((A.g_op_offset + op) / A.groups.group_size));
+            kbase = (const u64 *)((ckeys_t)(unsigned long long)A.groups.key)[grp];
+            kqbase = kbase + A.keyq_offset;
+        }
+        auto key_row = [&](int j, int k) -> const u64 * { return kbase + (((u64)j * 2 + k) * A.K + t) * N + rowoff; };
+        auto keyq_row = [&](int j, int k) -> const u64 * { return kqbase + (((u64)j * 2 + k) * A.n_q + q_slot) * N + rowoff; };
         auto mac_poly = [&](Acc acc[kRowE], const T x[kRowE], int j, int k) {
             u64 kv[kRowE], kq[kRowE];
             load_rowC(key_row(j, k), lane, kv);
@@ -2346,6 +2388,14 @@ void launch_sum_cts(const KernelEnv &env, int L, int size, u64 n_terms, const u6
     hipLaunchKernelGGL(k_sum_cts, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, in, out, env.primes, L, size * L, logN, n_terms);
 }
 
+void launch_sum_groups(const KernelEnv &env, int L, u64 n_cts, u32 n_groups, const u64 *in, const u32 *d_mult, u64 *out)
+{
+    if (!n_cts || !n_groups) return;
+    const int logN = env.logn1 + kRowLog;
+    const u64 threads = (n_cts * 2 * L) << (logN - 1);
+    hipLaunchKernelGGL(k_sum_groups, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, in, out, d_mult, env.primes, L, 2 * L, logN, n_cts, n_groups);
+}
+
 void launch_move_cts(const KernelEnv &env, u64 *dst, const u64 *src, const uint32_t *idx, u64 n, u64 elems_per_ct, bool scatter)
 {
     const u64 pairs = elems_per_ct / 2;
@@ -2377,13 +2427,15 @@ void launch_mul3(const KernelEnv &env, int L, u64 n_results, const u64 *a, const
 }
 
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
-               const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1)
+               const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1, const KsGroups *groups)
 {
     if (!n_ops) return;
+    if (groups && (mode != K1_GALOIS || addend)) throw std::runtime_error("grouped launch: rotations without addend only");
     if (no_c01 && mode != K1_MUL) throw std::runtime_error("no_c01: the ct x ct multiply only");
     if (no_c1 && mode != K1_GALOIS && mode != K1_CT3) throw std::runtime_error("no_c1: rotations and size-3 inputs only");
     K1Args A;
     A.no_c1 = no_c1 ? 1 : 0;
+    A.groups = groups ? *groups : KsGroups{};
     A.a = a; A.b = b; A.ix = ix; A.perm = perm; A.addend = addend;
     A.c01 = buf.c01; A.c01_item_stride = buf.c01_item_stride; A.c2n = buf.c2n; A.c2r = buf.c2r;
     A.n_ops = n_ops; A.op_offset = op_offset; A.L = L; A.logn1 = env.logn1; A.mode = (int)mode;
@@ -2460,8 +2512,9 @@ bool k3_can_fuse(const KernelEnv &env)
 }
 
 void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part, const K3Fuse *fuse, int n_split, u64 *split_part,
-               int n_split_u64)
+               int n_split_u64, const KsGroups *groups, u64 g_op_offset)
 {
+    if (groups && (n_split > 1 || (fuse && fuse->ta))) throw std::runtime_error("grouped keys: the 8-wave rotation instantiations only");
     if (n_split_u64 <= 0) n_split_u64 = n_split;
     if (n_split > 1 && (fuse || !split_part)) throw std::runtime_error("digit-split K3: unfused launches with a partial-sum buffer only");
     const unsigned char *prime_f64 = env.prime_f64;
@@ -2481,7 +2534,9 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.n_tt = 0;
         A.n_q = 0;
         for (int t = 0; t < env.K; ++t) A.n_q += prime_f64[t] == 0;
-        A.keyq = key + (u64)env.Ltop * 2 * env.K * env.N; // the quotient array follows the key in the same allocation
+        A.keyq_offset = (u64)env.Ltop * 2 * env.K * env.N; // the quotient array follows the key in the same allocation
+        A.keyq = key ? key + A.keyq_offset : nullptr;
+        A.groups = groups ? *groups : KsGroups{}; A.g_op_offset = g_op_offset;
         for (int tt = 0; tt <= L; ++tt) {
             if ((part == K3_SPECIAL_ONLY && tt != L) || (part == K3_DATA_ONLY && tt == L)) continue;
             if (fuse && (tt < fuse->tt_lo || tt >= fuse->tt_hi)) continue;
@@ -2537,6 +2592,11 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             const dim3 gd(g, (unsigned)A.n_split);
             if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 1>), gd, dim3(64), 0, st3, A, env.primes);
             else hipLaunchKernelGGL((k_k3<ArU64, 1>), gd, dim3(64), 0, st3, A, env.primes);
+        } else if (groups) {
+            if (pass == 0 && fuse) hipLaunchKernelGGL((k_k3<ArF64, 8, true, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+            else if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 8, false, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+            else if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 8, true, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+            else hipLaunchKernelGGL((k_k3<ArU64, 8, false, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
         } else if (pass == 0) {
             if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArF64, 8, true, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
             else if (fuse) hipLaunchKernelGGL((k_k3<ArF64, 8, true>), dim3(g), dim3(512), 0, st3, A, env.primes);

@@ -605,8 +605,10 @@ def test_rotate_each_batches_by_galois_element(pair, be):
         g.rotate_each(L, n, da, steps, da)  # not in place
 
 
-def test_rotate_sum_shares_naf_prefixes(pair, be):
-    """he355_rotate_sum (CKKS): out = in + sum_j rotate_vector(in, steps[j]) with every distinct NAF prefix key-switched once -- equal
+@pytest.mark.parametrize("walk", ["by_node", "by_level", "by_level_chunked"])
+def test_rotate_sum_shares_naf_prefixes(pair, be, walk):
+    """(walk: node by node -- batches of at most he355_set_latency_max ciphertexts -- or level by level with grouped key switches.)
+    he355_rotate_sum (CKKS): out = in + sum_j rotate_vector(in, steps[j]) with every distinct NAF prefix key-switched once -- equal
     bit for bit to the reference's loop of independent rotations + add_inplace (ckks row .cpp:502-514), fewer key switches."""
     g, o, rng = pair
     L, N = g.L, g.N
@@ -617,6 +619,8 @@ def test_rotate_sum_shares_naf_prefixes(pair, be):
             keys[e] = o.random_kswitch_key(rng)
             g.set_galois_key(e, keys[e])
     steps = [2 * j for j in range(1, 12)]  # 2 .. 22: NAF terms within +-32
+    g.set_latency_max(8 if walk == "by_node" else 0)
+    g.set_chunk(5 if walk == "by_level_chunked" else 1024)
     a = rand_cts(o, rng, 2, L)
     da = g.to_device(a)
     out = g.alloc(2 * 2 * L * N)
@@ -636,6 +640,8 @@ def test_rotate_sum_shares_naf_prefixes(pair, be):
     assert issued < unshared, (issued, unshared)
     with pytest.raises(be.HE355Error):
         g.rotate_sum(L, 2, da, steps, da)  # not in place
+    g.set_latency_max(8)  # the context is shared by the module's tests: back to the defaults
+    g.set_chunk(1024)
 
 
 def test_partially_overlapping_outputs_are_rejected(pair, be):

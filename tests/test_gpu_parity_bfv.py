@@ -230,8 +230,11 @@ def test_bfv_random_parameter_chains(be, oracle, seed):
     g.close()
 
 
-def test_rotate_sum_shares_naf_prefixes_bit_for_bit(pair, be):
-    """he355_rotate_sum: out = in + sum_j rotate_rows(in, j * spacers), the inner loop of MatMultRow (bfv row .cpp:519-531), with every
+@pytest.mark.parametrize("walk", ["by_node", "by_level", "by_level_chunked"])
+def test_rotate_sum_shares_naf_prefixes_bit_for_bit(pair, be, walk):
+    """(walk: the trie node by node -- what batches of at most he355_set_latency_max ciphertexts take -- or level by level, all nodes of
+    a level in one grouped kernel sequence in the NTT domain; `chunked`: with a chunk size that cuts through the groups.)
+    he355_rotate_sum: out = in + sum_j rotate_rows(in, j * spacers), the inner loop of MatMultRow (bfv row .cpp:519-531), with every
     distinct NAF prefix key-switched once.  It must equal the reference's unshared loop -- one Evaluator::rotate_internal per step,
     each from `in` -- bit for bit (the oracle's rotate), and issue fewer key switches: for steps j * 2^k, j = 1 .. 15, the trie has 15
     nodes while the loop runs 26 key switches."""
@@ -245,6 +248,8 @@ def test_rotate_sum_shares_naf_prefixes_bit_for_bit(pair, be):
             keys[e] = o.random_kswitch_key(rng)
             g.set_galois_key(e, keys[e])
         k += 1
+    g.set_latency_max(8 if walk == "by_node" else 0)
+    g.set_chunk(5 if walk == "by_level_chunked" else 1024)
     a = rand_cts(o, rng, 2, L)
     da = g.to_device(a)
     out = g.alloc(2 * 2 * L * N)
@@ -283,3 +288,5 @@ def test_rotate_sum_shares_naf_prefixes_bit_for_bit(pair, be):
         for s in (3 * spacers, 3 * spacers, -5 * spacers):
             want = o.add(want, o.rotate(a[r], s, keys))
         assert np.array_equal(got[r], want), r
+    g.set_latency_max(8)  # the context is shared by the module's tests: back to the defaults
+    g.set_chunk(1024)
