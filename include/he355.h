@@ -221,6 +221,10 @@ int he355_set_dual_stream(he355_ctx *ctx, int on); /* chunks alternate between t
  * Latency category is batch 1: src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:138-141).  Default 8 (HE355_LATENCY_MAX); 0: never.
  * Results are bit-identical either way. */
 int he355_set_latency_max(he355_ctx *ctx, uint64_t n);
+/* he355_rotate_sum walks its NAF-prefix trie level by level, all nodes of a level in one grouped key-switch sequence (default 1;
+ * HE355_LEVEL_WALK=0), or node by node (0: one sequence per node; what CKKS batches within the latency shape always take).  Results are
+ * bit-identical either way. */
+int he355_set_level_walk(he355_ctx *ctx, int on);
 /* ops processed per kernel sequence: default 1024 (HE355_CHUNK), i.e. BASELINE configs[2]'s batch in one piece (scratch ~ 117 MiB/op at
  * N=2^15, L=16).  The size actually used is halved until the scratch arena(s) fit in the device memory that is free at the call. */
 int he355_set_chunk(he355_ctx *ctx, uint64_t ops_per_chunk);

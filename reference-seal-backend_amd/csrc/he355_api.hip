@@ -264,6 +264,7 @@ public:
     const KernelEnv &env() const { return env_; }
     void set_chunk(size_t c) { chunk_ = c ? c : 1; }
     void set_latency_max(u64 n) { lat_max_ = n; }
+    void set_level_walk(bool on) { level_walk_ = on; }
 
     size_t key_elems() const { return P.Ltop * 2 * P.K * P.N; }
     size_t n_q_primes() const
@@ -519,15 +520,16 @@ public:
                          hipEvent_t after_k2 = nullptr, u64 *rescale_out = nullptr, const TensorOperands *ten = nullptr, const KsGroups *groups = nullptr,
                          u64 g_off = 0)
     {
-        if (groups && (rescale_out || with_tail || latency_shape_env(env_, nc) || !(k3_can_fuse(env_) && B.c01_item_stride == 2 * (size_t)L * P.N)))
+        if (groups && (rescale_out || with_tail || !(k3_can_fuse(env_) && B.c01_item_stride == 2 * (size_t)L * P.N)))
             throw std::logic_error("key_switch_tail: grouped keys need the fused mod-down path");
+        const bool lat = !groups && latency_shape_env(env_, nc); // (a grouped launch always takes the throughput shape)
         auto with_operands = [&](K3Fuse f) {
             if (ten) { f.ta = ten->a; f.tb = ten->b; f.tix = ten->ix; f.t_op_offset = ten->op_offset; f.c1_mode = ten->c1_mode; f.c1_src = ten->c1_src; }
             return f;
         };
         const size_t N = P.N, LN = (size_t)L * N;
         const int SP = (int)P.K - 1;
-        if (latency_shape_env(env_, nc)) {
+        if (lat) {
             // Few ciphertexts (HEBench's Latency category is batch 1: ckks eltwise .cpp:138-141): the throughput shape would leave one
             // wave walking all digits of a tile and one lane walking all targets of a column while the chip idles.  Same kernels,
             // unfused, with the serial loops dealt to more blocks: targets of a column over kLatTargets blocks (k_k2n, k_floor_colsn),
@@ -1033,18 +1035,22 @@ public:
         size_t depth = 0;
         std::vector<RotNode> trie = rotation_trie(steps, n_steps, depth);
         if (!n) return 0;
-        static const bool bfs_on = !(getenv("HE355_ROTSUM_BFS") && getenv("HE355_ROTSUM_BFS")[0] == '0');
+        const bool bfs_on = level_walk_;
         const KernelEnv nenv = ntt_env();
-        if (!bfs_on || trie.size() == 1 || !k3_can_fuse(nenv) || latency_shape_env(nenv, n) || n > 0xFFFFFFFFull / trie.size())
-            return rotate_sum_by_node(L, n, in, trie, depth, out);
-        require_keyswitch();
-        const bool bfv = P.scheme == kSchemeBFV;
         // levels of the trie; a node's position inside its level is its group index
         std::vector<std::vector<int>> levels(depth + 1);
+        size_t widest = 0;
         for (size_t id = 0; id < trie.size(); ++id) {
             trie[id].pos = (int)levels[(size_t)trie[id].level].size();
             levels[(size_t)trie[id].level].push_back((int)id);
+            widest = std::max(widest, levels[(size_t)trie[id].level].size());
         }
+        // node by node where that is the better shape: no fused path; CKKS batches so small that even the widest level stays within the
+        // latency shape (digit-split k_k3: he355_set_latency_max) -- a BFV context has no latency shape, its levels always go grouped
+        if (!bfs_on || trie.size() == 1 || !k3_can_fuse(nenv) || (P.scheme == kSchemeCKKS && latency_shape(n * widest)) || n > 0xFFFFFFFFull / trie.size())
+            return rotate_sum_by_node(L, n, in, trie, depth, out);
+        require_keyswitch();
+        const bool bfv = P.scheme == kSchemeBFV;
         PolyView pv{};
         pv.polys_per_item = 2 * L; pv.item_stride = per;
         for (int p2 = 0; p2 < 2 * L; ++p2) pv.prime_of[p2] = (unsigned char)(p2 % L);
@@ -1167,8 +1173,31 @@ public:
         u64 *ga = rot_tmp_, *gb = rot_tmp_ + n * per;
         for (size_t t = 0; t < depth; ++t) {
             std::map<uint32_t, std::vector<uint32_t>> groups; // Galois element -> ciphertexts whose t-th term it is
+            u64 m_all = 0;
             for (u64 i = 0; i < n; ++i)
-                if (t < terms[i].size()) groups[P.galois_elt_from_step(terms[i][t])].push_back((uint32_t)i);
+                if (t < terms[i].size()) { groups[P.galois_elt_from_step(terms[i][t])].push_back((uint32_t)i); ++m_all; }
+            if (P.scheme == kSchemeCKKS && level_walk_ && k3_can_fuse(env_) && !latency_shape(m_all) && groups.size() > 1) {
+                // ONE grouped key-switch sequence for every ciphertext that has a t-th term (groups of one op, each with its own Galois
+                // element and key, ordered by element so that neighbouring waves share key rows): the ciphertexts are read where they lie
+                // in `out` (KsGroups::src_block), the results land compactly in gb and are scattered back.  A loop over the elements
+                // issues one sequence per element over 1-14 ciphertexts each (logreg .cpp's collapse: 35 sequences for 100 samples).
+                std::vector<const uint32_t *> perms;
+                std::vector<const u64 *> keys;
+                std::vector<u32> src_block, mult, order;
+                for (const auto &g : groups)
+                    for (uint32_t i : g.second) {
+                        perms.push_back(perm(g.first));
+                        keys.push_back(galois_key(g.first));
+                        if (!keys.back()) throw std::invalid_argument("Galois key not present");
+                        src_block.push_back(i);
+                        mult.push_back(0);
+                        order.push_back(i);
+                    }
+                const GroupTables gt = upload_groups(perms, keys, src_block, mult, 1);
+                apply_galois_grouped(L, m_all, 1, out, gt.g, gb);
+                launch_move_cts(env_, out, gb, order.data(), m_all, per, true);
+                continue;
+            }
             for (const auto &g : groups) {
                 const u64 m = g.second.size();
                 launch_move_cts(env_, ga, out, g.second.data(), m, per, false);
@@ -1651,6 +1680,7 @@ private:
     bool dual_stream_ = true;
     u64 *rot_tmp_ = nullptr;
     size_t rot_tmp_bytes_ = 0;
+    bool level_walk_ = !(getenv("HE355_LEVEL_WALK") && getenv("HE355_LEVEL_WALK")[0] == '0'); // he355_rotate_sum: trie levels as grouped launches
     unsigned char *d_groups_ = nullptr; // group tables of the grouped key switches (upload_groups)
     size_t groups_bytes_ = 0;
     u64 *bfv_scratch_ = nullptr;
@@ -1863,6 +1893,7 @@ int he355_fill_uniform_at(he355_ctx *c, uint64_t *d_dst, uint64_t n_polys, const
 }
 int he355_set_dual_stream(he355_ctx *c, int on) { return guarded([&] { dev(c).set_dual_stream(on != 0); }); }
 int he355_set_latency_max(he355_ctx *c, uint64_t n) { return guarded([&] { dev(c).set_latency_max(n); }); }
+int he355_set_level_walk(he355_ctx *c, int on) { return guarded([&] { dev(c).set_level_walk(on != 0); }); }
 int he355_set_relin_key(he355_ctx *c, const uint64_t *h_key)
 {
     return guarded([&] { dev(c).key_from_host(dev(c).relin_slot(), h_key); });

@@ -572,8 +572,10 @@ def _naf_terms(step, N):
     return out
 
 
-def test_rotate_each_batches_by_galois_element(pair, be):
-    """he355_rotate_each: ciphertext i rotated by its own step (collapseCKKS's rotate_vector(dot_i, -i) loop), key switches batched
+@pytest.mark.parametrize("grouped", [True, False])
+def test_rotate_each_batches_by_galois_element(pair, be, grouped):
+    """(grouped: every ciphertext with a t-th NAF term in ONE key-switch sequence, each op with its own Galois element and key; else one
+    sequence per Galois element.)  he355_rotate_each: ciphertext i rotated by its own step (collapseCKKS's rotate_vector(dot_i, -i) loop), key switches batched
     per Galois element: equal to rotating one ciphertext at a time, which is the oracle's apply_galois chain of the NAF terms."""
     g, o, rng = pair
     L, N = g.L, g.N
@@ -588,7 +590,9 @@ def test_rotate_each_batches_by_galois_element(pair, be):
     a = rand_cts(o, rng, n, L)
     da = g.to_device(a)
     out = g.alloc(n * 2 * L * N)
+    g.set_level_walk(grouped)
     g.rotate_each(L, n, da, steps, out)
+    g.set_level_walk(True)
     got = out.download((n, 2, L, N))
     for r, s in enumerate(steps):
         w = a[r]
@@ -619,7 +623,8 @@ def test_rotate_sum_shares_naf_prefixes(pair, be, walk):
             keys[e] = o.random_kswitch_key(rng)
             g.set_galois_key(e, keys[e])
     steps = [2 * j for j in range(1, 12)]  # 2 .. 22: NAF terms within +-32
-    g.set_latency_max(8 if walk == "by_node" else 0)
+    g.set_level_walk(walk != "by_node")
+    g.set_latency_max(0)  # (two ciphertexts would otherwise stay within the latency shape, which is walked node by node)
     g.set_chunk(5 if walk == "by_level_chunked" else 1024)
     a = rand_cts(o, rng, 2, L)
     da = g.to_device(a)
@@ -640,7 +645,8 @@ def test_rotate_sum_shares_naf_prefixes(pair, be, walk):
     assert issued < unshared, (issued, unshared)
     with pytest.raises(be.HE355Error):
         g.rotate_sum(L, 2, da, steps, da)  # not in place
-    g.set_latency_max(8)  # the context is shared by the module's tests: back to the defaults
+    g.set_level_walk(True)  # the context is shared by the module's tests: back to the defaults
+    g.set_latency_max(8)
     g.set_chunk(1024)
 
 

@@ -248,7 +248,8 @@ def test_rotate_sum_shares_naf_prefixes_bit_for_bit(pair, be, walk):
             keys[e] = o.random_kswitch_key(rng)
             g.set_galois_key(e, keys[e])
         k += 1
-    g.set_latency_max(8 if walk == "by_node" else 0)
+    g.set_level_walk(walk != "by_node")
+    g.set_latency_max(0)  # (two ciphertexts would otherwise stay within the latency shape, which is walked node by node)
     g.set_chunk(5 if walk == "by_level_chunked" else 1024)
     a = rand_cts(o, rng, 2, L)
     da = g.to_device(a)
@@ -288,5 +289,6 @@ def test_rotate_sum_shares_naf_prefixes_bit_for_bit(pair, be, walk):
         for s in (3 * spacers, 3 * spacers, -5 * spacers):
             want = o.add(want, o.rotate(a[r], s, keys))
         assert np.array_equal(got[r], want), r
-    g.set_latency_max(8)  # the context is shared by the module's tests: back to the defaults
+    g.set_level_walk(True)  # the context is shared by the module's tests: back to the defaults
+    g.set_latency_max(8)
     g.set_chunk(1024)

@@ -285,6 +285,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--out", default="")
     ap.add_argument("--no-direct", action="store_true")
+    ap.add_argument("--exact-reps", action="store_true", help="--reps timed calls for Offline descriptors too (tools/bridge_ktrace.sh)")
     a = ap.parse_args()
     if be.device_count() < 1:
         raise SystemExit("bench_bridge.py needs an MI355X (no CPU fallback)")
@@ -295,7 +296,7 @@ def main():
     for i, case in enumerate(cases(backend, a.sizes)):
         if a.only and a.only.lower() not in (case.name() + " " + case.label).lower():
             continue
-        reps = a.reps if case.category == LATENCY else max(3, a.reps // 4)
+        reps = a.reps if (case.category == LATENCY or a.exact_reps) else max(3, a.reps // 4)
         r = run_case(backend, case, reps)
         rec = dict(descriptor=case.name(), sizes=case.label, params=dict(case.params), sample_counts=list(case.counts), pool=pool, **r)
         if not a.no_direct:
