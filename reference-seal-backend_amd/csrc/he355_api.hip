@@ -616,10 +616,12 @@ public:
     // ... for a given kernel environment (a BFV context runs its rotation chains in the NTT domain on the CKKS pipeline: ntt_env)
     bool latency_shape_env(const KernelEnv &e, u64 nc) const { return e.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
     // the kernel environment of a batch on stream `which`
-    KernelEnv batch_env(u64 /*nc*/, int which = 0) const
+    // ntt: the NTT-domain (CKKS) pipeline whatever the context's scheme (ntt_env)
+    KernelEnv batch_env(u64 /*nc*/, int which = 0, bool ntt = false) const
     {
         KernelEnv env = env_;
         env.stream = which ? stream2_ : stream_;
+        if (ntt) env.scheme = kSchemeCKKS;
         return env;
     }
     u64 *latency_partials(size_t elems, int which) // one buffer per stream: chunks of the two streams are in flight together
@@ -804,7 +806,9 @@ public:
     }
     // `addend` (optional, [n][2][L][N]; may alias `out`, never `in`): out = addend + galois(in) -- the add_inplace that follows
     // a rotation in accumulateCKKS/BFV and in the row-major MatMult is folded into the first kernel of the rotation.
-    void apply_galois(int L, u64 n, const u64 *in, uint32_t elt, u64 *out, const u64 *addend = nullptr)
+    // ntt_form (BFV contexts): the ciphertexts are held in NTT form (a rotation chain that was transformed on the way in runs on the fused
+    // NTT-domain pipeline: accumulate, rotate_sum)
+    void apply_galois(int L, u64 n, const u64 *in, uint32_t elt, u64 *out, const u64 *addend = nullptr, bool ntt_form = false)
     {
         use();
         check_level(L);
@@ -814,7 +818,7 @@ public:
         if (!key) throw std::invalid_argument("Galois key not present");
         // every kernel of the pipeline reads `in` while later ones already write `out`: any overlap (not just in == out) corrupts the input
         if (ranges_overlap(in, n * 2 * (size_t)L * P.N, out, n * 2 * (size_t)L * P.N)) throw std::invalid_argument("apply_galois cannot run in place: `out` overlaps `in`");
-        if (P.scheme == kSchemeBFV) {
+        if (P.scheme == kSchemeBFV && !ntt_form) {
             const uint32_t *gt = gather(elt);
             const size_t LN = (size_t)L * P.N;
             const size_t chunk = chunk_ops(n, L, false); // this call's chunk size
@@ -838,7 +842,7 @@ public:
             Scratch S = scratch(std::min<u64>(chunk, n), L); // arena sized for the batch actually processed
             KsBuffers B = S.ks;
             B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
-            const KernelEnv env = batch_env(nc);
+            const KernelEnv env = batch_env(nc, 0, true);
             // polynomial 1 of the rotated ciphertext is zero (or the addend's): on the fused path k_k1 does not write it and k_k3 takes it
             // from where it is (the addend may be `out`: the wave that reads a row is the one that writes it, afterwards)
             const bool c1_in_k3 = tensor_in_k3(env, L, nc, B);
@@ -851,7 +855,7 @@ public:
         HIPCHECK(hipGetLastError());
     }
     // Evaluator::rotate_internal: use the key of the step if present, otherwise the NAF decomposition
-    void rotate(int L, u64 n, const u64 *in, int step, u64 *out, const u64 *addend = nullptr)
+    void rotate(int L, u64 n, const u64 *in, int step, u64 *out, const u64 *addend = nullptr, bool ntt_form = false)
     {
         use();
         const size_t bytes = n * 2 * (size_t)L * P.N * 8;
@@ -865,7 +869,7 @@ public:
         if (step == 0) { plain_copy(); return; }
         const uint32_t elt = P.galois_elt_from_step(step);
         if (!elt) throw std::invalid_argument("step count too large");
-        if (galois_key(elt)) { apply_galois(L, n, in, elt, out, addend); return; }
+        if (galois_key(elt)) { apply_galois(L, n, in, elt, out, addend, ntt_form); return; }
         std::vector<int> naf;
         {
             const bool neg = step < 0;
@@ -897,7 +901,7 @@ public:
             u64 *dst = ((m - 1 - t) % 2 == 0) ? out : rot_tmp_;
             const uint32_t e = P.galois_elt_from_step(steps[t]);
             if (!e || !galois_key(e)) throw std::invalid_argument("Galois key not present");
-            apply_galois(L, n, cur, e, dst, t + 1 == m ? addend : nullptr); // the addend joins the last step only
+            apply_galois(L, n, cur, e, dst, t + 1 == m ? addend : nullptr, ntt_form); // the addend joins the last step only
             cur = dst;
         }
     }
@@ -1228,19 +1232,30 @@ public:
             const u64 row_count = count > half ? half : count;
             int rot = 64 - __builtin_clzll(row_count);
             if (((u64)1 << (rot - 1)) == row_count) --rot;
-            Indexer ixb{};
-            ixb.pairwise = 1;
-            (void)ixb;
+            // The chain of rotate_rows + add_inplace (and the column swap) runs in the NTT domain on the fused pipeline the CKKS path uses
+            // (Galois permutation in k_k1, mod-down inside k_k3, the latency shape for small batches): the ciphertexts are transformed
+            // once on the way in and once on the way out, every step in between is the same exact map on residues in either
+            // representation (see rotate_sum).  Two or more steps pay for the two transforms (20 transforms per key switch at L = 3).
+            // Measured through the bridge (profiles/r04_bridge_phases.jsonl): it wins where the fused pipeline has a shape of its own -- the
+            // latency shape (1 ciphertext at N = 2^14: 2.02 -> 1.59 ms) -- and in the throughput regime (1024 ciphertexts at N = 2^14:
+            // 44.1 -> 38.9 ms); in between (64-80 ciphertexts at N <= 2^14) the BFV kernels' launches fill the chip better: 1.47 -> 1.77 ms.
+            const int n_steps = rot + (count > half ? 1 : 0);
+            const bool ntt_chain = level_walk_ && n_steps >= 2 && k3_can_fuse(ntt_env()) && (n <= lat_max_ || n * P.N >= ((u64)1 << 23));
+            PolyView pv{};
+            pv.base = inout; pv.polys_per_item = 2 * L; pv.item_stride = 2 * (u64)L * P.N;
+            for (int p2 = 0; p2 < 2 * L; ++p2) pv.prime_of[p2] = (unsigned char)(p2 % L);
+            if (ntt_chain) launch_ntt_forward(env_, pv, (u32)n);
             u64 *cur = inout, *nxt = tmp; // ping-pong: nxt = cur + rotate(cur), one pipeline per step and no separate add
             for (int i = 0; i < rot; ++i) {
-                rotate(L, n, cur, 1 << i, nxt, cur); // rotate_rows + add_inplace
+                rotate(L, n, cur, 1 << i, nxt, cur, ntt_chain); // rotate_rows + add_inplace
                 std::swap(cur, nxt);
             }
             if (count > half) {
-                apply_galois(L, n, cur, (uint32_t)(2 * P.N - 1), nxt, cur); // rotate_columns + add_inplace
+                apply_galois(L, n, cur, (uint32_t)(2 * P.N - 1), nxt, cur, ntt_chain); // rotate_columns + add_inplace
                 std::swap(cur, nxt);
             }
             if (cur != inout) HIPCHECK(hipMemcpyAsync(inout, cur, n * 2 * (size_t)L * P.N * 8, hipMemcpyDeviceToDevice, stream_));
+            if (ntt_chain) launch_ntt_inverse(env_, pv, (u32)n);
             return;
         }
         const u64 slots = P.N / 2;

@@ -379,8 +379,8 @@ def test_cfg3_full_size_mul_relin_rescale(be, oracle):
     b = db.download((1, 2, L, N))[0]
     stride_in, stride_out = 2 * L * N, 2 * (L - 1) * N
     import ctypes as C
-    # 32 results against the oracle (its multithreaded batch loop): the first and last rows, both sides of every chunk boundary
-    # (chunks of 256 alternate between the two streams) and a spread in between
+    # 32 results against the oracle (its multithreaded batch loop): the first and last rows, both sides of every boundary of the
+    # 256-op chunks of the second pass below, and a spread in between.  (The default chunk is the whole batch: one chunk, one stream.)
     rows = sorted({0, 1, 2, 63, 127, 128, 200, 254, 255, 256, 257, 300, 383, 384, 500, 510, 511, 512, 513, 600, 639, 640, 700, 766, 767, 768, 769,
                    900, 1000, 1021, 1022, 1023})
     a_s = np.empty((len(rows), 2, L, N), dtype=np.uint64)
@@ -397,6 +397,13 @@ def test_cfg3_full_size_mul_relin_rescale(be, oracle):
     full = out.download()
     hi = out_hi.download()
     assert np.array_equal(full[512 * stride_out:], hi)
+    # the same batch cut into four chunks of 256 that alternate between the two streams (the schedule a smaller memory budget or
+    # he355_set_chunk selects): every result identical to the one-chunk run, hence to the oracle on the sampled rows
+    g.set_chunk(256)
+    out_4 = g.alloc(n * stride_out)
+    g.multiply_relin(L, n, da, db, be.Context.outer(0, n, 0, 1), out_4, rescale=True)
+    assert np.array_equal(full, out_4.download())
+    out_4.free()
     # and the result does not depend on the chunking of the batch
     g.set_chunk(7)
     out_c = g.alloc(64 * stride_out)
