@@ -584,7 +584,7 @@ def main():
         # cache, so the bytes that must cross HBM are fewer: operands read once per batch, results written once
         comp_op = wl.compulsory_bytes_per_op(global_b0, W.b1)
         tref = None
-        for tname in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):  # the newest committed PMC figure of this command
+        for tname in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):  # the newest committed PMC figure of this command
             tpath = os.path.join(ROOT, "profiles", tname)
             if args.config == "mul_relin_rescale" and os.path.exists(tpath):
                 tj = json.load(open(tpath))
