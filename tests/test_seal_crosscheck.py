@@ -17,7 +17,8 @@ SEAL_DIR = os.environ.get("SEAL_INSTALL_DIR", "")
 pytestmark = pytest.mark.skipif(not SEAL_DIR, reason="SEAL_INSTALL_DIR not set: Microsoft SEAL is not available offline")
 
 CASES = [("ckks", 8192, 2, 45, 45), ("ckks", 16384, 4, 45, 45), ("ckks", 32768, 16, 45, 45),  # the last: the headline chain {60, 45 x 15, 60}
-         ("bfv", 8192, 2, 40, 20), ("bfv", 16384, 3, 40, 20)]
+         ("bfv", 8192, 2, 40, 20), ("bfv", 16384, 3, 40, 20),
+         ("bfv", 32768, 3, 40, 20)]  # the last: BASELINE configs[4]'s chain {60, 40, 40, 60}, t = 786433 (exact_vectors_big.json: bfv_n32768_60_40_40_60)
 
 
 def _pinned(meta, who):
