@@ -2,7 +2,9 @@
 """Randomised differential run of the HIP path against the CPU oracle (test tool, GPU box): random ring sizes, prime chains (mixed
 fp64-/u64-engine primes, forced-u64 contexts), levels, batch sizes on both sides of the latency-shape boundary, chunk sizes with
 ragged tails; CKKS multiply -> relinearize (-> rescale), relinearize of size-3 ciphertexts, rotations and rotate_add; BFV (30 % of the
-cases) BEHZ multiply, relinearize and a row or column rotation -- every result compared bit for bit.  usage: tools/fuzz_parity.py <seconds> [seed]   (prints one line per case; exit 1 on the first mismatch)"""
+cases) BEHZ multiply, relinearize and a row or column rotation; and for both schemes the rotation chains of round 4 -- he355_rotate_sum
+(NAF-prefix trie, walked node by node or level by level with grouped key switches), he355_rotate_each, he355_accumulate -- every result
+compared bit for bit.  usage: tools/fuzz_parity.py <seconds> [seed]   (prints one line per case; exit 1 on the first mismatch)"""
 import importlib
 import os
 import sys
@@ -12,6 +14,46 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+def chains(be, g, o, rng, L, n, a, da):
+    """rotate_sum / rotate_each / accumulate against the oracle's rotate_internal restatement; returns (ok, what)"""
+    N = g.N
+    keys = {}
+    for k in range(5):  # +-1 .. +-16: every NAF term of a step in [-15, 15]
+        for st in (1 << k, -(1 << k)):
+            e = o.galois_elt(st)
+            keys[e] = o.random_kswitch_key(rng)
+            g.set_galois_key(e, keys[e])
+    walk = bool(rng.random() < 0.7)
+    g.set_level_walk(walk)
+    what = [f"walk{int(walk)}"]
+    steps = [int(x) for x in rng.integers(-15, 16, int(rng.integers(1, 9)))]
+    out = g.alloc(n * 2 * L * N)
+    g.rotate_sum(L, n, da, steps, out)
+    got = out.download((n, 2, L, N))
+    ok = True
+    for r in range(n):
+        want = a[r].copy()
+        for st in steps:
+            want = o.add(want, o.rotate(a[r], st, keys) if st else a[r])
+        ok = ok and np.array_equal(got[r], want)
+    what.append(f"rotsum{len(steps)}")
+    if ok and g.scheme == be.SCHEME_CKKS:
+        each = [int(x) for x in rng.integers(-15, 16, n)]
+        g.rotate_each(L, n, da, each, out)
+        got = out.download((n, 2, L, N))
+        ok = all(np.array_equal(got[r], o.rotate(a[r], each[r], keys) if each[r] else a[r]) for r in range(n))
+        what.append("roteach")
+    if ok:
+        count = int(rng.integers(2, 17))
+        acc, tmp = g.to_device(a), g.alloc(n * 2 * L * N)
+        g.accumulate(L, n, acc, count, tmp)
+        got = acc.download((n, 2, L, N))
+        ok = all(np.array_equal(got[r], o.accumulate(a[r], count, keys)) for r in range(n))
+        what.append(f"acc{count}")
+    g.set_level_walk(True)
+    return ok, what
 
 
 def main():
@@ -61,7 +103,11 @@ def main():
                 g.apply_galois(L, n, da, elt, rot)
                 gotr = rot.download((n, 2, L, N))
                 ok = all(np.array_equal(gotr[r], o.apply_galois(a[r], elt, gk)) for r in range(n))
-            print(f"case {case}: BFV N={N} bits={bits} t_bits={pb} L={L} n={n} multiply+relin+galois {'ok' if ok else 'MISMATCH'}", flush=True)
+            extra = []
+            if ok and g.K >= 2:
+                g.set_latency_max(int(rng.choice([0, 8])))
+                ok, extra = chains(be, g, o, rng, L, n, a, da)
+            print(f"case {case}: BFV N={N} bits={bits} t_bits={pb} L={L} n={n} multiply+relin+galois+{'+'.join(extra)} {'ok' if ok else 'MISMATCH'}", flush=True)
             g.close()
             if not ok:
                 return 1
@@ -143,6 +189,9 @@ def main():
                 gr = orot.download((n, 2, L, N))
                 ok = all(np.array_equal(gr[r], o.add(b[r], wr[r])) for r in range(n))
                 what.append("rot_add")
+        if ok and rng.random() < 0.6:
+            ok, extra = chains(be, g, o, rng, L, n, a, da)
+            what += extra
         print(f"case {case}: N={N} bits={bits} force_u64={int(force)} L={L} n={n} {'+'.join(what)} {'ok' if ok else 'MISMATCH'}", flush=True)
         g.close()
         if not ok:
