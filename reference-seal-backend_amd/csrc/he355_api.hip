@@ -1340,12 +1340,14 @@ public:
         for (u64 off = 0; off < n; off += c) {
             const u64 nc = std::min<u64>(c, n - off);
             launch_behz_extend(env_, Z, nc, off, a, b, ix, xq, xb);
-            vq.base = xq; launch_ntt_forward(env_, vq, (u32)(nc * 4));
-            vb.base = xb; launch_ntt_forward(env_, vb, (u32)(nc * 4));
-            launch_tensor4(env_, L, pq, nc, xq, dq);
-            launch_tensor4(env_, (int)S, pb, nc, xb, ds);
-            vq.base = dq; launch_ntt_inverse(env_, vq, (u32)(nc * 3));
-            vb.base = ds; launch_ntt_inverse(env_, vb, (u32)(nc * 3));
+            // forward column passes, then per (op, residue, row) ONE kernel for the forward row pass of the four polynomials, the dyadic
+            // tensor and the inverse row pass of the three products (k_behz_rows_tensor), then the inverse column passes
+            vq.base = xq; launch_cols_fwd(env_, vq, (u32)(nc * 4));
+            vb.base = xb; launch_cols_fwd(env_, vb, (u32)(nc * 4));
+            launch_behz_rows_tensor(env_, L, pq, nc, xq, dq);
+            launch_behz_rows_tensor(env_, (int)S, pb, nc, xb, ds);
+            vq.base = dq; launch_cols_inv(env_, vq, (u32)(nc * 3));
+            vb.base = ds; launch_cols_inv(env_, vb, (u32)(nc * 3));
             launch_behz_floor_sk(env_, Z, nc, dq, ds, out + off * 3 * (size_t)L * N);
         }
         HIPCHECK(hipGetLastError());

@@ -172,6 +172,11 @@ constexpr int kBehzMaxL = 16;
 void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk);
 // dyadic tensor of NTT-form polys x [n*4][Lx][N] (a0,a1,b0,b1) -> d [n*3][Lx][N]; residue i under prime prime_of[i]
 void launch_tensor4(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d);
+// BEHZ steps (3)-(5) on rows, fused: x [n*4][Lx][N] after launch_cols_fwd -> forward row pass of a0, a1, b0, b1, dyadic tensor, inverse row
+// pass -> d [n*3][Lx][N] ready for launch_cols_inv (one block = the four rows of one (op, residue, row); no HBM round trip between them)
+void launch_behz_rows_tensor(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d);
+void launch_cols_fwd(const KernelEnv &env, const PolyView &v, u32 n_items); // column half of the forward transform, in place
+void launch_cols_inv(const KernelEnv &env, const PolyView &v, u32 n_items); // column half of the inverse transform, in place
 // BEHZ steps (6)-(8): times t, fast floor, Shenoy-Kumaresan -> out [n][3][L][N]
 void launch_behz_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out);
 // coefficient-form Galois: c01[op][0] = sigma(in0), c01[op][1] = 0, tgt[op] = sigma(in1); gather table has the sign in bit 31

@@ -1879,6 +1879,82 @@ __global__ void __launch_bounds__(kBlock) k_tensor4(const u64 *x, u64 *d, const 
     reinterpret_cast<ulonglong2 *>(d + ((r * 3 + 2) * Lx + i) * N)[e2] = c2;
 }
 
+// BEHZ steps (3)-(5) on rows: forward row pass of the four polynomials a0, a1, b0, b1 of one (op, residue, row), the dyadic tensor
+// c0 = a0 b0, c1 = a0 b1 + a1 b0, c2 = a1 b1, and the inverse row pass of the three products, in ONE kernel: a block is four waves,
+// wave w transforms polynomial w's row; the canonical NTT-form rows meet in LDS (each wave's own exchange buffer, free once its
+// transform is done; every wave uses the same lane <-> element map, so the hand-over is slot-for-slot); waves 0..2 form one product
+// each and run its inverse row pass.  Replaces k_rows_fwd (4 polynomials) + k_tensor4 + k_rows_inv (3 polynomials): 35 instead of 105
+// polynomial transfers through HBM per (op, residue).  x [n*4][Lx][N] after the forward column pass (raw; canonical when N = 1024),
+// d [n*3][Lx][N] ready for the inverse column pass.
+struct BehzRowsArgs {
+    const u64 *x;
+    u64 *d;
+    u64 n_ops;
+    int Lx, logn1, n_r;
+    unsigned char r_list[64]; // residue slots handled by this launch (one arithmetic engine per launch)
+    unsigned char prime_of[64];
+};
+template <class Ar>
+__global__ void __launch_bounds__(kBlock) k_behz_rows_tensor(BehzRowsArgs A, const PrimeDev *primes)
+{
+    typedef typename Ar::T T;
+    __shared__ u64 lds[kWaves][kLdsRow];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 n1 = 1u << A.logn1;
+    const u64 N = (u64)n1 << kRowLog;
+    const u64 job = blockIdx.x; // (op, residue slot, row)
+    const u32 a_row = (u32)(job & (n1 - 1));
+    const u64 orr = job >> A.logn1;
+    const int r = A.r_list[orr % A.n_r];
+    const u64 op = orr / A.n_r;
+    const PrimeDev &P = primes[A.prime_of[r]];
+    const Ar ar = make_ar(P, (Ar *)nullptr);
+    const bool last = A.logn1 == 0;
+    const u64 rowoff = ((u64)r << (A.logn1 + kRowLog)) + ((u64)a_row << kRowLog);
+    // phase 1: this wave's polynomial through the forward row pass; canonical values parked in its exchange buffer
+    {
+        T x[kRowE];
+        u64 v[kRowE];
+        load_rowA(A.x + (op * 4 + wave) * A.Lx * N + rowoff, lane, v);
+#pragma unroll
+        for (int e = 0; e < kRowE; ++e) x[e] = last ? ar.from_canon(v[e]) : ar.from_raw(v[e]);
+        wave_rows_fwd(ar, tw_table(gtw(P.fwd), n1 + a_row), lane, lds[wave], x);
+#pragma unroll
+        for (int e = 0; e < kRowE; ++e) lds[wave][(e << 6) | lane] = ar.to_canon(x[e]);
+    }
+    __syncthreads();
+    // phase 2: one product per wave (waves 0..2), from the rows the other waves parked (slot-for-slot: same lane, same register)
+    const bool worker = wave < 3; // wave-uniform; wave 3 only keeps the barriers company
+    u64 c[kRowE];
+    if (worker) {
+        u64 p0[kRowE], p1[kRowE];
+        const int ia = wave == 2 ? 1 : 0, ib = wave == 0 ? 2 : 3; // c0: a0 b0; c1: a0 b1 (+ a1 b0); c2: a1 b1
+#pragma unroll
+        for (int e = 0; e < kRowE; ++e) { p0[e] = lds[ia][(e << 6) | lane]; p1[e] = lds[ib][(e << 6) | lane]; }
+        if (wave == 1) {
+            u64 q0[kRowE], q1[kRowE];
+#pragma unroll
+            for (int e = 0; e < kRowE; ++e) { q0[e] = lds[1][(e << 6) | lane]; q1[e] = lds[2][(e << 6) | lane]; }
+#pragma unroll
+            for (int e = 0; e < kRowE; ++e)
+                c[e] = ar.dy_out(ar.dy_add(ar.dy_mul(ar.dy_in(p0[e]), ar.dy_in(p1[e])), ar.dy_mul(ar.dy_in(q0[e]), ar.dy_in(q1[e]))));
+        } else {
+#pragma unroll
+            for (int e = 0; e < kRowE; ++e) c[e] = ar.dy_out(ar.dy_mul(ar.dy_in(p0[e]), ar.dy_in(p1[e])));
+        }
+    }
+    __syncthreads(); // every wave has read what it needs before any exchange buffer is written again
+    if (!worker) return;
+    T x[kRowE];
+#pragma unroll
+    for (int e = 0; e < kRowE; ++e) x[e] = ar.from_canon(c[e]);
+    wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
+    u64 v[kRowE];
+#pragma unroll
+    for (int e = 0; e < kRowE; ++e) v[e] = last ? ar.to_canon(x[e]) : ar.to_raw(x[e]);
+    store_rowA(A.d + (op * 3 + wave) * A.Lx * N + rowoff, lane, v);
+}
+
 __global__ void __launch_bounds__(kBlock) k_behz_floor_sk(BehzDev Z, const PrimeDev *primes, const u64 *dq, const u64 *ds, u64 *out, u64 n_polys, int logN)
 {
     const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
@@ -2692,6 +2768,48 @@ void launch_tensor4(const KernelEnv &env, int Lx, const unsigned char *prime_of,
     for (int i = 0; i < Lx; ++i) pm.p[i] = prime_of[i];
     const u64 threads = (n_ops * Lx) << (logN - 1);
     hipLaunchKernelGGL(k_tensor4, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, x, d, env.primes, pm, Lx, logN, n_ops);
+}
+void launch_behz_rows_tensor(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d)
+{
+    if (!n_ops) return;
+    BehzRowsArgs A;
+    A.x = x; A.d = d; A.n_ops = n_ops; A.Lx = Lx; A.logn1 = env.logn1;
+    for (int i = 0; i < Lx; ++i) A.prime_of[i] = prime_of[i];
+    for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine residues, pass 1: u64-engine residues
+        A.n_r = 0;
+        for (int i = 0; i < Lx; ++i)
+            if ((env.prime_f64[prime_of[i]] != 0) == (pass == 0)) A.r_list[A.n_r++] = (unsigned char)i;
+        if (!A.n_r) continue;
+        const unsigned g = (unsigned)((n_ops * A.n_r) << env.logn1);
+        if (pass == 0) hipLaunchKernelGGL(k_behz_rows_tensor<ArF64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+        else hipLaunchKernelGGL(k_behz_rows_tensor<ArU64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
+    }
+}
+void launch_cols_fwd(const KernelEnv &env, const PolyView &v, u32 n_items) // the column half of launch_ntt_forward (canonical -> raw)
+{
+    const u64 polys = (u64)n_items * v.polys_per_item;
+    if (!polys || env.logn1 == 0) return;
+    const unsigned g = (unsigned)(polys * 4);
+    switch (env.logn1) {
+    case 1: hipLaunchKernelGGL(k_cols_fwd<1>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+    case 2: hipLaunchKernelGGL(k_cols_fwd<2>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+    case 3: hipLaunchKernelGGL(k_cols_fwd<3>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+    case 4: hipLaunchKernelGGL(k_cols_fwd<4>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+    case 5: hipLaunchKernelGGL(k_cols_fwd<5>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+    }
+}
+void launch_cols_inv(const KernelEnv &env, const PolyView &v, u32 n_items) // the column half of launch_ntt_inverse (raw -> coefficients)
+{
+    const u64 polys = (u64)n_items * v.polys_per_item;
+    if (!polys || env.logn1 == 0) return;
+    const unsigned g = (unsigned)(polys * 4);
+    switch (env.logn1) {
+    case 1: hipLaunchKernelGGL(k_cols_inv<1>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+    case 2: hipLaunchKernelGGL(k_cols_inv<2>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+    case 3: hipLaunchKernelGGL(k_cols_inv<3>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+    case 4: hipLaunchKernelGGL(k_cols_inv<4>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+    case 5: hipLaunchKernelGGL(k_cols_inv<5>, dim3(g), dim3(kBlock), 0, env.stream, v, env.primes); break;
+    }
 }
 void launch_behz_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out)
 {
