@@ -980,28 +980,35 @@ public:
     GroupTables upload_groups(const std::vector<const uint32_t *> &perms, const std::vector<const u64 *> &keys, const std::vector<u32> &src_block,
                               const std::vector<u32> &mult, u32 group_size)
     {
-        const size_t G = perms.size(), bytes = G * (8 + 8 + 4 + 4);
-        if (bytes > groups_bytes_) {
+        const size_t G = perms.size(), bytes = (G * (8 + 8 + 4 + 4) + 255) & ~(size_t)255;
+        // The tables live in a ring in HBM: every upload takes the next region, so a region is never rewritten while kernels that were
+        // launched with it may still be running; when the ring wraps (or has to grow) the stream is drained first.  The copy itself is
+        // synchronous (complete on return, whatever the runtime does with pageable memory), and everything that reads the region is
+        // launched afterwards.
+        if (bytes > groups_bytes_ || groups_next_ + bytes > groups_bytes_) {
             HIPCHECK(hipStreamSynchronize(stream_));
-            pool_.raw_free(d_groups_);
-            d_groups_ = nullptr; groups_bytes_ = 0;
-            dmalloc(d_groups_, bytes * 2);
-            groups_bytes_ = bytes * 2;
+            if (bytes > groups_bytes_ / 4) {
+                pool_.raw_free(d_groups_);
+                d_groups_ = nullptr; groups_bytes_ = 0;
+                dmalloc(d_groups_, std::max<size_t>(bytes * 8, (size_t)64 << 10));
+                groups_bytes_ = std::max<size_t>(bytes * 8, (size_t)64 << 10);
+            }
+            groups_next_ = 0;
         }
-        std::vector<unsigned char> h(bytes);
+        unsigned char *d_tab = d_groups_ + groups_next_;
+        groups_next_ += bytes;
+        std::vector<unsigned char> h(bytes, 0);
         std::memcpy(h.data(), perms.data(), G * 8);
         std::memcpy(h.data() + G * 8, keys.data(), G * 8);
         std::memcpy(h.data() + G * 16, src_block.data(), G * 4);
         std::memcpy(h.data() + G * 20, mult.data(), G * 4);
-        // the previous level's kernels may still be reading the table: the copy is stream-ordered behind them, and the host buffer is
-        // consumed before hipMemcpyAsync returns (pageable memory is staged)
-        HIPCHECK(hipMemcpyAsync(d_groups_, h.data(), bytes, hipMemcpyHostToDevice, stream_));
+        HIPCHECK(hipMemcpy(d_tab, h.data(), bytes, hipMemcpyHostToDevice));
         GroupTables t;
-        t.g.perm = reinterpret_cast<const uint32_t *const *>(d_groups_);
-        t.g.key = reinterpret_cast<const u64 *const *>(d_groups_ + G * 8);
-        t.g.src_block = reinterpret_cast<const u32 *>(d_groups_ + G * 16);
+        t.g.perm = reinterpret_cast<const uint32_t *const *>(d_tab);
+        t.g.key = reinterpret_cast<const u64 *const *>(d_tab + G * 8);
+        t.g.src_block = reinterpret_cast<const u32 *>(d_tab + G * 16);
         t.g.group_size = group_size;
-        t.d_mult = reinterpret_cast<const u32 *>(d_groups_ + G * 20);
+        t.d_mult = reinterpret_cast<const u32 *>(d_tab + G * 20);
         return t;
     }
     // the kernel environment of the NTT-domain pipeline (a BFV context's tables are the same primes; only the data representation differs)
@@ -1699,7 +1706,7 @@ private:
     size_t rot_tmp_bytes_ = 0;
     bool level_walk_ = !(getenv("HE355_LEVEL_WALK") && getenv("HE355_LEVEL_WALK")[0] == '0'); // he355_rotate_sum: trie levels as grouped launches
     unsigned char *d_groups_ = nullptr; // group tables of the grouped key switches (upload_groups)
-    size_t groups_bytes_ = 0;
+    size_t groups_bytes_ = 0, groups_next_ = 0;
     u64 *bfv_scratch_ = nullptr;
     size_t bfv_bytes_ = 0;
     std::map<int, BehzDev> behz_;
