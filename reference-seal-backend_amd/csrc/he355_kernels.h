@@ -170,8 +170,6 @@ constexpr int kBehzMaxL = 16;
 // for the base-q transform.  xq [n*4][L][N], xbsk [n*4][L+1][N], coefficient form.
 // results op_offset .. op_offset + n_ops - 1 of the batch (the indexer sees the global result index)
 void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk);
-// dyadic tensor of NTT-form polys x [n*4][Lx][N] (a0,a1,b0,b1) -> d [n*3][Lx][N]; residue i under prime prime_of[i]
-void launch_tensor4(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d);
 // BEHZ steps (3)-(5) on rows, fused: x [n*4][Lx][N] after launch_cols_fwd -> forward row pass of a0, a1, b0, b1, dyadic tensor, inverse row
 // pass -> d [n*3][Lx][N] ready for launch_cols_inv (one block = the four rows of one (op, residue, row); no HBM round trip between them)
 void launch_behz_rows_tensor(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d);
