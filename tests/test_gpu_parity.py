@@ -941,6 +941,17 @@ def test_exact_model_big_fixture_gpu_bfv(be):
         rlh = rl.download((n, 2, L, N))[0][:, :, :3]
         q = np.array(d["primes"][:L], dtype=np.uint64)[None, :, None]
         assert np.array_equal(acc.download((n, 2, L, N))[0][:, :, :3], (want + rlh) % q)
+        # the same sum through he355_rotate_sum: node by node on the coefficient-form kernels, and level by level -- the NTT-domain walk
+        # with grouped key switches that BASELINE configs[4] runs (a BFV batch transformed on the way in and out)
+        g.rotate(L, n, rl, 1, rot)  # (checked against the model's digest above): the whole expected sum, every coefficient
+        full_want = (rot.download((n, 2, L, N)) + rl.download((n, 2, L, N))) % q[None]
+        for walk in (False, True):
+            g.set_level_walk(walk)
+            g.set_latency_max(0)
+            g.rotate_sum(L, n, rl, [1], acc)
+            assert np.array_equal(acc.download((n, 2, L, N)), full_want), walk
+        g.set_level_walk(True)
+        g.set_latency_max(8)
     g.close()
 
 
