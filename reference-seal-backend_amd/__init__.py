@@ -187,6 +187,12 @@ class DeviceBuffer:
             _check(lib().he355_download(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes))
         return out.reshape(shape)
 
+    def copy_into(self, dst: "DeviceBuffer", dst_offset_u64: int = 0, n_u64: int | None = None):
+        """device-to-device copy of the first n_u64 words of this slab to dst[dst_offset_u64:] (on the context's stream)"""
+        n = self.n if n_u64 is None else int(n_u64)
+        assert n <= self.n and dst_offset_u64 + n <= dst.n
+        _check(lib().he355_copy(self.ctx.h, C.c_void_p(dst.ptr.value + dst_offset_u64 * 8), self.ptr, n * 8))
+
     def free(self):
         if self.ptr:
             lib().he355_free(self.ctx.h, self.ptr)

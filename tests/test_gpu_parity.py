@@ -896,6 +896,32 @@ def test_exact_model_big_fixture_gpu(be, name):
     g.close()
 
 
+def test_exact_model_big_fixture_gpu_headline_launch_shape(be):
+    """The headline's launch shape itself -- 1024 ciphertext pairs in ONE chunk (op-groups per block, block rounds and k_k2n target
+    groups as batch 1024 selects them) -- held to the exact big-integer model: the fixture's pair replicated 1024 times on the device
+    (b as the one shared operand of the outer product), every one of the 1024 results of multiply -> relinearize -> rescale must be the
+    model's ciphertext.  No oracle involved."""
+    import test_exact_model as tem
+    name = "ckks_n32768_60_45x15_60"
+    if name not in tem.BIG:
+        pytest.skip("fixture case not generated (tests/golden/make_exact_vectors_big.py)")
+    f, d = tem.big_case_inputs(name)
+    N, L, n = f["N"], d["Ltop"], 1024
+    g = be.Context(be.SCHEME_CKKS, N, bit_sizes=f["bits"], device=0)
+    g.set_relin_key(d["rk"])
+    one = g.to_device(d["a"][None])
+    da = g.alloc(n * 2 * L * N)
+    for r in range(n):
+        one.copy_into(da, r * 2 * L * N)
+    db = g.to_device(d["b"][None])
+    out = g.alloc(n * 2 * (L - 1) * N)
+    g.multiply_relin(L, n, da, db, be.Context.outer(0, n, 0, 1), out, rescale=True)
+    got = out.download((n, 2, L - 1, N))
+    tem.check(f, "multiply_relin_rescale", got[0])
+    assert (got == got[0][None]).all(), "results of the 1024-op launch differ from each other"
+    g.close()
+
+
 def test_exact_model_big_fixture_gpu_bfv(be):
     """BASELINE configs[4]'s kernel instances against the exact big-integer model, no oracle involved: N = 2^15, {60, 40, 40, 60},
     t = 786433 -- he355_bfv_multiply (k_behz_extend, k_tensor4, k_behz_floor_sk), he355_relinearize (the BFV key switch and its
