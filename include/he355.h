@@ -74,6 +74,10 @@ uint64_t he355_data_modulus_count(const he355_ctx *ctx); /* L at the first data 
 uint64_t he355_modulus(const he355_ctx *ctx, uint64_t i);
 uint64_t he355_plain_modulus(const he355_ctx *ctx);
 int he355_prime_uses_fp64(const he355_ctx *ctx, uint64_t i); /* which arithmetic engine owns prime i */
+/* BFV: the auxiliary base of the BEHZ multiply at `level` data primes: out[0] = m_sk, out[1..] = B_0.. (at most cap entries written);
+ * returns their number, 0 for CKKS or a bad level.  SEAL's RNSTool (seal/util/rns.cpp, RNSTool::initialize) takes 61-bit primes; the
+ * product does not depend on the choice and the device takes primes of its fp64 engine (csrc/he_params.h, Params::aux). */
+uint64_t he355_bfv_aux_base(const he355_ctx *ctx, int level, uint64_t *out, uint64_t cap);
 uint32_t he355_galois_elt_from_step(const he355_ctx *ctx, int step);
 uint64_t he355_galois_elts_all(const he355_ctx *ctx, uint32_t *out, uint64_t cap);
 

@@ -70,6 +70,7 @@ def lib():
             "he355_poly_degree": (u64, [vp]), "he355_key_modulus_count": (u64, [vp]),
             "he355_data_modulus_count": (u64, [vp]), "he355_modulus": (u64, [vp, u64]),
             "he355_plain_modulus": (u64, [vp]), "he355_prime_uses_fp64": (i32, [vp, u64]),
+            "he355_bfv_aux_base": (u64, [vp, i32, _u64p, u64]),
             "he355_galois_elt_from_step": (u32, [vp, i32]),
             "he355_galois_elts_all": (u64, [vp, C.POINTER(u32), u64]),
             "he355_device_count": (i32, [C.POINTER(i32)]),
@@ -137,7 +138,7 @@ def lib():
 C_ABI_SYMBOLS = [
     "he355_last_error", "he355_ctx_create", "he355_ctx_create_primes", "he355_ctx_destroy", "he355_poly_degree",
     "he355_key_modulus_count", "he355_data_modulus_count", "he355_modulus", "he355_plain_modulus",
-    "he355_prime_uses_fp64", "he355_galois_elt_from_step", "he355_galois_elts_all", "he355_device_count",
+    "he355_prime_uses_fp64", "he355_bfv_aux_base", "he355_galois_elt_from_step", "he355_galois_elts_all", "he355_device_count",
     "he355_device_init", "he355_malloc", "he355_free", "he355_upload", "he355_download", "he355_copy", "he355_copy_peer", "he355_sync",
     "he355_fill_uniform", "he355_fill_uniform_at", "he355_set_dual_stream", "he355_set_relin_key", "he355_set_galois_key", "he355_set_relin_key_synthetic",
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
@@ -222,6 +223,12 @@ class Context:
         self._bufs = []
         if device is not None:
             self.device_init(device)
+
+    def bfv_aux_base(self, level: int | None = None) -> list[int]:
+        """[m_sk, B_0, B_1, ...]: the auxiliary base of the BEHZ multiply at `level` data primes (host-side; no device needed)."""
+        out = np.zeros(64, dtype=np.uint64)
+        n = lib().he355_bfv_aux_base(self.h, self.L if level is None else level, out.ctypes.data_as(_u64p), 64)
+        return [int(v) for v in out[:n]]
 
     def device_init(self, device: int = 0):
         _check(lib().he355_device_init(self.h, device))

@@ -1300,11 +1300,13 @@ public:
         HIPCHECK(hipMemcpy(d, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
         BehzDev Z{};
         Z.L = L;
+        Z.nB = T.nB;
+        if (T.nB > kBehzMaxB) throw std::invalid_argument("BFV multiply: auxiliary base too large for this build");
         Z.cq = d + o_cq; Z.inv_punct_q = d + o_ip; Z.q2bsk = d + o_q2b; Z.q2mt = d + o_q2m; Z.neg_inv_q_mod_mt = T.neg_inv_q_mod_mt;
         Z.q_mod_bsk = d + o_qmb; Z.inv_mt_bsk = d + o_imb; Z.inv_q_bsk = d + o_iqb; Z.t_mod_q = d + o_tq; Z.t_mod_bsk = d + o_tb;
         Z.inv_punct_B = d + o_ipB; Z.B2q = d + o_B2q; Z.B2msk = d + o_B2m; Z.inv_B_mod_msk = T.inv_B_mod_msk; Z.B_mod_q = d + o_Bq;
-        for (int j = 0; j < L; ++j) Z.bsk_prime[j] = (unsigned char)(P.K + 1 + j); // B_j
-        Z.bsk_prime[L] = (unsigned char)P.K;                                        // m_sk
+        for (int j = 0; j < T.nB; ++j) Z.bsk_prime[j] = (unsigned char)(P.K + 1 + j); // B_j
+        Z.bsk_prime[T.nB] = (unsigned char)P.K;                                        // m_sk
         return behz_[L] = Z;
     }
     // Evaluator::bfv_multiply (BEHZ), size 2 x 2 -> 3, coefficient form
@@ -1314,7 +1316,7 @@ public:
         check_level(L);
         if (P.scheme != kSchemeBFV) throw std::invalid_argument("he355_bfv_multiply needs a BFV context");
         const BehzDev &Z = behz(L);
-        const size_t N = P.N, S = (size_t)L + 1;
+        const size_t N = P.N, S = (size_t)Z.nB + 1;
         const size_t per_op = (4 * L + 4 * S + 3 * L + 3 * S) * N;
         size_t c = std::min<size_t>(chunk_, (size_t)n ? (size_t)n : 1);
         while (per_op * c * 8 > bfv_bytes_) { // as chunk_ops: halved until the arena is reserved
@@ -1803,6 +1805,18 @@ uint64_t he355_data_modulus_count(const he355_ctx *c) { return c->params->Ltop; 
 uint64_t he355_modulus(const he355_ctx *c, uint64_t i) { return i < c->params->K ? c->params->primes[i].q : 0; }
 uint64_t he355_plain_modulus(const he355_ctx *c) { return c->params->plain_modulus; }
 int he355_prime_uses_fp64(const he355_ctx *c, uint64_t i) { return i < c->params->K ? (int)c->params->primes[i].f64 : 0; }
+uint64_t he355_bfv_aux_base(const he355_ctx *c, int level, uint64_t *out, uint64_t cap)
+{
+    const Params &p = *c->params;
+    if (p.scheme != kSchemeBFV || level < 1 || (size_t)level > p.Ltop) return 0;
+    try {
+        const size_t nB = p.behz_nB(level);
+        for (size_t i = 0; i <= nB && i < cap; ++i) out[i] = p.aux[i].q;
+        return nB + 1;
+    } catch (const std::exception &) {
+        return 0;
+    }
+}
 uint32_t he355_galois_elt_from_step(const he355_ctx *c, int step) { return c->params->galois_elt_from_step(step); }
 uint64_t he355_galois_elts_all(const he355_ctx *c, uint32_t *out, uint64_t cap)
 {

@@ -147,27 +147,28 @@ struct FloorRowsArgs {
 };
 void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &args);
 // ---- BFV -------------------------------------------------------------------------------------------------
-// Device copy of BehzTables (he_params.h); all pointers are HBM.  Bsk order: B_0..B_{L-1}, m_sk.
+// Device copy of BehzTables (he_params.h); all pointers are HBM.  Bsk order: B_0..B_{nB-1}, m_sk (S = nB + 1).
 struct BehzDev {
-    int L, pad_;
+    int L, nB;
     const u64 *cq;          // [L]      2^32 * (Q/q_i)^-1 mod q_i  (fastbconv_m_tilde, merged constants)
     const u64 *inv_punct_q; // [L]
-    const u64 *q2bsk;       // [L+1][L]
+    const u64 *q2bsk;       // [S][L]
     const u64 *q2mt;        // [L]
     u64 neg_inv_q_mod_mt;
-    const u64 *q_mod_bsk, *inv_mt_bsk, *inv_q_bsk; // [L+1]
+    const u64 *q_mod_bsk, *inv_mt_bsk, *inv_q_bsk; // [S]
     const u64 *t_mod_q;     // [L]
-    const u64 *t_mod_bsk;   // [L+1]
-    const u64 *inv_punct_B; // [L]
-    const u64 *B2q;         // [L][L]
-    const u64 *B2msk;       // [L]
+    const u64 *t_mod_bsk;   // [S]
+    const u64 *inv_punct_B; // [nB]
+    const u64 *B2q;         // [L][nB]
+    const u64 *B2msk;       // [nB]
     u64 inv_B_mod_msk;
     const u64 *B_mod_q;     // [L]
     unsigned char bsk_prime[64]; // device prime index of Bsk element j
 };
-constexpr int kBehzMaxL = 16;
+constexpr int kBehzMaxL = 16; // base q
+constexpr int kBehzMaxB = 24; // base B (Params::behz_nB: 22 for sixteen 60-bit primes)
 // BEHZ steps (1)-(2): lift the four input polynomials of each pair to Bsk (fastbconv_m_tilde + sm_mrq) and copy them
-// for the base-q transform.  xq [n*4][L][N], xbsk [n*4][L+1][N], coefficient form.
+// for the base-q transform.  xq [n*4][L][N], xbsk [n*4][S][N], coefficient form.
 // results op_offset .. op_offset + n_ops - 1 of the batch (the indexer sees the global result index)
 void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk);
 // BEHZ steps (3)-(5) on rows, fused: x [n*4][Lx][N] after launch_cols_fwd -> forward row pass of a0, a1, b0, b1, dyadic tensor, inverse row

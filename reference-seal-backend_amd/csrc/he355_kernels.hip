@@ -1814,6 +1814,9 @@ __global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const Pri
 // =======================================================================================================
 __device__ __forceinline__ ModU64 mod_of(const PrimeDev *primes, int idx) { return make_modu(primes[idx]); }
 
+// ML / MB: compile-time bounds of the bases q and B (loops fully unrolled under them, per-residue values in registers): <4, 6> serves
+// the reference's default parameter sets ({60,40,40} and {60,40,40,40}), <kBehzMaxL, kBehzMaxB> everything else.
+template <int ML, int MB>
 __global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDev *primes, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk,
                                                         u64 n_ops, int logN, u64 op_offset)
 {
@@ -1823,14 +1826,15 @@ __global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDe
     if (pid >= n_ops * 4) return;
     const u64 r = pid >> 2;
     const int c = (int)((pid >> 1) & 1), k = (int)(pid & 1);
-    const int L = Z.L, S = L + 1;
+    constexpr int kUnrollB = MB <= 6 ? MB + 1 : 1; // the small instantiation unrolls its residue loops, the large one keeps them rolled
+    const int L = Z.L, S = Z.nB + 1;
     const u64 N = (u64)1 << logN, P1 = (u64)L * N;
     const u64 rg = op_offset + r; // result index in the whole batch: picks the operands (outer product or pairwise)
     const u64 *src = (c ? b + idx_b(ix, rg) * 2 * P1 : a + idx_a(ix, rg) * 2 * P1) + (u64)k * P1 + n;
-    u64 tmp[kBehzMaxL];
+    u64 tmp[ML];
     u64 mt_acc = 0;
 #pragma unroll
-    for (int i = 0; i < kBehzMaxL; ++i) {
+    for (int i = 0; i < ML; ++i) {
         if (i < L) {
             const u64 x = src[(u64)i * N];
             xq[(pid * L + i) * N + n] = x;
@@ -1840,11 +1844,13 @@ __global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDe
     }
     const u64 MT = (u64)1 << 32;
     const u64 rmt = (((mt_acc & 0xFFFFFFFFull) * Z.neg_inv_q_mod_mt) & 0xFFFFFFFFull); // -(x*m_tilde)_fast * Q^-1 mod m_tilde
-    for (int j = 0; j < S; ++j) {
+#pragma unroll kUnrollB
+    for (int j = 0; j < MB + 1; ++j) {
+        if (j >= S) break;
         const ModU64 mj = mod_of(primes, Z.bsk_prime[j]);
         u128 acc = 0;
 #pragma unroll
-        for (int i = 0; i < kBehzMaxL; ++i)
+        for (int i = 0; i < ML; ++i)
             if (i < L) acc += (u128)tmp[i] * Z.q2bsk[j * L + i];
         const u64 conv = barrett128(acc, mj);
         u64 rr = rmt;
@@ -1930,52 +1936,59 @@ __global__ void __launch_bounds__(kBlock) k_behz_rows_tensor(BehzRowsArgs A, con
     store_rowA(A.d + (op * 3 + wave) * A.Lx * N + rowoff, lane, v);
 }
 
+template <int ML, int MB>
 __global__ void __launch_bounds__(kBlock) k_behz_floor_sk(BehzDev Z, const PrimeDev *primes, const u64 *dq, const u64 *ds, u64 *out, u64 n_polys, int logN)
 {
     const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
     const u64 n = gid & (((u64)1 << logN) - 1);
     const u64 pid = gid >> logN; // (op, k)
     if (pid >= n_polys) return;
-    const int L = Z.L, S = L + 1;
+    constexpr int kUnrollB = MB <= 6 ? MB + 1 : 1, kUnrollL = ML <= 4 ? ML : 1;
+    const int L = Z.L, nB = Z.nB, S = nB + 1;
     const u64 N = (u64)1 << logN;
-    u64 tmp[kBehzMaxL], fl[kBehzMaxL + 1];
+    u64 tmp[ML], fl[MB];
     // (6) times t, then the base-q part prepared for the fast conversion
 #pragma unroll
-    for (int i = 0; i < kBehzMaxL; ++i)
+    for (int i = 0; i < ML; ++i)
         if (i < L) {
             const ModU64 mi = mod_of(primes, i);
             tmp[i] = mulmod(mulmod(dq[(pid * L + i) * N + n], Z.t_mod_q[i], mi), Z.inv_punct_q[i], mi);
         }
-    // (7) fast floor: (x_Bsk - FastBconv(x_q)) * Q^-1 mod p_j
-#pragma unroll
-    for (int j = 0; j < kBehzMaxL + 1; ++j)
+    // (7) fast floor: (x_Bsk - FastBconv(x_q)) * Q^-1 mod p_j;  (8) Shenoy-Kumaresan, first half: the B residues times
+    // (B/b_j)^-1 and their weighted sum mod m_sk
+    const ModU64 msk = mod_of(primes, Z.bsk_prime[nB]);
+    u128 accs = 0;
+    u64 fl_sk = 0;
+#pragma unroll kUnrollB
+    for (int j = 0; j < MB + 1; ++j)
         if (j < S) {
             const ModU64 mj = mod_of(primes, Z.bsk_prime[j]);
             u128 acc = 0;
 #pragma unroll
-            for (int i = 0; i < kBehzMaxL; ++i)
+            for (int i = 0; i < ML; ++i)
                 if (i < L) acc += (u128)tmp[i] * Z.q2bsk[j * L + i];
             const u64 conv = barrett128(acc, mj);
             const u64 xs = mulmod(ds[(pid * S + j) * N + n], Z.t_mod_bsk[j], mj);
-            fl[j] = mulmod(submod(xs, conv, mj.q), Z.inv_q_bsk[j], mj);
+            const u64 f = mulmod(submod(xs, conv, mj.q), Z.inv_q_bsk[j], mj);
+            if (j < nB) {
+                if (j < MB) { // (always; keeps the index static)
+                    fl[j] = mulmod(f, Z.inv_punct_B[j], mj);
+                    accs += (u128)fl[j] * Z.B2msk[j]; // < 2^122 each, at most 24 (16 with 61-bit primes) of them
+                }
+            } else {
+                fl_sk = f;
+            }
         }
-    // (8) Shenoy-Kumaresan: B -> q with the alpha_sk correction
-    const ModU64 msk = mod_of(primes, Z.bsk_prime[L]);
-    u128 accs = 0;
-#pragma unroll
-    for (int i = 0; i < kBehzMaxL; ++i)
-        if (i < L) {
-            tmp[i] = mulmod(fl[i], Z.inv_punct_B[i], mod_of(primes, Z.bsk_prime[i]));
-            accs += (u128)tmp[i] * Z.B2msk[i];
-        }
-    const u64 alpha = mulmod(submod(barrett128(accs, msk), fl[L], msk.q), Z.inv_B_mod_msk, msk);
+    const u64 alpha = mulmod(submod(barrett128(accs, msk), fl_sk, msk.q), Z.inv_B_mod_msk, msk);
     const bool neg = alpha > (msk.q >> 1);
-    for (int j = 0; j < L; ++j) {
+#pragma unroll kUnrollL
+    for (int j = 0; j < ML; ++j) {
+        if (j >= L) break;
         const ModU64 mj = mod_of(primes, j);
         u128 acc = 0;
 #pragma unroll
-        for (int i = 0; i < kBehzMaxL; ++i)
-            if (i < L) acc += (u128)tmp[i] * Z.B2q[j * L + i];
+        for (int i = 0; i < MB; ++i)
+            if (i < nB) acc += (u128)fl[i] * Z.B2q[j * nB + i];
         const u64 conv = barrett128(acc, mj);
         const u64 Bq = Z.B_mod_q[j];
         const u64 res = neg ? barrett128((u128)(msk.q - alpha) * Bq + conv, mj) : barrett128((u128)alpha * (Bq ? mj.q - Bq : 0) + conv, mj);
@@ -2475,7 +2488,10 @@ void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 
     if (!n_ops) return;
     const int logN = env.logn1 + kRowLog;
     const u64 threads = (n_ops * 4) << logN;
-    hipLaunchKernelGGL(k_behz_extend, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, a, b, ix, xq, xbsk, n_ops, logN, op_offset);
+    if (bz.L <= 4 && bz.nB <= 6)
+        hipLaunchKernelGGL((k_behz_extend<4, 6>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, a, b, ix, xq, xbsk, n_ops, logN, op_offset);
+    else
+        hipLaunchKernelGGL((k_behz_extend<kBehzMaxL, kBehzMaxB>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, a, b, ix, xq, xbsk, n_ops, logN, op_offset);
 }
 void launch_behz_rows_tensor(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d)
 {
@@ -2524,7 +2540,10 @@ void launch_behz_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, co
     if (!n_ops) return;
     const int logN = env.logn1 + kRowLog;
     const u64 threads = (n_ops * 3) << logN;
-    hipLaunchKernelGGL(k_behz_floor_sk, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, dq, ds, out, n_ops * 3, logN);
+    if (bz.L <= 4 && bz.nB <= 6)
+        hipLaunchKernelGGL((k_behz_floor_sk<4, 6>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, dq, ds, out, n_ops * 3, logN);
+    else
+        hipLaunchKernelGGL((k_behz_floor_sk<kBehzMaxL, kBehzMaxB>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, dq, ds, out, n_ops * 3, logN);
 }
 void launch_bfv_galois(const KernelEnv &env, int L, u64 n_ops, const u64 *in, const uint32_t *gather, u64 *c01, u64 c01_item_stride, u64 *tgt,
                        const u64 *addend)

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <stdexcept>
+#include <string>
 
 namespace he355 {
 
@@ -207,16 +208,103 @@ void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t)
         primes[i] = make_prime_tables(q, N, logn, !force_u64 && (q >> 47) == 0);
     }
     if (scheme == kSchemeBFV) {
+        if (t >= ((u64)1 << 32)) throw std::invalid_argument("plain modulus too large for the BEHZ base");
         // RNSTool::initialize: get_primes(2N, 61, |B| + 2) -> m_sk, gamma, B...  with |B| = |q| at every level
         // (the +1 case needs 32 + bits(t) + bits(q) >= 61|q| + 61, impossible for user primes <= 60 bits)
-        if (t >= ((u64)1 << 32)) throw std::invalid_argument("plain modulus too large for the BEHZ base");
         const std::vector<u64> ap = get_primes(2 * (u64)N, 61, Ltop + 2);
         gamma = ap[1];
-        aux.push_back(make_prime_tables(ap[0], N, logn, false));
-        for (size_t i = 0; i < Ltop; ++i) aux.push_back(make_prime_tables(ap[2 + i], N, logn, false));
+        const char *base = std::getenv("HE355_BEHZ_BASE");
+        aux_seal_base = base && std::string(base) == "seal";
+        if (aux_seal_base) {
+            aux.push_back(make_prime_tables(ap[0], N, logn, false));
+            for (size_t i = 0; i < Ltop; ++i) aux.push_back(make_prime_tables(ap[2 + i], N, logn, false));
+        } else {
+            // the device's own base (he_params.h, Params::aux): kAuxBits-bit primes 1 (mod 2N), none of them a coefficient modulus,
+            // as many as the Shenoy-Kumaresan bound asks for at the first level (behz_base_suffices)
+            std::vector<u64> cand = get_primes(2 * (u64)N, kAuxBits, 2 * K + 8);
+            cand.erase(std::remove_if(cand.begin(), cand.end(), [&](u64 v) { return std::find(chain.begin(), chain.end(), v) != chain.end(); }), cand.end());
+            size_t next = 0;
+            aux.push_back(make_prime_tables(cand[next++], N, logn, !force_u64)); // m_sk
+            do {
+                if (next == cand.size()) throw std::logic_error("auxiliary BEHZ base: candidate primes exhausted");
+                aux.push_back(make_prime_tables(cand[next++], N, logn, !force_u64));
+            } while (!behz_base_suffices((int)Ltop, aux.size() - 1));
+        }
         // + 1: the plain modulus rides along in the device prime array
         if (K + aux.size() + 1 > (size_t)kMaxPrimes) throw std::invalid_argument("too many primes for the device prime table");
     }
+}
+
+namespace {
+// little-endian multi-word unsigned integer: just enough for the one inequality below
+struct Wide {
+    std::vector<u64> w{1};
+    void mul(u64 m)
+    {
+        u64 carry = 0;
+        for (u64 &x : w) {
+            const u128 p = (u128)x * m + carry;
+            x = (u64)p;
+            carry = (u64)(p >> 64);
+        }
+        if (carry) w.push_back(carry);
+    }
+    void add(const Wide &o)
+    {
+        u64 carry = 0;
+        if (w.size() < o.w.size()) w.resize(o.w.size(), 0);
+        for (size_t i = 0; i < w.size(); ++i) {
+            const u128 p = (u128)w[i] + (i < o.w.size() ? o.w[i] : 0) + carry;
+            w[i] = (u64)p;
+            carry = (u64)(p >> 64);
+        }
+        if (carry) w.push_back(carry);
+    }
+    bool less_than(const Wide &o) const
+    {
+        size_t na = w.size(), nb = o.w.size();
+        while (na > 1 && !w[na - 1]) --na;
+        while (nb > 1 && !o.w[nb - 1]) --nb;
+        if (na != nb) return na < nb;
+        for (size_t i = na; i-- > 0;)
+            if (w[i] != o.w[i]) return w[i] < o.w[i];
+        return false;
+    }
+};
+} // namespace
+
+// Is {B_0..B_{nB-1}}, m_sk large enough for the BEHZ multiply at level L?  With Q = q_0..q_{L-1}, m_tilde = 2^32: the extended
+// operands satisfy |Y| <= Q (1/2 + L/2^32), the largest product coefficient (c1 = a0 b1 + a1 b0) is |Z| <= 2 N Y^2, and the fast
+// floor yields the integer V = (t Z - W) / Q with 0 <= W < L Q, so |V| <= t N Q (1 + L/2^31)^2 / 2 + L.  The Shenoy-Kumaresan step
+// returns V mod q_j exactly iff gamma = (V' - V) / B, which lies in (-|V|/B, nB + |V|/B), is told apart by its centred residue
+// mod m_sk: nB + |V|/B <= (m_sk - 1) / 2.  Sufficient, in integers (both sides times 2^62):
+//     t N Q (2^31 + L)^2 + 2 L 2^62  <  B (m_sk - 1 - 2 nB) 2^62.
+// (SEAL's own rule, 32 + bits(t) + bits(Q) < bits(B m_sk), is this inequality with N (1 + L/2^31)^2 rounded up to 2^32.)
+bool Params::behz_base_suffices(int L, size_t nB) const
+{
+    if (nB < 1 || 1 + nB > aux.size() || aux[0].q <= 1 + 2 * (u64)nB) return false;
+    Wide lhs, rhs;
+    lhs.mul(plain_modulus);
+    lhs.mul((u64)N);
+    for (int i = 0; i < L; ++i) lhs.mul(primes[i].q);
+    lhs.mul(((u64)1 << 31) + (u64)L);
+    lhs.mul(((u64)1 << 31) + (u64)L);
+    Wide extra;
+    extra.mul(2 * (u64)L);
+    extra.mul((u64)1 << 62);
+    lhs.add(extra);
+    for (size_t i = 0; i < nB; ++i) rhs.mul(aux[1 + i].q);
+    rhs.mul(aux[0].q - 1 - 2 * (u64)nB);
+    rhs.mul((u64)1 << 62);
+    return lhs.less_than(rhs);
+}
+
+size_t Params::behz_nB(int L) const
+{
+    if (aux_seal_base) return (size_t)L;
+    for (size_t nB = 1; 1 + nB <= aux.size(); ++nB)
+        if (behz_base_suffices(L, nB)) return nB;
+    throw std::logic_error("auxiliary BEHZ base too small");
 }
 
 std::vector<uint32_t> Params::galois_gather_coeff(uint32_t elt) const
@@ -238,15 +326,17 @@ std::vector<uint32_t> Params::galois_gather_coeff(uint32_t elt) const
 BehzTables Params::behz_tables(int L_) const
 {
     if (scheme != kSchemeBFV || L_ < 1 || (size_t)L_ > Ltop) throw std::invalid_argument("BEHZ tables need a BFV level");
-    const size_t L = (size_t)L_, S = L + 1;
+    const size_t L = (size_t)L_, nB = behz_nB(L_), S = nB + 1;
     BehzTables T;
     T.L = L_;
+    T.nB = (int)nB;
     auto qv = [&](size_t i) { return primes[i].q; };
-    auto bsk = [&](size_t j) { return j < L ? aux[1 + j].q : aux[0].q; }; // B_0..B_{L-1}, m_sk
+    auto bv = [&](size_t i) { return aux[1 + i].q; };
+    auto bsk = [&](size_t j) { return j < nB ? bv(j) : aux[0].q; }; // B_0..B_{nB-1}, m_sk
     const u64 MT = (u64)1 << 32, t = plain_modulus;
     T.inv_punct_q.resize(L); T.mtilde_q.resize(L); T.q2mt.resize(L); T.t_mod_q.resize(L); T.B_mod_q.resize(L);
     T.q2bsk.resize(S * L); T.q_mod_bsk.resize(S); T.inv_mt_bsk.resize(S); T.inv_q_bsk.resize(S); T.t_mod_bsk.resize(S);
-    T.inv_punct_B.resize(L); T.B2q.resize(L * L); T.B2msk.resize(L);
+    T.inv_punct_B.resize(nB); T.B2q.resize(L * nB); T.B2msk.resize(nB);
     for (size_t i = 0; i < L; ++i) {
         u64 p = 1, pm = 1;
         for (size_t k = 0; k < L; ++k)
@@ -282,29 +372,29 @@ BehzTables Params::behz_tables(int L_) const
     const u64 msk = aux[0].q;
     {
         u64 all = 1;
-        for (size_t k = 0; k < L; ++k) all = mm(all, aux[1 + k].q % msk, msk);
+        for (size_t k = 0; k < nB; ++k) all = mm(all, bv(k) % msk, msk);
         T.inv_B_mod_msk = invmod(all, msk);
     }
-    for (size_t i = 0; i < L; ++i) {
-        const u64 bi = aux[1 + i].q;
+    for (size_t i = 0; i < nB; ++i) {
+        const u64 bi = bv(i);
         u64 p = 1, pm = 1;
-        for (size_t k = 0; k < L; ++k)
+        for (size_t k = 0; k < nB; ++k)
             if (k != i) {
-                p = mm(p, aux[1 + k].q % bi, bi);
-                pm = mm(pm, aux[1 + k].q % msk, msk);
+                p = mm(p, bv(k) % bi, bi);
+                pm = mm(pm, bv(k) % msk, msk);
             }
         T.inv_punct_B[i] = invmod(p, bi);
         T.B2msk[i] = pm;
     }
     for (size_t j = 0; j < L; ++j) {
         u64 all = 1;
-        for (size_t k = 0; k < L; ++k) all = mm(all, aux[1 + k].q % qv(j), qv(j));
+        for (size_t k = 0; k < nB; ++k) all = mm(all, bv(k) % qv(j), qv(j));
         T.B_mod_q[j] = all;
-        for (size_t i = 0; i < L; ++i) {
+        for (size_t i = 0; i < nB; ++i) {
             u64 p = 1;
-            for (size_t k = 0; k < L; ++k)
-                if (k != i) p = mm(p, aux[1 + k].q % qv(j), qv(j));
-            T.B2q[j * L + i] = p;
+            for (size_t k = 0; k < nB; ++k)
+                if (k != i) p = mm(p, bv(k) % qv(j), qv(j));
+            T.B2q[j * nB + i] = p;
         }
     }
     return T;

@@ -34,22 +34,24 @@ struct PrimeTables {
     ArF64 arf() const;
 };
 
-// Per-level constants of the BEHZ multiply (RNSTool of SEAL, restated): base q = first L primes, B = B_0..B_{L-1}.
+// Per-level constants of the BEHZ multiply (RNSTool of SEAL, restated): base q = first L primes, B = B_0..B_{nB-1}, then m_sk
+// (S = nB + 1 residues).  The result of the multiply is the same integer for ANY auxiliary base large enough for the
+// Shenoy-Kumaresan step (Params::behz_nB), so the device picks primes of the fp64 engine; see the note at Params::aux.
 struct BehzTables {
-    int L = 0;
+    int L = 0, nB = 0;
     std::vector<u64> inv_punct_q;  // [L]        (Q/q_i)^-1 mod q_i
     std::vector<u64> mtilde_q;     // [L]        2^32 mod q_i
-    std::vector<u64> q2bsk;        // [L+1][L]   (Q/q_i) mod p_j   (p_j: B_0..B_{L-1}, m_sk)
+    std::vector<u64> q2bsk;        // [S][L]     (Q/q_i) mod p_j   (p_j: B_0..B_{nB-1}, m_sk)
     std::vector<u64> q2mt;         // [L]        (Q/q_i) mod 2^32
     u64 neg_inv_q_mod_mt = 0;      //            -Q^-1 mod 2^32
-    std::vector<u64> q_mod_bsk;    // [L+1]
-    std::vector<u64> inv_mt_bsk;   // [L+1]      (2^32)^-1 mod p_j
-    std::vector<u64> inv_q_bsk;    // [L+1]      Q^-1 mod p_j
+    std::vector<u64> q_mod_bsk;    // [S]
+    std::vector<u64> inv_mt_bsk;   // [S]        (2^32)^-1 mod p_j
+    std::vector<u64> inv_q_bsk;    // [S]        Q^-1 mod p_j
     std::vector<u64> t_mod_q;      // [L]
-    std::vector<u64> t_mod_bsk;    // [L+1]
-    std::vector<u64> inv_punct_B;  // [L]        (B/b_i)^-1 mod b_i
-    std::vector<u64> B2q;          // [L][L]     (B/b_i) mod q_j
-    std::vector<u64> B2msk;        // [L]        (B/b_i) mod m_sk
+    std::vector<u64> t_mod_bsk;    // [S]
+    std::vector<u64> inv_punct_B;  // [nB]       (B/b_i)^-1 mod b_i
+    std::vector<u64> B2q;          // [L][nB]    (B/b_i) mod q_j
+    std::vector<u64> B2msk;        // [nB]       (B/b_i) mod m_sk
     u64 inv_B_mod_msk = 0;
     std::vector<u64> B_mod_q;      // [L]
 };
@@ -68,11 +70,21 @@ public:
     size_t Ltop = 0;    // data residues at the first level
     u64 plain_modulus = 0;
     std::vector<PrimeTables> primes;
-    // BFV only: auxiliary BEHZ base (61-bit NTT primes from the same search rule): m_sk, then B_0..B_{Ltop-1};
-    // gamma is the second prime of that search (used by SEAL's decryption, not on the device).
-    // Device prime index of m_sk is K, of B_i is K + 1 + i.
+    // BFV only: auxiliary BEHZ base: m_sk, then B_0..B_{nB(Ltop)-1}.  Device prime index of m_sk is K, of B_i is K + 1 + i.
+    // SEAL's RNSTool takes 61-bit primes (get_primes(2N, 61, |q| + 2) -> m_sk, gamma, B...; |B| = |q|).  The product of the
+    // multiply does not depend on that choice: every step up to the fast floor is a modular identity in each auxiliary prime
+    // (the extended operands, their products and V = floor(t Z / Q) - beta are integers fixed by the base q and m_tilde = 2^32
+    // alone), and the Shenoy-Kumaresan step returns V mod q_j exactly as soon as nB + |V| / B <= (m_sk - 1) / 2
+    // (behz_base_suffices: the bound in integers; SEAL's own sizing rule is the same bound with N rounded up to 2^32).  So the
+    // device uses kAuxBits-bit primes, which the fp64 engine owns, and as many of them as the bound asks for (behz_nB) --
+    // for the reference's parameter sets the same NUMBER of auxiliary residues as SEAL, each at the fp64 engine's cost.
+    // HE355_BEHZ_BASE=seal selects SEAL's 61-bit base (A/B and cross-check; same bits out).
+    static constexpr int kAuxBits = 46;
     std::vector<PrimeTables> aux; // [0] = m_sk, [1 + i] = B_i
-    u64 gamma = 0;
+    bool aux_seal_base = false;
+    u64 gamma = 0;                // second prime of SEAL's 61-bit search (its decryption uses it; not used on the device)
+    size_t behz_nB(int L) const;  // number of B primes at level L
+    bool behz_base_suffices(int L, size_t nB) const; // the exact bound (he_params.cpp)
 
     u64 modulus(size_t i) const { return primes[i].q; }
     // GaloisTool rules (generator 3)

@@ -50,13 +50,14 @@ def test_chain_rule_golden(be):
 
 def test_prime_table_capacity_is_enforced(be):
     """Every per-prime table of the device side holds kMaxPrimes = 64 entries (key chain + BEHZ auxiliary primes + the plain
-    modulus).  A BFV context with 17 data primes is legal (it needs 18 + 19 + 1 = 38) -- round 1 overran a 16-entry array with it
-     -- while one whose tables would not fit is refused at creation, with the parameter error code, not a crash."""
+    modulus).  A BFV context with 17 data primes is legal (18 + 19 auxiliary 46-bit primes + 1 = 38; 18 + 19 + 1 with SEAL's
+    61-bit base too) -- round 1 overran a 16-entry array with it -- while one whose tables would not fit is refused at
+    creation, with the parameter error code, not a crash."""
     ok = be.Context(be.SCHEME_BFV, 32768, bit_sizes=[60] + [45] * 16 + [60], plain_bits=20)
     assert ok.L == 17 and ok.K == 18
     ok.close()
-    with pytest.raises(be.HE355Error) as ei:  # 31 data primes: 32 + 33 + 1 = 66 > 64
-        be.Context(be.SCHEME_BFV, 32768, bit_sizes=[28] * 32, plain_bits=20, sec128=False)
+    with pytest.raises(be.HE355Error) as ei:  # 39 data primes of 60 bits: 40 + 54 (or 40 with SEAL's base) + 1 > 64
+        be.Context(be.SCHEME_BFV, 32768, bit_sizes=[60] * 40, plain_bits=20, sec128=False)
     assert ei.value.code == be.E_PARAMS and "too many primes" in str(ei.value)
     big = be.Context(be.SCHEME_CKKS, 32768, bit_sizes=[28] * 32, sec128=False)  # CKKS has no auxiliary base: 32 primes are fine
     assert big.K == 32

@@ -230,6 +230,59 @@ def test_bfv_random_parameter_chains(be, oracle, seed):
     g.close()
 
 
+def _residues(o, values, L):
+    """Integer coefficient vector(s) -> residues [.., L, N] under the first L moduli."""
+    return np.stack([np.array([int(v) % q for v in values], dtype=np.uint64) for q in o.moduli[:L]])
+
+
+@pytest.mark.parametrize("base", ["device", "seal"])
+@pytest.mark.parametrize("name,N,bits,pb", [
+    ("default_d3", 4096, [60, 40, 40, 60], 20),          # <4, 6> instantiation of the coefficient kernels
+    ("six_data_primes", 2048, [50, 40, 40, 45, 40, 60, 60], 22),   # <16, 24>, both engines among the data primes
+    ("all_60_bit", 2048, [60, 60, 60, 60, 60], 31),      # the most auxiliary primes per data prime, the largest plain modulus
+])
+def test_bfv_multiply_is_independent_of_the_auxiliary_base(be, oracle, monkeypatch, base, name, N, bits, pb):
+    """The BEHZ product is fixed by the base q and m_tilde alone (he_params.h, Params::aux): the device's 46-bit auxiliary primes
+    (fp64 engine) and SEAL's 61-bit ones (HE355_BEHZ_BASE=seal) must both give the oracle's bits -- the oracle restates SEAL's
+    RNSTool with SEAL's base -- on random operands AND on operands that drive every bound of the Shenoy-Kumaresan step to its
+    extreme: all coefficients +-Q/2 with the signs that make the negacyclic sums of coefficient N-1 (no wrapped terms) and of
+    coefficient 0 (all but one term wrapped) as large as they get, and all coefficients Q-1 / 0 / 1."""
+    if base == "seal":
+        monkeypatch.setenv("HE355_BEHZ_BASE", "seal")
+    else:
+        monkeypatch.delenv("HE355_BEHZ_BASE", raising=False)
+    g = be.Context(be.SCHEME_BFV, N, bit_sizes=bits, plain_bits=pb, sec128=False, device=0)
+    o = oracle.Context(oracle.SCHEME_BFV, N, bit_sizes=bits, plain_bits=pb, sec128=False)
+    assert g.moduli == o.moduli and g.t == o.t
+    L = g.L
+    Q = 1
+    for q in o.moduli[:L]:
+        Q *= int(q)
+    h = Q // 2
+    alt = [h if i % 2 == 0 else h + 1 for i in range(N)]          # +Q/2, -Q/2 alternating
+    first_neg = [h + 1] + [h] * (N - 1)                            # coefficient 0: -a_0 b_0 ... all wrapped terms add up
+    polys = {
+        "plus_half": _residues(o, [h] * N, L), "minus_half": _residues(o, [h + 1] * N, L), "alternating": _residues(o, alt, L),
+        "first_negative": _residues(o, first_neg, L), "q_minus_1": _residues(o, [Q - 1] * N, L), "zero": _residues(o, [0] * N, L),
+        "one": _residues(o, [1] * N, L),
+    }
+    rng = np.random.default_rng(77)
+    cts = [np.stack([polys[x], polys[y]]) for x, y in [("plus_half", "plus_half"), ("minus_half", "plus_half"), ("alternating", "alternating"),
+                                                         ("first_negative", "minus_half"), ("q_minus_1", "q_minus_1"), ("zero", "one"),
+                                                         ("q_minus_1", "plus_half")]]
+    cts += [o.random_poly(rng, L, 2) for _ in range(2)]
+    a = np.stack(cts)
+    n = len(cts)
+    out = g.alloc(n * n * 3 * L * N)
+    da = g.to_device(a)
+    g.bfv_multiply(L, n * n, da, da, be.Context.outer(0, n, 0, n), out)
+    got = out.download((n * n, 3, L, N))
+    for i in range(n):
+        for x in range(n):
+            assert np.array_equal(got[i * n + x], o.bfv_multiply(a[i], a[x])), (base, name, i, x)
+    g.close()
+
+
 @pytest.mark.parametrize("walk", ["by_node", "by_level", "by_level_chunked"])
 def test_rotate_sum_shares_naf_prefixes_bit_for_bit(pair, be, walk):
     """(walk: the trie node by node -- what batches of at most he355_set_latency_max ciphertexts take -- or level by level, all nodes of
