@@ -1287,24 +1287,43 @@ public:
         if (it != behz_.end()) return it->second;
         if (L > kBehzMaxL) throw std::invalid_argument("BFV multiply supports at most 16 data primes in this build");
         const BehzTables T = P.behz_tables(L);
+        const int nB = T.nB, S = nB + 1;
+        if (nB > kBehzMaxB) throw std::invalid_argument("BFV multiply: auxiliary base too large for this build");
+        auto mm = [](u64 x, u64 y, u64 m) { return (u64)(((u128)x * y) % m); };
+        auto pj = [&](int j) { return j < nB ? P.aux[1 + j].q : P.aux[0].q; };
+        std::vector<u64> cq(L), f_cq(L), e_q2bsk((size_t)S * L), e_qmod(S), f_ds(S), f_neg((size_t)S * L), a_msk(nB);
+        for (int i = 0; i < L; ++i) {
+            const u64 q = P.primes[i].q;
+            cq[i] = mm(T.mtilde_q[i], T.inv_punct_q[i], q);
+            f_cq[i] = mm(T.t_mod_q[i], T.inv_punct_q[i], q);
+        }
+        for (int j = 0; j < S; ++j) {
+            const u64 p = pj(j);
+            const u64 c = j < nB ? mm(T.inv_q_bsk[j], T.inv_punct_B[j], p) : T.inv_q_bsk[j];
+            e_qmod[j] = mm(T.q_mod_bsk[j], T.inv_mt_bsk[j], p);
+            f_ds[j] = mm(T.t_mod_bsk[j], c, p);
+            for (int i = 0; i < L; ++i) {
+                e_q2bsk[(size_t)j * L + i] = mm(T.q2bsk[(size_t)j * L + i], T.inv_mt_bsk[j], p);
+                const u64 v = mm(T.q2bsk[(size_t)j * L + i], c, p);
+                f_neg[(size_t)j * L + i] = v ? p - v : 0;
+            }
+        }
+        const u64 msk = P.aux[0].q;
+        for (int j = 0; j < nB; ++j) a_msk[j] = mm(T.B2msk[j], T.inv_B_mod_msk, msk);
         std::vector<u64> blob;
         auto push = [&](const std::vector<u64> &v) { const size_t off = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return off; };
-        std::vector<u64> cq(L);
-        for (int i = 0; i < L; ++i) cq[i] = (u64)(((u128)T.mtilde_q[i] * T.inv_punct_q[i]) % P.primes[i].q);
-        const size_t o_cq = push(cq), o_ip = push(T.inv_punct_q), o_q2b = push(T.q2bsk), o_q2m = push(T.q2mt), o_qmb = push(T.q_mod_bsk),
-                     o_imb = push(T.inv_mt_bsk), o_iqb = push(T.inv_q_bsk), o_tq = push(T.t_mod_q), o_tb = push(T.t_mod_bsk), o_ipB = push(T.inv_punct_B),
-                     o_B2q = push(T.B2q), o_B2m = push(T.B2msk), o_Bq = push(T.B_mod_q);
+        const size_t o_cq = push(cq), o_q2m = push(T.q2mt), o_e2b = push(e_q2bsk), o_eqm = push(e_qmod), o_fcq = push(f_cq), o_fds = push(f_ds),
+                     o_fng = push(f_neg), o_am = push(a_msk), o_B2q = push(T.B2q), o_Bq = push(T.B_mod_q);
         u64 *d = nullptr;
         dmalloc(d, blob.size() * 8);
         owned_.push_back(d);
         HIPCHECK(hipMemcpy(d, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
         BehzDev Z{};
         Z.L = L;
-        Z.nB = T.nB;
-        if (T.nB > kBehzMaxB) throw std::invalid_argument("BFV multiply: auxiliary base too large for this build");
-        Z.cq = d + o_cq; Z.inv_punct_q = d + o_ip; Z.q2bsk = d + o_q2b; Z.q2mt = d + o_q2m; Z.neg_inv_q_mod_mt = T.neg_inv_q_mod_mt;
-        Z.q_mod_bsk = d + o_qmb; Z.inv_mt_bsk = d + o_imb; Z.inv_q_bsk = d + o_iqb; Z.t_mod_q = d + o_tq; Z.t_mod_bsk = d + o_tb;
-        Z.inv_punct_B = d + o_ipB; Z.B2q = d + o_B2q; Z.B2msk = d + o_B2m; Z.inv_B_mod_msk = T.inv_B_mod_msk; Z.B_mod_q = d + o_Bq;
+        Z.nB = nB;
+        Z.cq = d + o_cq; Z.q2mt = d + o_q2m; Z.neg_inv_q_mod_mt = T.neg_inv_q_mod_mt; Z.e_q2bsk = d + o_e2b; Z.e_qmod = d + o_eqm;
+        Z.f_cq = d + o_fcq; Z.f_ds = d + o_fds; Z.f_neg = d + o_fng;
+        Z.a_msk = d + o_am; Z.neg_inv_B = T.inv_B_mod_msk ? msk - T.inv_B_mod_msk : 0; Z.B2q = d + o_B2q; Z.B_mod_q = d + o_Bq;
         for (int j = 0; j < T.nB; ++j) Z.bsk_prime[j] = (unsigned char)(P.K + 1 + j); // B_j
         Z.bsk_prime[T.nB] = (unsigned char)P.K;                                        // m_sk
         return behz_[L] = Z;
@@ -1346,18 +1365,28 @@ public:
         for (size_t j = 0; j < S; ++j) { pb[j] = Z.bsk_prime[j]; vb.prime_of[j] = pb[j]; }
         vq.polys_per_item = L; vq.item_stride = (u64)L * N;
         vb.polys_per_item = (int)S; vb.item_stride = (u64)S * N;
+        const bool fuse_cols = behz_cols_fusable(env_, Z);
         for (u64 off = 0; off < n; off += c) {
             const u64 nc = std::min<u64>(c, n - off);
-            launch_behz_extend(env_, Z, nc, off, a, b, ix, xq, xb);
-            // forward column passes, then per (op, residue, row) ONE kernel for the forward row pass of the four polynomials, the dyadic
-            // tensor and the inverse row pass of the three products (k_behz_rows_tensor), then the inverse column passes
-            vq.base = xq; launch_cols_fwd(env_, vq, (u32)(nc * 4));
-            vb.base = xb; launch_cols_fwd(env_, vb, (u32)(nc * 4));
+            // extension to Bsk and forward column passes (one kernel where the fused shape applies), then per (op, residue, row) ONE
+            // kernel for the forward row pass of the four polynomials, the dyadic tensor and the inverse row pass of the three
+            // products (k_behz_rows_tensor), then the inverse column passes and steps (6)-(8) (again one kernel where it applies)
+            if (fuse_cols) {
+                launch_behz_extend_cols(env_, Z, nc, off, a, b, ix, xq, xb);
+            } else {
+                launch_behz_extend(env_, Z, nc, off, a, b, ix, xq, xb);
+                vq.base = xq; launch_cols_fwd(env_, vq, (u32)(nc * 4));
+                vb.base = xb; launch_cols_fwd(env_, vb, (u32)(nc * 4));
+            }
             launch_behz_rows_tensor(env_, L, pq, nc, xq, dq);
             launch_behz_rows_tensor(env_, (int)S, pb, nc, xb, ds);
-            vq.base = dq; launch_cols_inv(env_, vq, (u32)(nc * 3));
-            vb.base = ds; launch_cols_inv(env_, vb, (u32)(nc * 3));
-            launch_behz_floor_sk(env_, Z, nc, dq, ds, out + off * 3 * (size_t)L * N);
+            if (fuse_cols) {
+                launch_behz_cols_floor_sk(env_, Z, nc, dq, ds, out + off * 3 * (size_t)L * N);
+            } else {
+                vq.base = dq; launch_cols_inv(env_, vq, (u32)(nc * 3));
+                vb.base = ds; launch_cols_inv(env_, vb, (u32)(nc * 3));
+                launch_behz_floor_sk(env_, Z, nc, dq, ds, out + off * 3 * (size_t)L * N);
+            }
         }
         HIPCHECK(hipGetLastError());
     }

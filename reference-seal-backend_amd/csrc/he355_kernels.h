@@ -147,21 +147,28 @@ struct FloorRowsArgs {
 };
 void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &args);
 // ---- BFV -------------------------------------------------------------------------------------------------
-// Device copy of BehzTables (he_params.h); all pointers are HBM.  Bsk order: B_0..B_{nB-1}, m_sk (S = nB + 1).
+// Device constants of the BEHZ multiply, derived from BehzTables (he_params.h) with every chain of constant factors folded into one
+// (he355_api.hip, DeviceContext::behz): each step is then ONE 128-bit sum of products and ONE Barrett reduction -- same residues.
+// All pointers are HBM.  Bsk order: B_0..B_{nB-1}, m_sk (S = nB + 1); p_j the j-th of them.
 struct BehzDev {
     int L, nB;
-    const u64 *cq;          // [L]      2^32 * (Q/q_i)^-1 mod q_i  (fastbconv_m_tilde, merged constants)
-    const u64 *inv_punct_q; // [L]
-    const u64 *q2bsk;       // [S][L]
-    const u64 *q2mt;        // [L]
-    u64 neg_inv_q_mod_mt;
-    const u64 *q_mod_bsk, *inv_mt_bsk, *inv_q_bsk; // [S]
-    const u64 *t_mod_q;     // [L]
-    const u64 *t_mod_bsk;   // [S]
-    const u64 *inv_punct_B; // [nB]
-    const u64 *B2q;         // [L][nB]
-    const u64 *B2msk;       // [nB]
-    u64 inv_B_mod_msk;
+    // steps (1)-(2), base extension q -> Bsk with the Montgomery correction mod m_tilde = 2^32:
+    //   tmp_i = x_i cq_i mod q_i;  r = -(sum_i tmp_i q2mt_i) Q^-1 mod 2^32, centred;  out_j = sum_i tmp_i e_q2bsk_ji + r e_qmod_j mod p_j
+    const u64 *cq;          // [L]      2^32 (Q/q_i)^-1 mod q_i
+    const u64 *q2mt;        // [L]      (Q/q_i) mod 2^32
+    u64 neg_inv_q_mod_mt;   //          -Q^-1 mod 2^32
+    const u64 *e_q2bsk;     // [S][L]   (Q/q_i) 2^-32 mod p_j
+    const u64 *e_qmod;      // [S]      Q 2^-32 mod p_j
+    // steps (6)-(7), times t and fast floor, with (B/b_j)^-1 of step (8) folded in for j < nB:
+    //   tmp_i = d_i f_cq_i mod q_i;  fl_j = ds_j f_ds_j + sum_i tmp_i f_neg_ji mod p_j
+    const u64 *f_cq;        // [L]      t (Q/q_i)^-1 mod q_i
+    const u64 *f_ds;        // [S]      t Q^-1 c_j mod p_j,  c_j = (B/b_j)^-1 mod b_j (j < nB), 1 (m_sk)
+    const u64 *f_neg;       // [S][L]   -(Q/q_i) Q^-1 c_j mod p_j
+    // step (8), Shenoy-Kumaresan: alpha = sum_j fl_j a_msk_j + fl_sk neg_inv_B mod m_sk, centred;
+    //   out_i = sum_j fl_j B2q_ij - alpha B mod q_i
+    const u64 *a_msk;       // [nB]     (B/b_j) B^-1 mod m_sk
+    u64 neg_inv_B;          //          -B^-1 mod m_sk
+    const u64 *B2q;         // [L][nB]  (B/b_j) mod q_i
     const u64 *B_mod_q;     // [L]
     unsigned char bsk_prime[64]; // device prime index of Bsk element j
 };
@@ -171,6 +178,11 @@ constexpr int kBehzMaxB = 24; // base B (Params::behz_nB: 22 for sixteen 60-bit 
 // for the base-q transform.  xq [n*4][L][N], xbsk [n*4][S][N], coefficient form.
 // results op_offset .. op_offset + n_ops - 1 of the batch (the indexer sees the global result index)
 void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk);
+// N <= 8192, L <= 4, nB <= 6 (and HE355_BEHZ_FUSE != 0): the extension with the forward column passes of xq / xbsk in its epilogue,
+// and the inverse column passes of dq / ds in the prologue of steps (6)-(8) -- the coefficient-form copies never reach HBM
+bool behz_cols_fusable(const KernelEnv &env, const BehzDev &bz);
+void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk);
+void launch_behz_cols_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out);
 // BEHZ steps (3)-(5) on rows, fused: x [n*4][Lx][N] after launch_cols_fwd -> forward row pass of a0, a1, b0, b1, dyadic tensor, inverse row
 // pass -> d [n*3][Lx][N] ready for launch_cols_inv (one block = the four rows of one (op, residue, row); no HBM round trip between them)
 void launch_behz_rows_tensor(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d);

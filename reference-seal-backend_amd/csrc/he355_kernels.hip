@@ -1816,6 +1816,30 @@ __device__ __forceinline__ ModU64 mod_of(const PrimeDev *primes, int idx) { retu
 
 // ML / MB: compile-time bounds of the bases q and B (loops fully unrolled under them, per-residue values in registers): <4, 6> serves
 // the reference's default parameter sets ({60,40,40} and {60,40,40,40}), <kBehzMaxL, kBehzMaxB> everything else.
+// One coefficient through fastbconv_m_tilde's first half: tmp_i = x_i m_tilde (Q/q_i)^-1 mod q_i, and r = -(sum tmp_i Q/q_i) Q^-1 mod m_tilde
+template <int ML> __device__ __forceinline__ void behz_ext_prepare(const BehzDev &Z, const PrimeDev *primes, int L, const u64 x[ML], u64 tmp[ML], u64 &rmt)
+{
+    u64 mt_acc = 0;
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+        if (i < L) {
+            tmp[i] = mulmod(x[i], Z.cq[i], mod_of(primes, i));
+            mt_acc += (tmp[i] & 0xFFFFFFFFull) * Z.q2mt[i];
+        }
+    rmt = ((mt_acc & 0xFFFFFFFFull) * Z.neg_inv_q_mod_mt) & 0xFFFFFFFFull;
+}
+// ... and its residue mod Bsk element j after sm_mrq, (sum tmp_i (Q/q_i) + r Q) m_tilde^-1 mod p_j with r centred: one sum of
+// products (constants carry m_tilde^-1; at most 17 terms below 2^122), one reduction
+template <int ML> __device__ __forceinline__ u64 behz_ext_residue(const BehzDev &Z, const ModU64 &mj, int L, int j, const u64 tmp[ML], u64 rmt)
+{
+    const u64 MT = (u64)1 << 32;
+    const u64 rr = rmt >= (MT >> 1) ? rmt + (mj.q - MT) : rmt; // centred r as a residue mod p_j
+    u128 acc = (u128)rr * Z.e_qmod[j];
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+        if (i < L) acc += (u128)tmp[i] * Z.e_q2bsk[j * L + i];
+    return barrett128(acc, mj);
+}
 template <int ML, int MB>
 __global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDev *primes, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk,
                                                         u64 n_ops, int logN, u64 op_offset)
@@ -1831,32 +1855,88 @@ __global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDe
     const u64 N = (u64)1 << logN, P1 = (u64)L * N;
     const u64 rg = op_offset + r; // result index in the whole batch: picks the operands (outer product or pairwise)
     const u64 *src = (c ? b + idx_b(ix, rg) * 2 * P1 : a + idx_a(ix, rg) * 2 * P1) + (u64)k * P1 + n;
-    u64 tmp[ML];
-    u64 mt_acc = 0;
+    u64 x[ML], tmp[ML], rmt;
 #pragma unroll
-    for (int i = 0; i < ML; ++i) {
+    for (int i = 0; i < ML; ++i)
         if (i < L) {
-            const u64 x = src[(u64)i * N];
-            xq[(pid * L + i) * N + n] = x;
-            tmp[i] = mulmod(x, Z.cq[i], mod_of(primes, i)); // x * m_tilde * (Q/q_i)^-1 mod q_i
-            mt_acc += (tmp[i] & 0xFFFFFFFFull) * Z.q2mt[i];
+            x[i] = src[(u64)i * N];
+            xq[(pid * L + i) * N + n] = x[i];
         }
-    }
-    const u64 MT = (u64)1 << 32;
-    const u64 rmt = (((mt_acc & 0xFFFFFFFFull) * Z.neg_inv_q_mod_mt) & 0xFFFFFFFFull); // -(x*m_tilde)_fast * Q^-1 mod m_tilde
+    behz_ext_prepare<ML>(Z, primes, L, x, tmp, rmt);
 #pragma unroll kUnrollB
     for (int j = 0; j < MB + 1; ++j) {
         if (j >= S) break;
-        const ModU64 mj = mod_of(primes, Z.bsk_prime[j]);
-        u128 acc = 0;
+        xbsk[(pid * S + j) * N + n] = behz_ext_residue<ML>(Z, mod_of(primes, Z.bsk_prime[j]), L, j, tmp, rmt);
+    }
+}
+
+// Forward column pass of one residue's column held in registers (canonical in, raw out), by the engine that owns the prime.
+template <int LOGN1> __device__ __forceinline__ void col_fwd_store(const PrimeDev &P, const u64 v[1 << LOGN1], u64 *dst)
+{
+    constexpr int N1 = 1 << LOGN1;
+    if (P.f64) {
+        const ArF64 ar = make_ar(P, (ArF64 *)nullptr);
+        double y[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) y[a] = ar.from_canon(v[a]);
+        col_fwd<ArF64, LOGN1>(ar, y, ctw(P.fwd));
+#pragma unroll
+        for (int a = 0; a < N1; ++a) dst[a << kRowLog] = ar.to_raw(y[a]);
+    } else {
+        const ArU64 ar = make_ar(P, (ArU64 *)nullptr);
+        u64 y[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) y[a] = v[a];
+        col_fwd<ArU64, LOGN1>(ar, y, ctw(P.fwd));
+#pragma unroll
+        for (int a = 0; a < N1; ++a) dst[a << kRowLog] = y[a];
+    }
+}
+// BEHZ steps (1)-(2) AND the forward column pass of all L + S residues in one kernel (N <= 8192, L <= 4, nB <= 6), so that the
+// coefficient-form copies xq / xbsk never exist in HBM (k_behz_extend + k_cols_fwd x2 write them and read them back: 2 (L + S)
+// polynomial transfers per input polynomial saved).  A block = 64 columns x N1 rows of one input polynomial, one wave per row:
+// phase 1, lane (row e, column c) extends its coefficient to Bsk and parks the L + S residues in LDS [residue][e][c]; phase 2, wave w
+// takes residues w, w + N1, ...: each lane runs that residue's column pass on the N1 values of its column (wave-uniform prime, so
+// the engine branch does not diverge) and stores the raw rows.
+template <int LOGN1, int ML, int MB>
+__global__ void __launch_bounds__(64 << LOGN1) k_behz_extend_cols(BehzDev Z, const PrimeDev *primes, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk,
+                                                                  u64 op_offset)
+{
+    constexpr int N1 = 1 << LOGN1;
+    extern __shared__ u64 behz_sm[]; // [L + S][N1][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 pid = blockIdx.x >> 4; // (op, which ct, which poly); 16 column groups per polynomial
+    const u64 col = ((blockIdx.x & 15) << 6) | lane;
+    const u64 r = pid >> 2;
+    const int c = (int)((pid >> 1) & 1), k = (int)(pid & 1);
+    const int L = Z.L, S = Z.nB + 1;
+    const u64 N = (u64)N1 << kRowLog, P1 = (u64)L * N;
+    const u64 rg = op_offset + r;
+    {
+        const u64 *src = (c ? b + idx_b(ix, rg) * 2 * P1 : a + idx_a(ix, rg) * 2 * P1) + (u64)k * P1 + ((u64)wave << kRowLog) + col;
+        u64 x[ML], tmp[ML], rmt;
 #pragma unroll
         for (int i = 0; i < ML; ++i)
-            if (i < L) acc += (u128)tmp[i] * Z.q2bsk[j * L + i];
-        const u64 conv = barrett128(acc, mj);
-        u64 rr = rmt;
-        if (rr >= (MT >> 1)) rr += mj.q - MT; // centred r as a residue mod p_j
-        const u64 v = barrett128((u128)rr * Z.q_mod_bsk[j] + conv, mj);
-        xbsk[(pid * S + j) * N + n] = mulmod(v, Z.inv_mt_bsk[j], mj);
+            if (i < L) {
+                x[i] = src[(u64)i * N];
+                behz_sm[((i * N1 + wave) << 6) | lane] = x[i];
+            }
+        behz_ext_prepare<ML>(Z, primes, L, x, tmp, rmt);
+#pragma unroll
+        for (int j = 0; j < MB + 1; ++j) {
+            if (j >= S) break;
+            behz_sm[(((L + j) * N1 + wave) << 6) | lane] = behz_ext_residue<ML>(Z, mod_of(primes, Z.bsk_prime[j]), L, j, tmp, rmt);
+        }
+    }
+    __syncthreads();
+    for (int rr = wave; rr < L + S; rr += N1) {
+        const bool isq = rr < L;
+        const PrimeDev &P = primes[isq ? rr : Z.bsk_prime[rr - L]];
+        u64 *dst = (isq ? xq + (pid * L + rr) * N : xbsk + (pid * S + (rr - L)) * N) + col;
+        u64 v[N1];
+#pragma unroll
+        for (int e = 0; e < N1; ++e) v[e] = behz_sm[((rr * N1 + e) << 6) | lane];
+        col_fwd_store<LOGN1>(P, v, dst);
     }
 }
 
@@ -1936,6 +2016,54 @@ __global__ void __launch_bounds__(kBlock) k_behz_rows_tensor(BehzRowsArgs A, con
     store_rowA(A.d + (op * 3 + wave) * A.Lx * N + rowoff, lane, v);
 }
 
+// BEHZ steps (6)-(8) for one coefficient: dq[i] (base q), ds[j] (Bsk) canonical residues of a product -> its L output residues.
+// Constant factors are folded (BehzDev): every line below is one sum of products below 2^122 (at most 25 of them) and one reduction.
+template <int ML, int MB>
+__device__ __forceinline__ void behz_floor_sk_coeff(const BehzDev &Z, const PrimeDev *primes, const u64 dq[ML], const u64 ds[MB + 1], u64 res[ML])
+{
+    constexpr int kUnrollB = MB <= 6 ? MB + 1 : 1, kUnrollL = ML <= 4 ? ML : 1; // the large instantiation keeps its residue loops rolled
+    const int L = Z.L, nB = Z.nB, S = nB + 1;
+    u64 tmp[ML], fl[MB];
+    // (6) times t, and the base-q part prepared for the fast conversion (canonical: the conversion depends on the representative)
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+        if (i < L) tmp[i] = mulmod(dq[i], Z.f_cq[i], mod_of(primes, i));
+    // (7) fast floor (t x_Bsk - FastBconv(t x_q)) Q^-1 mod p_j, times (B/b_j)^-1 for the B part; (8) first half: alpha_sk
+    const ModU64 msk = mod_of(primes, Z.bsk_prime[nB]);
+    u128 accs = 0;
+#pragma unroll kUnrollB
+    for (int j = 0; j < MB + 1; ++j)
+        if (j < S) {
+            const ModU64 mj = mod_of(primes, Z.bsk_prime[j]);
+            u128 acc = (u128)ds[j] * Z.f_ds[j];
+#pragma unroll
+            for (int i = 0; i < ML; ++i)
+                if (i < L) acc += (u128)tmp[i] * Z.f_neg[j * L + i];
+            const u64 f = barrett128(acc, mj);
+            if (j < nB) {
+                if (j < MB) { // (always; keeps the index static)
+                    fl[j] = f;
+                    accs += (u128)f * Z.a_msk[j];
+                }
+            } else {
+                accs += (u128)f * Z.neg_inv_B;
+            }
+        }
+    const u64 alpha = barrett128(accs, msk);
+    const bool neg = alpha > (msk.q >> 1);
+    // (8) second half: B -> q with the alpha_sk correction
+#pragma unroll kUnrollL
+    for (int j = 0; j < ML; ++j) {
+        if (j >= L) break;
+        const ModU64 mj = mod_of(primes, j);
+        const u64 Bq = Z.B_mod_q[j];
+        u128 acc = neg ? (u128)(msk.q - alpha) * Bq : (u128)alpha * (Bq ? mj.q - Bq : 0);
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+            if (i < nB) acc += (u128)fl[i] * Z.B2q[j * nB + i];
+        res[j] = barrett128(acc, mj);
+    }
+}
 template <int ML, int MB>
 __global__ void __launch_bounds__(kBlock) k_behz_floor_sk(BehzDev Z, const PrimeDev *primes, const u64 *dq, const u64 *ds, u64 *out, u64 n_polys, int logN)
 {
@@ -1944,56 +2072,78 @@ __global__ void __launch_bounds__(kBlock) k_behz_floor_sk(BehzDev Z, const Prime
     const u64 pid = gid >> logN; // (op, k)
     if (pid >= n_polys) return;
     constexpr int kUnrollB = MB <= 6 ? MB + 1 : 1, kUnrollL = ML <= 4 ? ML : 1;
-    const int L = Z.L, nB = Z.nB, S = nB + 1;
+    const int L = Z.L, S = Z.nB + 1;
     const u64 N = (u64)1 << logN;
-    u64 tmp[ML], fl[MB];
-    // (6) times t, then the base-q part prepared for the fast conversion
-#pragma unroll
+    u64 vq[ML], vs[MB + 1], res[ML];
+#pragma unroll kUnrollL
     for (int i = 0; i < ML; ++i)
-        if (i < L) {
-            const ModU64 mi = mod_of(primes, i);
-            tmp[i] = mulmod(mulmod(dq[(pid * L + i) * N + n], Z.t_mod_q[i], mi), Z.inv_punct_q[i], mi);
-        }
-    // (7) fast floor: (x_Bsk - FastBconv(x_q)) * Q^-1 mod p_j;  (8) Shenoy-Kumaresan, first half: the B residues times
-    // (B/b_j)^-1 and their weighted sum mod m_sk
-    const ModU64 msk = mod_of(primes, Z.bsk_prime[nB]);
-    u128 accs = 0;
-    u64 fl_sk = 0;
+        if (i < L) vq[i] = dq[(pid * L + i) * N + n];
 #pragma unroll kUnrollB
     for (int j = 0; j < MB + 1; ++j)
-        if (j < S) {
-            const ModU64 mj = mod_of(primes, Z.bsk_prime[j]);
-            u128 acc = 0;
-#pragma unroll
-            for (int i = 0; i < ML; ++i)
-                if (i < L) acc += (u128)tmp[i] * Z.q2bsk[j * L + i];
-            const u64 conv = barrett128(acc, mj);
-            const u64 xs = mulmod(ds[(pid * S + j) * N + n], Z.t_mod_bsk[j], mj);
-            const u64 f = mulmod(submod(xs, conv, mj.q), Z.inv_q_bsk[j], mj);
-            if (j < nB) {
-                if (j < MB) { // (always; keeps the index static)
-                    fl[j] = mulmod(f, Z.inv_punct_B[j], mj);
-                    accs += (u128)fl[j] * Z.B2msk[j]; // < 2^122 each, at most 24 (16 with 61-bit primes) of them
-                }
-            } else {
-                fl_sk = f;
-            }
-        }
-    const u64 alpha = mulmod(submod(barrett128(accs, msk), fl_sk, msk.q), Z.inv_B_mod_msk, msk);
-    const bool neg = alpha > (msk.q >> 1);
+        if (j < S) vs[j] = ds[(pid * S + j) * N + n];
+    behz_floor_sk_coeff<ML, MB>(Z, primes, vq, vs, res);
 #pragma unroll kUnrollL
-    for (int j = 0; j < ML; ++j) {
-        if (j >= L) break;
-        const ModU64 mj = mod_of(primes, j);
-        u128 acc = 0;
+    for (int j = 0; j < ML; ++j)
+        if (j < L) out[(pid * L + j) * N + n] = res[j];
+}
+
+// Inverse column pass of one residue's column (raw in, canonical out, in registers), by the engine that owns the prime.
+template <int LOGN1> __device__ __forceinline__ void col_inv_load(const PrimeDev &P, const u64 *src, u64 v[1 << LOGN1])
+{
+    constexpr int N1 = 1 << LOGN1;
+    if (P.f64) {
+        const ArF64 ar = make_ar(P, (ArF64 *)nullptr);
+        double y[N1];
 #pragma unroll
-        for (int i = 0; i < MB; ++i)
-            if (i < nB) acc += (u128)fl[i] * Z.B2q[j * nB + i];
-        const u64 conv = barrett128(acc, mj);
-        const u64 Bq = Z.B_mod_q[j];
-        const u64 res = neg ? barrett128((u128)(msk.q - alpha) * Bq + conv, mj) : barrett128((u128)alpha * (Bq ? mj.q - Bq : 0) + conv, mj);
-        out[(pid * L + j) * N + n] = res;
+        for (int a = 0; a < N1; ++a) y[a] = ar.from_raw(src[a << kRowLog]);
+        col_inv<ArF64, LOGN1>(ar, y, ctw(P.inv), P.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) v[a] = ar.to_canon(y[a]);
+    } else {
+        const ArU64 ar = make_ar(P, (ArU64 *)nullptr);
+        u64 y[N1];
+#pragma unroll
+        for (int a = 0; a < N1; ++a) y[a] = src[a << kRowLog];
+        col_inv<ArU64, LOGN1>(ar, y, ctw(P.inv), P.inv_w0_scaled);
+#pragma unroll
+        for (int a = 0; a < N1; ++a) v[a] = ar.to_canon(y[a]);
     }
+}
+// The inverse column pass of all L + S residues AND BEHZ steps (6)-(8) in one kernel (N <= 8192, L <= 4, nB <= 6): the mirror image of
+// k_behz_extend_cols -- phase 1, wave w runs the column passes of residues w, w + N1, ... for the block's 64 columns and parks the
+// canonical values in LDS [residue][e][c]; phase 2, lane (row e, column c) takes its coefficient's L + S residues through the fast
+// floor and the Shenoy-Kumaresan conversion.  The coefficient-form products never exist in HBM.
+template <int LOGN1, int ML, int MB>
+__global__ void __launch_bounds__(64 << LOGN1) k_behz_cols_floor_sk(BehzDev Z, const PrimeDev *primes, const u64 *dq, const u64 *ds, u64 *out)
+{
+    constexpr int N1 = 1 << LOGN1;
+    extern __shared__ u64 behz_sm[]; // [L + S][N1][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 pid = blockIdx.x >> 4; // (op, k)
+    const u64 col = ((blockIdx.x & 15) << 6) | lane;
+    const int L = Z.L, S = Z.nB + 1;
+    const u64 N = (u64)N1 << kRowLog;
+    for (int rr = wave; rr < L + S; rr += N1) {
+        const bool isq = rr < L;
+        const PrimeDev &P = primes[isq ? rr : Z.bsk_prime[rr - L]];
+        const u64 *src = (isq ? dq + (pid * L + rr) * N : ds + (pid * S + (rr - L)) * N) + col;
+        u64 v[N1];
+        col_inv_load<LOGN1>(P, src, v);
+#pragma unroll
+        for (int e = 0; e < N1; ++e) behz_sm[((rr * N1 + e) << 6) | lane] = v[e];
+    }
+    __syncthreads();
+    u64 vq[ML], vs[MB + 1], res[ML];
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+        if (i < L) vq[i] = behz_sm[((i * N1 + wave) << 6) | lane];
+#pragma unroll
+    for (int j = 0; j < MB + 1; ++j)
+        if (j < S) vs[j] = behz_sm[(((L + j) * N1 + wave) << 6) | lane];
+    behz_floor_sk_coeff<ML, MB>(Z, primes, vq, vs, res);
+#pragma unroll
+    for (int j = 0; j < ML; ++j)
+        if (j < L) out[(pid * L + j) * N + ((u64)wave << kRowLog) + col] = res[j];
 }
 
 // coefficient-form automorphism as a gather (2 polys of a size-2 ciphertext)
@@ -2492,6 +2642,35 @@ void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 
         hipLaunchKernelGGL((k_behz_extend<4, 6>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, a, b, ix, xq, xbsk, n_ops, logN, op_offset);
     else
         hipLaunchKernelGGL((k_behz_extend<kBehzMaxL, kBehzMaxB>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, a, b, ix, xq, xbsk, n_ops, logN, op_offset);
+}
+bool behz_cols_fusable(const KernelEnv &env, const BehzDev &bz)
+{
+    static const bool on = [] { const char *e = std::getenv("HE355_BEHZ_FUSE"); return !(e && e[0] == '0'); }();
+    return on && bz.L <= 4 && bz.nB <= 6 && env.logn1 >= 1 && env.logn1 <= 3;
+}
+void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk)
+{
+    if (!n_ops) return;
+    if (!behz_cols_fusable(env, bz)) throw std::logic_error("launch_behz_extend_cols: shape not covered by the fused kernel");
+    const dim3 g((unsigned)(n_ops * 4 * 16)), blk(64u << env.logn1);
+    const size_t lds = (size_t)(bz.L + bz.nB + 1) * (64u << env.logn1) * 8;
+    switch (env.logn1) {
+    case 1: hipLaunchKernelGGL((k_behz_extend_cols<1, 4, 6>), g, blk, lds, env.stream, bz, env.primes, a, b, ix, xq, xbsk, op_offset); break;
+    case 2: hipLaunchKernelGGL((k_behz_extend_cols<2, 4, 6>), g, blk, lds, env.stream, bz, env.primes, a, b, ix, xq, xbsk, op_offset); break;
+    default: hipLaunchKernelGGL((k_behz_extend_cols<3, 4, 6>), g, blk, lds, env.stream, bz, env.primes, a, b, ix, xq, xbsk, op_offset); break;
+    }
+}
+void launch_behz_cols_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out)
+{
+    if (!n_ops) return;
+    if (!behz_cols_fusable(env, bz)) throw std::logic_error("launch_behz_cols_floor_sk: shape not covered by the fused kernel");
+    const dim3 g((unsigned)(n_ops * 3 * 16)), blk(64u << env.logn1);
+    const size_t lds = (size_t)(bz.L + bz.nB + 1) * (64u << env.logn1) * 8;
+    switch (env.logn1) {
+    case 1: hipLaunchKernelGGL((k_behz_cols_floor_sk<1, 4, 6>), g, blk, lds, env.stream, bz, env.primes, dq, ds, out); break;
+    case 2: hipLaunchKernelGGL((k_behz_cols_floor_sk<2, 4, 6>), g, blk, lds, env.stream, bz, env.primes, dq, ds, out); break;
+    default: hipLaunchKernelGGL((k_behz_cols_floor_sk<3, 4, 6>), g, blk, lds, env.stream, bz, env.primes, dq, ds, out); break;
+    }
 }
 void launch_behz_rows_tensor(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d)
 {
