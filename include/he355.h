@@ -20,6 +20,8 @@
  *   he355_relinearize           evaluator()->relinearize_inplace              src/engine/seal_context.cpp:390,447
  *   he355_multiply_accumulate   multiply + add_inplace over the inner dimension  src/benchmarks/ckks/seal_ckks_matmult_cipherbatchaxis_benchmark.cpp:404-420
  *   he355_relinearize_rescale   relinearize_inplace + rescale_to_next_inplace    same file :436-437
+ *   he355_bfv_multiply_relin_accumulate  multiply + relinearize_inplace + add_inplace over the inner dimension
+ *                                                         src/benchmarks/bfv/seal_bfv_matmult_cipherbatchaxis_benchmark.cpp:398-410
  *   he355_rescale               evaluator()->rescale_to_next_inplace          src/engine/seal_context.cpp:391,448
  *   he355_rotate                evaluator()->rotate_vector (CKKS) / rotate_rows (BFV)      src/engine/seal_context.cpp:337,302
  *   he355_apply_galois(2N-1)    evaluator()->rotate_columns_inplace (BFV)                   src/engine/seal_context.cpp:308
@@ -156,6 +158,11 @@ int he355_sum(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_in,
  * src/benchmarks/ckks/seal_ckks_matmult_cipherbatchaxis_benchmark.cpp:404-420 */
 int he355_multiply_accumulate(he355_ctx *ctx, int L, uint64_t rows, uint64_t cols, uint64_t inner, const uint64_t *d_a, uint64_t a_stride_i,
                               uint64_t a_stride_k, const uint64_t *d_b, uint64_t b_stride_k, uint64_t b_stride_j, uint64_t *d_out);
+/* BFV: out(i,j) = sum_k relinearize(multiply(a(i,k), b(k,j))), size-2 results [rows*cols][2][L][N], same addressing -- the
+ * multiply / relinearize_inplace / add_inplace loop of src/benchmarks/bfv/seal_bfv_matmult_cipherbatchaxis_benchmark.cpp:398-410 with
+ * the inner index inside the batch (rows*cols <= 65535) */
+int he355_bfv_multiply_relin_accumulate(he355_ctx *ctx, int L, uint64_t rows, uint64_t cols, uint64_t inner, const uint64_t *d_a, uint64_t a_stride_i,
+                                        uint64_t a_stride_k, const uint64_t *d_b, uint64_t b_stride_k, uint64_t b_stride_j, uint64_t *d_out);
 /* relinearize_inplace + rescale_to_next_inplace of size-3 ciphertexts (same file :436-437): [n][3][L][N] -> [n][2][L-1][N] */
 int he355_relinearize_rescale(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_ct3, uint64_t *d_out);
 int he355_rescale(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_in, uint64_t *d_out);         /* -> [n][size][L-1][N] */

@@ -106,6 +106,7 @@ def lib():
             "he355_mod_switch_drop": (i32, [vp, i32, i32, u64, vp, vp]),
             "he355_sum": (i32, [vp, i32, i32, u64, vp, vp]),
             "he355_multiply_accumulate": (i32, [vp, i32, u64, u64, u64, vp, u64, u64, vp, u64, u64, vp]),
+            "he355_bfv_multiply_relin_accumulate": (i32, [vp, i32, u64, u64, u64, vp, u64, u64, vp, u64, u64, vp]),
             "he355_rescale": (i32, [vp, i32, i32, u64, vp, vp]),
             "he355_apply_galois": (i32, [vp, i32, u64, vp, u32, vp]),
             "he355_rotate": (i32, [vp, i32, u64, vp, i32, vp]),
@@ -142,7 +143,7 @@ C_ABI_SYMBOLS = [
     "he355_device_init", "he355_malloc", "he355_free", "he355_upload", "he355_download", "he355_copy", "he355_copy_peer", "he355_sync",
     "he355_fill_uniform", "he355_fill_uniform_at", "he355_set_dual_stream", "he355_set_relin_key", "he355_set_galois_key", "he355_set_relin_key_synthetic",
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
-    "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_multiply_plain", "he355_add_plain",
+    "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_bfv_multiply_relin_accumulate", "he355_multiply_plain", "he355_add_plain",
     "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_keygen_relin", "he355_keygen_galois", "he355_ckks_encode", "he355_ckks_decode",
     "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_rotate_each", "he355_rotate_sum", "he355_accumulate", "he355_encrypt_zero", "he355_set_zero_stream",
     "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk", "he355_set_latency_max", "he355_set_level_walk", "he355_mem_info", "he355_alloc_stats", "he355_pool_trim", "he355_bridge_abi", "he355_bridge_group_load_bytes",
@@ -375,6 +376,10 @@ class Context:
 
     def multiply_accumulate(self, L, rows, cols, inner, a, a_stride_i, a_stride_k, b, b_stride_k, b_stride_j, out):
         _check(lib().he355_multiply_accumulate(self.h, L, rows, cols, inner, a.ptr, a_stride_i, a_stride_k, b.ptr, b_stride_k, b_stride_j, out.ptr))
+
+    def bfv_multiply_relin_accumulate(self, L, rows, cols, inner, a, a_stride_i, a_stride_k, b, b_stride_k, b_stride_j, out):
+        _check(lib().he355_bfv_multiply_relin_accumulate(self.h, L, rows, cols, inner, a.ptr, a_stride_i, a_stride_k, b.ptr, b_stride_k,
+                                                         b_stride_j, out.ptr))
 
     def rescale(self, L, size, n, inp, out):
         _check(lib().he355_rescale(self.h, L, size, n, inp.ptr, out.ptr))

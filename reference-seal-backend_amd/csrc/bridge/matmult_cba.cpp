@@ -225,16 +225,10 @@ AB::Handle MatMultCipherBatchAxisBenchmark::operate(AB::Handle h_remote_packed, 
         HeContextWrapper::check(he355_relinearize_rescale(ctx, L, n, c3->d, result->d), "relinearize+rescale");
         HeContextWrapper::check(he355_sync(ctx), "synchronise");
     } else {
-        std::shared_ptr<DeviceCiphers> c3 = m_p_ctx_wrapper->allocResult(n, 3, L, 1.0);
-        std::shared_ptr<DeviceCiphers> tmp = m_p_ctx_wrapper->allocResult(n, 2, L, 1.0);
         result = m_p_ctx_wrapper->allocResult(n, 2, L, 1.0);
-        const he355_indexer pair{0, 0, 1, 1, 0};
-        for (std::uint64_t k = 0; k < c0; ++k) {
-            const he355_indexer ix{k * r0, k * c1, c1, 0, 0};
-            HeContextWrapper::check(he355_bfv_multiply(ctx, L, n, in.m[0]->d, in.m[1]->d, ix, c3->d), "multiply");
-            HeContextWrapper::check(he355_relinearize(ctx, L, n, c3->d, k ? tmp->d : result->d), "relinearize");
-            if (k) HeContextWrapper::check(he355_add(ctx, L, 2, n, result->d, tmp->d, pair, result->d), "add");
-        }
+        // multiply / relinearize_inplace / add_inplace over the inner index (bfv cipherbatchaxis .cpp:398-410), the inner index inside the batch
+        HeContextWrapper::check(he355_bfv_multiply_relin_accumulate(ctx, L, r0, c1, c0, in.m[0]->d, 1, r0, in.m[1]->d, c1, 1, result->d),
+                                "multiply+relinearize+add");
         HeContextWrapper::check(he355_sync(ctx), "synchronise");
     }
     return this->getEngine().createHandle<decltype(result)>(sizeof(result), 0, std::move(result));

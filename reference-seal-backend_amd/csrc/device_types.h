@@ -36,6 +36,23 @@ struct Indexer {
 };
 HE_HD u64 idx_a(const Indexer &ix, u64 r) { return ix.pairwise ? ix.a_base + r : ix.a_base + r / ix.b1; }
 HE_HD u64 idx_b(const Indexer &ix, u64 r) { return ix.pairwise ? ix.b_base + r : ix.b_base + r % ix.b1; }
+// Operand selection of the BFV multiply: result r = (g, i, j) with g = r / gs, i = (r % gs) / b1, j = (r % gs) % b1 takes
+// a[a_base + g a_sg + i a_si] x b[b_base + g b_sg + j b_sj] -- pairwise (gs = 1), outer product (gs = "infinity") and the product
+// terms of a matrix product over the inner index g (he355_bfv_multiply_relin_accumulate) in one form.  Used by the BEHZ extension
+// kernels only (block-uniform there), so the other kernels' Indexer arithmetic stays what it was.
+struct Indexer3 {
+    u64 a_base, b_base, gs, b1, a_sg, a_si, b_sg, b_sj;
+};
+HE_HD Indexer3 to_ix3(const Indexer &ix)
+{
+    Indexer3 x;
+    x.a_base = ix.a_base; x.b_base = ix.b_base;
+    if (ix.pairwise) { x.gs = 1; x.b1 = 1; x.a_sg = 1; x.b_sg = 1; x.a_si = 0; x.b_sj = 0; }
+    else { x.gs = ~(u64)0; x.b1 = ix.b1; x.a_sg = 0; x.b_sg = 0; x.a_si = 1; x.b_sj = 1; }
+    return x;
+}
+HE_HD u64 idx_a(const Indexer3 &ix, u64 r) { return ix.a_base + (r / ix.gs) * ix.a_sg + ((r % ix.gs) / ix.b1) * ix.a_si; }
+HE_HD u64 idx_b(const Indexer3 &ix, u64 r) { return ix.b_base + (r / ix.gs) * ix.b_sg + ((r % ix.gs) % ix.b1) * ix.b_sj; }
 
 // A batch of residue polynomials for the generic transform kernels:
 // poly p of item it lives at base + it*item_stride + p*N and belongs to prime prime_of[p] (255 = skip).

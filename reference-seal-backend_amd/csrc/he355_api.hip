@@ -1328,8 +1328,46 @@ public:
         Z.bsk_prime[T.nB] = (unsigned char)P.K;                                        // m_sk
         return behz_[L] = Z;
     }
+    // out(i, j) = sum_k relinearize(multiply(a(i, k), b(k, j))): the multiply / relinearize_inplace / add_inplace loop of the BFV
+    // CipherBatchAxis matrix product (bfv cipherbatchaxis .cpp:398-410) with the inner index as part of the batch -- one multiply and
+    // one relinearization over rows * cols * k ciphertext pairs, then the sums over k (modular additions: any order, same residues).
+    void bfv_multiply_relin_accumulate(int L, u64 rows, u64 cols, u64 inner, const u64 *a, u64 a_stride_i, u64 a_stride_k, const u64 *b,
+                                       u64 b_stride_k, u64 b_stride_j, u64 *out)
+    {
+        use();
+        check_level(L);
+        if (P.scheme != kSchemeBFV) throw std::invalid_argument("he355_bfv_multiply_relin_accumulate needs a BFV context");
+        if (inner < 1 || inner > 0x7fffffff) throw std::invalid_argument("inner dimension out of range");
+        const u64 n = rows * cols;
+        if (!n) return;
+        if (n > 65535) throw std::invalid_argument("he355_bfv_multiply_relin_accumulate: more than 65535 results per call");
+        const size_t LN = (size_t)L * P.N;
+        const u64 kc = std::max<u64>(1, std::min<u64>(inner, (u64)4096 / n)); // inner indices per pass: about 4096 products in flight
+        u64 *c3 = static_cast<u64 *>(pool_alloc(n * kc * 3 * LN * 8));
+        u64 *r2 = nullptr;
+        try {
+            r2 = static_cast<u64 *>(pool_alloc(n * kc * 2 * LN * 8));
+            for (u64 k0 = 0; k0 < inner; k0 += kc) {
+                const u64 kn = std::min<u64>(kc, inner - k0);
+                Indexer3 ix{};
+                ix.a_base = k0 * a_stride_k; ix.b_base = k0 * b_stride_k;
+                ix.gs = n; ix.b1 = cols; ix.a_sg = a_stride_k; ix.a_si = a_stride_i; ix.b_sg = b_stride_k; ix.b_sj = b_stride_j;
+                bfv_multiply3(L, n * kn, a, b, ix, c3);
+                relinearize(L, n * kn, c3, r2);
+                launch_sum_cts(env_, L, 2, kn, r2, out, n, k0 != 0);
+            }
+            HIPCHECK(hipGetLastError());
+        } catch (...) {
+            pool_free(c3);
+            if (r2) pool_free(r2);
+            throw;
+        }
+        pool_free(c3);
+        pool_free(r2);
+    }
     // Evaluator::bfv_multiply (BEHZ), size 2 x 2 -> 3, coefficient form
-    void bfv_multiply(int L, u64 n, const u64 *a, const u64 *b, Indexer ix, u64 *out)
+    void bfv_multiply(int L, u64 n, const u64 *a, const u64 *b, Indexer ix, u64 *out) { bfv_multiply3(L, n, a, b, to_ix3(ix), out); }
+    void bfv_multiply3(int L, u64 n, const u64 *a, const u64 *b, Indexer3 ix, u64 *out)
     {
         use();
         check_level(L);
@@ -2003,6 +2041,11 @@ int he355_multiply(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const uin
 int he355_bfv_multiply(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const uint64_t *b, he355_indexer ix, uint64_t *out)
 {
     return guarded([&] { dev(c).bfv_multiply(L, n, a, b, to_ix(ix), out); });
+}
+int he355_bfv_multiply_relin_accumulate(he355_ctx *c, int L, uint64_t rows, uint64_t cols, uint64_t inner, const uint64_t *a, uint64_t a_stride_i,
+                                        uint64_t a_stride_k, const uint64_t *b, uint64_t b_stride_k, uint64_t b_stride_j, uint64_t *out)
+{
+    return guarded([&] { dev(c).bfv_multiply_relin_accumulate(L, rows, cols, inner, a, a_stride_i, a_stride_k, b, b_stride_k, b_stride_j, out); });
 }
 int he355_multiply_relin(he355_ctx *c, int L, uint64_t n, const uint64_t *a, const uint64_t *b, he355_indexer ix, int rescale, uint64_t *out)
 {

@@ -47,7 +47,8 @@ void launch_addsub(const KernelEnv &env, int L, int size, u64 n_results, const u
 void launch_mul3(const KernelEnv &env, int L, u64 n_results, const u64 *a, const u64 *b, Indexer ix, u64 *out);
 void launch_plain_op(const KernelEnv &env, int L, int size, u64 n_results, const u64 *ct, const u64 *pt, Indexer ix, u64 *out, int mode); // 0 mul, 1 add
 void launch_drop_residues(const KernelEnv &env, int L, int L_to, u64 n_polys, const u64 *in, u64 *out);
-void launch_sum_cts(const KernelEnv &env, int L, int size, u64 n_terms, const u64 *in, u64 *out);
+// out[c] (+)= sum_r in[r * n_out + c], c < n_out
+void launch_sum_cts(const KernelEnv &env, int L, int size, u64 n_terms, const u64 *in, u64 *out, u64 n_out = 1, bool accumulate = false);
 void launch_mul3_acc(const KernelEnv &env, int L, u64 rows, u64 cols, int inner, const u64 *a, u64 a_stride_i, u64 a_stride_k, const u64 *b,
                      u64 b_stride_k, u64 b_stride_j, u64 *out);
 
@@ -177,11 +178,11 @@ constexpr int kBehzMaxB = 24; // base B (Params::behz_nB: 22 for sixteen 60-bit 
 // BEHZ steps (1)-(2): lift the four input polynomials of each pair to Bsk (fastbconv_m_tilde + sm_mrq) and copy them
 // for the base-q transform.  xq [n*4][L][N], xbsk [n*4][S][N], coefficient form.
 // results op_offset .. op_offset + n_ops - 1 of the batch (the indexer sees the global result index)
-void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk);
+void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk);
 // N <= 8192, L <= 4, nB <= 6 (and HE355_BEHZ_FUSE != 0): the extension with the forward column passes of xq / xbsk in its epilogue,
 // and the inverse column passes of dq / ds in the prologue of steps (6)-(8) -- the coefficient-form copies never reach HBM
 bool behz_cols_fusable(const KernelEnv &env, const BehzDev &bz);
-void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk);
+void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk);
 void launch_behz_cols_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out);
 // BEHZ steps (3)-(5) on rows, fused: x [n*4][Lx][N] after launch_cols_fwd -> forward row pass of a0, a1, b0, b1, dyadic tensor, inverse row
 // pass -> d [n*3][Lx][N] ready for launch_cols_inv (one block = the four rows of one (op, residue, row); no HBM round trip between them)

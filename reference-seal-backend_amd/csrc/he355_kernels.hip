@@ -442,19 +442,23 @@ __global__ void __launch_bounds__(kBlock) k_drop_residues(const u64 *in, u64 *ou
 
 // Sum of n ciphertexts (the add_inplace accumulation of collapseCKKS, seal_context.cpp:401): out = sum_r in[r].
 // One thread = 2 coefficients of one residue polynomial of the result; it walks the n terms.
-__global__ void __launch_bounds__(kBlock) k_sum_cts(const u64 *in, u64 *out, const PrimeDev *primes, int L, int polys, int logN, u64 n_terms)
+// blockIdx.y = result c of n_out: out[c] = (accumulate ? out[c] : 0) + sum_r in[r * n_out + c] (n_out = 1: the sum of a run of ciphertexts;
+// n_out > 1: the sums over the inner index of a matrix product's terms, he355_bfv_multiply_relin_accumulate)
+__global__ void __launch_bounds__(kBlock) k_sum_cts(const u64 *in, u64 *out, const PrimeDev *primes, int L, int polys, int logN, u64 n_terms, int accumulate)
 {
     const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
     const u64 p = gid >> (logN - 1), e2 = gid & (((u64)1 << (logN - 1)) - 1);
     if (p >= (u64)polys) return;
+    const u64 c = blockIdx.y, n_out = gridDim.y;
     const u64 q = primes[p % L].q;
     const u64 ctn = (u64)polys << logN;
-    ulonglong2 s = make_ulonglong2(0, 0);
+    ulonglong2 *po = reinterpret_cast<ulonglong2 *>(out + c * ctn + (p << logN)) + e2;
+    ulonglong2 s = accumulate ? *po : make_ulonglong2(0, 0);
     for (u64 r = 0; r < n_terms; ++r) {
-        const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(in + r * ctn + (p << logN))[e2];
+        const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(in + (r * n_out + c) * ctn + (p << logN))[e2];
         s.x = addmod(s.x, x.x, q); s.y = addmod(s.y, x.y, q);
     }
-    reinterpret_cast<ulonglong2 *>(out + (p << logN))[e2] = s;
+    *po = s;
 }
 
 // Sum over the groups of a grouped launch: out[c] (+)= sum_g mult[g] * in[g * n_cts + c] (mult: how many rotation steps end at trie node g;
@@ -1841,7 +1845,7 @@ template <int ML> __device__ __forceinline__ u64 behz_ext_residue(const BehzDev 
     return barrett128(acc, mj);
 }
 template <int ML, int MB>
-__global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDev *primes, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk,
+__global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDev *primes, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk,
                                                         u64 n_ops, int logN, u64 op_offset)
 {
     const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
@@ -1899,7 +1903,7 @@ template <int LOGN1> __device__ __forceinline__ void col_fwd_store(const PrimeDe
 // takes residues w, w + N1, ...: each lane runs that residue's column pass on the N1 values of its column (wave-uniform prime, so
 // the engine branch does not diverge) and stores the raw rows.
 template <int LOGN1, int ML, int MB>
-__global__ void __launch_bounds__(64 << LOGN1) k_behz_extend_cols(BehzDev Z, const PrimeDev *primes, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk,
+__global__ void __launch_bounds__(64 << LOGN1) k_behz_extend_cols(BehzDev Z, const PrimeDev *primes, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk,
                                                                   u64 op_offset)
 {
     constexpr int N1 = 1 << LOGN1;
@@ -2337,11 +2341,14 @@ void launch_drop_residues(const KernelEnv &env, int L, int L_to, u64 n_polys, co
     const u64 threads = (n_polys * L_to) << (logN - 1);
     hipLaunchKernelGGL(k_drop_residues, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, in, out, L, L_to, logN, n_polys);
 }
-void launch_sum_cts(const KernelEnv &env, int L, int size, u64 n_terms, const u64 *in, u64 *out)
+void launch_sum_cts(const KernelEnv &env, int L, int size, u64 n_terms, const u64 *in, u64 *out, u64 n_out, bool accumulate)
 {
+    if (!n_out) return;
+    if (n_out > 65535) throw std::invalid_argument("sum over the inner index: too many results for one launch");
     const int logN = env.logn1 + kRowLog;
     const u64 threads = ((u64)size * L) << (logN - 1);
-    hipLaunchKernelGGL(k_sum_cts, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, in, out, env.primes, L, size * L, logN, n_terms);
+    hipLaunchKernelGGL(k_sum_cts, dim3(grid_for(threads, kBlock), (unsigned)n_out), dim3(kBlock), 0, env.stream, in, out, env.primes, L, size * L, logN, n_terms,
+                       accumulate ? 1 : 0);
 }
 
 void launch_sum_groups(const KernelEnv &env, int L, u64 n_cts, u32 n_groups, const u64 *in, const u32 *d_mult, u64 *out)
@@ -2633,7 +2640,7 @@ void launch_rows_inv_select(const KernelEnv &env, int prime, u64 n_polys, const 
                        env.logn1);
 }
 
-void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk)
+void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk)
 {
     if (!n_ops) return;
     const int logN = env.logn1 + kRowLog;
@@ -2648,7 +2655,7 @@ bool behz_cols_fusable(const KernelEnv &env, const BehzDev &bz)
     static const bool on = [] { const char *e = std::getenv("HE355_BEHZ_FUSE"); return !(e && e[0] == '0'); }();
     return on && bz.L <= 4 && bz.nB <= 6 && env.logn1 >= 1 && env.logn1 <= 3;
 }
-void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, u64 *xq, u64 *xbsk)
+void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk)
 {
     if (!n_ops) return;
     if (!behz_cols_fusable(env, bz)) throw std::logic_error("launch_behz_extend_cols: shape not covered by the fused kernel");

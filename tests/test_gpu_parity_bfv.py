@@ -230,6 +230,55 @@ def test_bfv_random_parameter_chains(be, oracle, seed):
     g.close()
 
 
+@pytest.mark.parametrize("name,N,bits,rows,cols,inner,layout", [
+    ("default_shape", 4096, [60, 40, 40, 60], 3, 2, 4, "cba"),     # M0 column-major, M1 row-major: the bridge's layout
+    ("row_major_both", 2048, [50, 40, 50], 2, 3, 5, "row"),        # other strides
+    ("several_passes", 1024, [50, 40, 50], 2, 3, 700, "cba"),      # more than 4096 / (rows * cols) inner indices: two passes over k
+])
+def test_bfv_multiply_relin_accumulate_equals_the_reference_loop(be, oracle, name, N, bits, rows, cols, inner, layout):
+    """he355_bfv_multiply_relin_accumulate against the loop it replaces (bfv cipherbatchaxis .cpp:398-410): for every (i, j), multiply,
+    relinearize_inplace, add_inplace over the inner index -- here with the inner index inside the batch."""
+    g = be.Context(be.SCHEME_BFV, N, bit_sizes=bits, plain_bits=20, sec128=False, device=0)
+    o = oracle.Context(oracle.SCHEME_BFV, N, bit_sizes=bits, plain_bits=20, sec128=False)
+    assert g.moduli == o.moduli
+    rng = np.random.default_rng(rows * 100 + inner)
+    L = g.L
+    distinct = min(inner, 6)  # the oracle's work: distinct products only; the long run repeats them
+    a = np.stack([o.random_poly(rng, L, 2) for _ in range(rows * distinct)])
+    b = np.stack([o.random_poly(rng, L, 2) for _ in range(distinct * cols)])
+    rk = o.random_kswitch_key(rng)
+    g.set_relin_key(rk)
+    if layout == "cba":   # a(i, k) at k * rows + i, b(k, j) at k * cols + j
+        ai = lambda i, k: (k % distinct) * rows + i
+        bi = lambda k, j: (k % distinct) * cols + j
+        a_si, a_sk, b_sk, b_sj = 1, rows, cols, 1
+    else:                 # a(i, k) at i * inner + k, b(k, j) at k * cols + j
+        ai = lambda i, k: i * distinct + (k % distinct)
+        bi = lambda k, j: (k % distinct) * cols + j
+        a_si, a_sk, b_sk, b_sj = inner, 1, cols, 1
+    # device operands laid out for the full inner range
+    A = np.zeros((rows * inner, 2, L, N), dtype=np.uint64)
+    B = np.zeros((inner * cols, 2, L, N), dtype=np.uint64)
+    for k in range(inner):
+        for i in range(rows):
+            A[i * a_si + k * a_sk] = a[ai(i, k)]
+        for j in range(cols):
+            B[k * b_sk + j * b_sj] = b[bi(k, j)]
+    out = g.alloc(rows * cols * 2 * L * N)
+    g.bfv_multiply_relin_accumulate(L, rows, cols, inner, g.to_device(A), a_si, a_sk, g.to_device(B), b_sk, b_sj, out)
+    got = out.download((rows * cols, 2, L, N))
+    mods = np.array(o.moduli[:L], dtype=object)
+    for i in range(rows):
+        for j in range(cols):
+            terms = [o.relinearize(o.bfv_multiply(a[ai(i, k)], b[bi(k, j)]), rk) for k in range(distinct)]
+            acc = np.zeros((2, L, N), dtype=object)
+            for k in range(inner):
+                acc = acc + terms[k % distinct].astype(object)
+            want = np.stack([[acc[p][l] % int(mods[l]) for l in range(L)] for p in range(2)]).astype(np.uint64)
+            assert np.array_equal(got[i * cols + j], want), (name, i, j)
+    g.close()
+
+
 def _residues(o, values, L):
     """Integer coefficient vector(s) -> residues [.., L, N] under the first L moduli."""
     return np.stack([np.array([int(v) % q for v in values], dtype=np.uint64) for q in o.moduli[:L]])
