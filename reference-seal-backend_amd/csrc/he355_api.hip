@@ -718,9 +718,8 @@ public:
                 KsBuffers B = S.ks;
                 B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
                 const u64 *src = ct3 + off * 3 * LN;
-                // (c0, c1) of each size-3 ciphertext -> out; c2 is the key-switch target
-                HIPCHECK(hipMemcpy2DAsync(B.c01, 2 * LN * 8, src, 3 * LN * 8, 2 * LN * 8, nc, hipMemcpyDeviceToDevice, stream_));
-                bfv_key_switch(L, nc, S, B, d_relin_, src + 2 * LN, 3 * LN);
+                // out = (c0, c1) of each size-3 ciphertext (read where they lie by the last kernel) + the key-switched c2
+                bfv_key_switch(L, nc, S, B, d_relin_, src + 2 * LN, 3 * LN, src, 3 * LN);
             }
             HIPCHECK(hipGetLastError());
             return;
@@ -1429,12 +1428,13 @@ public:
         HIPCHECK(hipGetLastError());
     }
     // key switching for BFV: the target is in coefficient form; result added into c01 (coefficient form)
-    void bfv_key_switch(int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, const u64 *target, u64 target_op_stride)
+    void bfv_key_switch(int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, const u64 *target, u64 target_op_stride,
+                        const u64 *add01 = nullptr, u64 add01_item_stride = 0)
     {
         launch_k2(env_, L, nc, B, target, target_op_stride);
         launch_k3(env_, L, nc, B, key);
         launch_bfv_tail_sp(env_, nc * 2, B.tpr, S.rlr);
-        launch_bfv_tail_fin(env_, L, nc, B.t, S.rlr, B.c01, B.c01_item_stride);
+        launch_bfv_tail_fin(env_, L, nc, B.t, S.rlr, B.c01, B.c01_item_stride, add01, add01_item_stride);
     }
     // ---- client side on the device -----------------------------------------------------
     void set_public_key(const u64 *h_pk) // [2][K][N], NTT form

@@ -197,7 +197,9 @@ void launch_bfv_galois(const KernelEnv &env, int L, u64 n_ops, const u64 *in, co
 // BFV key-switch tails: finish the inverse transform of the special-prime sums and round (-> rp), then finish every data
 // prime's inverse transform, apply the floor step in coefficient form and add into c01
 void launch_bfv_tail_sp(const KernelEnv &env, u64 n_polys, const u64 *tpr, u64 *rp);
-void launch_bfv_tail_fin(const KernelEnv &env, int L, u64 n_ops, const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride);
+// c01 = add01 + key-switched part (add01 == nullptr: c01 += ...; relinearize hands the size-3 input's (c0, c1) here, nothing is copied)
+void launch_bfv_tail_fin(const KernelEnv &env, int L, u64 n_ops, const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride, const u64 *add01 = nullptr,
+                         u64 add01_item_stride = 0);
 
 // inverse row pass of one residue of each poly: src [(op,k)] residue `prime` -> tail [(op,k)][N]
 void launch_rows_inv_select(const KernelEnv &env, int prime, u64 n_polys, const u64 *src, u64 src_poly_stride, u64 *tail);

@@ -2226,7 +2226,7 @@ __launch_bounds__(kBlock, HE355_TAILFIN_WAVES)
 #else
 __launch_bounds__(kBlock)
 #endif
-k_bfv_tail_fin(const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride, const PrimeDev *primes,
+k_bfv_tail_fin(const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride, const u64 *add01, u64 add01_item_stride, const PrimeDev *primes,
                                                          const FloorConst *fcs, int L, int K)
 {
     constexpr int N1 = 1 << LOGN1;
@@ -2264,13 +2264,14 @@ k_bfv_tail_fin(const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride, const
     const ModU64 mi = make_modu(Pi);
     const u64 qi = Pi.q, qs = Ps.q;
     u64 *dst = c01 + op * c01_item_stride + ((u64)k * L + i) * N;
+    const u64 *add = add01 + op * add01_item_stride + ((u64)k * L + i) * N; // what the key-switched part is added to (may be dst itself)
 #pragma unroll
     for (int a = 0; a < N1; ++a) {
         const u64 r = rp[ok * N + (a << kRowLog) + col];
         const u64 delta = submod(qs > qi ? barrett64(r, mi) : r, fc.half_mod, qi);
         const u64 res = mul_shoup(submod(c[a], delta, qi), fc.inv, fc.inv_shoup, qi);
         const u64 idx = (a << kRowLog) + col;
-        dst[idx] = addmod(dst[idx], res, qi);
+        dst[idx] = addmod(add[idx], res, qi);
     }
 }
 
@@ -2754,17 +2755,19 @@ void launch_bfv_tail_sp(const KernelEnv &env, u64 n_polys, const u64 *tpr, u64 *
     case 5: hipLaunchKernelGGL(k_bfv_tail_sp<5>, dim3(g), dim3(kBlock), 0, env.stream, tpr, rp, env.primes, sp); break;
     }
 }
-void launch_bfv_tail_fin(const KernelEnv &env, int L, u64 n_ops, const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride)
+void launch_bfv_tail_fin(const KernelEnv &env, int L, u64 n_ops, const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride, const u64 *add01,
+                         u64 add01_item_stride)
 {
+    if (!add01) { add01 = c01; add01_item_stride = c01_item_stride; }
     if (!n_ops) return;
     const unsigned g = (unsigned)(n_ops * 2 * L * 4);
     switch (env.logn1) {
-    case 0: hipLaunchKernelGGL(k_bfv_tail_fin<0>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
-    case 1: hipLaunchKernelGGL(k_bfv_tail_fin<1>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
-    case 2: hipLaunchKernelGGL(k_bfv_tail_fin<2>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
-    case 3: hipLaunchKernelGGL(k_bfv_tail_fin<3>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
-    case 4: hipLaunchKernelGGL(k_bfv_tail_fin<4>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
-    case 5: hipLaunchKernelGGL(k_bfv_tail_fin<5>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    case 0: hipLaunchKernelGGL(k_bfv_tail_fin<0>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, add01, add01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    case 1: hipLaunchKernelGGL(k_bfv_tail_fin<1>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, add01, add01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    case 2: hipLaunchKernelGGL(k_bfv_tail_fin<2>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, add01, add01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    case 3: hipLaunchKernelGGL(k_bfv_tail_fin<3>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, add01, add01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    case 4: hipLaunchKernelGGL(k_bfv_tail_fin<4>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, add01, add01_item_stride, env.primes, env.floor_consts, L, env.K); break;
+    case 5: hipLaunchKernelGGL(k_bfv_tail_fin<5>, dim3(g), dim3(kBlock), 0, env.stream, t, rp, c01, c01_item_stride, add01, add01_item_stride, env.primes, env.floor_consts, L, env.K); break;
     }
 }
 
