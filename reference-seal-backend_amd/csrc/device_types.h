@@ -53,6 +53,29 @@ HE_HD Indexer3 to_ix3(const Indexer &ix)
 }
 HE_HD u64 idx_a(const Indexer3 &ix, u64 r) { return ix.a_base + (r / ix.gs) * ix.a_sg + ((r % ix.gs) / ix.b1) * ix.a_si; }
 HE_HD u64 idx_b(const Indexer3 &ix, u64 r) { return ix.b_base + (r / ix.gs) * ix.b_sg + ((r % ix.gs) % ix.b1) * ix.b_sj; }
+// Which ciphertexts the BEHZ extension reads.  lists == 0: item 2 r + c is operand c of result op_offset + r (every result extends
+// its own two operands).  lists == 1: the DISTINCT operands of a batch, each once -- items 0 .. na-1 are a(g, i) = item / I, item % I,
+// items na .. na+nb-1 are b(g, j) = (item - na) / J, (item - na) % J (the multiply then reads result r's operands at ordinals
+// ord_a(r), ord_b(r)).
+struct BehzSrc {
+    const u64 *a, *b;
+    Indexer3 ix;
+    u64 op_offset;
+    u64 I, J, na;
+    int lists, pad_;
+};
+HE_HD const u64 *behz_src_ct(const BehzSrc &s, u64 item, u64 ct_words)
+{
+    if (!s.lists) {
+        const u64 rg = s.op_offset + (item >> 1);
+        return (item & 1) ? s.b + idx_b(s.ix, rg) * ct_words : s.a + idx_a(s.ix, rg) * ct_words;
+    }
+    if (item < s.na) return s.a + (s.ix.a_base + (item / s.I) * s.ix.a_sg + (item % s.I) * s.ix.a_si) * ct_words;
+    const u64 e = item - s.na;
+    return s.b + (s.ix.b_base + (e / s.J) * s.ix.b_sg + (e % s.J) * s.ix.b_sj) * ct_words;
+}
+HE_HD u64 ord_a(const BehzSrc &s, u64 r) { return (r / s.ix.gs) * s.I + (r % s.ix.gs) / s.ix.b1; }
+HE_HD u64 ord_b(const BehzSrc &s, u64 r) { return s.na + (r / s.ix.gs) * s.J + (r % s.ix.gs) % s.ix.b1; }
 
 // A batch of residue polynomials for the generic transform kernels:
 // poly p of item it lives at base + it*item_stride + p*N and belongs to prime prime_of[p] (255 = skip).

@@ -1366,52 +1366,99 @@ public:
     }
     // Evaluator::bfv_multiply (BEHZ), size 2 x 2 -> 3, coefficient form
     void bfv_multiply(int L, u64 n, const u64 *a, const u64 *b, Indexer ix, u64 *out) { bfv_multiply3(L, n, a, b, to_ix3(ix), out); }
+    // the BFV multiply's scratch arena holds at least `bytes` afterwards, or false (not enough device memory: the caller halves its chunk)
+    bool reserve_bfv_scratch(size_t bytes)
+    {
+        if (bytes <= bfv_bytes_) return true;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)bytes > 0.9 * (double)(free_b + bfv_bytes_ + pool_.cached_bytes())) return false;
+        try {
+            HIPCHECK(hipStreamSynchronize(stream_));
+            pool_.raw_free(bfv_scratch_);
+            bfv_scratch_ = nullptr; bfv_bytes_ = 0;
+            dmalloc(bfv_scratch_, bytes);
+            bfv_bytes_ = bytes;
+            return true;
+        } catch (const OutOfDeviceMemory &) {
+            return false;
+        }
+    }
     void bfv_multiply3(int L, u64 n, const u64 *a, const u64 *b, Indexer3 ix, u64 *out)
     {
         use();
         check_level(L);
         if (P.scheme != kSchemeBFV) throw std::invalid_argument("he355_bfv_multiply needs a BFV context");
+        if (!n) return;
         const BehzDev &Z = behz(L);
         const size_t N = P.N, S = (size_t)Z.nB + 1;
-        const size_t per_op = (4 * L + 4 * S + 3 * L + 3 * S) * N;
-        size_t c = std::min<size_t>(chunk_, (size_t)n ? (size_t)n : 1);
-        while (per_op * c * 8 > bfv_bytes_) { // as chunk_ops: halved until the arena is reserved
-            size_t free_b = 0, total_b = 0;
-            const bool fits = hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
-                              (double)(per_op * c * 8) <= 0.9 * (double)(free_b + bfv_bytes_ + pool_.cached_bytes());
-            if (fits) {
-                try {
-                    HIPCHECK(hipStreamSynchronize(stream_));
-                    pool_.raw_free(bfv_scratch_);
-                    bfv_scratch_ = nullptr; bfv_bytes_ = 0;
-                    dmalloc(bfv_scratch_, per_op * c * 8);
-                    bfv_bytes_ = per_op * c * 8;
-                    break;
-                } catch (const OutOfDeviceMemory &) {
-                    if (c == 1) throw;
-                }
-            } else if (c == 1) {
-                throw OutOfDeviceMemory("HIP error: out of device memory: the BFV multiply scratch of one ciphertext does not fit");
-            }
-            c = (c + 1) / 2;
-        }
-        u64 *xq = bfv_scratch_, *xb = xq + c * 4 * L * N, *dq = xb + c * 4 * S * N, *ds = dq + c * 3 * L * N;
         PolyView vq{}, vb{};
-        unsigned char pq[64], pb[64];
-        for (int i = 0; i < L; ++i) { pq[i] = (unsigned char)i; vq.prime_of[i] = pq[i]; }
-        for (size_t j = 0; j < S; ++j) { pb[j] = Z.bsk_prime[j]; vb.prime_of[j] = pb[j]; }
+        for (int i = 0; i < L; ++i) vq.prime_of[i] = (unsigned char)i;
+        for (size_t j = 0; j < S; ++j) vb.prime_of[j] = Z.bsk_prime[j];
         vq.polys_per_item = L; vq.item_stride = (u64)L * N;
         vb.polys_per_item = (int)S; vb.item_stride = (u64)S * N;
         const bool fuse_cols = behz_cols_fusable(env_, Z);
+        BehzSrc src{};
+        src.a = a; src.b = b; src.ix = ix;
+        // Distinct operands: result r = (g, i, j) reads a(g, i) and b(g, j).  Where every operand serves several results (outer products,
+        // the terms of a matrix product) each is extended to Bsk and transformed ONCE (steps (1)-(3) per operand instead of per result:
+        // SEAL's multiply recomputes them for every pair, the values are the same), and a result costs its dyadic tensor, three inverse
+        // transforms and steps (6)-(8).
+        static const bool hoist_on = [] { const char *e = std::getenv("HE355_BEHZ_HOIST"); return !(e && e[0] == '0'); }();
+        const u64 gsz = std::min<u64>(ix.gs, n), G = ix.gs >= n ? 1 : (n + ix.gs - 1) / ix.gs;
+        src.I = (gsz + ix.b1 - 1) / ix.b1; src.J = std::min<u64>(ix.b1, gsz); src.na = G * src.I;
+        const u64 n_cts = src.na + G * src.J;
+        const size_t e_words = (size_t)n_cts * 2 * (L + S) * N, per_res = (3 * L + 3 * S) * N;
+        bool lists = hoist_on && (G == 1 || (n % ix.gs == 0 && ix.gs % ix.b1 == 0)) && n_cts <= n; // at least two times fewer extensions than the 2 n of the per-pair path
+        size_t c = std::min<size_t>(chunk_, (size_t)n);
+        if (lists) {
+            while (!reserve_bfv_scratch((e_words + per_res * c) * 8) && c > 1) c = (c + 1) / 2;
+            lists = (e_words + per_res * c) * 8 <= bfv_bytes_; // else: the operand set does not fit beside one result -- per-pair path below
+        }
+        if (lists) {
+            src.lists = 1;
+            u64 *eq = bfv_scratch_, *eb = eq + (size_t)n_cts * 2 * L * N, *dq = eb + (size_t)n_cts * 2 * S * N, *ds = dq + c * 3 * L * N;
+            if (fuse_cols) {
+                launch_behz_extend_cols(env_, Z, src, n_cts, eq, eb);
+            } else {
+                launch_behz_extend(env_, Z, src, n_cts, eq, eb);
+                vq.base = eq; launch_cols_fwd(env_, vq, (u32)(n_cts * 2));
+                vb.base = eb; launch_cols_fwd(env_, vb, (u32)(n_cts * 2));
+            }
+            vq.base = eq; launch_rows_fwd(env_, vq, (u32)(n_cts * 2));
+            vb.base = eb; launch_rows_fwd(env_, vb, (u32)(n_cts * 2));
+            for (u64 off = 0; off < n; off += c) {
+                const u64 nc = std::min<u64>(c, n - off);
+                launch_behz_tensor_inv(env_, Z, src, nc, off, eq, eb, dq, ds);
+                if (fuse_cols) {
+                    launch_behz_cols_floor_sk(env_, Z, nc, dq, ds, out + off * 3 * (size_t)L * N);
+                } else {
+                    vq.base = dq; launch_cols_inv(env_, vq, (u32)(nc * 3));
+                    vb.base = ds; launch_cols_inv(env_, vb, (u32)(nc * 3));
+                    launch_behz_floor_sk(env_, Z, nc, dq, ds, out + off * 3 * (size_t)L * N);
+                }
+            }
+            HIPCHECK(hipGetLastError());
+            return;
+        }
+        const size_t per_op = (4 * L + 4 * S) * N + per_res;
+        while (!reserve_bfv_scratch(per_op * c * 8)) { // as chunk_ops: halved until the arena is reserved
+            if (c == 1) throw OutOfDeviceMemory("HIP error: out of device memory: the BFV multiply scratch of one ciphertext does not fit");
+            c = (c + 1) / 2;
+        }
+        u64 *xq = bfv_scratch_, *xb = xq + c * 4 * L * N, *dq = xb + c * 4 * S * N, *ds = dq + c * 3 * L * N;
+        unsigned char pq[64], pb[64];
+        for (int i = 0; i < L; ++i) pq[i] = (unsigned char)i;
+        for (size_t j = 0; j < S; ++j) pb[j] = Z.bsk_prime[j];
         for (u64 off = 0; off < n; off += c) {
             const u64 nc = std::min<u64>(c, n - off);
             // extension to Bsk and forward column passes (one kernel where the fused shape applies), then per (op, residue, row) ONE
             // kernel for the forward row pass of the four polynomials, the dyadic tensor and the inverse row pass of the three
             // products (k_behz_rows_tensor), then the inverse column passes and steps (6)-(8) (again one kernel where it applies)
+            src.op_offset = off;
             if (fuse_cols) {
-                launch_behz_extend_cols(env_, Z, nc, off, a, b, ix, xq, xb);
+                launch_behz_extend_cols(env_, Z, src, nc * 2, xq, xb);
             } else {
-                launch_behz_extend(env_, Z, nc, off, a, b, ix, xq, xb);
+                launch_behz_extend(env_, Z, src, nc * 2, xq, xb);
                 vq.base = xq; launch_cols_fwd(env_, vq, (u32)(nc * 4));
                 vb.base = xb; launch_cols_fwd(env_, vb, (u32)(nc * 4));
             }

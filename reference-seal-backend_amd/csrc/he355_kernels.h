@@ -178,11 +178,16 @@ constexpr int kBehzMaxB = 24; // base B (Params::behz_nB: 22 for sixteen 60-bit 
 // BEHZ steps (1)-(2): lift the four input polynomials of each pair to Bsk (fastbconv_m_tilde + sm_mrq) and copy them
 // for the base-q transform.  xq [n*4][L][N], xbsk [n*4][S][N], coefficient form.
 // results op_offset .. op_offset + n_ops - 1 of the batch (the indexer sees the global result index)
-void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk);
+// n_cts ciphertext items selected by `src` (device_types.h, BehzSrc: the two operands of every result, or each distinct operand once)
+void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_cts, u64 *xq, u64 *xbsk);
 // N <= 8192, L <= 4, nB <= 6 (and HE355_BEHZ_FUSE != 0): the extension with the forward column passes of xq / xbsk in its epilogue,
 // and the inverse column passes of dq / ds in the prologue of steps (6)-(8) -- the coefficient-form copies never reach HBM
 bool behz_cols_fusable(const KernelEnv &env, const BehzDev &bz);
-void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk);
+void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_cts, u64 *xq, u64 *xbsk);
+// operands transformed once each (src.lists): dyadic tensor + inverse row pass of results op_offset .. op_offset + n_ops - 1
+void launch_behz_tensor_inv(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_ops, u64 op_offset, const u64 *eq, const u64 *ebsk, u64 *dq,
+                            u64 *ds);
+void launch_rows_fwd(const KernelEnv &env, const PolyView &v, u32 n_items); // row half of the forward transform, in place
 void launch_behz_cols_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out);
 // BEHZ steps (3)-(5) on rows, fused: x [n*4][Lx][N] after launch_cols_fwd -> forward row pass of a0, a1, b0, b1, dyadic tensor, inverse row
 // pass -> d [n*3][Lx][N] ready for launch_cols_inv (one block = the four rows of one (op, residue, row); no HBM round trip between them)

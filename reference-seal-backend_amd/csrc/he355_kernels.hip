@@ -1845,20 +1845,17 @@ template <int ML> __device__ __forceinline__ u64 behz_ext_residue(const BehzDev 
     return barrett128(acc, mj);
 }
 template <int ML, int MB>
-__global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDev *primes, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk,
-                                                        u64 n_ops, int logN, u64 op_offset)
+__global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDev *primes, BehzSrc src_of, u64 *xq, u64 *xbsk, u64 n_polys, int logN)
 {
     const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
     const u64 n = gid & (((u64)1 << logN) - 1);
-    const u64 pid = gid >> logN; // (op, which ct, which poly)
-    if (pid >= n_ops * 4) return;
-    const u64 r = pid >> 2;
-    const int c = (int)((pid >> 1) & 1), k = (int)(pid & 1);
+    const u64 pid = gid >> logN; // (ciphertext item, which poly)
+    if (pid >= n_polys) return;
+    const int k = (int)(pid & 1);
     constexpr int kUnrollB = MB <= 6 ? MB + 1 : 1; // the small instantiation unrolls its residue loops, the large one keeps them rolled
     const int L = Z.L, S = Z.nB + 1;
     const u64 N = (u64)1 << logN, P1 = (u64)L * N;
-    const u64 rg = op_offset + r; // result index in the whole batch: picks the operands (outer product or pairwise)
-    const u64 *src = (c ? b + idx_b(ix, rg) * 2 * P1 : a + idx_a(ix, rg) * 2 * P1) + (u64)k * P1 + n;
+    const u64 *src = behz_src_ct(src_of, pid >> 1, 2 * P1) + (u64)k * P1 + n;
     u64 x[ML], tmp[ML], rmt;
 #pragma unroll
     for (int i = 0; i < ML; ++i)
@@ -1903,21 +1900,18 @@ template <int LOGN1> __device__ __forceinline__ void col_fwd_store(const PrimeDe
 // takes residues w, w + N1, ...: each lane runs that residue's column pass on the N1 values of its column (wave-uniform prime, so
 // the engine branch does not diverge) and stores the raw rows.
 template <int LOGN1, int ML, int MB>
-__global__ void __launch_bounds__(64 << LOGN1) k_behz_extend_cols(BehzDev Z, const PrimeDev *primes, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk,
-                                                                  u64 op_offset)
+__global__ void __launch_bounds__(64 << LOGN1) k_behz_extend_cols(BehzDev Z, const PrimeDev *primes, BehzSrc src_of, u64 *xq, u64 *xbsk)
 {
     constexpr int N1 = 1 << LOGN1;
     extern __shared__ u64 behz_sm[]; // [L + S][N1][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u64 pid = blockIdx.x >> 4; // (op, which ct, which poly); 16 column groups per polynomial
+    const u64 pid = blockIdx.x >> 4; // (ciphertext item, which poly); 16 column groups per polynomial
     const u64 col = ((blockIdx.x & 15) << 6) | lane;
-    const u64 r = pid >> 2;
-    const int c = (int)((pid >> 1) & 1), k = (int)(pid & 1);
+    const int k = (int)(pid & 1);
     const int L = Z.L, S = Z.nB + 1;
     const u64 N = (u64)N1 << kRowLog, P1 = (u64)L * N;
-    const u64 rg = op_offset + r;
     {
-        const u64 *src = (c ? b + idx_b(ix, rg) * 2 * P1 : a + idx_a(ix, rg) * 2 * P1) + (u64)k * P1 + ((u64)wave << kRowLog) + col;
+        const u64 *src = behz_src_ct(src_of, pid >> 1, 2 * P1) + (u64)k * P1 + ((u64)wave << kRowLog) + col;
         u64 x[ML], tmp[ML], rmt;
 #pragma unroll
         for (int i = 0; i < ML; ++i)
@@ -2018,6 +2012,68 @@ __global__ void __launch_bounds__(kBlock) k_behz_rows_tensor(BehzRowsArgs A, con
 #pragma unroll
     for (int e = 0; e < kRowE; ++e) v[e] = last ? ar.to_canon(x[e]) : ar.to_raw(x[e]);
     store_rowA(A.d + (op * 3 + wave) * A.Lx * N + rowoff, lane, v);
+}
+
+// BEHZ steps (4)-(5) when the operands were transformed once each (BehzSrc lists: he355_api.hip, bfv_multiply3): one WAVE per
+// (result, residue, row, product k): it reads the canonical NTT-form rows of its operands where the one-off transform left them
+// (layout C, as k_rows_fwd stores them), forms c0 = a0 b0, c1 = a0 b1 + a1 b0 or c2 = a1 b1 and runs the inverse row pass.  No
+// barrier, no LDS hand-over; an operand row read by many results comes from L2 / MALL.  e [(ordinal * 2 + poly)][Lx][N],
+// d [(r * 3 + k)][Lx][N] ready for the inverse column pass.
+struct BehzTensorArgs {
+    const u64 *e[2]; // base q, base Bsk
+    u64 *d[2];
+    int Lx[2];
+    BehzSrc src;     // result -> operand ordinals
+    u64 n_ops, op_offset;
+    int logn1, n_r;
+    unsigned char r_base[64], r_idx[64], r_prime[64];
+};
+template <class Ar>
+__global__ void __launch_bounds__(kBlock) k_behz_tensor_inv(BehzTensorArgs A, const PrimeDev *primes, u64 total_jobs)
+{
+    typedef typename Ar::T T;
+    __shared__ u64 lds[kWaves][kLdsRow];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u64 job = (u64)blockIdx.x * kWaves + wave; // (op, residue slot, row, k)
+    if (job >= total_jobs) return;                   // (waves are independent: no barrier below)
+    const u32 n1 = 1u << A.logn1;
+    const u64 N = (u64)n1 << kRowLog;
+    const int k = (int)(job % 3);
+    const u64 j1 = job / 3;
+    const u32 a_row = (u32)(j1 & (n1 - 1));
+    const u64 orr = j1 >> A.logn1;
+    const int slot = (int)(orr % A.n_r);
+    const u64 op = orr / A.n_r;
+    const int base = A.r_base[slot], r = A.r_idx[slot], Lx = A.Lx[base];
+    const PrimeDev &P = primes[A.r_prime[slot]];
+    const Ar ar = make_ar(P, (Ar *)nullptr);
+    const bool last = A.logn1 == 0;
+    const u64 rowoff = ((u64)r << (A.logn1 + kRowLog)) + ((u64)a_row << kRowLog);
+    const u64 oa = ord_a(A.src, A.op_offset + op), ob = ord_b(A.src, A.op_offset + op);
+    const u64 *ea = A.e[base] + oa * 2 * Lx * N + rowoff, *eb = A.e[base] + ob * 2 * Lx * N + rowoff;
+    const u64 P1 = (u64)Lx * N;
+    T x[kRowE];
+    {
+        u64 p0[kRowE], p1[kRowE];
+        load_rowC(ea + (k == 2 ? P1 : 0), lane, p0); // c0: a0 b0; c1: a0 b1 (+ a1 b0); c2: a1 b1
+        load_rowC(eb + (k == 0 ? 0 : P1), lane, p1);
+        if (k == 1) {
+            u64 q0[kRowE], q1[kRowE];
+            load_rowC(ea + P1, lane, q0);
+            load_rowC(eb, lane, q1);
+#pragma unroll
+            for (int e = 0; e < kRowE; ++e)
+                x[e] = ar.from_canon(ar.dy_out(ar.dy_add(ar.dy_mul(ar.dy_in(p0[e]), ar.dy_in(p1[e])), ar.dy_mul(ar.dy_in(q0[e]), ar.dy_in(q1[e])))));
+        } else {
+#pragma unroll
+            for (int e = 0; e < kRowE; ++e) x[e] = ar.from_canon(ar.dy_out(ar.dy_mul(ar.dy_in(p0[e]), ar.dy_in(p1[e]))));
+        }
+    }
+    wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
+    u64 v[kRowE];
+#pragma unroll
+    for (int e = 0; e < kRowE; ++e) v[e] = last ? ar.to_canon(x[e]) : ar.to_raw(x[e]);
+    store_rowA(A.d[base] + (op * 3 + k) * Lx * N + rowoff, lane, v);
 }
 
 // BEHZ steps (6)-(8) for one coefficient: dq[i] (base q), ds[j] (Bsk) canonical residues of a product -> its L output residues.
@@ -2641,31 +2697,31 @@ void launch_rows_inv_select(const KernelEnv &env, int prime, u64 n_polys, const 
                        env.logn1);
 }
 
-void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk)
+void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_cts, u64 *xq, u64 *xbsk)
 {
-    if (!n_ops) return;
+    if (!n_cts) return;
     const int logN = env.logn1 + kRowLog;
-    const u64 threads = (n_ops * 4) << logN;
+    const u64 threads = (n_cts * 2) << logN;
     if (bz.L <= 4 && bz.nB <= 6)
-        hipLaunchKernelGGL((k_behz_extend<4, 6>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, a, b, ix, xq, xbsk, n_ops, logN, op_offset);
+        hipLaunchKernelGGL((k_behz_extend<4, 6>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, src, xq, xbsk, n_cts * 2, logN);
     else
-        hipLaunchKernelGGL((k_behz_extend<kBehzMaxL, kBehzMaxB>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, a, b, ix, xq, xbsk, n_ops, logN, op_offset);
+        hipLaunchKernelGGL((k_behz_extend<kBehzMaxL, kBehzMaxB>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, src, xq, xbsk, n_cts * 2, logN);
 }
 bool behz_cols_fusable(const KernelEnv &env, const BehzDev &bz)
 {
     static const bool on = [] { const char *e = std::getenv("HE355_BEHZ_FUSE"); return !(e && e[0] == '0'); }();
     return on && bz.L <= 4 && bz.nB <= 6 && env.logn1 >= 1 && env.logn1 <= 3;
 }
-void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer3 ix, u64 *xq, u64 *xbsk)
+void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_cts, u64 *xq, u64 *xbsk)
 {
-    if (!n_ops) return;
+    if (!n_cts) return;
     if (!behz_cols_fusable(env, bz)) throw std::logic_error("launch_behz_extend_cols: shape not covered by the fused kernel");
-    const dim3 g((unsigned)(n_ops * 4 * 16)), blk(64u << env.logn1);
+    const dim3 g((unsigned)(n_cts * 2 * 16)), blk(64u << env.logn1);
     const size_t lds = (size_t)(bz.L + bz.nB + 1) * (64u << env.logn1) * 8;
     switch (env.logn1) {
-    case 1: hipLaunchKernelGGL((k_behz_extend_cols<1, 4, 6>), g, blk, lds, env.stream, bz, env.primes, a, b, ix, xq, xbsk, op_offset); break;
-    case 2: hipLaunchKernelGGL((k_behz_extend_cols<2, 4, 6>), g, blk, lds, env.stream, bz, env.primes, a, b, ix, xq, xbsk, op_offset); break;
-    default: hipLaunchKernelGGL((k_behz_extend_cols<3, 4, 6>), g, blk, lds, env.stream, bz, env.primes, a, b, ix, xq, xbsk, op_offset); break;
+    case 1: hipLaunchKernelGGL((k_behz_extend_cols<1, 4, 6>), g, blk, lds, env.stream, bz, env.primes, src, xq, xbsk); break;
+    case 2: hipLaunchKernelGGL((k_behz_extend_cols<2, 4, 6>), g, blk, lds, env.stream, bz, env.primes, src, xq, xbsk); break;
+    default: hipLaunchKernelGGL((k_behz_extend_cols<3, 4, 6>), g, blk, lds, env.stream, bz, env.primes, src, xq, xbsk); break;
     }
 }
 void launch_behz_cols_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out)
@@ -2695,6 +2751,34 @@ void launch_behz_rows_tensor(const KernelEnv &env, int Lx, const unsigned char *
         if (pass == 0) hipLaunchKernelGGL(k_behz_rows_tensor<ArF64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
         else hipLaunchKernelGGL(k_behz_rows_tensor<ArU64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
     }
+}
+void launch_behz_tensor_inv(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_ops, u64 op_offset, const u64 *eq, const u64 *ebsk, u64 *dq,
+                            u64 *ds)
+{
+    if (!n_ops) return;
+    BehzTensorArgs A;
+    const int S = bz.nB + 1;
+    A.e[0] = eq; A.e[1] = ebsk; A.d[0] = dq; A.d[1] = ds; A.Lx[0] = bz.L; A.Lx[1] = S;
+    A.src = src; A.n_ops = n_ops; A.op_offset = op_offset; A.logn1 = env.logn1;
+    for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine residues of both bases, pass 1: u64-engine residues
+        A.n_r = 0;
+        for (int i = 0; i < bz.L + S; ++i) {
+            const int base = i < bz.L ? 0 : 1, idx = base ? i - bz.L : i, prime = base ? bz.bsk_prime[idx] : idx;
+            if ((env.prime_f64[prime] != 0) != (pass == 0)) continue;
+            A.r_base[A.n_r] = (unsigned char)base; A.r_idx[A.n_r] = (unsigned char)idx; A.r_prime[A.n_r] = (unsigned char)prime;
+            ++A.n_r;
+        }
+        if (!A.n_r) continue;
+        const u64 jobs = ((n_ops * A.n_r) << env.logn1) * 3;
+        if (pass == 0) hipLaunchKernelGGL(k_behz_tensor_inv<ArF64>, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes, jobs);
+        else hipLaunchKernelGGL(k_behz_tensor_inv<ArU64>, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes, jobs);
+    }
+}
+void launch_rows_fwd(const KernelEnv &env, const PolyView &v, u32 n_items) // the row half of launch_ntt_forward (raw, or canonical when N = 1024, -> NTT form)
+{
+    const u64 jobs = ((u64)n_items * v.polys_per_item) << env.logn1;
+    if (!jobs) return;
+    hipLaunchKernelGGL(k_rows_fwd, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, v, env.primes, jobs, env.logn1, env.logn1 > 0 ? 1 : 0);
 }
 void launch_cols_fwd(const KernelEnv &env, const PolyView &v, u32 n_items) // the column half of launch_ntt_forward (canonical -> raw)
 {
