@@ -1899,7 +1899,7 @@ template <int LOGN1> __device__ __forceinline__ void col_fwd_store(const PrimeDe
 // phase 1, lane (row e, column c) extends its coefficient to Bsk and parks the L + S residues in LDS [residue][e][c]; phase 2, wave w
 // takes residues w, w + N1, ...: each lane runs that residue's column pass on the N1 values of its column (wave-uniform prime, so
 // the engine branch does not diverge) and stores the raw rows.
-template <int LOGN1, int ML, int MB>
+template <int LOGN1, int ML, int MB, bool EXACT>
 __global__ void __launch_bounds__(64 << LOGN1) k_behz_extend_cols(BehzDev Z, const PrimeDev *primes, BehzSrc src_of, u64 *xq, u64 *xbsk)
 {
     constexpr int N1 = 1 << LOGN1;
@@ -1908,7 +1908,7 @@ __global__ void __launch_bounds__(64 << LOGN1) k_behz_extend_cols(BehzDev Z, con
     const u64 pid = blockIdx.x >> 4; // (ciphertext item, which poly); 16 column groups per polynomial
     const u64 col = ((blockIdx.x & 15) << 6) | lane;
     const int k = (int)(pid & 1);
-    const int L = Z.L, S = Z.nB + 1;
+    const int L = EXACT ? ML : Z.L, S = (EXACT ? MB : Z.nB) + 1;
     const u64 N = (u64)N1 << kRowLog, P1 = (u64)L * N;
     {
         const u64 *src = behz_src_ct(src_of, pid >> 1, 2 * P1) + (u64)k * P1 + ((u64)wave << kRowLog) + col;
@@ -2079,10 +2079,10 @@ __global__ void __launch_bounds__(kBlock) k_behz_tensor_inv(BehzTensorArgs A, co
 // BEHZ steps (6)-(8) for one coefficient: dq[i] (base q), ds[j] (Bsk) canonical residues of a product -> its L output residues.
 // Constant factors are folded (BehzDev): every line below is one sum of products below 2^122 (at most 25 of them) and one reduction.
 template <int ML, int MB>
-__device__ __forceinline__ void behz_floor_sk_coeff(const BehzDev &Z, const PrimeDev *primes, const u64 dq[ML], const u64 ds[MB + 1], u64 res[ML])
+__device__ __forceinline__ void behz_floor_sk_coeff(const BehzDev &Z, const PrimeDev *primes, int L, int nB, const u64 dq[ML], const u64 ds[MB + 1], u64 res[ML])
 {
     constexpr int kUnrollB = MB <= 6 ? MB + 1 : 1, kUnrollL = ML <= 4 ? ML : 1; // the large instantiation keeps its residue loops rolled
-    const int L = Z.L, nB = Z.nB, S = nB + 1;
+    const int S = nB + 1;
     u64 tmp[ML], fl[MB];
     // (6) times t, and the base-q part prepared for the fast conversion (canonical: the conversion depends on the representative)
 #pragma unroll
@@ -2141,7 +2141,7 @@ __global__ void __launch_bounds__(kBlock) k_behz_floor_sk(BehzDev Z, const Prime
 #pragma unroll kUnrollB
     for (int j = 0; j < MB + 1; ++j)
         if (j < S) vs[j] = ds[(pid * S + j) * N + n];
-    behz_floor_sk_coeff<ML, MB>(Z, primes, vq, vs, res);
+    behz_floor_sk_coeff<ML, MB>(Z, primes, L, Z.nB, vq, vs, res);
 #pragma unroll kUnrollL
     for (int j = 0; j < ML; ++j)
         if (j < L) out[(pid * L + j) * N + n] = res[j];
@@ -2173,7 +2173,9 @@ template <int LOGN1> __device__ __forceinline__ void col_inv_load(const PrimeDev
 // k_behz_extend_cols -- phase 1, wave w runs the column passes of residues w, w + N1, ... for the block's 64 columns and parks the
 // canonical values in LDS [residue][e][c]; phase 2, lane (row e, column c) takes its coefficient's L + S residues through the fast
 // floor and the Shenoy-Kumaresan conversion.  The coefficient-form products never exist in HBM.
-template <int LOGN1, int ML, int MB>
+// EXACT: L == ML and nB == MB (the reference's own parameter sets: {60,40}, {60,40,40}, {60,40,40,40} with as many auxiliary primes):
+// every residue loop has a compile-time trip count -- straight-line code, no guards.
+template <int LOGN1, int ML, int MB, bool EXACT>
 __global__ void __launch_bounds__(64 << LOGN1) k_behz_cols_floor_sk(BehzDev Z, const PrimeDev *primes, const u64 *dq, const u64 *ds, u64 *out)
 {
     constexpr int N1 = 1 << LOGN1;
@@ -2181,7 +2183,7 @@ __global__ void __launch_bounds__(64 << LOGN1) k_behz_cols_floor_sk(BehzDev Z, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 pid = blockIdx.x >> 4; // (op, k)
     const u64 col = ((blockIdx.x & 15) << 6) | lane;
-    const int L = Z.L, S = Z.nB + 1;
+    const int L = EXACT ? ML : Z.L, nB = EXACT ? MB : Z.nB, S = nB + 1;
     const u64 N = (u64)N1 << kRowLog;
     for (int rr = wave; rr < L + S; rr += N1) {
         const bool isq = rr < L;
@@ -2200,7 +2202,7 @@ __global__ void __launch_bounds__(64 << LOGN1) k_behz_cols_floor_sk(BehzDev Z, c
 #pragma unroll
     for (int j = 0; j < MB + 1; ++j)
         if (j < S) vs[j] = behz_sm[(((L + j) * N1 + wave) << 6) | lane];
-    behz_floor_sk_coeff<ML, MB>(Z, primes, vq, vs, res);
+    behz_floor_sk_coeff<ML, MB>(Z, primes, L, nB, vq, vs, res);
 #pragma unroll
     for (int j = 0; j < ML; ++j)
         if (j < L) out[(pid * L + j) * N + ((u64)wave << kRowLog) + col] = res[j];
@@ -2718,11 +2720,18 @@ void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, const Behz
     if (!behz_cols_fusable(env, bz)) throw std::logic_error("launch_behz_extend_cols: shape not covered by the fused kernel");
     const dim3 g((unsigned)(n_cts * 2 * 16)), blk(64u << env.logn1);
     const size_t lds = (size_t)(bz.L + bz.nB + 1) * (64u << env.logn1) * 8;
+#define HE355_EXT(LOGN1, ML, MB, EXACT) hipLaunchKernelGGL((k_behz_extend_cols<LOGN1, ML, MB, EXACT>), g, blk, lds, env.stream, bz, env.primes, src, xq, xbsk)
     switch (env.logn1) {
-    case 1: hipLaunchKernelGGL((k_behz_extend_cols<1, 4, 6>), g, blk, lds, env.stream, bz, env.primes, src, xq, xbsk); break;
-    case 2: hipLaunchKernelGGL((k_behz_extend_cols<2, 4, 6>), g, blk, lds, env.stream, bz, env.primes, src, xq, xbsk); break;
-    default: hipLaunchKernelGGL((k_behz_extend_cols<3, 4, 6>), g, blk, lds, env.stream, bz, env.primes, src, xq, xbsk); break;
+    case 1: HE355_EXT(1, 4, 6, false); break;
+    case 2: HE355_EXT(2, 4, 6, false); break;
+    default:
+        if (bz.L == 2 && bz.nB == 2) HE355_EXT(3, 2, 2, true);
+        else if (bz.L == 3 && bz.nB == 3) HE355_EXT(3, 3, 3, true);
+        else if (bz.L == 4 && bz.nB == 4) HE355_EXT(3, 4, 4, true);
+        else HE355_EXT(3, 4, 6, false);
+        break;
     }
+#undef HE355_EXT
 }
 void launch_behz_cols_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out)
 {
@@ -2730,11 +2739,18 @@ void launch_behz_cols_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_op
     if (!behz_cols_fusable(env, bz)) throw std::logic_error("launch_behz_cols_floor_sk: shape not covered by the fused kernel");
     const dim3 g((unsigned)(n_ops * 3 * 16)), blk(64u << env.logn1);
     const size_t lds = (size_t)(bz.L + bz.nB + 1) * (64u << env.logn1) * 8;
+#define HE355_FLR(LOGN1, ML, MB, EXACT) hipLaunchKernelGGL((k_behz_cols_floor_sk<LOGN1, ML, MB, EXACT>), g, blk, lds, env.stream, bz, env.primes, dq, ds, out)
     switch (env.logn1) {
-    case 1: hipLaunchKernelGGL((k_behz_cols_floor_sk<1, 4, 6>), g, blk, lds, env.stream, bz, env.primes, dq, ds, out); break;
-    case 2: hipLaunchKernelGGL((k_behz_cols_floor_sk<2, 4, 6>), g, blk, lds, env.stream, bz, env.primes, dq, ds, out); break;
-    default: hipLaunchKernelGGL((k_behz_cols_floor_sk<3, 4, 6>), g, blk, lds, env.stream, bz, env.primes, dq, ds, out); break;
+    case 1: HE355_FLR(1, 4, 6, false); break;
+    case 2: HE355_FLR(2, 4, 6, false); break;
+    default:
+        if (bz.L == 2 && bz.nB == 2) HE355_FLR(3, 2, 2, true);
+        else if (bz.L == 3 && bz.nB == 3) HE355_FLR(3, 3, 3, true);
+        else if (bz.L == 4 && bz.nB == 4) HE355_FLR(3, 4, 4, true);
+        else HE355_FLR(3, 4, 6, false);
+        break;
     }
+#undef HE355_FLR
 }
 void launch_behz_rows_tensor(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d)
 {
