@@ -72,11 +72,17 @@ def main():
             K = int(rng.integers(2, 6))
             bits = [int(x) for x in rng.integers(35, 61, K)]
             pb = int(rng.integers(16, 23))
+            seal_base = bool(rng.random() < 0.2)  # SEAL's 61-bit auxiliary base instead of the device's 46-bit one (same bits out)
+            if seal_base:
+                os.environ["HE355_BEHZ_BASE"] = "seal"
             try:
-                g = be.Context(be.SCHEME_BFV, N, bit_sizes=bits, plain_bits=pb, sec128=False, device=0)
-            except be.HE355Error as e:
-                print(f"case {case}: BFV N={N} bits={bits} skipped ({str(e)[:60]})", flush=True)
-                continue
+                try:
+                    g = be.Context(be.SCHEME_BFV, N, bit_sizes=bits, plain_bits=pb, sec128=False, device=0)
+                except be.HE355Error as e:
+                    print(f"case {case}: BFV N={N} bits={bits} skipped ({str(e)[:60]})", flush=True)
+                    continue
+            finally:
+                os.environ.pop("HE355_BEHZ_BASE", None)
             o = oracle.Context(oracle.SCHEME_BFV, N, bit_sizes=bits, plain_bits=pb, sec128=False)
             assert g.moduli == o.moduli and g.t == o.t
             L, n = g.L, int(rng.choice([1, 2, 3, 5, 9]))
@@ -88,6 +94,15 @@ def main():
             g.bfv_multiply(L, n, da, db, be.Context.pairwise(), c3)
             got3 = c3.download((n, 3, L, N))
             ok = all(np.array_equal(got3[r], o.bfv_multiply(a[r], b[r])) for r in range(n))
+            shape = "pairwise"
+            if ok and n >= 2:  # outer product (operands transformed once each where that pays) with a ragged last row
+                nres = int(rng.integers(n, n * n + 1))
+                co = g.alloc(nres * 3 * L * N)
+                g.bfv_multiply(L, nres, da, db, be.Context.outer(0, (nres + n - 1) // n, 0, n), co)
+                goto = co.download((nres, 3, L, N))
+                ok = all(np.array_equal(goto[r], o.bfv_multiply(a[r // n], b[r % n])) for r in range(nres))
+                shape += f"+outer{nres}"
+                co.free()
             if ok:
                 rk = o.random_kswitch_key(rng)
                 g.set_relin_key(rk)
@@ -95,6 +110,24 @@ def main():
                 g.relinearize(L, n, c3, out)
                 got = out.download((n, 2, L, N))
                 ok = all(np.array_equal(got[r], o.relinearize(got3[r], rk)) for r in range(n))
+            if ok and n >= 2 and N <= 2048:  # the matrix product over an inner index: out(i, j) = sum_k relin(a(i, k) * b(k, j))
+                rows, inner = int(rng.integers(1, n + 1)), min(n, int(rng.integers(1, 4)))
+                cols = max(1, n // inner)
+                rows = min(rows, max(1, n // inner))
+                outm = g.alloc(rows * cols * 2 * L * N)
+                # a(i, k) at k * rows + i (needs inner * rows <= n), b(k, j) at k * cols + j
+                g.bfv_multiply_relin_accumulate(L, rows, cols, inner, da, 1, rows, db, cols, 1, outm)
+                gotm = outm.download((rows * cols, 2, L, N))
+                mods = [int(q) for q in o.moduli[:L]]
+                for i in range(rows):
+                    for j in range(cols):
+                        acc = np.zeros((2, L, N), dtype=object)
+                        for k in range(inner):
+                            acc = acc + o.relinearize(o.bfv_multiply(a[k * rows + i], b[k * cols + j]), rk).astype(object)
+                        want = np.stack([[acc[pp][l] % mods[l] for l in range(L)] for pp in range(2)]).astype(np.uint64)
+                        ok = ok and np.array_equal(gotm[i * cols + j], want)
+                shape += f"+mat{rows}x{inner}x{cols}"
+                outm.free()
             if ok:
                 elt = 2 * N - 1 if rng.random() < 0.3 else g.galois_elt(int(rng.choice([1, 2, -1, 4])))
                 gk = o.random_kswitch_key(rng)
@@ -107,7 +140,7 @@ def main():
             if ok and g.K >= 2:
                 g.set_latency_max(int(rng.choice([0, 8])))
                 ok, extra = chains(be, g, o, rng, L, n, a, da)
-            print(f"case {case}: BFV N={N} bits={bits} t_bits={pb} L={L} n={n} multiply+relin+galois+{'+'.join(extra)} {'ok' if ok else 'MISMATCH'}", flush=True)
+            print(f"case {case}: BFV N={N} bits={bits} t_bits={pb}{' seal-base' if seal_base else ''} L={L} n={n} multiply[{shape}]+relin+galois+{'+'.join(extra)} {'ok' if ok else 'MISMATCH'}", flush=True)
             g.close()
             if not ok:
                 return 1
