@@ -705,6 +705,29 @@ __global__ void __launch_bounds__(kBlock) k_k1(K1Args A, const PrimeDev *primes)
     const u64 op = oi / A.n_i;
     k1_job<Ar, MODE>(A, primes[i], op, i, a_row, lane, lds[wave], valid);
 }
+// Latency shape: the fp64-engine residues (blocks 0 .. n_f - 1) and the u64-engine residues of one key switch in ONE launch (see k_k3_dual)
+template <int MODE, class Ar>
+__device__ __forceinline__ void k1_block(const K1Args &A, const PrimeDev *primes, const unsigned bid_x, u64 (*lds)[kLdsRow])
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 n1 = 1u << A.logn1;
+    const u64 total = A.n_ops * A.n_i * n1;
+    u64 job = (u64)bid_x * kWaves + wave;
+    const bool valid = job < total;
+    if (!valid) job = total - 1;
+    const u32 a_row = (u32)(job & (n1 - 1));
+    const u64 oi = job >> A.logn1;
+    const int i = A.i_list[oi % A.n_i];
+    const u64 op = oi / A.n_i;
+    k1_job<Ar, MODE>(A, primes[i], op, i, a_row, lane, lds[wave], valid);
+}
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_k1_dual(K1Args AF, K1Args AU, unsigned n_f, const PrimeDev *primes)
+{
+    __shared__ u64 lds[kWaves][kLdsRow];
+    if (blockIdx.x < n_f) k1_block<MODE, ArF64>(AF, primes, blockIdx.x, lds);
+    else k1_block<MODE, ArU64>(AU, primes, blockIdx.x - n_f, lds);
+}
 
 // =======================================================================================================
 // K2: per (op, digit j, column): finish the inverse transform, lift to every key prime, forward column pass
@@ -1029,63 +1052,24 @@ __device__ __forceinline__ void k2n_targets_u64(const K2Args &A, const PrimeDev 
 template <int LOGN1, bool WIDE>
 __global__ void __launch_bounds__(kBlock, WIDE ? K2N_WAVES_WIDE : K2N_WAVES) k_k2n(K2Args A, const PrimeDev *primes)
 {
-    constexpr int N1 = 1 << LOGN1;
-    constexpr u64 N = (u64)N1 << kRowLog;
-    const u64 oj = blockIdx.x >> 2;
-    const u32 cb = blockIdx.x & 3;
-    const int col = (int)(cb << 8) | threadIdx.x;
-    const u32 oj32 = (u32)oj; // n_ops * L < 2^32
-    const int j = A.dig_list[__builtin_amdgcn_readfirstlane(oj32 % (u32)A.n_dig)];
-    const u64 op = __builtin_amdgcn_readfirstlane(oj32 / (u32)A.n_dig);
-    const u64 *src = A.c2r + op * A.src_op_stride + (u64)j * N;
-    const PrimeDev &Pj = primes[j];
-    const bool coeff_in = A.src_is_coeff || LOGN1 == 0; // BFV: coefficient form already; N = 1024: the row pass was the whole inverse
-    constexpr bool kTile = N1 >= 8;
-    __shared__ __attribute__((aligned(16))) unsigned char tiles[kTile ? kWaves : 1][kTile ? N1 * 384 : 16];
-    unsigned char *tile = tiles[kTile ? threadIdx.x >> 6 : 0];
-    if constexpr (WIDE) { // 60-bit digits: integers
-        u64 c[N1];
-        if (coeff_in) {
-#pragma unroll
-            for (int a = 0; a < N1; ++a) c[a] = src[(a << kRowLog) + col];
-        } else {
-            const ArU64 ar = make_ar(Pj, (ArU64 *)nullptr);
-            u64 x[N1];
-#pragma unroll
-            for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
-            col_inv<ArU64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
-#pragma unroll
-            for (int a = 0; a < N1; ++a) c[a] = ar.to_canon(x[a]);
-        }
-        k2n_targets_f64<LOGN1, false>(A, primes, Pj, j, op, c, col, tile);
-        k2n_targets_u64<LOGN1>(A, primes, Pj, j, op, c, col);
-    } else {
-    double c[N1];
-    if (coeff_in) {
-#pragma unroll
-        for (int a = 0; a < N1; ++a) c[a] = u52_to_f64(src[(a << kRowLog) + col]);
-    } else if (Pj.f64) {
-        const ArF64 ar = make_ar(Pj, (ArF64 *)nullptr);
-#pragma unroll
-        for (int a = 0; a < N1; ++a) c[a] = ar.from_raw(src[(a << kRowLog) + col]);
-        col_inv<ArF64, LOGN1>(ar, c, ctw(Pj.inv), Pj.inv_w0_scaled);
-#pragma unroll
-        for (int a = 0; a < N1; ++a) c[a] = ar.canon(c[a]);
-    } else { // a u64-engine prime below 2^52
-        const ArU64 ar = make_ar(Pj, (ArU64 *)nullptr);
-        u64 x[N1];
-#pragma unroll
-        for (int a = 0; a < N1; ++a) x[a] = src[(a << kRowLog) + col];
-        col_inv<ArU64, LOGN1>(ar, x, ctw(Pj.inv), Pj.inv_w0_scaled);
-#pragma unroll
-        for (int a = 0; a < N1; ++a) c[a] = u52_to_f64(ar.to_canon(x[a]));
-    }
-    k2n_targets_f64<LOGN1, true>(A, primes, Pj, j, op, c, col, tile);
-    u64 cu[N1]; // the fp64 targets are done: the column continues as integers (the doubles die here)
-#pragma unroll
-    for (int a = 0; a < N1; ++a) cu[a] = f64_to_u52(c[a]);
-    k2n_targets_u64<LOGN1>(A, primes, Pj, j, op, cu, col);
-    }
+#define K2N_BID_X blockIdx.x
+#include "k2n_body.inc"
+#undef K2N_BID_X
+}
+// Latency shape: the digits below 2^52 (blocks 0 .. n_n - 1) and the 60-bit digits of one key switch in ONE launch (see k_k3_dual);
+// blockIdx.y = target group for both (same tsplit).
+template <int LOGN1, bool WIDE>
+__device__ __forceinline__ void k2n_body_fn(const K2Args &A, const PrimeDev *primes, const unsigned bid_x)
+{
+#define K2N_BID_X bid_x
+#include "k2n_body.inc"
+#undef K2N_BID_X
+}
+template <int LOGN1>
+__global__ void __launch_bounds__(kBlock) k_k2n_dual(K2Args AN, K2Args AW, unsigned n_n, const PrimeDev *primes)
+{
+    if (blockIdx.x < n_n) k2n_body_fn<LOGN1, false>(AN, primes, blockIdx.x);
+    else k2n_body_fn<LOGN1, true>(AW, primes, blockIdx.x - n_n);
 }
 
 // =======================================================================================================
@@ -1163,308 +1147,31 @@ struct K3Args {
 template <class Ar, int WAVES, bool FUSE = false, bool TENSOR = false, bool GROUPED = false>
 __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *primes)
 {
-    static_assert(!TENSOR || FUSE, "the operand rows enter through the fused epilogue's sums");
-    static_assert(!GROUPED || !TENSOR, "grouped keys are for rotations");
-    constexpr int kWaves = WAVES, kBlock = WAVES * 64; // this kernel's own block shape (shadows the file-wide one)
-    typedef typename Ar::T T;
-    typedef typename Ar::Acc Acc;
-    constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
-    constexpr bool kPacked = kF64;                    // this engine's digit rows are 48-bit packed (k_k2n wrote them so)
-    constexpr int kDigitPieces = kPacked ? 6 : 8;
-    __shared__ u64 lds[kWaves][kLdsRow];
-    __shared__ __attribute__((aligned(16))) u64 stage[kWaves][kRowN];
-    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 n1 = 1u << A.logn1;
-    const u64 N = (u64)n1 << kRowLog;
-    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so all op-groups of one
-    // (tt,row) tile are placed on the same XCD back to back: its 2*L key rows stay in that XCD's L2.
-    // A block stays on its tile for og_per_block consecutive op-groups (4 ops each): the twiddle staging and the block
-    // start-up are paid once per og_per_block * 4 ops instead of once per 4.
-    const u64 n_og = (A.n_ops + kWaves - 1) / kWaves;
-    const u64 n_ogb = (n_og + A.og_per_block - 1) / A.og_per_block;
-    const u64 total_tiles = (u64)A.n_tt * n1;
-    const u64 s = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-    const u64 tile = (s / n_ogb) * 8 + xcd;
-    if (tile >= total_tiles) return; // whole block exits together
-    const u64 og_first = (s % n_ogb) * A.og_per_block;
-    const int tt = A.tt_list[tile >> A.logn1];
-    const int q_slot = A.q_slot[tile >> A.logn1];
-    const u32 a_row = (u32)(tile & (n1 - 1));
-    const int t = (tt == A.L) ? A.K - 1 : tt;
-    const PrimeDev &P = primes[t];
-    const Ar ar = make_ar(P, (Ar *)nullptr);
-    const u64 rowoff = (u64)a_row << kRowLog;
-    // this block's forward twiddles of row (t, a_row), staged once in LDS
-    const auto twr = stage_row_twiddles<Ar, kBlock>(P, ar, n1 + a_row, twl_raw);
-    __syncthreads();
-    for (u32 g = 0; g < A.og_per_block; ++g) {
-        const u64 og = og_first + g;
-        if (og >= n_og) break; // block-uniform
-        u64 op = og * kWaves + wave;
-        const bool valid = op < A.n_ops;
-        if (!valid) op = A.n_ops - 1;
-        Acc acc0[kRowE], acc1[kRowE];
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) { acc0[r] = 0; acc1[r] = 0; }
-        auto tensor_init = [&]() {
-            if constexpr (TENSOR) {
-                // ct x ct multiply: c0 = a0 b0 and c1 = a0 b1 + a1 b0 are not read back from k_k1's c01 rows, they start the sums -- here,
-                // where no other row is live yet (the first digit row is on its way into LDS meanwhile).  The floor step computes
-                // (sums - x) * P^-1 + addend (mod-down) or ((sums * P^-1 + addend) - x) * q_last^-1 (with the rescale); this instantiation is
-                // handed key residues that carry the factor P^-1 already (DeviceContext::relin_scaled), so its sums ARE sums * P^-1 and the
-                // addend joins them as it is: the results are sums' - x * P^-1 and (sums' - x) * q_last^-1 (floor_fin_s / floor_fin2_s), the
-                // same residues exactly (modular identities), with two products per element fewer at this end and one fewer at that.
-                const u64 tr = A.t_op_offset + op;
-                const u64 LNt = (u64)A.L * N;
-                const u64 *pa = A.ta + idx_a(A.tix, tr) * 2 * LNt + (u64)tt * N + rowoff;
-                const u64 *pb = A.tb + idx_b(A.tix, tr) * 2 * LNt + (u64)tt * N + rowoff;
-                u64 a0[kRowE], a1[kRowE], b0[kRowE], b1[kRowE];
-                load_rowC(pa, lane, a0); load_rowC(pb, lane, b0);
-                load_rowC(pa + LNt, lane, a1); load_rowC(pb + LNt, lane, b1);
-#pragma unroll
-                for (int r = 0; r < kRowE; ++r) {
-                    const T x0 = ar.dy_in(a0[r]), x1 = ar.dy_in(a1[r]), y0 = ar.dy_in(b0[r]), y1 = ar.dy_in(b1[r]);
-                    acc0[r] = ar.acc_from_lazy(ar.dy_mul(x0, y0));
-                    acc1[r] = ar.acc_from_lazy(ar.dy_add(ar.dy_mul(x0, y1), ar.dy_mul(x1, y0)));
-                }
-            }
-        };
-        // u64 engine: products added since the accumulators were last brought under 4q (wave-uniform); acc_flush before anything reads them
-        constexpr int kRun = Ar::kAccRun;
-        int pend = 0;
-        auto acc_flush = [&]() {
-            if constexpr (kRun > 1) {
-                if (pend) {
-#pragma unroll
-                    for (int r = 0; r < kRowE; ++r) { acc0[r] = ar.acc_reduce(acc0[r]); acc1[r] = ar.acc_reduce(acc1[r]); }
-                    pend = 0;
-                }
-            }
-        };
-        auto acc_step = [&]() { // after one product went into every accumulator
-            if constexpr (kRun > 1) {
-                if (++pend == kRun) acc_flush();
-            }
-        };
-        auto mac_row = [&](Acc acc[kRowE], const T x[kRowE], const u64 kv[kRowE], const u64 kq[kRowE]) {
-#pragma unroll
-            for (int r = 0; r < kRowE; ++r) {
-                if constexpr (kRun > 1) ar.acc_mac_lazy(acc[r], x[r], ar.key_in(kv[r]), Ar::kKeyQuotient ? kq[r] : 0);
-                else ar.acc_mac(acc[r], x[r], ar.key_in(kv[r]), Ar::kKeyQuotient ? kq[r] : 0);
-            }
-        };
-        const u64 *kbase = A.key, *kqbase = A.keyq;
-        if constexpr (GROUPED) { // this wave's op names its key (one scalar load per op)
-            typedef const __attribute__((address_space(4))) unsigned long long *ckeys_t;
-            const u32 grp = __builtin_amdgcn_readfirstlane((u32)((A.g_op_offset + op) / A.groups.group_size));
-            kbase = (const u64 *)((ckeys_t)(unsigned long long)A.groups.key)[grp];
-            kqbase = kbase + A.keyq_offset;
-        }
-        auto key_row = [&](int j, int k) -> const u64 * { return kbase + (((u64)j * 2 + k) * A.K + t) * N + rowoff; };
-        auto keyq_row = [&](int j, int k) -> const u64 * { return kqbase + (((u64)j * 2 + k) * A.n_q + q_slot) * N + rowoff; };
-        auto mac_poly = [&](Acc acc[kRowE], const T x[kRowE], int j, int k) {
-            u64 kv[kRowE], kq[kRowE];
-            load_rowC(key_row(j, k), lane, kv);
-            if constexpr (Ar::kKeyQuotient) load_rowC(keyq_row(j, k), lane, kq);
-            mac_row(acc, x, kv, kq);
-        };
-        auto mac_digit = [&](const T x[kRowE], int j) {
-            mac_poly(acc0, x, j, 0);
-            mac_poly(acc1, x, j, 1);
-            acc_step();
-        };
-        // digits that go through the forward row pass: all of them, except (CKKS) the one that lives under this very
-        // prime -- that one is the NTT-form target itself and is multiplied in directly
-        const bool has_own = A.ckks && tt < A.L;
-        const int nd = A.L - (has_own ? 1 : 0);
-        auto digit = [&](int i) -> int { return (has_own && i >= tt) ? i + 1 : i; };
-        // this block's share of the transformed digits: all of them, or group blockIdx.y of n_split (unfused instantiations only)
-        const int split = FUSE ? 1 : (A.n_split > 1 ? A.n_split : 1), grp = split > 1 ? (int)blockIdx.y : 0;
-        const int i_begin = nd * grp / split, i_end = nd * (grp + 1) / split;
-        auto src_row = [&](int j) -> const u64 * { return A.d + ((op * (A.L + 1) + tt) * A.L + j) * N + rowoff; };
-        if (i_begin < i_end) dma_row_to_lds<kDigitPieces>(src_row(digit(i_begin)), stage[wave], lane);
-        tensor_init();
-        if (has_own && grp == 0) {
-            if constexpr (TENSOR) {
-                // the digit that lives under this prime is c2 = a1 b1 in NTT form: formed here (k_k1 writes no c2n row for a ct x ct
-                // multiply) from the two operand rows tensor_init has just pulled through the caches
-                const u64 tr = A.t_op_offset + op;
-                const u64 LNt = (u64)A.L * N;
-                u64 a1[kRowE], b1[kRowE];
-                load_rowC(A.ta + (idx_a(A.tix, tr) * 2 + 1) * LNt + (u64)tt * N + rowoff, lane, a1);
-                load_rowC(A.tb + (idx_b(A.tix, tr) * 2 + 1) * LNt + (u64)tt * N + rowoff, lane, b1);
-                T x[kRowE];
-#pragma unroll
-                for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(ar.dy_out(ar.dy_mul(ar.dy_in(a1[r]), ar.dy_in(b1[r])))); // as the c2n row would read
-                mac_digit(x, tt);
-            } else {
-                T x[kRowE];
-                u64 v[kRowE];
-                load_rowC(FUSE && A.c1_mode == 3 ? A.c1_src + (op * 3 + 2) * ((u64)A.L * N) + (u64)tt * N + rowoff : A.c2n + (op * A.L + tt) * N + rowoff, lane, v);
-#pragma unroll
-                for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
-                mac_digit(x, tt);
-            }
-        }
-        if constexpr (FUSE) {
-            // One digit per wave, mod-down (and rescale) finished here.  The correction rows ride the same pipeline as the digit
-            // rows: rows [0, nd) are digits (transform + key MAC), rows nd, nd+1 the special-prime correction of polynomial
-            // 0 / 1 (transform, then (sums - x) * P^-1 + c01), rows nd+2, nd+3 the rescale correction (transform, then
-            // (result - x) * q_last^-1).  Every row is prefetched into the LDS landing buffer behind the previous row's math.
-            // resc: the rescale is finished here too.  Its correction slab already holds delta2 + P^-1 * delta1 (k_floor_cols folded
-            // the mod-down correction in), so there are two correction rows per tile either way:
-            //   mod-down only: rows nd, nd+1 from cols:   c01 <- (sums - x) * P^-1 + c01
-            //   with rescale : rows nd, nd+1 from cols2:  out <- ((sums * P^-1 + c01) - x) * q_last^-1
-            const bool resc = A.cols2 != nullptr;
-            const int n_rows = nd + 2;
-            const u64 LN = (u64)A.L * N, L1N = (u64)(A.L - 1) * N;
-            auto row_ptr = [&](int i) -> const u64 * {
-                if (i < nd) return src_row(digit(i));
-                if (!resc) return A.cols + ((op * 2 + (i - nd)) * A.L + tt) * N + rowoff;
-                return A.cols2 + ((op * 2 + (i - nd)) * (A.L - 1) + tt) * N + rowoff;
-            };
-            const FloorConst fc = A.fc[(A.K - 1) * A.K + t];
-            const FloorConst fc2 = A.fc[(resc ? A.L - 1 : 0) * A.K + t];
-            if (nd == 0) dma_row_to_lds(row_ptr(0), stage[wave], lane); // no digit row was primed above
-            // digit rows: transform + key MAC (the last one prefetches the first correction row)
-            for (int i = 0; i < nd; ++i) {
-                T x[1][kRowE];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's row has landed in LDS
-                if constexpr (kPacked) {
-                    lds_rowA48(stage[wave], lane, x[0]);
-                } else {
-                    u64 v[kRowE];
-                    lds_rowA(stage[wave], lane, v);
-#pragma unroll
-                    for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffer drained into registers
-                // next row, behind this step's math: a digit row (packed for this engine) or the first correction row (64-bit words)
-                if (i + 1 < nd) dma_row_to_lds<kDigitPieces>(row_ptr(i + 1), stage[wave], lane);
-                else dma_row_to_lds(row_ptr(i + 1), stage[wave], lane);
-                if constexpr (!Ar::kKeyQuotient) {
-                    // both key rows of the digit are requested before the second exchange (the hook runs after phase B's math): they
-                    // land behind the exchange and phase C instead of in front of the multiply-accumulate, which used to wait out
-                    // two L2 round trips per step (poly 0, then poly 1)
-                    u64 kv0[kRowE], kv1[kRowE];
-                    const int j = digit(i);
-                    wave_rows_fwd_n(ar, twr, lane, lds[wave], x, [&]() { load_rowC(key_row(j, 0), lane, kv0); load_rowC(key_row(j, 1), lane, kv1); });
-                    // the 32 products, kMacG at a time (interleaved chains: at two waves per SIMD a serial chain issues at 3/4 of the
-                    // pipe's rate)
-                    if constexpr (kF64) {
-#pragma unroll
-                        for (int r0 = 0; r0 < kRowE; r0 += kMacG / 2) {
-                            double xs[kMacG], ks[kMacG], pr[kMacG];
-#pragma unroll
-                            for (int k = 0; k < kMacG / 2; ++k) {
-                                xs[2 * k] = x[0][r0 + k]; ks[2 * k] = ar.key_in(kv0[r0 + k]);
-                                xs[2 * k + 1] = x[0][r0 + k]; ks[2 * k + 1] = ar.key_in(kv1[r0 + k]);
-                            }
-                            ar.template mulmod_vv_g<kMacG>(xs, ks, pr);
-#pragma unroll
-                            for (int k = 0; k < kMacG / 2; ++k) { acc0[r0 + k] += pr[2 * k]; acc1[r0 + k] += pr[2 * k + 1]; }
-                        }
-                    }
-                } else { // u64 engine: the digit rows are transformed over the wide lazy range (one correction per row, not per butterfly)
-                    wave_rows_fwd_n<Ar, decltype(twr), NoHook, true>(ar, twr, lane, lds[wave], x);
-                    mac_digit(x[0], digit(i));
-                }
-            }
-            acc_flush();
-            // correction rows: transform + floor step(s)
-#pragma unroll 1
-            for (int i = nd; i < n_rows; ++i) {
-                T x[1][kRowE];
-                u64 v[kRowE], av[kRowE];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                lds_rowA(stage[wave], lane, v);
-#pragma unroll
-                for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (i + 1 < n_rows) dma_row_to_lds(row_ptr(i + 1), stage[wave], lane);
-                const int k = i - nd;
-                u64 *c01_row = A.c01 + op * A.c01_item_stride + k * LN + (u64)tt * N + rowoff;
-                // the addend, in flight during the transform -- or nothing: for a ct x ct multiply (A.ta) it entered the accumulators before the digits
-                if constexpr (TENSOR) {
-                    // (no addend row: it entered the sums before the digits)
-                } else if (k == 1 && A.c1_mode == 1) { // a rotation without addend: polynomial 1 starts from zero (k_k1 wrote no row of zeros)
-#pragma unroll
-                    for (int r = 0; r < kRowE; ++r) av[r] = 0;
-                } else if (A.c1_mode == 3) { // relinearize of a size-3 ciphertext: c0, c1 read from the input itself (k_k1 copied nothing)
-                    load_rowC(A.c1_src + (op * 3 + k) * LN + (u64)tt * N + rowoff, lane, av);
-                } else { // ... with addend: its polynomial 1, read where it lies
-                    load_rowC(k == 1 && A.c1_mode == 2 ? A.c1_src + (op * 2 + 1) * LN + (u64)tt * N + rowoff : c01_row, lane, av);
-                }
-                wave_rows_fwd_n(ar, twr, lane, lds[wave], x);
-                const Acc *acc = k == 0 ? acc0 : acc1;
-                if constexpr (TENSOR) { // sums formed with scaled key residues, addend inside them
-                    if (!resc) {
-#pragma unroll
-                        for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin_s(ar.acc_canon(acc[r]), x[0][r], fc.inv, fc.inv_shoup, fc.inv_d, fc.inv_i);
-                        if (valid) store_rowC(c01_row, lane, v);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin2_s(ar.acc_canon(acc[r]), x[0][r], fc2);
-                        if (valid) store_rowC(A.out2 + (op * 2 + k) * L1N + (u64)tt * N + rowoff, lane, v);
-                    }
-                } else if (!resc) {
-#pragma unroll
-                    for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin(ar.acc_canon(acc[r]), x[0][r], fc.inv, fc.inv_shoup, fc.inv_d, fc.inv_i, av[r]);
-                    if (valid) store_rowC(c01_row, lane, v);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < kRowE; ++r) v[r] = ar.floor_fin2(ar.acc_canon(acc[r]), x[0][r], fc, fc2, av[r]);
-                    if (valid) store_rowC(A.out2 + (op * 2 + k) * L1N + (u64)tt * N + rowoff, lane, v);
-                }
-            }
-        } else {
-            for (int i = i_begin; i < i_end; ++i) {
-                T x[1][kRowE];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this step's row has landed in the staging buffer
-                if constexpr (kPacked) {
-                    lds_rowA48(stage[wave], lane, x[0]);
-                } else {
-                    u64 v[kRowE];
-                    lds_rowA(stage[wave], lane, v);
-#pragma unroll
-                    for (int r = 0; r < kRowE; ++r) x[0][r] = ar.from_raw(v[r]);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffer drained into registers
-                if (i + 1 < i_end) dma_row_to_lds<kDigitPieces>(src_row(digit(i + 1)), stage[wave], lane); // next step's row, behind this step's math
-                wave_rows_fwd_n<Ar, decltype(twr), NoHook, true>(ar, twr, lane, lds[wave], x);
-                mac_digit(x[0], digit(i));
-            }
-            acc_flush();
-            // Epilogue: canonical sums, NTT form, layout C.  Data primes -> t; special prime -> tp.  Where the next step is the
-            // inverse transform of these very rows (the special prime always; every prime for BFV, whose key switch returns to
-            // coefficient form) the wave runs the inverse row pass right here and writes the raw rows (special prime -> tpr).
-            const bool inv_here = tt == A.L || !A.ckks;
-            const bool last = A.logn1 == 0;
-#pragma unroll 1
-            for (int k = 0; k < 2; ++k) {
-                u64 v[kRowE];
-                const Acc *acc = k == 0 ? acc0 : acc1;
-#pragma unroll
-                for (int r = 0; r < kRowE; ++r) v[r] = ar.acc_canon(acc[r]);
-                if (split > 1) { // a partial sum: k_k3_combine finishes the tile
-                    if (valid) store_rowC(A.part + (((u64)grp * A.n_ops * 2 + op * 2 + k) * (A.L + 1) + tt) * N + rowoff, lane, v);
-                    continue;
-                }
-                if (!inv_here) {
-                    if (valid) store_rowC(A.t + ((op * 2 + k) * A.L + tt) * N + rowoff, lane, v);
-                    continue;
-                }
-                T x[kRowE];
-#pragma unroll
-                for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(v[r]);
-                wave_rows_inv(ar, P, last, n1 + a_row, lane, lds[wave], x);
-#pragma unroll
-                for (int r = 0; r < kRowE; ++r) v[r] = last ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
-                u64 *dst = tt < A.L ? A.t + ((op * 2 + k) * A.L + tt) * N + rowoff : A.tpr + (op * 2 + k) * N + rowoff;
-                if (valid) store_rowA(dst, lane, v);
-            }
-        }
+#define K3_BID_X blockIdx.x
+#define K3_BID_Y blockIdx.y
+#include "k3_body.inc"
+#undef K3_BID_X
+#undef K3_BID_Y
+}
+// Latency shape: the fp64-engine tiles (blocks 0 .. n_f - 1) and the u64-engine tiles of one key switch in ONE launch -- the two
+// single-wave instantiations side by side (blockIdx.y = digit group; each engine has its own count, surplus blocks leave at once).
+// A batch-1 key switch is a chain of launches of 5-12 us each, bound by launch and dependent-chain latency: one launch instead of
+// two per stage takes the shorter engine's time out of the chain.  (The same body text as k_k3, behind a function boundary here.)
+template <class Ar, int WAVES, bool FUSE, bool TENSOR, bool GROUPED>
+__device__ __forceinline__ void k3_body_fn(const K3Args &A, const PrimeDev *primes, const unsigned bid_x, const unsigned bid_y)
+{
+#define K3_BID_X bid_x
+#define K3_BID_Y bid_y
+#include "k3_body.inc"
+#undef K3_BID_X
+#undef K3_BID_Y
+}
+__global__ void __launch_bounds__(64) k_k3_dual(K3Args AF, K3Args AU, unsigned n_f, const PrimeDev *primes)
+{
+    if (blockIdx.x < n_f) {
+        if ((int)blockIdx.y < (AF.n_split > 1 ? AF.n_split : 1)) k3_body_fn<ArF64, 1, false, false, false>(AF, primes, blockIdx.x, blockIdx.y);
+    } else {
+        if ((int)blockIdx.y < (AU.n_split > 1 ? AU.n_split : 1)) k3_body_fn<ArU64, 1, false, false, false>(AU, primes, blockIdx.x - n_f, blockIdx.y);
     }
 }
 
@@ -1758,13 +1465,12 @@ struct FloorRowsDev {
     unsigned char i_list[64];
 };
 
+// (a device function: the latency shape runs both engines' instantiations in one launch, k_floor_rows_dual, on one set of LDS buffers)
 template <class Ar, bool TAIL>
-__global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const PrimeDev *primes)
+__device__ __forceinline__ void floor_rows_block(const FloorRowsDev &A, const PrimeDev *primes, const unsigned bid_x, u64 (*lds)[kLdsRow],
+                                                 unsigned char *twl_raw)
 {
     typedef typename Ar::T T;
-    constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
-    __shared__ u64 lds[kWaves][kLdsRow];
-    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 n1 = 1u << A.logn1;
     const u64 N = (u64)n1 << kRowLog;
@@ -1772,8 +1478,8 @@ __global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const Pri
     // wave per step: the row's twiddles are staged in LDS once and every later access is a ds_read.
     const u64 n_jobs = A.n_ops * A.a.n_src;
     const u64 n_jb = (n_jobs + A.jobs_per_block - 1) / A.jobs_per_block;
-    const u64 tile = blockIdx.x / n_jb;
-    const u64 j_begin = (blockIdx.x % n_jb) * A.jobs_per_block;
+    const u64 tile = bid_x / n_jb;
+    const u64 j_begin = (bid_x % n_jb) * A.jobs_per_block;
     const u64 j_end = j_begin + A.jobs_per_block < n_jobs ? j_begin + A.jobs_per_block : n_jobs;
     const int i = A.i_list[tile >> A.logn1];
     const u32 a_row = (u32)(tile & (n1 - 1));
@@ -1810,6 +1516,22 @@ __global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const Pri
             store_rowA(A.a.tail + (op * A.a.n_src + k) * N + rowoff, lane, v);
         }
     }
+}
+template <class Ar, bool TAIL>
+__global__ void __launch_bounds__(kBlock) k_floor_rows(FloorRowsDev A, const PrimeDev *primes)
+{
+    constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
+    __shared__ u64 lds[kWaves][kLdsRow];
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
+    floor_rows_block<Ar, TAIL>(A, primes, blockIdx.x, lds, twl_raw);
+}
+// Latency shape: the fp64-engine targets (blocks 0 .. n_f - 1) and the u64-engine targets of one floor step in ONE launch (see k_k3_dual)
+__global__ void __launch_bounds__(kBlock) k_floor_rows_dual(FloorRowsDev AF, FloorRowsDev AU, unsigned n_f, const PrimeDev *primes)
+{
+    __shared__ u64 lds[kWaves][kLdsRow];
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kRowTw * 16];
+    if (blockIdx.x < n_f) floor_rows_block<ArF64, false>(AF, primes, blockIdx.x, lds, twl_raw);
+    else floor_rows_block<ArU64, false>(AU, primes, blockIdx.x - n_f, lds, twl_raw);
 }
 
 // =======================================================================================================
@@ -2448,6 +2170,13 @@ void launch_mul3(const KernelEnv &env, int L, u64 n_results, const u64 *a, const
     hipLaunchKernelGGL(k_mul3, dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, a, b, out, ix, env.primes, L, logN, n_results);
 }
 
+// Latency shape: the two engines' launches of a stage as one kernel (k_k1_dual, k_k2n_dual, k_k3_dual, k_floor_rows_dual); HE355_DUAL_ENGINE=0: one
+// launch per engine as in the throughput shape.
+static bool dual_engine_launches()
+{
+    static const bool off = getenv("HE355_DUAL_ENGINE") && getenv("HE355_DUAL_ENGINE")[0] == '0';
+    return !off;
+}
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
                const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1, const KsGroups *groups)
 {
@@ -2461,24 +2190,37 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
     A.a = a; A.b = b; A.ix = ix; A.perm = perm; A.addend = addend;
     A.c01 = buf.c01; A.c01_item_stride = buf.c01_item_stride; A.c2n = buf.c2n; A.c2r = buf.c2r;
     A.n_ops = n_ops; A.op_offset = op_offset; A.L = L; A.logn1 = env.logn1; A.mode = (int)mode;
+    K1Args AP[2];
+    unsigned gp[2] = {0, 0};
     for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine residues, pass 1: u64-engine residues
         A.n_i = 0;
         for (int i = 0; i < L; ++i)
             if ((env.prime_f64[i] != 0) == (pass == 0)) A.i_list[A.n_i++] = (unsigned char)i;
-        if (!A.n_i) continue;
-        const u64 jobs = (n_ops * A.n_i) << env.logn1;
-        const dim3 grid(grid_for(jobs, kWaves));
-        const hipStream_t st = env.stream;
+        AP[pass] = A;
+        gp[pass] = A.n_i ? grid_for((n_ops * A.n_i) << env.logn1, kWaves) : 0;
+    }
+    const hipStream_t st = env.stream;
+    if (gp[0] && gp[1] && n_ops <= 8 && mode != K1_MUL_C2 && !(mode == K1_MUL && no_c01) && dual_engine_launches()) { // latency shape: one launch
+        const dim3 grid(gp[0] + gp[1]);
+        if (mode == K1_MUL) hipLaunchKernelGGL((k_k1_dual<K1_MUL>), grid, dim3(kBlock), 0, st, AP[0], AP[1], gp[0], env.primes);
+        else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1_dual<K1_CT3>), grid, dim3(kBlock), 0, st, AP[0], AP[1], gp[0], env.primes);
+        else hipLaunchKernelGGL((k_k1_dual<K1_GALOIS>), grid, dim3(kBlock), 0, st, AP[0], AP[1], gp[0], env.primes);
+        return;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        if (!gp[pass]) continue;
+        const dim3 grid(gp[pass]);
+        const K1Args &AA = AP[pass];
         if (pass == 0) {
-            if (mode == K1_MUL && no_c01) hipLaunchKernelGGL((k_k1<K1_MUL_C2, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
-            else if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
-            else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
-            else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArF64>), grid, dim3(kBlock), 0, st, A, env.primes);
+            if (mode == K1_MUL && no_c01) hipLaunchKernelGGL((k_k1<K1_MUL_C2, ArF64>), grid, dim3(kBlock), 0, st, AA, env.primes);
+            else if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArF64>), grid, dim3(kBlock), 0, st, AA, env.primes);
+            else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArF64>), grid, dim3(kBlock), 0, st, AA, env.primes);
+            else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArF64>), grid, dim3(kBlock), 0, st, AA, env.primes);
         } else {
-            if (mode == K1_MUL && no_c01) hipLaunchKernelGGL((k_k1<K1_MUL_C2, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
-            else if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
-            else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
-            else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArU64>), grid, dim3(kBlock), 0, st, A, env.primes);
+            if (mode == K1_MUL && no_c01) hipLaunchKernelGGL((k_k1<K1_MUL_C2, ArU64>), grid, dim3(kBlock), 0, st, AA, env.primes);
+            else if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArU64>), grid, dim3(kBlock), 0, st, AA, env.primes);
+            else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1<K1_CT3, ArU64>), grid, dim3(kBlock), 0, st, AA, env.primes);
+            else hipLaunchKernelGGL((k_k1<K1_GALOIS, ArU64>), grid, dim3(kBlock), 0, st, AA, env.primes);
         }
     }
 }
@@ -2493,6 +2235,24 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     A.d = buf.d; A.n_ops = n_ops; A.L = L; A.K = env.K; A.ckks = env.scheme == 2;
     A.f64_mask = 0; A.tsplit = tsplit > 1 ? tsplit : 1;
     for (int t = 0; t < env.K; ++t) A.f64_mask |= (u64)(env.prime_f64[t] != 0) << t;
+    if (tsplit > 1 && dual_engine_launches()) { // latency shape (the caller fixed the target split): both digit kinds in one launch
+        K2Args AK[2];
+        unsigned gk[2] = {0, 0};
+        for (int wide = 0; wide < 2; ++wide) {
+            A.n_dig = 0;
+            for (int j = 0; j < L; ++j)
+                if ((env.prime_q[j] >> 52 != 0) == (wide != 0)) A.dig_list[A.n_dig++] = (unsigned char)j;
+            AK[wide] = A;
+            gk[wide] = (unsigned)(n_ops * A.n_dig * 4);
+        }
+        if (gk[0] && gk[1]) {
+            const dim3 gd(gk[0] + gk[1], (unsigned)A.tsplit);
+#define HE355_K2D(L1) case L1: hipLaunchKernelGGL((k_k2n_dual<L1>), gd, dim3(kBlock), 0, env.stream, AK[0], AK[1], gk[0], env.primes); break;
+            switch (env.logn1) { HE355_K2D(0) HE355_K2D(1) HE355_K2D(2) HE355_K2D(3) HE355_K2D(4) HE355_K2D(5) }
+#undef HE355_K2D
+            return;
+        }
+    }
     for (int wide = 0; wide < 2; ++wide) { // digits below 2^52, then the 60-bit ones: one instantiation each
         A.n_dig = 0;
         for (int j = 0; j < L; ++j)
@@ -2542,6 +2302,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     const unsigned char *prime_f64 = env.prime_f64;
     if (!n_ops) return;
     if (fuse && (part != K3_DATA_ONLY || !k3_can_fuse(env))) throw std::runtime_error("fused mod-down: data-prime tiles only");
+    struct { K3Args A; unsigned g; bool f64; } lat[2];
+    int n_lat = 0;
     for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine primes, pass 1: u64-engine primes
         K3Args A;
         A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tp = buf.tp; A.tpr = buf.tpr;
@@ -2610,10 +2372,9 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             (void)hipEventRecord(pr->start[slot], env.stream);
         }
         const hipStream_t st3 = env.stream;
-        if (waves == 1) {
-            const dim3 gd(g, (unsigned)A.n_split);
-            if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 1>), gd, dim3(64), 0, st3, A, env.primes);
-            else hipLaunchKernelGGL((k_k3<ArU64, 1>), gd, dim3(64), 0, st3, A, env.primes);
+        if (waves == 1) { // latency shape: launched below, both engines in one kernel where both have tiles
+            lat[n_lat].A = A; lat[n_lat].g = g; lat[n_lat].f64 = pass == 0;
+            ++n_lat;
         } else if (groups) {
             if (pass == 0 && fuse) hipLaunchKernelGGL((k_k3<ArF64, 8, true, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
             else if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 8, false, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
@@ -2629,6 +2390,16 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             else hipLaunchKernelGGL((k_k3<ArU64, 8>), dim3(g), dim3(512), 0, st3, A, env.primes);
         }
         if (slot >= 0) (void)hipEventRecord(pr->stop[slot], env.stream);
+    }
+    if (n_lat == 2 && dual_engine_launches()) {
+        const unsigned ny = (unsigned)std::max(lat[0].A.n_split, lat[1].A.n_split);
+        hipLaunchKernelGGL(k_k3_dual, dim3(lat[0].g + lat[1].g, ny), dim3(64), 0, env.stream, lat[0].A, lat[1].A, lat[0].g, env.primes);
+    } else {
+        for (int i = 0; i < n_lat; ++i) {
+            const dim3 gd(lat[i].g, (unsigned)lat[i].A.n_split);
+            if (lat[i].f64) hipLaunchKernelGGL((k_k3<ArF64, 1>), gd, dim3(64), 0, env.stream, lat[i].A, env.primes);
+            else hipLaunchKernelGGL((k_k3<ArU64, 1>), gd, dim3(64), 0, env.stream, lat[i].A, env.primes);
+        }
     }
     // (the inverse row pass of the special-prime sums, and of every prime's sums for BFV, happened in the kernel's epilogue)
 }
@@ -2673,6 +2444,23 @@ void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &arg
     // per block: up to 8 jobs per wave, fewer when that would leave CUs without blocks
     u32 jpb = 8 * kWaves;
     while (jpb > (u32)kWaves && (((u64)args.n_tgt << env.logn1) * ((n_jobs + jpb - 1) / jpb) < 256u * 8 || jpb / 2 >= n_jobs)) jpb >>= 1;
+    if (n_ops <= 8 && args.tail_prime < 0 && dual_engine_launches()) { // latency shape, no tail prime: both engines in one launch
+        FloorRowsDev AE[2];
+        unsigned ge[2] = {0, 0};
+        for (int e = 0; e < 2; ++e) {
+            FloorRowsDev &A = AE[e];
+            A.a = args; A.fc = env.floor_consts; A.n_ops = n_ops; A.K = env.K; A.logn1 = env.logn1;
+            A.jobs_per_block = jpb;
+            A.n_i = 0;
+            for (int i = 0; i < args.n_tgt; ++i)
+                if ((prime_f64[i] != 0) == (e == 0)) A.i_list[A.n_i++] = (unsigned char)i;
+            ge[e] = (unsigned)((((u64)A.n_i) << env.logn1) * ((n_jobs + jpb - 1) / jpb));
+        }
+        if (ge[0] && ge[1]) {
+            hipLaunchKernelGGL(k_floor_rows_dual, dim3(ge[0] + ge[1]), dim3(kBlock), 0, env.stream, AE[0], AE[1], ge[0], env.primes);
+            return;
+        }
+    }
     for (int pass = 0; pass < 4; ++pass) { // (engine, tail) combinations; the tail prime gets its own launch
         const bool f64 = pass < 2, tail = pass & 1;
         FloorRowsDev A;

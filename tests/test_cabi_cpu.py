@@ -113,7 +113,7 @@ def test_product_never_touches_oracle():
         if "_obj" in dp or dp.endswith("lib"):
             continue
         for f in fs:
-            if f.endswith((".h", ".hip", ".cpp", ".py", "Makefile")):
+            if f.endswith((".h", ".hip", ".inc", ".cpp", ".py", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 if re.search(r"he_oracle|libhe_oracle|import oracle|from oracle|oracle/", txt):
                     # the package docstring may say it never imports oracle
