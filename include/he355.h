@@ -133,7 +133,9 @@ int he355_sub(he355_ctx *ctx, int L, int size, uint64_t n, const uint64_t *d_a, 
 /* CKKS multiply: [.][2][L][N] x [.][2][L][N] -> [n][3][L][N] */
 int he355_multiply(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, uint64_t *d_out);
 /* BFV multiply (BEHZ, coefficient form): [.][2][L][N] x [.][2][L][N] -> [n][3][L][N]
- * (evaluator()->multiply, src/benchmarks/bfv/seal_bfv_element_wise_benchmark.cpp:325, seal_bfv_dot_product_benchmark.cpp:311) */
+ * (evaluator()->multiply, src/benchmarks/bfv/seal_bfv_element_wise_benchmark.cpp:325, seal_bfv_dot_product_benchmark.cpp:311).
+ * In an outer-product batch every operand serves several results: each is extended to the auxiliary base and transformed once
+ * (the values SEAL recomputes per pair), a result then costs its dyadic tensor, three inverse transforms and the floor. */
 int he355_bfv_multiply(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, uint64_t *d_out);
 /* multiply -> relinearize (-> rescale): out [n][2][L][N] or [n][2][L-1][N].  Give d_out a slab of its own: then the tensor product's
  * c0, c1 never travel through HBM (the key-switch kernel forms them from the operand rows); a d_out that overlaps an operand is
