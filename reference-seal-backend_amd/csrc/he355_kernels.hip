@@ -1149,30 +1149,55 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
 {
 #define K3_BID_X blockIdx.x
 #define K3_BID_Y blockIdx.y
+#define K3_LDS_DECL                                                                                                            \
+    __shared__ u64 lds[kWaves][kLdsRow];                                                                                       \
+    __shared__ __attribute__((aligned(16))) u64 stage[kWaves][kRowN];                                                          \
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
 #include "k3_body.inc"
 #undef K3_BID_X
 #undef K3_BID_Y
+#undef K3_LDS_DECL
 }
-// Latency shape: the fp64-engine tiles (blocks 0 .. n_f - 1) and the u64-engine tiles of one key switch in ONE launch -- the two
-// single-wave instantiations side by side (blockIdx.y = digit group; each engine has its own count, surplus blocks leave at once).
-// A batch-1 key switch is a chain of launches of 5-12 us each, bound by launch and dependent-chain latency: one launch instead of
-// two per stage takes the shorter engine's time out of the chain.  (The same body text as k_k3, behind a function boundary here.)
+// Both engines' tiles of one stage in ONE launch: the fp64-engine blocks (0 .. n_f - 1) and the u64-engine blocks side by side, on one
+// set of LDS arrays.  Two uses.  Latency shape (k_k3_dual, single-wave blocks; blockIdx.y = digit group, each engine with its own
+// count, surplus blocks leave at once): a batch-1 key switch is a chain of launches of 5-12 us each, bound by launch and
+// dependent-chain latency, and one launch instead of two per stage takes the shorter engine's time out of the chain.  Small grids of
+// the throughput shape (k_k3_dual8: tens of ciphertexts at N = 8192 are 30-130 blocks per engine on 256 CUs): the two launches
+// would run one after the other on a mostly idle chip.  (The same body text as k_k3, behind a function boundary here -- which is
+// why the large grids, the headline's among them, keep the template kernels.)
 template <class Ar, int WAVES, bool FUSE, bool TENSOR, bool GROUPED>
-__device__ __forceinline__ void k3_body_fn(const K3Args &A, const PrimeDev *primes, const unsigned bid_x, const unsigned bid_y)
+__device__ __forceinline__ void k3_body_fn(const K3Args &A, const PrimeDev *primes, const unsigned bid_x, const unsigned bid_y, u64 (*lds)[kLdsRow],
+                                           u64 (*stage)[kRowN], unsigned char *twl_raw)
 {
 #define K3_BID_X bid_x
 #define K3_BID_Y bid_y
+#define K3_LDS_DECL
 #include "k3_body.inc"
 #undef K3_BID_X
 #undef K3_BID_Y
+#undef K3_LDS_DECL
 }
 __global__ void __launch_bounds__(64) k_k3_dual(K3Args AF, K3Args AU, unsigned n_f, const PrimeDev *primes)
 {
+    __shared__ u64 lds[1][kLdsRow];
+    __shared__ __attribute__((aligned(16))) u64 stage[1][kRowN];
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kRowTw * 16];
     if (blockIdx.x < n_f) {
-        if ((int)blockIdx.y < (AF.n_split > 1 ? AF.n_split : 1)) k3_body_fn<ArF64, 1, false, false, false>(AF, primes, blockIdx.x, blockIdx.y);
+        if ((int)blockIdx.y < (AF.n_split > 1 ? AF.n_split : 1))
+            k3_body_fn<ArF64, 1, false, false, false>(AF, primes, blockIdx.x, blockIdx.y, lds, stage, twl_raw);
     } else {
-        if ((int)blockIdx.y < (AU.n_split > 1 ? AU.n_split : 1)) k3_body_fn<ArU64, 1, false, false, false>(AU, primes, blockIdx.x - n_f, blockIdx.y);
+        if ((int)blockIdx.y < (AU.n_split > 1 ? AU.n_split : 1))
+            k3_body_fn<ArU64, 1, false, false, false>(AU, primes, blockIdx.x - n_f, blockIdx.y, lds, stage, twl_raw);
     }
+}
+template <bool FUSE, bool TENSOR, bool GROUPED>
+__global__ void __launch_bounds__(512) k_k3_dual8(K3Args AF, K3Args AU, unsigned n_f, const PrimeDev *primes)
+{
+    __shared__ u64 lds[8][kLdsRow];
+    __shared__ __attribute__((aligned(16))) u64 stage[8][kRowN];
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kRowTw * 16];
+    if (blockIdx.x < n_f) k3_body_fn<ArF64, 8, FUSE, TENSOR, GROUPED>(AF, primes, blockIdx.x, 0, lds, stage, twl_raw);
+    else k3_body_fn<ArU64, 8, FUSE, TENSOR, GROUPED>(AU, primes, blockIdx.x - n_f, 0, lds, stage, twl_raw);
 }
 
 // The sums of a digit-split k_k3 launch: part [n_split][n_ops * 2][L + 1][N] canonical -> t (data primes, canonical NTT form) and tpr
@@ -2177,6 +2202,12 @@ static bool dual_engine_launches()
     static const bool off = getenv("HE355_DUAL_ENGINE") && getenv("HE355_DUAL_ENGINE")[0] == '0';
     return !off;
 }
+// ... also for small grids of the throughput shape: up to this many blocks for both engines together (two per CU)
+static unsigned dual_max_blocks()
+{
+    static const unsigned v = getenv("HE355_DUAL_MAX_BLOCKS") ? (unsigned)atoi(getenv("HE355_DUAL_MAX_BLOCKS")) : 512u;
+    return v;
+}
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
                const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1, const KsGroups *groups)
 {
@@ -2200,7 +2231,8 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
         gp[pass] = A.n_i ? grid_for((n_ops * A.n_i) << env.logn1, kWaves) : 0;
     }
     const hipStream_t st = env.stream;
-    if (gp[0] && gp[1] && n_ops <= 8 && mode != K1_MUL_C2 && !(mode == K1_MUL && no_c01) && dual_engine_launches()) { // latency shape: one launch
+    if (gp[0] && gp[1] && (n_ops <= 8 || gp[0] + gp[1] <= dual_max_blocks()) && mode != K1_MUL_C2 && !(mode == K1_MUL && no_c01) &&
+        dual_engine_launches()) { // latency shape / small grids: one launch for both engines
         const dim3 grid(gp[0] + gp[1]);
         if (mode == K1_MUL) hipLaunchKernelGGL((k_k1_dual<K1_MUL>), grid, dim3(kBlock), 0, st, AP[0], AP[1], gp[0], env.primes);
         else if (mode == K1_CT3) hipLaunchKernelGGL((k_k1_dual<K1_CT3>), grid, dim3(kBlock), 0, st, AP[0], AP[1], gp[0], env.primes);
@@ -2235,52 +2267,52 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     A.d = buf.d; A.n_ops = n_ops; A.L = L; A.K = env.K; A.ckks = env.scheme == 2;
     A.f64_mask = 0; A.tsplit = tsplit > 1 ? tsplit : 1;
     for (int t = 0; t < env.K; ++t) A.f64_mask |= (u64)(env.prime_f64[t] != 0) << t;
-    if (tsplit > 1 && dual_engine_launches()) { // latency shape (the caller fixed the target split): both digit kinds in one launch
-        K2Args AK[2];
-        unsigned gk[2] = {0, 0};
-        for (int wide = 0; wide < 2; ++wide) {
-            A.n_dig = 0;
-            for (int j = 0; j < L; ++j)
-                if ((env.prime_q[j] >> 52 != 0) == (wide != 0)) A.dig_list[A.n_dig++] = (unsigned char)j;
-            AK[wide] = A;
-            gk[wide] = (unsigned)(n_ops * A.n_dig * 4);
-        }
-        if (gk[0] && gk[1]) {
-            const dim3 gd(gk[0] + gk[1], (unsigned)A.tsplit);
+    // Small grids: the targets of a (digit, column block) dealt to 2 or 4 blocks (blockIdx.y, as the latency shape does) when
+    // that fills the rounds of blocks better -- 512 blocks run at a time (two per CU); a block pays the digit's inverse column
+    // pass once and a forward column pass + stores per target.  64 BFV ciphertexts at L = 3: 768 blocks = 1.5 rounds of all four
+    // targets, or 3 full rounds of two targets each.  Only taken for a modelled gain of 5 % or more (the headline's 61440 blocks
+    // stay whole); HE355_K2_TSPLIT=<n> fixes it.
+    static const int ts_env = getenv("HE355_K2_TSPLIT") ? atoi(getenv("HE355_K2_TSPLIT")) : 0;
+    auto target_split = [&](unsigned gw) {
+        if (tsplit > 1) return tsplit;
+        if (ts_env > 0) return ts_env;
+        int ts = 1;
+        const int n_tgt = L + 1 - (A.ckks ? 1 : 0);
+        auto cost = [&](int c) { return (double)(((u64)gw * c + 511) / 512) * (1.0 + 1.2 * ((n_tgt + c - 1) / c)); };
+        const double c1 = cost(1);
+        double best = c1;
+        for (int c = 2; c <= 4; c <<= 1)
+            if (cost(c) < best * 0.95 && cost(c) < c1 * 0.95) { best = cost(c); ts = c; }
+        return ts;
+    };
+    K2Args AK[2];
+    unsigned gk[2] = {0, 0};
+    for (int wide = 0; wide < 2; ++wide) { // digits below 2^52, then the 60-bit ones: one instantiation each
+        A.n_dig = 0;
+        for (int j = 0; j < L; ++j)
+            if ((env.prime_q[j] >> 52 != 0) == (wide != 0)) A.dig_list[A.n_dig++] = (unsigned char)j;
+        AK[wide] = A;
+        gk[wide] = (unsigned)(n_ops * A.n_dig * 4);
+    }
+    if (gk[0] && gk[1] && dual_engine_launches()) { // latency shape or a small grid: both digit kinds in one launch (k_k2n_dual)
+        const int ts = target_split(gk[0] + gk[1]);
+        if (tsplit > 1 || (gk[0] + gk[1]) * (unsigned)ts <= dual_max_blocks()) {
+            AK[0].tsplit = AK[1].tsplit = ts;
+            const dim3 gd(gk[0] + gk[1], (unsigned)ts);
 #define HE355_K2D(L1) case L1: hipLaunchKernelGGL((k_k2n_dual<L1>), gd, dim3(kBlock), 0, env.stream, AK[0], AK[1], gk[0], env.primes); break;
             switch (env.logn1) { HE355_K2D(0) HE355_K2D(1) HE355_K2D(2) HE355_K2D(3) HE355_K2D(4) HE355_K2D(5) }
 #undef HE355_K2D
             return;
         }
     }
-    for (int wide = 0; wide < 2; ++wide) { // digits below 2^52, then the 60-bit ones: one instantiation each
-        A.n_dig = 0;
-        for (int j = 0; j < L; ++j)
-            if ((env.prime_q[j] >> 52 != 0) == (wide != 0)) A.dig_list[A.n_dig++] = (unsigned char)j;
-        if (!A.n_dig) continue;
-        const unsigned gw = (unsigned)(n_ops * A.n_dig * 4);
-        // Small grids: the targets of a (digit, column block) dealt to 2 or 4 blocks (blockIdx.y, as the latency shape does) when
-        // that fills the rounds of blocks better -- 512 blocks run at a time (two per CU); a block pays the digit's inverse column
-        // pass once and a forward column pass + stores per target.  64 BFV ciphertexts at L = 3: 768 blocks = 1.5 rounds of all four
-        // targets, or 3 full rounds of two targets each.  Only taken for a modelled gain of 5 % or more (the headline's 61440 blocks
-        // stay whole); HE355_K2_TSPLIT=<n> fixes it.
-        static const int ts_env = getenv("HE355_K2_TSPLIT") ? atoi(getenv("HE355_K2_TSPLIT")) : 0;
-        int ts = tsplit > 1 ? tsplit : 1;
-        if (tsplit <= 1 && ts_env > 0) ts = ts_env;
-        else if (tsplit <= 1) {
-            const int n_tgt = L + 1 - (A.ckks ? 1 : 0);
-            auto cost = [&](int c) { return (double)(((u64)gw * c + 511) / 512) * (1.0 + 1.2 * ((n_tgt + c - 1) / c)); };
-            const double c1 = cost(1);
-            double best = c1;
-            for (int c = 2; c <= 4; c <<= 1)
-                if (cost(c) < best * 0.95 && cost(c) < c1 * 0.95) { best = cost(c); ts = c; }
-        }
-        A.tsplit = ts;
-        const dim3 gd(gw, (unsigned)A.tsplit);
+    for (int wide = 0; wide < 2; ++wide) {
+        if (!gk[wide]) continue;
+        AK[wide].tsplit = target_split(gk[wide]);
+        const dim3 gd(gk[wide], (unsigned)AK[wide].tsplit);
 #define HE355_K2N(L1)                                                                                                         \
     case L1:                                                                                                                  \
-        if (wide) hipLaunchKernelGGL((k_k2n<L1, true>), gd, dim3(kBlock), 0, env.stream, A, env.primes);                      \
-        else hipLaunchKernelGGL((k_k2n<L1, false>), gd, dim3(kBlock), 0, env.stream, A, env.primes);                          \
+        if (wide) hipLaunchKernelGGL((k_k2n<L1, true>), gd, dim3(kBlock), 0, env.stream, AK[wide], env.primes);               \
+        else hipLaunchKernelGGL((k_k2n<L1, false>), gd, dim3(kBlock), 0, env.stream, AK[wide], env.primes);                   \
         break;
         switch (env.logn1) { HE355_K2N(0) HE355_K2N(1) HE355_K2N(2) HE355_K2N(3) HE355_K2N(4) HE355_K2N(5) }
 #undef HE355_K2N
@@ -2302,8 +2334,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     const unsigned char *prime_f64 = env.prime_f64;
     if (!n_ops) return;
     if (fuse && (part != K3_DATA_ONLY || !k3_can_fuse(env))) throw std::runtime_error("fused mod-down: data-prime tiles only");
-    struct { K3Args A; unsigned g; bool f64; } lat[2];
-    int n_lat = 0;
+    struct { K3Args A; unsigned g; bool f64; int waves; } pend[2];
+    int n_pend = 0;
     for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine primes, pass 1: u64-engine primes
         K3Args A;
         A.d = buf.d; A.c2n = buf.c2n; A.key = key; A.t = buf.t; A.tp = buf.tp; A.tpr = buf.tpr;
@@ -2359,7 +2391,32 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.og_per_block = ogpb;
         const u64 n_ogb = (n_og + ogpb - 1) / ogpb;
         const unsigned g = (unsigned)(((tiles + 7) / 8) * 8 * n_ogb);
-        KernelProbe *pr = pass == 0 ? env.probe : nullptr;
+        pend[n_pend].A = A; pend[n_pend].g = g; pend[n_pend].f64 = pass == 0; pend[n_pend].waves = waves;
+        ++n_pend;
+    }
+    const hipStream_t st3 = env.stream;
+    const bool tensor = fuse && fuse->ta;
+    if (n_pend == 2 && pend[0].waves == 1 && dual_engine_launches()) { // latency shape
+        const unsigned ny = (unsigned)std::max(pend[0].A.n_split, pend[1].A.n_split);
+        hipLaunchKernelGGL(k_k3_dual, dim3(pend[0].g + pend[1].g, ny), dim3(64), 0, st3, pend[0].A, pend[1].A, pend[0].g, env.primes);
+        return;
+    }
+    // throughput shape, small grids (up to two blocks per CU for both engines together): both engines in one launch
+    if (n_pend == 2 && pend[0].waves == 8 && pend[0].g + pend[1].g <= dual_max_blocks() && dual_engine_launches()) {
+        const dim3 gd(pend[0].g + pend[1].g);
+#define HE355_K3D8(F, T, G) hipLaunchKernelGGL((k_k3_dual8<F, T, G>), gd, dim3(512), 0, st3, pend[0].A, pend[1].A, pend[0].g, env.primes)
+        if (groups) { if (fuse) HE355_K3D8(true, false, true); else HE355_K3D8(false, false, true); }
+        else if (tensor) HE355_K3D8(true, true, false);
+        else if (fuse) HE355_K3D8(true, false, false);
+        else HE355_K3D8(false, false, false);
+#undef HE355_K3D8
+        return;
+    }
+    for (int i = 0; i < n_pend; ++i) {
+        const K3Args &A = pend[i].A;
+        const unsigned g = pend[i].g;
+        const bool f64 = pend[i].f64;
+        KernelProbe *pr = f64 && pend[i].waves == 8 ? env.probe : nullptr;
         int slot = -1;
         if (pr && pr->used < KernelProbe::kCap) {
             slot = pr->used++;
@@ -2371,35 +2428,25 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             pr->ops += n_ops;
             (void)hipEventRecord(pr->start[slot], env.stream);
         }
-        const hipStream_t st3 = env.stream;
-        if (waves == 1) { // latency shape: launched below, both engines in one kernel where both have tiles
-            lat[n_lat].A = A; lat[n_lat].g = g; lat[n_lat].f64 = pass == 0;
-            ++n_lat;
+        if (pend[i].waves == 1) {
+            const dim3 gd(g, (unsigned)A.n_split);
+            if (f64) hipLaunchKernelGGL((k_k3<ArF64, 1>), gd, dim3(64), 0, st3, A, env.primes);
+            else hipLaunchKernelGGL((k_k3<ArU64, 1>), gd, dim3(64), 0, st3, A, env.primes);
         } else if (groups) {
-            if (pass == 0 && fuse) hipLaunchKernelGGL((k_k3<ArF64, 8, true, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
-            else if (pass == 0) hipLaunchKernelGGL((k_k3<ArF64, 8, false, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+            if (f64 && fuse) hipLaunchKernelGGL((k_k3<ArF64, 8, true, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+            else if (f64) hipLaunchKernelGGL((k_k3<ArF64, 8, false, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
             else if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 8, true, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
             else hipLaunchKernelGGL((k_k3<ArU64, 8, false, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
-        } else if (pass == 0) {
-            if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArF64, 8, true, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+        } else if (f64) {
+            if (tensor) hipLaunchKernelGGL((k_k3<ArF64, 8, true, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
             else if (fuse) hipLaunchKernelGGL((k_k3<ArF64, 8, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
             else hipLaunchKernelGGL((k_k3<ArF64, 8>), dim3(g), dim3(512), 0, st3, A, env.primes);
         } else {
-            if (fuse && A.ta) hipLaunchKernelGGL((k_k3<ArU64, 8, true, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
+            if (tensor) hipLaunchKernelGGL((k_k3<ArU64, 8, true, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
             else if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 8, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
             else hipLaunchKernelGGL((k_k3<ArU64, 8>), dim3(g), dim3(512), 0, st3, A, env.primes);
         }
         if (slot >= 0) (void)hipEventRecord(pr->stop[slot], env.stream);
-    }
-    if (n_lat == 2 && dual_engine_launches()) {
-        const unsigned ny = (unsigned)std::max(lat[0].A.n_split, lat[1].A.n_split);
-        hipLaunchKernelGGL(k_k3_dual, dim3(lat[0].g + lat[1].g, ny), dim3(64), 0, env.stream, lat[0].A, lat[1].A, lat[0].g, env.primes);
-    } else {
-        for (int i = 0; i < n_lat; ++i) {
-            const dim3 gd(lat[i].g, (unsigned)lat[i].A.n_split);
-            if (lat[i].f64) hipLaunchKernelGGL((k_k3<ArF64, 1>), gd, dim3(64), 0, env.stream, lat[i].A, env.primes);
-            else hipLaunchKernelGGL((k_k3<ArU64, 1>), gd, dim3(64), 0, env.stream, lat[i].A, env.primes);
-        }
     }
     // (the inverse row pass of the special-prime sums, and of every prime's sums for BFV, happened in the kernel's epilogue)
 }
@@ -2444,7 +2491,7 @@ void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &arg
     // per block: up to 8 jobs per wave, fewer when that would leave CUs without blocks
     u32 jpb = 8 * kWaves;
     while (jpb > (u32)kWaves && (((u64)args.n_tgt << env.logn1) * ((n_jobs + jpb - 1) / jpb) < 256u * 8 || jpb / 2 >= n_jobs)) jpb >>= 1;
-    if (n_ops <= 8 && args.tail_prime < 0 && dual_engine_launches()) { // latency shape, no tail prime: both engines in one launch
+    if (args.tail_prime < 0 && dual_engine_launches()) { // no tail prime; latency shape or small grids: both engines in one launch
         FloorRowsDev AE[2];
         unsigned ge[2] = {0, 0};
         for (int e = 0; e < 2; ++e) {
@@ -2456,7 +2503,7 @@ void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &arg
                 if ((prime_f64[i] != 0) == (e == 0)) A.i_list[A.n_i++] = (unsigned char)i;
             ge[e] = (unsigned)((((u64)A.n_i) << env.logn1) * ((n_jobs + jpb - 1) / jpb));
         }
-        if (ge[0] && ge[1]) {
+        if (ge[0] && ge[1] && (n_ops <= 8 || ge[0] + ge[1] <= dual_max_blocks())) {
             hipLaunchKernelGGL(k_floor_rows_dual, dim3(ge[0] + ge[1]), dim3(kBlock), 0, env.stream, AE[0], AE[1], ge[0], env.primes);
             return;
         }
