@@ -1323,6 +1323,24 @@ public:
         Z.cq = d + o_cq; Z.q2mt = d + o_q2m; Z.neg_inv_q_mod_mt = T.neg_inv_q_mod_mt; Z.e_q2bsk = d + o_e2b; Z.e_qmod = d + o_eqm;
         Z.f_cq = d + o_fcq; Z.f_ds = d + o_fds; Z.f_neg = d + o_fng;
         Z.a_msk = d + o_am; Z.neg_inv_B = T.inv_B_mod_msk ? msk - T.inv_B_mod_msk : 0; Z.B2q = d + o_B2q; Z.B_mod_q = d + o_Bq;
+        // the doubles of steps (6)-(8) (BehzDev::f64aux): every auxiliary prime on the fp64 engine
+        Z.f64aux = 1;
+        for (int j = 0; j < S; ++j) Z.f64aux &= (int)(j < nB ? P.aux[1 + j].f64 : P.aux[0].f64);
+        {
+            std::vector<double> dd;
+            auto pushd = [&](const std::vector<u64> &v) { const size_t off = dd.size(); for (u64 x : v) dd.push_back((double)x); return off; };
+            std::vector<u64> f_neg_hi((size_t)S * L);
+            for (int j = 0; j < S; ++j)
+                for (int i = 0; i < L; ++i) f_neg_hi[(size_t)j * L + i] = mm(f_neg[(size_t)j * L + i], ((u64)1 << 30) % pj(j), pj(j));
+            const size_t q_fcq = pushd(f_cq), q_fds = pushd(f_ds), q_fng = pushd(f_neg), q_fnh = pushd(f_neg_hi), q_am = pushd(a_msk), q_B2q = pushd(T.B2q),
+                         q_Bq = pushd(T.B_mod_q);
+            double *ddev = nullptr;
+            dmalloc(ddev, dd.size() * 8);
+            owned_.push_back(ddev);
+            HIPCHECK(hipMemcpy(ddev, dd.data(), dd.size() * 8, hipMemcpyHostToDevice));
+            Z.f_cq_d = ddev + q_fcq; Z.f_ds_d = ddev + q_fds; Z.f_neg_d = ddev + q_fng; Z.f_neg_hi_d = ddev + q_fnh; Z.a_msk_d = ddev + q_am;
+            Z.neg_inv_B_d = (double)Z.neg_inv_B; Z.B2q_d = ddev + q_B2q; Z.B_mod_q_d = ddev + q_Bq;
+        }
         for (int j = 0; j < T.nB; ++j) Z.bsk_prime[j] = (unsigned char)(P.K + 1 + j); // B_j
         Z.bsk_prime[T.nB] = (unsigned char)P.K;                                        // m_sk
         return behz_[L] = Z;

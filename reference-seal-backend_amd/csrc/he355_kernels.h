@@ -172,6 +172,19 @@ struct BehzDev {
     const u64 *B2q;         // [L][nB]  (B/b_j) mod q_i
     const u64 *B_mod_q;     // [L]
     unsigned char bsk_prime[64]; // device prime index of Bsk element j
+    // The same constants of steps (6)-(8) as doubles, for the fp64 engine: used when every auxiliary prime is below 2^47 (f64aux;
+    // the device's own base).  A residue mod an auxiliary prime is then a handful of exact fp64 products (ArF64::mulmod_vv) instead of
+    // 128-bit sums and a Barrett reduction; base-q residues of fp64-engine primes likewise, those of the 60-bit primes stay integers
+    // (their value enters the auxiliary sums as hi * 2^30 + lo: f_neg_hi_d = f_neg * 2^30 mod p_j).
+    int f64aux, pad_;
+    const double *f_cq_d;     // [L]
+    const double *f_ds_d;     // [S]
+    const double *f_neg_d;    // [S][L]
+    const double *f_neg_hi_d; // [S][L]
+    const double *a_msk_d;    // [nB]
+    double neg_inv_B_d;
+    const double *B2q_d;      // [L][nB]
+    const double *B_mod_q_d;  // [L]
 };
 constexpr int kBehzMaxL = 16; // base q
 constexpr int kBehzMaxB = 24; // base B (Params::behz_nB: 22 for sixteen 60-bit primes)

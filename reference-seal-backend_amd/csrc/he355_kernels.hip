@@ -1871,6 +1871,83 @@ __device__ __forceinline__ void behz_floor_sk_coeff(const BehzDev &Z, const Prim
         res[j] = barrett128(acc, mj);
     }
 }
+// The same steps on the fp64 engine, for an auxiliary base of primes below 2^47 (BehzDev::f64aux): a residue mod an auxiliary prime,
+// alpha_sk and the outputs under fp64-engine base-q primes are sums of exact fp64 products (ArF64::mulmod_vv: centred, |.| <= p (1/2 +
+// eps); at most 27 of them, canon() brings the sum home); the 60-bit base-q primes keep their integer arithmetic and enter the
+// auxiliary sums as hi * 2^30 + lo.  The same residues as behz_floor_sk_coeff, at a third of its instructions.
+template <int ML, int MB>
+__device__ __forceinline__ void behz_floor_sk_coeff_f64(const BehzDev &Z, const PrimeDev *primes, int L, int nB, const u64 dq[ML], const u64 ds[MB + 1],
+                                                        u64 res[ML])
+{
+    constexpr int kUnrollB = MB <= 6 ? MB + 1 : 1, kUnrollL = ML <= 4 ? ML : 1;
+    const int S = nB + 1;
+    double ta[ML], tb[ML]; // tmp_i: fp64-engine prime: ta = the canonical value; 60-bit prime: ta = its low 30 bits, tb = the rest
+    // (6) times t, and the base-q part prepared for the fast conversion (canonical: the conversion depends on the representative)
+#pragma unroll
+    for (int i = 0; i < ML; ++i)
+        if (i < L) {
+            const PrimeDev &Pi = primes[i];
+            if (Pi.f64) {
+                const ArF64 ar = make_ar(Pi, (ArF64 *)nullptr);
+                ta[i] = ar.canon2(ar.mulmod_vv(u52_to_f64(dq[i]), Z.f_cq_d[i]));
+                tb[i] = 0.0;
+            } else {
+                const u64 t = mulmod(dq[i], Z.f_cq[i], make_modu(Pi));
+                ta[i] = u52_to_f64(t & (((u64)1 << 30) - 1));
+                tb[i] = u52_to_f64(t >> 30);
+            }
+        }
+    // (7) fast floor times (B/b_j)^-1, (8) first half: alpha_sk
+    const ArF64 arsk = make_ar(primes[Z.bsk_prime[nB]], (ArF64 *)nullptr);
+    double fl[MB], acc_sk = 0.0;
+#pragma unroll kUnrollB
+    for (int j = 0; j < MB + 1; ++j)
+        if (j < S) {
+            const ArF64 arj = make_ar(primes[Z.bsk_prime[j]], (ArF64 *)nullptr);
+            double sum = arj.mulmod_vv(u52_to_f64(ds[j]), Z.f_ds_d[j]);
+#pragma unroll
+            for (int i = 0; i < ML; ++i)
+                if (i < L) {
+                    sum += arj.mulmod_vv(ta[i], Z.f_neg_d[j * L + i]);
+                    if (!primes[i].f64) sum += arj.mulmod_vv(tb[i], Z.f_neg_hi_d[j * L + i]);
+                }
+            const double f = arj.canon(sum);
+            if (j < nB) {
+                if (j < MB) { // (always; keeps the index static)
+                    fl[j] = f;
+                    acc_sk += arsk.mulmod_vv(f, Z.a_msk_d[j]);
+                }
+            } else {
+                acc_sk += arsk.mulmod_vv(f, Z.neg_inv_B_d);
+            }
+        }
+    const double alpha = arsk.canon(acc_sk);
+    const bool neg = alpha > (arsk.q - 1.0) * 0.5; // alpha > floor(m_sk / 2), m_sk odd
+    const double am = neg ? arsk.q - alpha : alpha; // |gamma|
+    // (8) second half: B -> q with the alpha_sk correction
+#pragma unroll kUnrollL
+    for (int i = 0; i < ML; ++i) {
+        if (i >= L) break;
+        const PrimeDev &Pi = primes[i];
+        if (Pi.f64) {
+            const ArF64 ar = make_ar(Pi, (ArF64 *)nullptr);
+            const double Bq = Z.B_mod_q_d[i];
+            double sum = ar.mulmod_vv(am, neg ? Bq : ar.q - Bq);
+#pragma unroll
+            for (int j = 0; j < MB; ++j)
+                if (j < nB) sum += ar.mulmod_vv(fl[j], Z.B2q_d[i * nB + j]);
+            res[i] = f64_to_u52(ar.canon(sum));
+        } else {
+            const ModU64 mi = make_modu(Pi);
+            const u64 Bq = Z.B_mod_q[i];
+            u128 acc = (u128)f64_to_u52(am) * (neg ? Bq : (Bq ? mi.q - Bq : 0));
+#pragma unroll
+            for (int j = 0; j < MB; ++j)
+                if (j < nB) acc += (u128)f64_to_u52(fl[j]) * Z.B2q[i * nB + j];
+            res[i] = barrett128(acc, mi);
+        }
+    }
+}
 template <int ML, int MB>
 __global__ void __launch_bounds__(kBlock) k_behz_floor_sk(BehzDev Z, const PrimeDev *primes, const u64 *dq, const u64 *ds, u64 *out, u64 n_polys, int logN)
 {
@@ -1888,7 +1965,8 @@ __global__ void __launch_bounds__(kBlock) k_behz_floor_sk(BehzDev Z, const Prime
 #pragma unroll kUnrollB
     for (int j = 0; j < MB + 1; ++j)
         if (j < S) vs[j] = ds[(pid * S + j) * N + n];
-    behz_floor_sk_coeff<ML, MB>(Z, primes, L, Z.nB, vq, vs, res);
+    if (Z.f64aux) behz_floor_sk_coeff_f64<ML, MB>(Z, primes, L, Z.nB, vq, vs, res);
+    else behz_floor_sk_coeff<ML, MB>(Z, primes, L, Z.nB, vq, vs, res);
 #pragma unroll kUnrollL
     for (int j = 0; j < ML; ++j)
         if (j < L) out[(pid * L + j) * N + n] = res[j];
@@ -1949,7 +2027,8 @@ __global__ void __launch_bounds__(64 << LOGN1) k_behz_cols_floor_sk(BehzDev Z, c
 #pragma unroll
     for (int j = 0; j < MB + 1; ++j)
         if (j < S) vs[j] = behz_sm[(((L + j) * N1 + wave) << 6) | lane];
-    behz_floor_sk_coeff<ML, MB>(Z, primes, L, nB, vq, vs, res);
+    if (Z.f64aux) behz_floor_sk_coeff_f64<ML, MB>(Z, primes, L, nB, vq, vs, res);
+    else behz_floor_sk_coeff<ML, MB>(Z, primes, L, nB, vq, vs, res);
 #pragma unroll
     for (int j = 0; j < ML; ++j)
         if (j < L) out[(pid * L + j) * N + ((u64)wave << kRowLog) + col] = res[j];
