@@ -135,7 +135,8 @@ int he355_multiply(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const
 /* BFV multiply (BEHZ, coefficient form): [.][2][L][N] x [.][2][L][N] -> [n][3][L][N]
  * (evaluator()->multiply, src/benchmarks/bfv/seal_bfv_element_wise_benchmark.cpp:325, seal_bfv_dot_product_benchmark.cpp:311).
  * In an outer-product batch every operand serves several results: each is extended to the auxiliary base and transformed once
- * (the values SEAL recomputes per pair), a result then costs its dyadic tensor, three inverse transforms and the floor. */
+ * (the values SEAL recomputes per pair), a result then costs its dyadic tensor, three inverse transforms and the floor.
+ * d_out may not overlap an operand (HE355_E_INVALID_ARGS). */
 int he355_bfv_multiply(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_a, const uint64_t *d_b, he355_indexer ix, uint64_t *d_out);
 /* multiply -> relinearize (-> rescale): out [n][2][L][N] or [n][2][L-1][N].  Give d_out a slab of its own: then the tensor product's
  * c0, c1 never travel through HBM (the key-switch kernel forms them from the operand rows); a d_out that overlaps an operand is
@@ -162,7 +163,7 @@ int he355_multiply_accumulate(he355_ctx *ctx, int L, uint64_t rows, uint64_t col
                               uint64_t a_stride_k, const uint64_t *d_b, uint64_t b_stride_k, uint64_t b_stride_j, uint64_t *d_out);
 /* BFV: out(i,j) = sum_k relinearize(multiply(a(i,k), b(k,j))), size-2 results [rows*cols][2][L][N], same addressing -- the
  * multiply / relinearize_inplace / add_inplace loop of src/benchmarks/bfv/seal_bfv_matmult_cipherbatchaxis_benchmark.cpp:398-410 with
- * the inner index inside the batch (rows*cols <= 65535) */
+ * the inner index inside the batch; d_out may not overlap an operand */
 int he355_bfv_multiply_relin_accumulate(he355_ctx *ctx, int L, uint64_t rows, uint64_t cols, uint64_t inner, const uint64_t *d_a, uint64_t a_stride_i,
                                         uint64_t a_stride_k, const uint64_t *d_b, uint64_t b_stride_k, uint64_t b_stride_j, uint64_t *d_out);
 /* relinearize_inplace + rescale_to_next_inplace of size-3 ciphertexts (same file :436-437): [n][3][L][N] -> [n][2][L-1][N] */

@@ -1357,8 +1357,11 @@ public:
         if (inner < 1 || inner > 0x7fffffff) throw std::invalid_argument("inner dimension out of range");
         const u64 n = rows * cols;
         if (!n) return;
-        if (n > 65535) throw std::invalid_argument("he355_bfv_multiply_relin_accumulate: more than 65535 results per call");
         const size_t LN = (size_t)L * P.N;
+        // `out` is written after each pass over the inner index and the operands are read again by the next one
+        const size_t a_cts = (size_t)((inner - 1) * a_stride_k + (rows - 1) * a_stride_i + 1), b_cts = (size_t)((inner - 1) * b_stride_k + (cols - 1) * b_stride_j + 1);
+        if (ranges_overlap(out, n * 2 * LN, a, a_cts * 2 * LN) || ranges_overlap(out, n * 2 * LN, b, b_cts * 2 * LN))
+            throw std::invalid_argument("he355_bfv_multiply_relin_accumulate: `out` overlaps an operand");
         const u64 kc = std::max<u64>(1, std::min<u64>(inner, (u64)4096 / n)); // inner indices per pass: about 4096 products in flight
         u64 *c3 = static_cast<u64 *>(pool_alloc(n * kc * 3 * LN * 8));
         u64 *r2 = nullptr;
@@ -1426,6 +1429,11 @@ public:
         src.I = (gsz + ix.b1 - 1) / ix.b1; src.J = std::min<u64>(ix.b1, gsz); src.na = G * src.I;
         const u64 n_cts = src.na + G * src.J;
         const size_t e_words = (size_t)n_cts * 2 * (L + S) * N, per_res = (3 * L + 3 * S) * N;
+        {   // a chunk's results are written before the next chunk's operands are read: `out` needs a slab of its own
+            const size_t a_cts = (size_t)(ix.a_base + (G - 1) * ix.a_sg + (src.I - 1) * ix.a_si + 1), b_cts = (size_t)(ix.b_base + (G - 1) * ix.b_sg + (src.J - 1) * ix.b_sj + 1);
+            if (ranges_overlap(out, (size_t)n * 3 * L * N, a, a_cts * 2 * L * N) || ranges_overlap(out, (size_t)n * 3 * L * N, b, b_cts * 2 * L * N))
+                throw std::invalid_argument("he355_bfv_multiply: `out` overlaps an operand");
+        }
         bool lists = hoist_on && (G == 1 || (n % ix.gs == 0 && ix.gs % ix.b1 == 0)) && n_cts <= n; // at least two times fewer extensions than the 2 n of the per-pair path
         size_t c = std::min<size_t>(chunk_, (size_t)n);
         if (lists) {

@@ -442,14 +442,15 @@ __global__ void __launch_bounds__(kBlock) k_drop_residues(const u64 *in, u64 *ou
 
 // Sum of n ciphertexts (the add_inplace accumulation of collapseCKKS, seal_context.cpp:401): out = sum_r in[r].
 // One thread = 2 coefficients of one residue polynomial of the result; it walks the n terms.
-// blockIdx.y = result c of n_out: out[c] = (accumulate ? out[c] : 0) + sum_r in[r * n_out + c] (n_out = 1: the sum of a run of ciphertexts;
+// blockIdx.y + c_first = result c of n_out: out[c] = (accumulate ? out[c] : 0) + sum_r in[r * n_out + c] (n_out = 1: the sum of a run of ciphertexts;
 // n_out > 1: the sums over the inner index of a matrix product's terms, he355_bfv_multiply_relin_accumulate)
-__global__ void __launch_bounds__(kBlock) k_sum_cts(const u64 *in, u64 *out, const PrimeDev *primes, int L, int polys, int logN, u64 n_terms, int accumulate)
+__global__ void __launch_bounds__(kBlock) k_sum_cts(const u64 *in, u64 *out, const PrimeDev *primes, int L, int polys, int logN, u64 n_terms, int accumulate,
+                                                    u64 n_out, u64 c_first)
 {
     const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
     const u64 p = gid >> (logN - 1), e2 = gid & (((u64)1 << (logN - 1)) - 1);
     if (p >= (u64)polys) return;
-    const u64 c = blockIdx.y, n_out = gridDim.y;
+    const u64 c = c_first + blockIdx.y;
     const u64 q = primes[p % L].q;
     const u64 ctn = (u64)polys << logN;
     ulonglong2 *po = reinterpret_cast<ulonglong2 *>(out + c * ctn + (p << logN)) + e2;
@@ -1165,8 +1166,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_k3(K3Args A, const PrimeDev *pri
 // the throughput shape (k_k3_dual8: tens of ciphertexts at N = 8192 are 30-130 blocks per engine on 256 CUs): the two launches
 // would run one after the other on a mostly idle chip.  (The same body text as k_k3, behind a function boundary here -- which is
 // why the large grids, the headline's among them, keep the template kernels.)
-template <class Ar, int WAVES, bool FUSE, bool TENSOR, bool GROUPED>
-__device__ __forceinline__ void k3_body_fn(const K3Args &A, const PrimeDev *primes, const unsigned bid_x, const unsigned bid_y, u64 (*lds)[kLdsRow],
+// (ARGS: `const K3Args &` for the single-wave instantiations, `const K3Args` for the 8-wave ones -- whichever lets the compiler keep the
+// argument struct in the kernarg segment instead of copying it to scratch: 0 vs 416 B and 68-244 vs 880-960 B per lane, tools/kres.py)
+template <class Ar, int WAVES, bool FUSE, bool TENSOR, bool GROUPED, class ARGS>
+__device__ __forceinline__ void k3_body_fn(ARGS A, const PrimeDev *primes, const unsigned bid_x, const unsigned bid_y, u64 (*lds)[kLdsRow],
                                            u64 (*stage)[kRowN], unsigned char *twl_raw)
 {
 #define K3_BID_X bid_x
@@ -1184,10 +1187,10 @@ __global__ void __launch_bounds__(64) k_k3_dual(K3Args AF, K3Args AU, unsigned n
     __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kRowTw * 16];
     if (blockIdx.x < n_f) {
         if ((int)blockIdx.y < (AF.n_split > 1 ? AF.n_split : 1))
-            k3_body_fn<ArF64, 1, false, false, false>(AF, primes, blockIdx.x, blockIdx.y, lds, stage, twl_raw);
+            k3_body_fn<ArF64, 1, false, false, false, const K3Args &>(AF, primes, blockIdx.x, blockIdx.y, lds, stage, twl_raw);
     } else {
         if ((int)blockIdx.y < (AU.n_split > 1 ? AU.n_split : 1))
-            k3_body_fn<ArU64, 1, false, false, false>(AU, primes, blockIdx.x - n_f, blockIdx.y, lds, stage, twl_raw);
+            k3_body_fn<ArU64, 1, false, false, false, const K3Args &>(AU, primes, blockIdx.x - n_f, blockIdx.y, lds, stage, twl_raw);
     }
 }
 template <bool FUSE, bool TENSOR, bool GROUPED>
@@ -1196,8 +1199,8 @@ __global__ void __launch_bounds__(512) k_k3_dual8(K3Args AF, K3Args AU, unsigned
     __shared__ u64 lds[8][kLdsRow];
     __shared__ __attribute__((aligned(16))) u64 stage[8][kRowN];
     __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kRowTw * 16];
-    if (blockIdx.x < n_f) k3_body_fn<ArF64, 8, FUSE, TENSOR, GROUPED>(AF, primes, blockIdx.x, 0, lds, stage, twl_raw);
-    else k3_body_fn<ArU64, 8, FUSE, TENSOR, GROUPED>(AU, primes, blockIdx.x - n_f, 0, lds, stage, twl_raw);
+    if (blockIdx.x < n_f) k3_body_fn<ArF64, 8, FUSE, TENSOR, GROUPED, const K3Args>(AF, primes, blockIdx.x, 0, lds, stage, twl_raw);
+    else k3_body_fn<ArU64, 8, FUSE, TENSOR, GROUPED, const K3Args>(AU, primes, blockIdx.x - n_f, 0, lds, stage, twl_raw);
 }
 
 // The sums of a digit-split k_k3 launch: part [n_split][n_ops * 2][L + 1][N] canonical -> t (data primes, canonical NTT form) and tpr
@@ -2228,12 +2231,13 @@ void launch_drop_residues(const KernelEnv &env, int L, int L_to, u64 n_polys, co
 }
 void launch_sum_cts(const KernelEnv &env, int L, int size, u64 n_terms, const u64 *in, u64 *out, u64 n_out, bool accumulate)
 {
-    if (!n_out) return;
-    if (n_out > 65535) throw std::invalid_argument("sum over the inner index: too many results for one launch");
     const int logN = env.logn1 + kRowLog;
     const u64 threads = ((u64)size * L) << (logN - 1);
-    hipLaunchKernelGGL(k_sum_cts, dim3(grid_for(threads, kBlock), (unsigned)n_out), dim3(kBlock), 0, env.stream, in, out, env.primes, L, size * L, logN, n_terms,
-                       accumulate ? 1 : 0);
+    for (u64 c0 = 0; c0 < n_out; c0 += 65535) { // gridDim.y holds 65535 results
+        const unsigned ny = (unsigned)std::min<u64>(65535, n_out - c0);
+        hipLaunchKernelGGL(k_sum_cts, dim3(grid_for(threads, kBlock), ny), dim3(kBlock), 0, env.stream, in, out, env.primes, L, size * L, logN, n_terms,
+                           accumulate ? 1 : 0, n_out, c0);
+    }
 }
 
 void launch_sum_groups(const KernelEnv &env, int L, u64 n_cts, u32 n_groups, const u64 *in, const u32 *d_mult, u64 *out)

@@ -279,6 +279,37 @@ def test_bfv_multiply_relin_accumulate_equals_the_reference_loop(be, oracle, nam
     g.close()
 
 
+def test_bfv_multiply_rejects_outputs_that_overlap_an_operand(be, oracle):
+    """A chunk's products are written before the next chunk's operands are read (and the matrix-product entry reads its operands once
+    per pass over the inner index): `out` inside an operand slab is refused with an invalid-argument error instead of corrupting it."""
+    import ctypes as C
+
+    class View:
+        def __init__(self, buf, off):
+            self.ptr = C.c_void_p(buf.ptr.value + off * 8)
+
+    N, bits = 1024, [50, 40, 50]
+    g = be.Context(be.SCHEME_BFV, N, bit_sizes=bits, plain_bits=20, sec128=False, device=0)
+    o = oracle.Context(oracle.SCHEME_BFV, N, bit_sizes=bits, plain_bits=20, sec128=False)
+    rng = np.random.default_rng(3)
+    L = g.L
+    per = 2 * L * N
+    g.set_relin_key(o.random_kswitch_key(rng))
+    a = g.to_device(np.stack([o.random_poly(rng, L, 2) for _ in range(4)]))
+    big = g.alloc(4 * per + 4 * 3 * L * N)  # operands first, room for the products behind them
+    a.copy_into(big, 0, 4 * per)
+    inside = View(big, per)
+    behind = View(big, 4 * per)
+    for call in (lambda: g.bfv_multiply(L, 4, big, a, be.Context.pairwise(), inside), lambda: g.bfv_multiply(L, 4, a, big, be.Context.outer(0, 2, 0, 2), inside),
+                 lambda: g.bfv_multiply_relin_accumulate(L, 2, 1, 2, big, 1, 2, a, 1, 1, inside)):
+        with pytest.raises(be.HE355Error) as ei:
+            call()
+        assert ei.value.code == be.E_INVALID_ARGS
+    g.bfv_multiply(L, 4, big, a, be.Context.pairwise(), behind)  # disjoint ranges inside one allocation are fine
+    g.sync()
+    g.close()
+
+
 def _residues(o, values, L):
     """Integer coefficient vector(s) -> residues [.., L, N] under the first L moduli."""
     return np.stack([np.array([int(v) % q for v in values], dtype=np.uint64) for q in o.moduli[:L]])
