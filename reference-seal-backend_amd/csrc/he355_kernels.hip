@@ -2285,10 +2285,10 @@ static bool dual_engine_launches()
     static const bool off = getenv("HE355_DUAL_ENGINE") && getenv("HE355_DUAL_ENGINE")[0] == '0';
     return !off;
 }
-// ... also for small grids of the throughput shape: up to this many blocks for both engines together (two per CU)
+// ... also for small grids of the throughput shape: up to this many blocks for both engines together (four per CU; profiles/r04_dual_engine_latency.txt)
 static unsigned dual_max_blocks()
 {
-    static const unsigned v = getenv("HE355_DUAL_MAX_BLOCKS") ? (unsigned)atoi(getenv("HE355_DUAL_MAX_BLOCKS")) : 512u;
+    static const unsigned v = getenv("HE355_DUAL_MAX_BLOCKS") ? (unsigned)atoi(getenv("HE355_DUAL_MAX_BLOCKS")) : 1024u;
     return v;
 }
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
