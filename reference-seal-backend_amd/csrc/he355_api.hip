@@ -510,10 +510,19 @@ public:
         const u64 *c1_src = nullptr;
     };
     // true when key_switch_tail will take a fused path for this batch, i.e. when k_k3's epilogue is where c0, c1 are consumed
+    // The fused mod-down runs the special prime's tiles as a launch of their own, ahead of the data primes' (their epilogue needs its
+    // result): n1 rows x nc / 8 op-groups of blocks.  With a handful of ciphertexts at a small ring that launch is a few dozen blocks
+    // on 256 CUs -- as long as the data primes' launch and nearly idle -- and the unfused sequence (every prime's tiles in ONE launch,
+    // then the two floor kernels) is the shorter chain.  HE355_FUSE_MIN_BLOCKS=<n>: fuse from n such blocks up.
+    bool fuse_pays(const KernelEnv &e, u64 nc) const
+    {
+        static const u64 min_blocks = getenv("HE355_FUSE_MIN_BLOCKS") ? (u64)atoll(getenv("HE355_FUSE_MIN_BLOCKS")) : 128;
+        return ((u64)1 << e.logn1) * ((nc + 7) / 8) >= min_blocks;
+    }
     bool tensor_in_k3(const KernelEnv &env_, int L, u64 nc, const KsBuffers &B) const
     {
         static const bool on = !(getenv("HE355_C01_RECOMPUTE") && getenv("HE355_C01_RECOMPUTE")[0] == '0');
-        return on && !latency_shape_env(env_, nc) && k3_can_fuse(env_) && B.c01_item_stride == 2 * (size_t)L * P.N;
+        return on && !latency_shape_env(env_, nc) && k3_can_fuse(env_) && fuse_pays(env_, nc) && B.c01_item_stride == 2 * (size_t)L * P.N;
     }
     // groups (grouped rotations, fused path only): per-group keys; g_off: index of the chunk's first op in the grouped batch
     bool key_switch_tail(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail,
@@ -544,7 +553,7 @@ public:
         }
         launch_k2(env_, L, nc, B);
         if (after_k2) HIPCHECK(hipEventRecord(after_k2, env_.stream));
-        if (k3_can_fuse(env_) && B.c01_item_stride == 2 * LN) {
+        if (k3_can_fuse(env_) && B.c01_item_stride == 2 * LN && (groups || fuse_pays(env_, nc))) {
             // special prime first, its correction through the column pass, then the data primes with the mod-down finished
             // inside K3 (the sums never go to HBM)
             launch_k3(env_, L, nc, B, key, K3_SPECIAL_ONLY, nullptr, 1, nullptr, 0, groups, g_off);
