@@ -1481,9 +1481,6 @@ public:
             c = (c + 1) / 2;
         }
         u64 *xq = bfv_scratch_, *xb = xq + c * 4 * L * N, *dq = xb + c * 4 * S * N, *ds = dq + c * 3 * L * N;
-        unsigned char pq[64], pb[64];
-        for (int i = 0; i < L; ++i) pq[i] = (unsigned char)i;
-        for (size_t j = 0; j < S; ++j) pb[j] = Z.bsk_prime[j];
         for (u64 off = 0; off < n; off += c) {
             const u64 nc = std::min<u64>(c, n - off);
             // extension to Bsk and forward column passes (one kernel where the fused shape applies), then per (op, residue, row) ONE
@@ -1497,8 +1494,7 @@ public:
                 vq.base = xq; launch_cols_fwd(env_, vq, (u32)(nc * 4));
                 vb.base = xb; launch_cols_fwd(env_, vb, (u32)(nc * 4));
             }
-            launch_behz_rows_tensor(env_, L, pq, nc, xq, dq);
-            launch_behz_rows_tensor(env_, (int)S, pb, nc, xb, ds);
+            launch_behz_rows_tensor(env_, Z, nc, xq, xb, dq, ds);
             if (fuse_cols) {
                 launch_behz_cols_floor_sk(env_, Z, nc, dq, ds, out + off * 3 * (size_t)L * N);
             } else {

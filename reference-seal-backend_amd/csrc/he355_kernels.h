@@ -204,7 +204,7 @@ void launch_rows_fwd(const KernelEnv &env, const PolyView &v, u32 n_items); // r
 void launch_behz_cols_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *dq, const u64 *ds, u64 *out);
 // BEHZ steps (3)-(5) on rows, fused: x [n*4][Lx][N] after launch_cols_fwd -> forward row pass of a0, a1, b0, b1, dyadic tensor, inverse row
 // pass -> d [n*3][Lx][N] ready for launch_cols_inv (one block = the four rows of one (op, residue, row); no HBM round trip between them)
-void launch_behz_rows_tensor(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d);
+void launch_behz_rows_tensor(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *xq, const u64 *xbsk, u64 *dq, u64 *ds);
 void launch_cols_fwd(const KernelEnv &env, const PolyView &v, u32 n_items); // column half of the forward transform, in place
 void launch_cols_inv(const KernelEnv &env, const PolyView &v, u32 n_items); // column half of the inverse transform, in place
 // BEHZ steps (6)-(8): times t, fast floor, Shenoy-Kumaresan -> out [n][3][L][N]

@@ -1696,35 +1696,37 @@ __global__ void __launch_bounds__(64 << LOGN1) k_behz_extend_cols(BehzDev Z, con
 // polynomial transfers through HBM per (op, residue).  x [n*4][Lx][N] after the forward column pass (raw; canonical when N = 1024),
 // d [n*3][Lx][N] ready for the inverse column pass.
 struct BehzRowsArgs {
-    const u64 *x;
-    u64 *d;
+    const u64 *x[2]; // base q, base Bsk: [n*4][Lx][N]
+    u64 *d[2];       //                   [n*3][Lx][N]
+    int Lx[2];
     u64 n_ops;
-    int Lx, logn1, n_r;
-    unsigned char r_list[64]; // residue slots handled by this launch (one arithmetic engine per launch)
-    unsigned char prime_of[64];
+    int logn1, n_r;
+    unsigned char r_base[64], r_idx[64], r_prime[64]; // the residues of one arithmetic engine: base, index in it, device prime
 };
+// (body as a device function: k_behz_rows_tensor_dual runs the blocks of both engines in one launch when the grids are small)
 template <class Ar>
-__global__ void __launch_bounds__(kBlock) k_behz_rows_tensor(BehzRowsArgs A, const PrimeDev *primes)
+__device__ __forceinline__ void behz_rows_tensor_block(const BehzRowsArgs &A, const PrimeDev *primes, const u64 job, u64 (*lds)[kLdsRow])
 {
     typedef typename Ar::T T;
-    __shared__ u64 lds[kWaves][kLdsRow];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 n1 = 1u << A.logn1;
     const u64 N = (u64)n1 << kRowLog;
-    const u64 job = blockIdx.x; // (op, residue slot, row)
-    const u32 a_row = (u32)(job & (n1 - 1));
+    const u32 a_row = (u32)(job & (n1 - 1)); // job = (op, residue slot, row)
     const u64 orr = job >> A.logn1;
-    const int r = A.r_list[orr % A.n_r];
+    const int slot = (int)(orr % A.n_r);
     const u64 op = orr / A.n_r;
-    const PrimeDev &P = primes[A.prime_of[r]];
+    const int base = A.r_base[slot], r = A.r_idx[slot], Lx = A.Lx[base];
+    const PrimeDev &P = primes[A.r_prime[slot]];
     const Ar ar = make_ar(P, (Ar *)nullptr);
     const bool last = A.logn1 == 0;
     const u64 rowoff = ((u64)r << (A.logn1 + kRowLog)) + ((u64)a_row << kRowLog);
+    const u64 *xin = A.x[base];
+    u64 *dout = A.d[base];
     // phase 1: this wave's polynomial through the forward row pass; canonical values parked in its exchange buffer
     {
         T x[kRowE];
         u64 v[kRowE];
-        load_rowA(A.x + (op * 4 + wave) * A.Lx * N + rowoff, lane, v);
+        load_rowA(xin + (op * 4 + wave) * Lx * N + rowoff, lane, v);
 #pragma unroll
         for (int e = 0; e < kRowE; ++e) x[e] = last ? ar.from_canon(v[e]) : ar.from_raw(v[e]);
         wave_rows_fwd(ar, tw_table(gtw(P.fwd), n1 + a_row), lane, lds[wave], x);
@@ -1761,7 +1763,19 @@ __global__ void __launch_bounds__(kBlock) k_behz_rows_tensor(BehzRowsArgs A, con
     u64 v[kRowE];
 #pragma unroll
     for (int e = 0; e < kRowE; ++e) v[e] = last ? ar.to_canon(x[e]) : ar.to_raw(x[e]);
-    store_rowA(A.d + (op * 3 + wave) * A.Lx * N + rowoff, lane, v);
+    store_rowA(dout + (op * 3 + wave) * Lx * N + rowoff, lane, v);
+}
+template <class Ar>
+__global__ void __launch_bounds__(kBlock) k_behz_rows_tensor(BehzRowsArgs A, const PrimeDev *primes)
+{
+    __shared__ u64 lds[kWaves][kLdsRow];
+    behz_rows_tensor_block<Ar>(A, primes, blockIdx.x, lds);
+}
+__global__ void __launch_bounds__(kBlock) k_behz_rows_tensor_dual(BehzRowsArgs AF, BehzRowsArgs AU, unsigned n_f, const PrimeDev *primes)
+{
+    __shared__ u64 lds[kWaves][kLdsRow];
+    if (blockIdx.x < n_f) behz_rows_tensor_block<ArF64>(AF, primes, blockIdx.x, lds);
+    else behz_rows_tensor_block<ArU64>(AU, primes, blockIdx.x - n_f, lds);
 }
 
 // BEHZ steps (4)-(5) when the operands were transformed once each (BehzSrc lists: he355_api.hip, bfv_multiply3): one WAVE per
@@ -1779,13 +1793,13 @@ struct BehzTensorArgs {
     unsigned char r_base[64], r_idx[64], r_prime[64];
 };
 template <class Ar>
-__global__ void __launch_bounds__(kBlock) k_behz_tensor_inv(BehzTensorArgs A, const PrimeDev *primes, u64 total_jobs)
+__device__ __forceinline__ void behz_tensor_inv_block(const BehzTensorArgs &A, const PrimeDev *primes, const u64 total_jobs, const unsigned bid_x,
+                                                      u64 (*lds)[kLdsRow])
 {
     typedef typename Ar::T T;
-    __shared__ u64 lds[kWaves][kLdsRow];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u64 job = (u64)blockIdx.x * kWaves + wave; // (op, residue slot, row, k)
-    if (job >= total_jobs) return;                   // (waves are independent: no barrier below)
+    const u64 job = (u64)bid_x * kWaves + wave; // (op, residue slot, row, k)
+    if (job >= total_jobs) return;              // (waves are independent: no barrier below)
     const u32 n1 = 1u << A.logn1;
     const u64 N = (u64)n1 << kRowLog;
     const int k = (int)(job % 3);
@@ -1824,6 +1838,18 @@ __global__ void __launch_bounds__(kBlock) k_behz_tensor_inv(BehzTensorArgs A, co
 #pragma unroll
     for (int e = 0; e < kRowE; ++e) v[e] = last ? ar.to_canon(x[e]) : ar.to_raw(x[e]);
     store_rowA(A.d[base] + (op * 3 + k) * Lx * N + rowoff, lane, v);
+}
+template <class Ar>
+__global__ void __launch_bounds__(kBlock) k_behz_tensor_inv(BehzTensorArgs A, const PrimeDev *primes, u64 total_jobs)
+{
+    __shared__ u64 lds[kWaves][kLdsRow];
+    behz_tensor_inv_block<Ar>(A, primes, total_jobs, blockIdx.x, lds);
+}
+__global__ void __launch_bounds__(kBlock) k_behz_tensor_inv_dual(BehzTensorArgs AF, BehzTensorArgs AU, u64 jobs_f, u64 jobs_u, unsigned n_f, const PrimeDev *primes)
+{
+    __shared__ u64 lds[kWaves][kLdsRow];
+    if (blockIdx.x < n_f) behz_tensor_inv_block<ArF64>(AF, primes, jobs_f, blockIdx.x, lds);
+    else behz_tensor_inv_block<ArU64>(AU, primes, jobs_u, blockIdx.x - n_f, lds);
 }
 
 // BEHZ steps (6)-(8) for one coefficient: dq[i] (base q), ds[j] (Bsk) canonical residues of a product -> its L output residues.
@@ -2670,31 +2696,16 @@ void launch_behz_cols_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_op
     }
 #undef HE355_FLR
 }
-void launch_behz_rows_tensor(const KernelEnv &env, int Lx, const unsigned char *prime_of, u64 n_ops, const u64 *x, u64 *d)
+void launch_behz_rows_tensor(const KernelEnv &env, const BehzDev &bz, u64 n_ops, const u64 *xq, const u64 *xbsk, u64 *dq, u64 *ds)
 {
     if (!n_ops) return;
-    BehzRowsArgs A;
-    A.x = x; A.d = d; A.n_ops = n_ops; A.Lx = Lx; A.logn1 = env.logn1;
-    for (int i = 0; i < Lx; ++i) A.prime_of[i] = prime_of[i];
-    for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine residues, pass 1: u64-engine residues
-        A.n_r = 0;
-        for (int i = 0; i < Lx; ++i)
-            if ((env.prime_f64[prime_of[i]] != 0) == (pass == 0)) A.r_list[A.n_r++] = (unsigned char)i;
-        if (!A.n_r) continue;
-        const unsigned g = (unsigned)((n_ops * A.n_r) << env.logn1);
-        if (pass == 0) hipLaunchKernelGGL(k_behz_rows_tensor<ArF64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
-        else hipLaunchKernelGGL(k_behz_rows_tensor<ArU64>, dim3(g), dim3(kBlock), 0, env.stream, A, env.primes);
-    }
-}
-void launch_behz_tensor_inv(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_ops, u64 op_offset, const u64 *eq, const u64 *ebsk, u64 *dq,
-                            u64 *ds)
-{
-    if (!n_ops) return;
-    BehzTensorArgs A;
+    BehzRowsArgs AE[2];
+    unsigned ge[2] = {0, 0};
     const int S = bz.nB + 1;
-    A.e[0] = eq; A.e[1] = ebsk; A.d[0] = dq; A.d[1] = ds; A.Lx[0] = bz.L; A.Lx[1] = S;
-    A.src = src; A.n_ops = n_ops; A.op_offset = op_offset; A.logn1 = env.logn1;
     for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine residues of both bases, pass 1: u64-engine residues
+        BehzRowsArgs &A = AE[pass];
+        A.x[0] = xq; A.x[1] = xbsk; A.d[0] = dq; A.d[1] = ds; A.Lx[0] = bz.L; A.Lx[1] = S;
+        A.n_ops = n_ops; A.logn1 = env.logn1;
         A.n_r = 0;
         for (int i = 0; i < bz.L + S; ++i) {
             const int base = i < bz.L ? 0 : 1, idx = base ? i - bz.L : i, prime = base ? bz.bsk_prime[idx] : idx;
@@ -2702,11 +2713,42 @@ void launch_behz_tensor_inv(const KernelEnv &env, const BehzDev &bz, const BehzS
             A.r_base[A.n_r] = (unsigned char)base; A.r_idx[A.n_r] = (unsigned char)idx; A.r_prime[A.n_r] = (unsigned char)prime;
             ++A.n_r;
         }
-        if (!A.n_r) continue;
-        const u64 jobs = ((n_ops * A.n_r) << env.logn1) * 3;
-        if (pass == 0) hipLaunchKernelGGL(k_behz_tensor_inv<ArF64>, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes, jobs);
-        else hipLaunchKernelGGL(k_behz_tensor_inv<ArU64>, dim3(grid_for(jobs, kWaves)), dim3(kBlock), 0, env.stream, A, env.primes, jobs);
+        ge[pass] = (unsigned)((n_ops * A.n_r) << env.logn1);
     }
+    if (ge[0] && ge[1] && ge[0] + ge[1] <= dual_max_blocks() && dual_engine_launches()) {
+        hipLaunchKernelGGL(k_behz_rows_tensor_dual, dim3(ge[0] + ge[1]), dim3(kBlock), 0, env.stream, AE[0], AE[1], ge[0], env.primes);
+        return;
+    }
+    if (ge[0]) hipLaunchKernelGGL(k_behz_rows_tensor<ArF64>, dim3(ge[0]), dim3(kBlock), 0, env.stream, AE[0], env.primes);
+    if (ge[1]) hipLaunchKernelGGL(k_behz_rows_tensor<ArU64>, dim3(ge[1]), dim3(kBlock), 0, env.stream, AE[1], env.primes);
+}
+void launch_behz_tensor_inv(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_ops, u64 op_offset, const u64 *eq, const u64 *ebsk, u64 *dq,
+                            u64 *ds)
+{
+    if (!n_ops) return;
+    BehzTensorArgs AE[2];
+    u64 jobs[2] = {0, 0};
+    const int S = bz.nB + 1;
+    for (int pass = 0; pass < 2; ++pass) { // pass 0: fp64-engine residues of both bases, pass 1: u64-engine residues
+        BehzTensorArgs &A = AE[pass];
+        A.e[0] = eq; A.e[1] = ebsk; A.d[0] = dq; A.d[1] = ds; A.Lx[0] = bz.L; A.Lx[1] = S;
+        A.src = src; A.n_ops = n_ops; A.op_offset = op_offset; A.logn1 = env.logn1;
+        A.n_r = 0;
+        for (int i = 0; i < bz.L + S; ++i) {
+            const int base = i < bz.L ? 0 : 1, idx = base ? i - bz.L : i, prime = base ? bz.bsk_prime[idx] : idx;
+            if ((env.prime_f64[prime] != 0) != (pass == 0)) continue;
+            A.r_base[A.n_r] = (unsigned char)base; A.r_idx[A.n_r] = (unsigned char)idx; A.r_prime[A.n_r] = (unsigned char)prime;
+            ++A.n_r;
+        }
+        jobs[pass] = ((n_ops * A.n_r) << env.logn1) * 3;
+    }
+    const unsigned g0 = grid_for(jobs[0], kWaves), g1 = grid_for(jobs[1], kWaves);
+    if (jobs[0] && jobs[1] && g0 + g1 <= dual_max_blocks() && dual_engine_launches()) {
+        hipLaunchKernelGGL(k_behz_tensor_inv_dual, dim3(g0 + g1), dim3(kBlock), 0, env.stream, AE[0], AE[1], jobs[0], jobs[1], g0, env.primes);
+        return;
+    }
+    if (jobs[0]) hipLaunchKernelGGL(k_behz_tensor_inv<ArF64>, dim3(g0), dim3(kBlock), 0, env.stream, AE[0], env.primes, jobs[0]);
+    if (jobs[1]) hipLaunchKernelGGL(k_behz_tensor_inv<ArU64>, dim3(g1), dim3(kBlock), 0, env.stream, AE[1], env.primes, jobs[1]);
 }
 void launch_rows_fwd(const KernelEnv &env, const PolyView &v, u32 n_items) // the row half of launch_ntt_forward (raw, or canonical when N = 1024, -> NTT form)
 {
