@@ -833,6 +833,26 @@ def test_exact_model_fixture_gpu(be, name):
         g.multiply(L, 1, da, db, pw, c3)
         g.relinearize_rescale(L, 1, c3, out2)
         tem.check(f, "multiply_relin_rescale", out2.download((2, L - 1, N)))
+    if not ckks:
+        # the BEHZ multiply's other launch shapes against the model: an outer product whose operands are extended and transformed once
+        # each (2 x 2 results from the lists [a, a] and [b, b]: every result is a x b), and the matrix-product entry over an inner index
+        # of 3 (out = 3 relin(a x b): the model's relinearized product added three times)
+        a2, b2 = g.to_device(np.stack([d["a"], d["a"]])), g.to_device(np.stack([d["b"], d["b"]]))
+        o4 = g.alloc(4 * 3 * L * N)
+        g.bfv_multiply(L, 4, a2, b2, be.Context.outer(0, 2, 0, 2), o4)
+        for r, got in enumerate(o4.download((4, 3, L, N))):
+            tem.check(f, "bfv_multiply", got)
+        a3, b3 = g.to_device(np.stack([d["a"]] * 3)), g.to_device(np.stack([d["b"]] * 3))
+        acc = g.alloc(2 * L * N)
+        g.bfv_multiply_relin_accumulate(L, 1, 1, 3, a3, 1, 1, b3, 1, 1, acc)
+        c3 = g.alloc(3 * L * N)
+        g.bfv_multiply(L, 1, da, db, pw, c3)
+        one = g.alloc(2 * L * N)
+        g.relinearize(L, 1, c3, one)
+        rl = one.download((2, L, N))
+        tem.check(f, "bfv_multiply_relin", rl)
+        q = np.array(d["primes"][:L], dtype=object)[None, :, None]
+        assert np.array_equal(acc.download((2, L, N)), ((3 * rl.astype(object)) % q).astype(np.uint64))
     # Evaluator::rotate_internal without a key for step 3: the NAF terms -1, +4 through he355_rotate
     g3 = be.Context(be.SCHEME_CKKS if ckks else be.SCHEME_BFV, N, bit_sizes=f["bits"], plain_bits=0 if ckks else 20, sec128=False, device=0)
     for elt, key in d["gk"].items():
