@@ -530,7 +530,7 @@ public:
                          u64 g_off = 0)
     {
         if (groups && (rescale_out || with_tail || !(k3_can_fuse(env_) && B.c01_item_stride == 2 * (size_t)L * P.N)))
-            throw std::logic_error("key_switch_tail: grouped keys need the fused mod-down path");
+            throw std::logic_error("key_switch_tail: grouped keys are for plain rotations into a ciphertext slab");
         const bool lat = !groups && latency_shape_env(env_, nc); // (a grouped launch always takes the throughput shape)
         auto with_operands = [&](K3Fuse f) {
             if (ten) { f.ta = ten->a; f.tb = ten->b; f.tix = ten->ix; f.t_op_offset = ten->op_offset; f.c1_mode = ten->c1_mode; f.c1_src = ten->c1_src; }
@@ -553,7 +553,7 @@ public:
         }
         launch_k2(env_, L, nc, B);
         if (after_k2) HIPCHECK(hipEventRecord(after_k2, env_.stream));
-        if (k3_can_fuse(env_) && B.c01_item_stride == 2 * LN && (groups || fuse_pays(env_, nc))) {
+        if (k3_can_fuse(env_) && B.c01_item_stride == 2 * LN && fuse_pays(env_, nc)) {
             // special prime first, its correction through the column pass, then the data primes with the mod-down finished
             // inside K3 (the sums never go to HBM)
             launch_k3(env_, L, nc, B, key, K3_SPECIAL_ONLY, nullptr, 1, nullptr, 0, groups, g_off);
@@ -579,7 +579,7 @@ public:
             return false;
         }
         if (ten) throw std::logic_error("key_switch_tail: c0, c1 were left to a fused k_k3 that is not running");
-        launch_k3(env_, L, nc, B, key);
+        launch_k3(env_, L, nc, B, key, K3_ALL, nullptr, 1, nullptr, 0, groups, g_off);
         launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
         return key_switch_floor_rows(env_, L, nc, S, B, with_tail);
     }
@@ -1040,9 +1040,10 @@ public:
             KsBuffers B = S.ks;
             B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
             TensorOperands ten;
-            ten.c1_mode = 1; // polynomial 1 of the rotated ciphertext is zero: the fused k_k3 starts it from there
-            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, nullptr, B, nullptr, false, true, &groups);
-            key_switch_tail(env, L, nc, S, B, nullptr, false, nullptr, nullptr, &ten, &groups, off);
+            ten.c1_mode = 1; // polynomial 1 of the rotated ciphertext is zero: the fused k_k3 starts it from there ...
+            const bool fused = fuse_pays(env, nc); // ... (small grids take the unfused sequence: k_k1 writes the zero polynomial, k_floor_rows adds into it)
+            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, nullptr, B, nullptr, false, fused, &groups);
+            key_switch_tail(env, L, nc, S, B, nullptr, false, nullptr, nullptr, fused ? &ten : nullptr, &groups, off);
         }
     }
     u64 rotate_sum(int L, u64 n, const u64 *in, const int *steps, u64 n_steps, u64 *out)
