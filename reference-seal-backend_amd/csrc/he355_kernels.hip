@@ -1180,27 +1180,28 @@ __device__ __forceinline__ void k3_body_fn(ARGS A, const PrimeDev *primes, const
 #undef K3_BID_Y
 #undef K3_LDS_DECL
 }
-__global__ void __launch_bounds__(64) k_k3_dual(K3Args AF, K3Args AU, unsigned n_f, const PrimeDev *primes)
+__global__ void __launch_bounds__(64) k_k3_dual(K3Args AF, K3Args AU, unsigned n_u, const PrimeDev *primes)
 {
     __shared__ u64 lds[1][kLdsRow];
     __shared__ __attribute__((aligned(16))) u64 stage[1][kRowN];
     __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kRowTw * 16];
-    if (blockIdx.x < n_f) {
-        if ((int)blockIdx.y < (AF.n_split > 1 ? AF.n_split : 1))
-            k3_body_fn<ArF64, 1, false, false, false, const K3Args &>(AF, primes, blockIdx.x, blockIdx.y, lds, stage, twl_raw);
-    } else {
+    if (blockIdx.x < n_u) { // the u64-engine blocks first: the longer ones (see k_k3_dual8)
         if ((int)blockIdx.y < (AU.n_split > 1 ? AU.n_split : 1))
-            k3_body_fn<ArU64, 1, false, false, false, const K3Args &>(AU, primes, blockIdx.x - n_f, blockIdx.y, lds, stage, twl_raw);
+            k3_body_fn<ArU64, 1, false, false, false, const K3Args &>(AU, primes, blockIdx.x, blockIdx.y, lds, stage, twl_raw);
+    } else {
+        if ((int)blockIdx.y < (AF.n_split > 1 ? AF.n_split : 1))
+            k3_body_fn<ArF64, 1, false, false, false, const K3Args &>(AF, primes, blockIdx.x - n_u, blockIdx.y, lds, stage, twl_raw);
     }
 }
 template <bool FUSE, bool TENSOR, bool GROUPED>
-__global__ void __launch_bounds__(512) k_k3_dual8(K3Args AF, K3Args AU, unsigned n_f, const PrimeDev *primes)
+// (the u64-engine blocks come FIRST: they run 2.5 times as long as an fp64-engine block, and dispatched last they would be the launch's tail)
+__global__ void __launch_bounds__(512) k_k3_dual8(K3Args AF, K3Args AU, unsigned n_u, const PrimeDev *primes)
 {
     __shared__ u64 lds[8][kLdsRow];
     __shared__ __attribute__((aligned(16))) u64 stage[8][kRowN];
     __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kRowTw * 16];
-    if (blockIdx.x < n_f) k3_body_fn<ArF64, 8, FUSE, TENSOR, GROUPED, const K3Args>(AF, primes, blockIdx.x, 0, lds, stage, twl_raw);
-    else k3_body_fn<ArU64, 8, FUSE, TENSOR, GROUPED, const K3Args>(AU, primes, blockIdx.x - n_f, 0, lds, stage, twl_raw);
+    if (blockIdx.x < n_u) k3_body_fn<ArU64, 8, FUSE, TENSOR, GROUPED, const K3Args>(AU, primes, blockIdx.x, 0, lds, stage, twl_raw);
+    else k3_body_fn<ArF64, 8, FUSE, TENSOR, GROUPED, const K3Args>(AF, primes, blockIdx.x - n_u, 0, lds, stage, twl_raw);
 }
 
 // The sums of a digit-split k_k3 launch: part [n_split][n_ops * 2][L + 1][N] canonical -> t (data primes, canonical NTT form) and tpr
@@ -2507,13 +2508,13 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     const bool tensor = fuse && fuse->ta;
     if (n_pend == 2 && pend[0].waves == 1 && dual_engine_launches()) { // latency shape
         const unsigned ny = (unsigned)std::max(pend[0].A.n_split, pend[1].A.n_split);
-        hipLaunchKernelGGL(k_k3_dual, dim3(pend[0].g + pend[1].g, ny), dim3(64), 0, st3, pend[0].A, pend[1].A, pend[0].g, env.primes);
+        hipLaunchKernelGGL(k_k3_dual, dim3(pend[0].g + pend[1].g, ny), dim3(64), 0, st3, pend[0].A, pend[1].A, pend[1].g, env.primes);
         return;
     }
     // throughput shape, small grids (up to two blocks per CU for both engines together): both engines in one launch
     if (n_pend == 2 && pend[0].waves == 8 && pend[0].g + pend[1].g <= dual_max_blocks() && dual_engine_launches()) {
         const dim3 gd(pend[0].g + pend[1].g);
-#define HE355_K3D8(F, T, G) hipLaunchKernelGGL((k_k3_dual8<F, T, G>), gd, dim3(512), 0, st3, pend[0].A, pend[1].A, pend[0].g, env.primes)
+#define HE355_K3D8(F, T, G) hipLaunchKernelGGL((k_k3_dual8<F, T, G>), gd, dim3(512), 0, st3, pend[0].A, pend[1].A, pend[1].g, env.primes)
         if (groups) { if (fuse) HE355_K3D8(true, false, true); else HE355_K3D8(false, false, true); }
         else if (tensor) HE355_K3D8(true, true, false);
         else if (fuse) HE355_K3D8(true, false, false);
