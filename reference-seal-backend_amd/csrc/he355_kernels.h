@@ -193,7 +193,7 @@ constexpr int kBehzMaxB = 24; // base B (Params::behz_nB: 22 for sixteen 60-bit 
 // results op_offset .. op_offset + n_ops - 1 of the batch (the indexer sees the global result index)
 // n_cts ciphertext items selected by `src` (device_types.h, BehzSrc: the two operands of every result, or each distinct operand once)
 void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_cts, u64 *xq, u64 *xbsk);
-// N <= 8192, L <= 4, nB <= 6 (and HE355_BEHZ_FUSE != 0): the extension with the forward column passes of xq / xbsk in its epilogue,
+// N <= 16384, L <= 4, nB <= 6 (and HE355_BEHZ_FUSE != 0): the extension with the forward column passes of xq / xbsk in its epilogue,
 // and the inverse column passes of dq / ds in the prologue of steps (6)-(8) -- the coefficient-form copies never reach HBM
 bool behz_cols_fusable(const KernelEnv &env, const BehzDev &bz);
 void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_cts, u64 *xq, u64 *xbsk);

@@ -1644,7 +1644,7 @@ template <int LOGN1> __device__ __forceinline__ void col_fwd_store(const PrimeDe
         for (int a = 0; a < N1; ++a) dst[a << kRowLog] = y[a];
     }
 }
-// BEHZ steps (1)-(2) AND the forward column pass of all L + S residues in one kernel (N <= 8192, L <= 4, nB <= 6), so that the
+// BEHZ steps (1)-(2) AND the forward column pass of all L + S residues in one kernel (N <= 16384, L <= 4, nB <= 6), so that the
 // coefficient-form copies xq / xbsk never exist in HBM (k_behz_extend + k_cols_fwd x2 write them and read them back: 2 (L + S)
 // polynomial transfers per input polynomial saved).  A block = 64 columns x N1 rows of one input polynomial, one wave per row:
 // phase 1, lane (row e, column c) extends its coefficient to Bsk and parks the L + S residues in LDS [residue][e][c]; phase 2, wave w
@@ -2024,7 +2024,7 @@ template <int LOGN1> __device__ __forceinline__ void col_inv_load(const PrimeDev
         for (int a = 0; a < N1; ++a) v[a] = ar.to_canon(y[a]);
     }
 }
-// The inverse column pass of all L + S residues AND BEHZ steps (6)-(8) in one kernel (N <= 8192, L <= 4, nB <= 6): the mirror image of
+// The inverse column pass of all L + S residues AND BEHZ steps (6)-(8) in one kernel (N <= 16384, L <= 4, nB <= 6): the mirror image of
 // k_behz_extend_cols -- phase 1, wave w runs the column passes of residues w, w + N1, ... for the block's 64 columns and parks the
 // canonical values in LDS [residue][e][c]; phase 2, lane (row e, column c) takes its coefficient's L + S residues through the fast
 // floor and the Shenoy-Kumaresan conversion.  The coefficient-form products never exist in HBM.
@@ -2657,7 +2657,7 @@ void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, const BehzSrc &
 bool behz_cols_fusable(const KernelEnv &env, const BehzDev &bz)
 {
     static const bool on = [] { const char *e = std::getenv("HE355_BEHZ_FUSE"); return !(e && e[0] == '0'); }();
-    return on && bz.L <= 4 && bz.nB <= 6 && env.logn1 >= 1 && env.logn1 <= 3;
+    return on && bz.L <= 4 && bz.nB <= 6 && env.logn1 >= 1 && env.logn1 <= 4;
 }
 void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_cts, u64 *xq, u64 *xbsk)
 {
@@ -2669,6 +2669,7 @@ void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, const Behz
     switch (env.logn1) {
     case 1: HE355_EXT(1, 4, 6, false); break;
     case 2: HE355_EXT(2, 4, 6, false); break;
+    case 4: HE355_EXT(4, 4, 6, false); break; // N = 16384: 1024 threads, 8 KiB of LDS per residue
     default:
         if (bz.L == 2 && bz.nB == 2) HE355_EXT(3, 2, 2, true);
         else if (bz.L == 3 && bz.nB == 3) HE355_EXT(3, 3, 3, true);
@@ -2688,6 +2689,7 @@ void launch_behz_cols_floor_sk(const KernelEnv &env, const BehzDev &bz, u64 n_op
     switch (env.logn1) {
     case 1: HE355_FLR(1, 4, 6, false); break;
     case 2: HE355_FLR(2, 4, 6, false); break;
+    case 4: HE355_FLR(4, 4, 6, false); break;
     default:
         if (bz.L == 2 && bz.nB == 2) HE355_FLR(3, 2, 2, true);
         else if (bz.L == 3 && bz.nB == 3) HE355_FLR(3, 3, 3, true);
