@@ -68,7 +68,7 @@ def main():
     while time.time() < t_end:
         case += 1
         if rng.random() < 0.3:  # BFV: BEHZ multiply, relinearize, a row / column rotation (also added to another ciphertext)
-            N = int(rng.choice([1024, 2048, 4096, 8192]))
+            N = int(rng.choice([1024, 2048, 4096, 8192, 16384], p=[0.25, 0.25, 0.2, 0.15, 0.15]))
             K = int(rng.integers(2, 6))
             bits = [int(x) for x in rng.integers(35, 61, K)]
             pb = int(rng.integers(16, 23))
