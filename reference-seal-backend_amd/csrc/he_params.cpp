@@ -221,7 +221,7 @@ void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t)
         } else {
             // the device's own base (he_params.h, Params::aux): kAuxBits-bit primes 1 (mod 2N), none of them a coefficient modulus,
             // as many as the Shenoy-Kumaresan bound asks for at the first level (behz_base_suffices)
-            std::vector<u64> cand = get_primes(2 * (u64)N, kAuxBits, 2 * K + 8);
+            std::vector<u64> cand = get_primes(2 * (u64)N, kAuxBits, 3 * K + 16);
             cand.erase(std::remove_if(cand.begin(), cand.end(), [&](u64 v) { return std::find(chain.begin(), chain.end(), v) != chain.end(); }), cand.end());
             size_t next = 0;
             aux.push_back(make_prime_tables(cand[next++], N, logn, !force_u64)); // m_sk
