@@ -1193,15 +1193,20 @@ __global__ void __launch_bounds__(64) k_k3_dual(K3Args AF, K3Args AU, unsigned n
             k3_body_fn<ArF64, 1, false, false, false, const K3Args &>(AF, primes, blockIdx.x - n_u, blockIdx.y, lds, stage, twl_raw);
     }
 }
-template <bool FUSE, bool TENSOR, bool GROUPED>
-// (the u64-engine blocks come FIRST: they run 2.5 times as long as an fp64-engine block, and dispatched last they would be the launch's tail)
+// (the u64-engine blocks come FIRST: they run 2.5 times as long as an fp64-engine block, and dispatched last they would be the launch's tail;
+// UW = 4: the u64-engine blocks work with their first four waves, one per SIMD -- see launch_k3)
+template <bool FUSE, bool TENSOR, bool GROUPED, int UW = 8>
 __global__ void __launch_bounds__(512) k_k3_dual8(K3Args AF, K3Args AU, unsigned n_u, const PrimeDev *primes)
 {
     __shared__ u64 lds[8][kLdsRow];
     __shared__ __attribute__((aligned(16))) u64 stage[8][kRowN];
     __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kRowTw * 16];
-    if (blockIdx.x < n_u) k3_body_fn<ArU64, 8, FUSE, TENSOR, GROUPED, const K3Args>(AU, primes, blockIdx.x, 0, lds, stage, twl_raw);
-    else k3_body_fn<ArF64, 8, FUSE, TENSOR, GROUPED, const K3Args>(AF, primes, blockIdx.x - n_u, 0, lds, stage, twl_raw);
+    if (blockIdx.x < n_u) {
+        if (UW == 4 && threadIdx.x >= 256) return; // (wave-uniform: whole waves leave before any barrier)
+        k3_body_fn<ArU64, UW, FUSE, TENSOR, GROUPED, const K3Args>(AU, primes, blockIdx.x, 0, lds, stage, twl_raw);
+    } else {
+        k3_body_fn<ArF64, 8, FUSE, TENSOR, GROUPED, const K3Args>(AF, primes, blockIdx.x - n_u, 0, lds, stage, twl_raw);
+    }
 }
 
 // The sums of a digit-split k_k3 launch: part [n_split][n_ops * 2][L + 1][N] canonical -> t (data primes, canonical NTT form) and tpr
@@ -2475,8 +2480,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             }
         }
         if (!A.n_tt) continue;
-        const int waves = A.n_split > 1 ? 1 : 8; // latency shape: one wave per block, one (tile, op, digit group) each; else the 8-wave shape
-        const u64 n_og = (n_ops + waves - 1) / waves;
+        int waves = A.n_split > 1 ? 1 : 8; // latency shape: one wave per block, one (tile, op, digit group) each; else the 8-wave shape
         const u64 tiles = (u64)A.n_tt << env.logn1;
         // enough blocks to keep every CU busy for several rounds, few enough that start-up costs are amortised
         static const u32 og_env = getenv("HE355_K3_OG") ? (u32)atoi(getenv("HE355_K3_OG")) : 0;
@@ -2487,20 +2491,37 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         // rounds x (groups x work per group + start-up), ties to the larger.  (Maximum for the 8-wave shape: 4 once a tile has 128
         // op-groups -- chunks of 1024 ciphertexts: 50.3 vs 50.9 ms per step with 2 -- and 2 below that, where 4 measured slower;
         // profiles/r03_chunk_sweep.txt.)  HE355_K3_OG=<n> fixes the size.
-        const u32 og_max = waves == 8 ? (n_og >= 128 ? 4 : 2) : 4;
-        u32 ogpb = og_env ? og_env : og_max;
-        if (!og_env) {
-            const double work = (pass == 0 ? 7.0 : 14.0) * (L + 2), startup = 4.0; // us per op-group (one row step per digit + epilogue), per block
-            double best = 0;
-            for (u32 c = og_max; c >= 1; c >>= 1) {
-                const u64 blocks = tiles * ((n_og + c - 1) / c);
-                const double cost = (double)((blocks + 255) / 256) * (c * work + startup);
-                if (c == og_max || cost < best * 0.999) { best = cost; ogpb = c; }
+        u64 n_og = 0;
+        u32 ogpb = 1;
+        unsigned g = 0;
+        auto size_grid = [&](int w) {
+            n_og = (n_ops + w - 1) / w;
+            const u32 og_max = w == 8 ? (n_og >= 128 ? 4 : 2) : 4;
+            ogpb = og_env ? og_env : og_max;
+            if (!og_env) {
+                const double work = (pass == 0 ? 7.0 : 14.0) * (L + 2) * (w == 4 ? 0.5 : 1.0), startup = 4.0; // us per op-group (one row step per digit + epilogue), per block
+                double best = 0;
+                for (u32 c = og_max; c >= 1; c >>= 1) {
+                    const u64 blocks = tiles * ((n_og + c - 1) / c);
+                    const double cost = (double)((blocks + 255) / 256) * (c * work + startup);
+                    if (c == og_max || cost < best * 0.999) { best = cost; ogpb = c; }
+                }
             }
+            const u64 n_ogb = (n_og + ogpb - 1) / ogpb;
+            g = (unsigned)(((tiles + 7) / 8) * 8 * n_ogb);
+        };
+        size_grid(waves);
+        // u64-engine tiles of a small grid (at most half the CUs busy with 8-wave blocks): FOUR waves per block -- one per SIMD, each at
+        // the full issue rate instead of half of it, and twice the blocks; the serial digit loop of a tile is what such a launch lasts
+        static const unsigned four_max = getenv("HE355_K3_FOUR_WAVES_MAX") ? (unsigned)atoi(getenv("HE355_K3_FOUR_WAVES_MAX")) : 128u;
+        if (pass == 1 && waves == 8 && g <= four_max) {
+            size_grid(4);
+            // (a CU holds ONE block of either shape -- the LDS arrays -- so the four-wave blocks must still fit one round together with the
+            // fp64-engine blocks they may share the launch with)
+            if (g + (n_pend ? pend[0].g : 0) <= 256) waves = 4;
+            else size_grid(8);
         }
         A.og_per_block = ogpb;
-        const u64 n_ogb = (n_og + ogpb - 1) / ogpb;
-        const unsigned g = (unsigned)(((tiles + 7) / 8) * 8 * n_ogb);
         pend[n_pend].A = A; pend[n_pend].g = g; pend[n_pend].f64 = pass == 0; pend[n_pend].waves = waves;
         ++n_pend;
     }
@@ -2514,7 +2535,11 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     // throughput shape, small grids (up to two blocks per CU for both engines together): both engines in one launch
     if (n_pend == 2 && pend[0].waves == 8 && pend[0].g + pend[1].g <= dual_max_blocks() && dual_engine_launches()) {
         const dim3 gd(pend[0].g + pend[1].g);
-#define HE355_K3D8(F, T, G) hipLaunchKernelGGL((k_k3_dual8<F, T, G>), gd, dim3(512), 0, st3, pend[0].A, pend[1].A, pend[1].g, env.primes)
+#define HE355_K3D8(F, T, G)                                                                                                                     \
+    do {                                                                                                                                        \
+        if (pend[1].waves == 4) hipLaunchKernelGGL((k_k3_dual8<F, T, G, 4>), gd, dim3(512), 0, st3, pend[0].A, pend[1].A, pend[1].g, env.primes); \
+        else hipLaunchKernelGGL((k_k3_dual8<F, T, G, 8>), gd, dim3(512), 0, st3, pend[0].A, pend[1].A, pend[1].g, env.primes);                    \
+    } while (0)
         if (groups) { if (fuse) HE355_K3D8(true, false, true); else HE355_K3D8(false, false, true); }
         else if (tensor) HE355_K3D8(true, true, false);
         else if (fuse) HE355_K3D8(true, false, false);
@@ -2542,6 +2567,12 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             const dim3 gd(g, (unsigned)A.n_split);
             if (f64) hipLaunchKernelGGL((k_k3<ArF64, 1>), gd, dim3(64), 0, st3, A, env.primes);
             else hipLaunchKernelGGL((k_k3<ArU64, 1>), gd, dim3(64), 0, st3, A, env.primes);
+        } else if (pend[i].waves == 4) { // (u64 engine, small grid)
+            if (groups && fuse) hipLaunchKernelGGL((k_k3<ArU64, 4, true, false, true>), dim3(g), dim3(256), 0, st3, A, env.primes);
+            else if (groups) hipLaunchKernelGGL((k_k3<ArU64, 4, false, false, true>), dim3(g), dim3(256), 0, st3, A, env.primes);
+            else if (tensor) hipLaunchKernelGGL((k_k3<ArU64, 4, true, true>), dim3(g), dim3(256), 0, st3, A, env.primes);
+            else if (fuse) hipLaunchKernelGGL((k_k3<ArU64, 4, true>), dim3(g), dim3(256), 0, st3, A, env.primes);
+            else hipLaunchKernelGGL((k_k3<ArU64, 4>), dim3(g), dim3(256), 0, st3, A, env.primes);
         } else if (groups) {
             if (f64 && fuse) hipLaunchKernelGGL((k_k3<ArF64, 8, true, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
             else if (f64) hipLaunchKernelGGL((k_k3<ArF64, 8, false, false, true>), dim3(g), dim3(512), 0, st3, A, env.primes);
