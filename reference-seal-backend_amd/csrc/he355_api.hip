@@ -1294,65 +1294,16 @@ public:
     {
         auto it = behz_.find(L);
         if (it != behz_.end()) return it->second;
-        if (L > kBehzMaxL) throw std::invalid_argument("BFV multiply supports at most 16 data primes in this build");
-        const BehzTables T = P.behz_tables(L);
-        const int nB = T.nB, S = nB + 1;
-        if (nB > kBehzMaxB) throw std::invalid_argument("BFV multiply: auxiliary base too large for this build");
-        auto mm = [](u64 x, u64 y, u64 m) { return (u64)(((u128)x * y) % m); };
-        auto pj = [&](int j) { return j < nB ? P.aux[1 + j].q : P.aux[0].q; };
-        std::vector<u64> cq(L), f_cq(L), e_q2bsk((size_t)S * L), e_qmod(S), f_ds(S), f_neg((size_t)S * L), a_msk(nB);
-        for (int i = 0; i < L; ++i) {
-            const u64 q = P.primes[i].q;
-            cq[i] = mm(T.mtilde_q[i], T.inv_punct_q[i], q);
-            f_cq[i] = mm(T.t_mod_q[i], T.inv_punct_q[i], q);
-        }
-        for (int j = 0; j < S; ++j) {
-            const u64 p = pj(j);
-            const u64 c = j < nB ? mm(T.inv_q_bsk[j], T.inv_punct_B[j], p) : T.inv_q_bsk[j];
-            e_qmod[j] = mm(T.q_mod_bsk[j], T.inv_mt_bsk[j], p);
-            f_ds[j] = mm(T.t_mod_bsk[j], c, p);
-            for (int i = 0; i < L; ++i) {
-                e_q2bsk[(size_t)j * L + i] = mm(T.q2bsk[(size_t)j * L + i], T.inv_mt_bsk[j], p);
-                const u64 v = mm(T.q2bsk[(size_t)j * L + i], c, p);
-                f_neg[(size_t)j * L + i] = v ? p - v : 0;
-            }
-        }
-        const u64 msk = P.aux[0].q;
-        for (int j = 0; j < nB; ++j) a_msk[j] = mm(T.B2msk[j], T.inv_B_mod_msk, msk);
-        std::vector<u64> blob;
-        auto push = [&](const std::vector<u64> &v) { const size_t off = blob.size(); blob.insert(blob.end(), v.begin(), v.end()); return off; };
-        const size_t o_cq = push(cq), o_q2m = push(T.q2mt), o_e2b = push(e_q2bsk), o_eqm = push(e_qmod), o_fcq = push(f_cq), o_fds = push(f_ds),
-                     o_fng = push(f_neg), o_am = push(a_msk), o_B2q = push(T.B2q), o_Bq = push(T.B_mod_q);
+        const BehzHost H = P.behz_host(L); // the folded constants (he_params.cpp), as two flat arrays
         u64 *d = nullptr;
-        dmalloc(d, blob.size() * 8);
+        dmalloc(d, H.words.size() * 8);
         owned_.push_back(d);
-        HIPCHECK(hipMemcpy(d, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
-        BehzDev Z{};
-        Z.L = L;
-        Z.nB = nB;
-        Z.cq = d + o_cq; Z.q2mt = d + o_q2m; Z.neg_inv_q_mod_mt = T.neg_inv_q_mod_mt; Z.e_q2bsk = d + o_e2b; Z.e_qmod = d + o_eqm;
-        Z.f_cq = d + o_fcq; Z.f_ds = d + o_fds; Z.f_neg = d + o_fng;
-        Z.a_msk = d + o_am; Z.neg_inv_B = T.inv_B_mod_msk ? msk - T.inv_B_mod_msk : 0; Z.B2q = d + o_B2q; Z.B_mod_q = d + o_Bq;
-        // the doubles of steps (6)-(8) (BehzDev::f64aux): every auxiliary prime on the fp64 engine
-        Z.f64aux = 1;
-        for (int j = 0; j < S; ++j) Z.f64aux &= (int)(j < nB ? P.aux[1 + j].f64 : P.aux[0].f64);
-        {
-            std::vector<double> dd;
-            auto pushd = [&](const std::vector<u64> &v) { const size_t off = dd.size(); for (u64 x : v) dd.push_back((double)x); return off; };
-            std::vector<u64> f_neg_hi((size_t)S * L);
-            for (int j = 0; j < S; ++j)
-                for (int i = 0; i < L; ++i) f_neg_hi[(size_t)j * L + i] = mm(f_neg[(size_t)j * L + i], ((u64)1 << 30) % pj(j), pj(j));
-            const size_t q_fcq = pushd(f_cq), q_fds = pushd(f_ds), q_fng = pushd(f_neg), q_fnh = pushd(f_neg_hi), q_am = pushd(a_msk), q_B2q = pushd(T.B2q),
-                         q_Bq = pushd(T.B_mod_q);
-            double *ddev = nullptr;
-            dmalloc(ddev, dd.size() * 8);
-            owned_.push_back(ddev);
-            HIPCHECK(hipMemcpy(ddev, dd.data(), dd.size() * 8, hipMemcpyHostToDevice));
-            Z.f_cq_d = ddev + q_fcq; Z.f_ds_d = ddev + q_fds; Z.f_neg_d = ddev + q_fng; Z.f_neg_hi_d = ddev + q_fnh; Z.a_msk_d = ddev + q_am;
-            Z.neg_inv_B_d = (double)Z.neg_inv_B; Z.B2q_d = ddev + q_B2q; Z.B_mod_q_d = ddev + q_Bq;
-        }
-        for (int j = 0; j < T.nB; ++j) Z.bsk_prime[j] = (unsigned char)(P.K + 1 + j); // B_j
-        Z.bsk_prime[T.nB] = (unsigned char)P.K;                                        // m_sk
+        HIPCHECK(hipMemcpy(d, H.words.data(), H.words.size() * 8, hipMemcpyHostToDevice));
+        double *ddev = nullptr;
+        dmalloc(ddev, H.doubles.size() * 8);
+        owned_.push_back(ddev);
+        HIPCHECK(hipMemcpy(ddev, H.doubles.data(), H.doubles.size() * 8, hipMemcpyHostToDevice));
+        const BehzDev Z = H.view(d, ddev, P.K);
         return behz_[L] = Z;
     }
     // out(i, j) = sum_k relinearize(multiply(a(i, k), b(k, j))): the multiply / relinearize_inplace / add_inplace loop of the BFV

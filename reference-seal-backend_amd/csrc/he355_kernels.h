@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
+#include "behz_core.h"
 
 namespace he355 {
 
@@ -148,46 +149,7 @@ struct FloorRowsArgs {
 };
 void launch_floor_rows(const KernelEnv &env, u64 n_ops, const FloorRowsArgs &args);
 // ---- BFV -------------------------------------------------------------------------------------------------
-// Device constants of the BEHZ multiply, derived from BehzTables (he_params.h) with every chain of constant factors folded into one
-// (he355_api.hip, DeviceContext::behz): each step is then ONE 128-bit sum of products and ONE Barrett reduction -- same residues.
-// All pointers are HBM.  Bsk order: B_0..B_{nB-1}, m_sk (S = nB + 1); p_j the j-th of them.
-struct BehzDev {
-    int L, nB;
-    // steps (1)-(2), base extension q -> Bsk with the Montgomery correction mod m_tilde = 2^32:
-    //   tmp_i = x_i cq_i mod q_i;  r = -(sum_i tmp_i q2mt_i) Q^-1 mod 2^32, centred;  out_j = sum_i tmp_i e_q2bsk_ji + r e_qmod_j mod p_j
-    const u64 *cq;          // [L]      2^32 (Q/q_i)^-1 mod q_i
-    const u64 *q2mt;        // [L]      (Q/q_i) mod 2^32
-    u64 neg_inv_q_mod_mt;   //          -Q^-1 mod 2^32
-    const u64 *e_q2bsk;     // [S][L]   (Q/q_i) 2^-32 mod p_j
-    const u64 *e_qmod;      // [S]      Q 2^-32 mod p_j
-    // steps (6)-(7), times t and fast floor, with (B/b_j)^-1 of step (8) folded in for j < nB:
-    //   tmp_i = d_i f_cq_i mod q_i;  fl_j = ds_j f_ds_j + sum_i tmp_i f_neg_ji mod p_j
-    const u64 *f_cq;        // [L]      t (Q/q_i)^-1 mod q_i
-    const u64 *f_ds;        // [S]      t Q^-1 c_j mod p_j,  c_j = (B/b_j)^-1 mod b_j (j < nB), 1 (m_sk)
-    const u64 *f_neg;       // [S][L]   -(Q/q_i) Q^-1 c_j mod p_j
-    // step (8), Shenoy-Kumaresan: alpha = sum_j fl_j a_msk_j + fl_sk neg_inv_B mod m_sk, centred;
-    //   out_i = sum_j fl_j B2q_ij - alpha B mod q_i
-    const u64 *a_msk;       // [nB]     (B/b_j) B^-1 mod m_sk
-    u64 neg_inv_B;          //          -B^-1 mod m_sk
-    const u64 *B2q;         // [L][nB]  (B/b_j) mod q_i
-    const u64 *B_mod_q;     // [L]
-    unsigned char bsk_prime[64]; // device prime index of Bsk element j
-    // The same constants of steps (6)-(8) as doubles, for the fp64 engine: used when every auxiliary prime is below 2^47 (f64aux;
-    // the device's own base).  A residue mod an auxiliary prime is then a handful of exact fp64 products (ArF64::mulmod_vv) instead of
-    // 128-bit sums and a Barrett reduction; base-q residues of fp64-engine primes likewise, those of the 60-bit primes stay integers
-    // (their value enters the auxiliary sums as hi * 2^30 + lo: f_neg_hi_d = f_neg * 2^30 mod p_j).
-    int f64aux, pad_;
-    const double *f_cq_d;     // [L]
-    const double *f_ds_d;     // [S]
-    const double *f_neg_d;    // [S][L]
-    const double *f_neg_hi_d; // [S][L]
-    const double *a_msk_d;    // [nB]
-    double neg_inv_B_d;
-    const double *B2q_d;      // [L][nB]
-    const double *B_mod_q_d;  // [L]
-};
-constexpr int kBehzMaxL = 16; // base q
-constexpr int kBehzMaxB = 24; // base B (Params::behz_nB: 22 for sixteen 60-bit primes)
+// (BehzDev, kBehzMaxL / kBehzMaxB and the per-coefficient BEHZ arithmetic: behz_core.h -- host-compilable, the lane simulator runs it on the CPU)
 // BEHZ steps (1)-(2): lift the four input polynomials of each pair to Bsk (fastbconv_m_tilde + sm_mrq) and copy them
 // for the base-q transform.  xq [n*4][L][N], xbsk [n*4][S][N], coefficient form.
 // results op_offset .. op_offset + n_ops - 1 of the batch (the indexer sees the global result index)

@@ -1576,30 +1576,6 @@ __device__ __forceinline__ ModU64 mod_of(const PrimeDev *primes, int idx) { retu
 
 // ML / MB: compile-time bounds of the bases q and B (loops fully unrolled under them, per-residue values in registers): <4, 6> serves
 // the reference's default parameter sets ({60,40,40} and {60,40,40,40}), <kBehzMaxL, kBehzMaxB> everything else.
-// One coefficient through fastbconv_m_tilde's first half: tmp_i = x_i m_tilde (Q/q_i)^-1 mod q_i, and r = -(sum tmp_i Q/q_i) Q^-1 mod m_tilde
-template <int ML> __device__ __forceinline__ void behz_ext_prepare(const BehzDev &Z, const PrimeDev *primes, int L, const u64 x[ML], u64 tmp[ML], u64 &rmt)
-{
-    u64 mt_acc = 0;
-#pragma unroll
-    for (int i = 0; i < ML; ++i)
-        if (i < L) {
-            tmp[i] = mulmod(x[i], Z.cq[i], mod_of(primes, i));
-            mt_acc += (tmp[i] & 0xFFFFFFFFull) * Z.q2mt[i];
-        }
-    rmt = ((mt_acc & 0xFFFFFFFFull) * Z.neg_inv_q_mod_mt) & 0xFFFFFFFFull;
-}
-// ... and its residue mod Bsk element j after sm_mrq, (sum tmp_i (Q/q_i) + r Q) m_tilde^-1 mod p_j with r centred: one sum of
-// products (constants carry m_tilde^-1; at most 17 terms below 2^122), one reduction
-template <int ML> __device__ __forceinline__ u64 behz_ext_residue(const BehzDev &Z, const ModU64 &mj, int L, int j, const u64 tmp[ML], u64 rmt)
-{
-    const u64 MT = (u64)1 << 32;
-    const u64 rr = rmt >= (MT >> 1) ? rmt + (mj.q - MT) : rmt; // centred r as a residue mod p_j
-    u128 acc = (u128)rr * Z.e_qmod[j];
-#pragma unroll
-    for (int i = 0; i < ML; ++i)
-        if (i < L) acc += (u128)tmp[i] * Z.e_q2bsk[j * L + i];
-    return barrett128(acc, mj);
-}
 template <int ML, int MB>
 __global__ void __launch_bounds__(kBlock) k_behz_extend(BehzDev Z, const PrimeDev *primes, BehzSrc src_of, u64 *xq, u64 *xbsk, u64 n_polys, int logN)
 {
@@ -1858,131 +1834,6 @@ __global__ void __launch_bounds__(kBlock) k_behz_tensor_inv_dual(BehzTensorArgs 
     else behz_tensor_inv_block<ArU64>(AU, primes, jobs_u, blockIdx.x - n_f, lds);
 }
 
-// BEHZ steps (6)-(8) for one coefficient: dq[i] (base q), ds[j] (Bsk) canonical residues of a product -> its L output residues.
-// Constant factors are folded (BehzDev): every line below is one sum of products below 2^122 (at most 25 of them) and one reduction.
-template <int ML, int MB>
-__device__ __forceinline__ void behz_floor_sk_coeff(const BehzDev &Z, const PrimeDev *primes, int L, int nB, const u64 dq[ML], const u64 ds[MB + 1], u64 res[ML])
-{
-    constexpr int kUnrollB = MB <= 6 ? MB + 1 : 1, kUnrollL = ML <= 4 ? ML : 1; // the large instantiation keeps its residue loops rolled
-    const int S = nB + 1;
-    u64 tmp[ML], fl[MB];
-    // (6) times t, and the base-q part prepared for the fast conversion (canonical: the conversion depends on the representative)
-#pragma unroll
-    for (int i = 0; i < ML; ++i)
-        if (i < L) tmp[i] = mulmod(dq[i], Z.f_cq[i], mod_of(primes, i));
-    // (7) fast floor (t x_Bsk - FastBconv(t x_q)) Q^-1 mod p_j, times (B/b_j)^-1 for the B part; (8) first half: alpha_sk
-    const ModU64 msk = mod_of(primes, Z.bsk_prime[nB]);
-    u128 accs = 0;
-#pragma unroll kUnrollB
-    for (int j = 0; j < MB + 1; ++j)
-        if (j < S) {
-            const ModU64 mj = mod_of(primes, Z.bsk_prime[j]);
-            u128 acc = (u128)ds[j] * Z.f_ds[j];
-#pragma unroll
-            for (int i = 0; i < ML; ++i)
-                if (i < L) acc += (u128)tmp[i] * Z.f_neg[j * L + i];
-            const u64 f = barrett128(acc, mj);
-            if (j < nB) {
-                if (j < MB) { // (always; keeps the index static)
-                    fl[j] = f;
-                    accs += (u128)f * Z.a_msk[j];
-                }
-            } else {
-                accs += (u128)f * Z.neg_inv_B;
-            }
-        }
-    const u64 alpha = barrett128(accs, msk);
-    const bool neg = alpha > (msk.q >> 1);
-    // (8) second half: B -> q with the alpha_sk correction
-#pragma unroll kUnrollL
-    for (int j = 0; j < ML; ++j) {
-        if (j >= L) break;
-        const ModU64 mj = mod_of(primes, j);
-        const u64 Bq = Z.B_mod_q[j];
-        u128 acc = neg ? (u128)(msk.q - alpha) * Bq : (u128)alpha * (Bq ? mj.q - Bq : 0);
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-            if (i < nB) acc += (u128)fl[i] * Z.B2q[j * nB + i];
-        res[j] = barrett128(acc, mj);
-    }
-}
-// The same steps on the fp64 engine, for an auxiliary base of primes below 2^47 (BehzDev::f64aux): a residue mod an auxiliary prime,
-// alpha_sk and the outputs under fp64-engine base-q primes are sums of exact fp64 products (ArF64::mulmod_vv: centred, |.| <= p (1/2 +
-// eps); at most 27 of them, canon() brings the sum home); the 60-bit base-q primes keep their integer arithmetic and enter the
-// auxiliary sums as hi * 2^30 + lo.  The same residues as behz_floor_sk_coeff, at a third of its instructions.
-template <int ML, int MB>
-__device__ __forceinline__ void behz_floor_sk_coeff_f64(const BehzDev &Z, const PrimeDev *primes, int L, int nB, const u64 dq[ML], const u64 ds[MB + 1],
-                                                        u64 res[ML])
-{
-    constexpr int kUnrollB = MB <= 6 ? MB + 1 : 1, kUnrollL = ML <= 4 ? ML : 1;
-    const int S = nB + 1;
-    double ta[ML], tb[ML]; // tmp_i: fp64-engine prime: ta = the canonical value; 60-bit prime: ta = its low 30 bits, tb = the rest
-    // (6) times t, and the base-q part prepared for the fast conversion (canonical: the conversion depends on the representative)
-#pragma unroll
-    for (int i = 0; i < ML; ++i)
-        if (i < L) {
-            const PrimeDev &Pi = primes[i];
-            if (Pi.f64) {
-                const ArF64 ar = make_ar(Pi, (ArF64 *)nullptr);
-                ta[i] = ar.canon2(ar.mulmod_vv(u52_to_f64(dq[i]), Z.f_cq_d[i]));
-                tb[i] = 0.0;
-            } else {
-                const u64 t = mulmod(dq[i], Z.f_cq[i], make_modu(Pi));
-                ta[i] = u52_to_f64(t & (((u64)1 << 30) - 1));
-                tb[i] = u52_to_f64(t >> 30);
-            }
-        }
-    // (7) fast floor times (B/b_j)^-1, (8) first half: alpha_sk
-    const ArF64 arsk = make_ar(primes[Z.bsk_prime[nB]], (ArF64 *)nullptr);
-    double fl[MB], acc_sk = 0.0;
-#pragma unroll kUnrollB
-    for (int j = 0; j < MB + 1; ++j)
-        if (j < S) {
-            const ArF64 arj = make_ar(primes[Z.bsk_prime[j]], (ArF64 *)nullptr);
-            double sum = arj.mulmod_vv(u52_to_f64(ds[j]), Z.f_ds_d[j]);
-#pragma unroll
-            for (int i = 0; i < ML; ++i)
-                if (i < L) {
-                    sum += arj.mulmod_vv(ta[i], Z.f_neg_d[j * L + i]);
-                    if (!primes[i].f64) sum += arj.mulmod_vv(tb[i], Z.f_neg_hi_d[j * L + i]);
-                }
-            const double f = arj.canon(sum);
-            if (j < nB) {
-                if (j < MB) { // (always; keeps the index static)
-                    fl[j] = f;
-                    acc_sk += arsk.mulmod_vv(f, Z.a_msk_d[j]);
-                }
-            } else {
-                acc_sk += arsk.mulmod_vv(f, Z.neg_inv_B_d);
-            }
-        }
-    const double alpha = arsk.canon(acc_sk);
-    const bool neg = alpha > (arsk.q - 1.0) * 0.5; // alpha > floor(m_sk / 2), m_sk odd
-    const double am = neg ? arsk.q - alpha : alpha; // |gamma|
-    // (8) second half: B -> q with the alpha_sk correction
-#pragma unroll kUnrollL
-    for (int i = 0; i < ML; ++i) {
-        if (i >= L) break;
-        const PrimeDev &Pi = primes[i];
-        if (Pi.f64) {
-            const ArF64 ar = make_ar(Pi, (ArF64 *)nullptr);
-            const double Bq = Z.B_mod_q_d[i];
-            double sum = ar.mulmod_vv(am, neg ? Bq : ar.q - Bq);
-#pragma unroll
-            for (int j = 0; j < MB; ++j)
-                if (j < nB) sum += ar.mulmod_vv(fl[j], Z.B2q_d[i * nB + j]);
-            res[i] = f64_to_u52(ar.canon(sum));
-        } else {
-            const ModU64 mi = make_modu(Pi);
-            const u64 Bq = Z.B_mod_q[i];
-            u128 acc = (u128)f64_to_u52(am) * (neg ? Bq : (Bq ? mi.q - Bq : 0));
-#pragma unroll
-            for (int j = 0; j < MB; ++j)
-                if (j < nB) acc += (u128)f64_to_u52(fl[j]) * Z.B2q[i * nB + j];
-            res[i] = barrett128(acc, mi);
-        }
-    }
-}
 template <int ML, int MB>
 __global__ void __launch_bounds__(kBlock) k_behz_floor_sk(BehzDev Z, const PrimeDev *primes, const u64 *dq, const u64 *ds, u64 *out, u64 n_polys, int logN)
 {

@@ -400,6 +400,65 @@ BehzTables Params::behz_tables(int L_) const
     return T;
 }
 
+BehzHost Params::behz_host(int L) const
+{
+    if (L > kBehzMaxL) throw std::invalid_argument("BFV multiply supports at most 16 data primes in this build");
+    const BehzTables T = behz_tables(L);
+    const int nB = T.nB, S = nB + 1;
+    if (nB > kBehzMaxB) throw std::invalid_argument("BFV multiply: auxiliary base too large for this build");
+    auto pj = [&](int j) { return j < nB ? aux[1 + j].q : aux[0].q; };
+    std::vector<u64> cq(L), f_cq(L), e_q2bsk((size_t)S * L), e_qmod(S), f_ds(S), f_neg((size_t)S * L), f_neg_hi((size_t)S * L), a_msk(nB);
+    for (int i = 0; i < L; ++i) {
+        const u64 q = primes[i].q;
+        cq[i] = mm(T.mtilde_q[i], T.inv_punct_q[i], q);
+        f_cq[i] = mm(T.t_mod_q[i], T.inv_punct_q[i], q);
+    }
+    for (int j = 0; j < S; ++j) {
+        const u64 p = pj(j);
+        const u64 c = j < nB ? mm(T.inv_q_bsk[j], T.inv_punct_B[j], p) : T.inv_q_bsk[j];
+        e_qmod[j] = mm(T.q_mod_bsk[j], T.inv_mt_bsk[j], p);
+        f_ds[j] = mm(T.t_mod_bsk[j], c, p);
+        for (int i = 0; i < L; ++i) {
+            e_q2bsk[(size_t)j * L + i] = mm(T.q2bsk[(size_t)j * L + i], T.inv_mt_bsk[j], p);
+            const u64 v = mm(T.q2bsk[(size_t)j * L + i], c, p);
+            f_neg[(size_t)j * L + i] = v ? p - v : 0;
+            f_neg_hi[(size_t)j * L + i] = mm(f_neg[(size_t)j * L + i], ((u64)1 << 30) % p, p);
+        }
+    }
+    const u64 msk = aux[0].q;
+    for (int j = 0; j < nB; ++j) a_msk[j] = mm(T.B2msk[j], T.inv_B_mod_msk, msk);
+    BehzHost H;
+    H.L = L; H.nB = nB;
+    H.neg_inv_q_mod_mt = T.neg_inv_q_mod_mt;
+    H.neg_inv_B = T.inv_B_mod_msk ? msk - T.inv_B_mod_msk : 0;
+    auto push = [&](const std::vector<u64> &v) { const size_t off = H.words.size(); H.words.insert(H.words.end(), v.begin(), v.end()); return off; };
+    H.o_cq = push(cq); H.o_q2m = push(T.q2mt); H.o_e2b = push(e_q2bsk); H.o_eqm = push(e_qmod); H.o_fcq = push(f_cq); H.o_fds = push(f_ds);
+    H.o_fng = push(f_neg); H.o_am = push(a_msk); H.o_B2q = push(T.B2q); H.o_Bq = push(T.B_mod_q);
+    // the doubles of steps (6)-(8) (BehzDev::f64aux): used when every auxiliary prime is on the fp64 engine; entries that belong to a
+    // 60-bit base-q prime are not exact as doubles and are never read (those residues keep their integer arithmetic)
+    H.f64aux = 1;
+    for (int j = 0; j < S; ++j) H.f64aux &= (int)(j < nB ? aux[1 + j].f64 : aux[0].f64);
+    auto pushd = [&](const std::vector<u64> &v) { const size_t off = H.doubles.size(); for (u64 x : v) H.doubles.push_back((double)x); return off; };
+    H.q_fcq = pushd(f_cq); H.q_fds = pushd(f_ds); H.q_fng = pushd(f_neg); H.q_fnh = pushd(f_neg_hi); H.q_am = pushd(a_msk); H.q_B2q = pushd(T.B2q);
+    H.q_Bq = pushd(T.B_mod_q);
+    return H;
+}
+
+BehzDev BehzHost::view(const u64 *w, const double *d, size_t K) const
+{
+    BehzDev Z{};
+    Z.L = L; Z.nB = nB;
+    Z.cq = w + o_cq; Z.q2mt = w + o_q2m; Z.neg_inv_q_mod_mt = neg_inv_q_mod_mt; Z.e_q2bsk = w + o_e2b; Z.e_qmod = w + o_eqm;
+    Z.f_cq = w + o_fcq; Z.f_ds = w + o_fds; Z.f_neg = w + o_fng;
+    Z.a_msk = w + o_am; Z.neg_inv_B = neg_inv_B; Z.B2q = w + o_B2q; Z.B_mod_q = w + o_Bq;
+    Z.f64aux = f64aux;
+    Z.f_cq_d = d + q_fcq; Z.f_ds_d = d + q_fds; Z.f_neg_d = d + q_fng; Z.f_neg_hi_d = d + q_fnh; Z.a_msk_d = d + q_am;
+    Z.neg_inv_B_d = (double)neg_inv_B; Z.B2q_d = d + q_B2q; Z.B_mod_q_d = d + q_Bq;
+    for (int j = 0; j < nB; ++j) Z.bsk_prime[j] = (unsigned char)(K + 1 + j); // B_j
+    Z.bsk_prime[nB] = (unsigned char)K;                                        // m_sk
+    return Z;
+}
+
 PrimeTables Params::make_prime_tables(u64 q, size_t N, int logn, bool f64)
 {
     PrimeTables pt;

@@ -12,6 +12,7 @@
 
 #include "device_types.h"
 #include "modarith.h"
+#include "behz_core.h"
 
 namespace he355 {
 
@@ -56,6 +57,20 @@ struct BehzTables {
     std::vector<u64> B_mod_q;      // [L]
 };
 
+// The constants the BEHZ kernels run on (behz_core.h, BehzDev), derived from BehzTables with every chain of constant factors folded into
+// one, as two flat arrays (u64 words and their double twins for the fp64 engine) plus the offsets of each table in them.  view() makes
+// the BehzDev whose pointers address copies of the two arrays at `w` / `d`: device buffers for the product (he355_api.hip), the host
+// vectors themselves for the lane simulator (tests/csim/sim_behz.cpp).
+struct BehzHost {
+    int L = 0, nB = 0, f64aux = 0;
+    u64 neg_inv_q_mod_mt = 0, neg_inv_B = 0;
+    std::vector<u64> words;
+    std::vector<double> doubles;
+    size_t o_cq = 0, o_q2m = 0, o_e2b = 0, o_eqm = 0, o_fcq = 0, o_fds = 0, o_fng = 0, o_am = 0, o_B2q = 0, o_Bq = 0;
+    size_t q_fcq = 0, q_fds = 0, q_fng = 0, q_fnh = 0, q_am = 0, q_B2q = 0, q_Bq = 0;
+    BehzDev view(const u64 *w, const double *d, size_t K) const; // K: device prime index of m_sk (B_j follow at K + 1 + j)
+};
+
 class Params {
 public:
     // bit_sizes is the key-level chain; sec128 enforces SEAL's tc128 cap.  Throws std::invalid_argument.
@@ -95,6 +110,7 @@ public:
     // coefficient form: out[o] = (+/-) in[src & 0x7fffffff], negated when bit 31 of the entry is set
     std::vector<uint32_t> galois_gather_coeff(uint32_t elt) const;
     BehzTables behz_tables(int L) const;
+    BehzHost behz_host(int L) const; // folded constants of level L (throws std::invalid_argument beyond kBehzMaxL / kBehzMaxB)
 
     // number theory helpers (also used by the client-side code)
     static bool is_prime(u64 v);
