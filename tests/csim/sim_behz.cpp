@@ -124,3 +124,25 @@ int sim_behz_floor(void *h, int L, const uint64_t *dq, const uint64_t *ds, uint6
 }
 
 } // extern "C"
+
+// Operand selection of the BFV multiply (device_types.h: Indexer3, BehzSrc) on the CPU: for result r, the operand indices idx_a / idx_b,
+// the operand ordinals ord_a / ord_b of the transformed-once lists, and the ciphertext index the extension reads for list item `item`
+// (in units of ciphertexts: the functions are called with bases 0 and a ciphertext size of one word).
+extern "C" void sim_behz_src_map(const uint64_t *ix8 /* a_base, b_base, gs, b1, a_sg, a_si, b_sg, b_sj */, uint64_t I, uint64_t J, uint64_t na, uint64_t r,
+                                 uint64_t item, uint64_t *out /* idx_a, idx_b, ord_a, ord_b, list item's source (a: index, b: 2^62 + index) */)
+{
+    static const u64 base_a[1] = {0};
+    BehzSrc s{};
+    s.a = base_a;
+    s.b = base_a + ((u64)1 << 59); // (never dereferenced: only the distance to `a` is read back)
+    s.ix.a_base = ix8[0]; s.ix.b_base = ix8[1]; s.ix.gs = ix8[2]; s.ix.b1 = ix8[3];
+    s.ix.a_sg = ix8[4]; s.ix.a_si = ix8[5]; s.ix.b_sg = ix8[6]; s.ix.b_sj = ix8[7];
+    s.I = I; s.J = J; s.na = na; s.lists = 1;
+    out[0] = idx_a(s.ix, r);
+    out[1] = idx_b(s.ix, r);
+    out[2] = ord_a(s, r);
+    out[3] = ord_b(s, r);
+    const u64 *p = behz_src_ct(s, item, 1);
+    const u64 off = (u64)(p - s.a);
+    out[4] = off >= ((u64)1 << 59) ? ((u64)1 << 62) + (off - ((u64)1 << 59)) : off;
+}

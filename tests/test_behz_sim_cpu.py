@@ -122,3 +122,44 @@ def test_behz_coefficient_arithmetic_equals_integer_arithmetic(sim, monkeypatch,
                     assert [int(v) for v in out] == want, (L, D, variant)
     finally:
         sim.sim_behz_destroy(h)
+
+
+def _lists(n, gs, b1):
+    """The distinct-operand lists of a batch as DeviceContext::bfv_multiply3 sizes them (he355_api.hip)."""
+    gsz = min(gs, n)
+    G = 1 if gs >= n else (n + gs - 1) // gs
+    I, J = (gsz + b1 - 1) // b1, min(b1, gsz)
+    return G, I, J, G * I
+
+
+@pytest.mark.parametrize("name,n,ix", [
+    # a_base, b_base, gs, b1, a_sg, a_si, b_sg, b_sj
+    ("outer_3x2", 6, (0, 0, 2 ** 64 - 1, 2, 0, 1, 0, 1)),
+    ("outer_ragged", 10, (5, 7, 2 ** 64 - 1, 4, 0, 1, 0, 1)),          # last row of the outer product incomplete
+    ("matrix_10x9x8", 720, (0, 0, 80, 8, 10, 1, 8, 1)),                # the CipherBatchAxis layout: a(i,k) at k*10+i, b(k,j) at k*8+j
+    ("matrix_row_major", 30, (2, 3, 6, 3, 1, 5, 3, 1)),                # a(i,k) at i*5+k, b(k,j) at k*3+j, bases > 0
+])
+def test_transformed_once_lists_address_each_results_operands(sim, name, n, ix):
+    """The invariant the hoisted BFV multiply rests on: the list item a result's ordinal points at was extended from that result's
+    operand (behz_src_ct(lists, ord(r)) == idx(r)), ordinals stay inside the lists, and every list item serves at least one result."""
+    sim.sim_behz_src_map.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    a_base, b_base, gs, b1, a_sg, a_si, b_sg, b_sj = ix
+    G, I, J, na = _lists(n, gs, b1)
+    nb = G * J
+    ixa = arr(ix)
+    used = set()
+    for r in range(n):
+        out = (C.c_uint64 * 5)()
+        sim.sim_behz_src_map(ixa, I, J, na, r, 0, out)
+        ia, ib, oa, ob = (int(out[k]) for k in range(4))
+        g, rr = (r // gs, r % gs) if gs < 2 ** 63 else (0, r)
+        assert ia == a_base + g * a_sg + (rr // b1) * a_si and ib == b_base + g * b_sg + (rr % b1) * b_sj
+        assert 0 <= oa < na <= ob < na + nb
+        for item, want, is_b in ((oa, ia, False), (ob, ib, True)):
+            sim.sim_behz_src_map(ixa, I, J, na, r, item, out)
+            src = int(out[4])
+            assert (src >= 2 ** 62) == is_b and (src - 2 ** 62 if is_b else src) == want, (name, r, item)
+        used.update((oa, ob))
+    if n % min(gs, n) == 0 and min(gs, n) % b1 == 0:
+        assert used == set(range(na + nb))  # complete groups: no list item is extended in vain
+    assert na + nb <= n  # (the shapes here are ones the product hoists)
