@@ -334,7 +334,6 @@ class BfvAdd(Workload):
 
     def setup(self):
         c, L, N = self.ctx, self.L, self.N
-        self.b1 = 1
         self.fill_operands()
         self.d_out = c.alloc(max(1, self.n) * 2 * L * N)
 
@@ -361,6 +360,23 @@ class BfvAdd(Workload):
 
 
 WORKLOADS = {w.name: w for w in (MulRelinRescale, MulRelin, EltwiseMul, DotProduct, BfvMatMul, BfvAdd)}
+
+
+N_SIMD = 1024  # 256 CUs x 4 SIMDs
+
+
+def committed_counters(config, b1, n_results):
+    """(json, path) of the newest profiles/r*_<config>[_b1x<b1>]_kernel_bounds.json whose step had the same shape, else None"""
+    import glob
+    tag = config + (f"_b1x{b1}" if b1 > 1 else "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_kernel_bounds.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if j.get("hbm_bytes_per_op"):
+            return j, "profiles/" + os.path.basename(path)
+    return None
 
 
 def synthetic_key_host(ctx, o, seed):
@@ -394,6 +410,8 @@ def dry_run(args, rank, world, dist, torch) -> int:
     if world > 1:
         dist.init_process_group(backend="gloo")
     W = WORKLOADS[args.config]
+    if args.b1 > 0:
+        W = type(W.__name__ + f"_b1_{args.b1}", (W,), {"b1": args.b1})
     batch = args.batch or W.default_batch
     global_b0 = batch * world if args.scaling == "weak" else batch
     sh = load_sharding().shard_outer_product(global_b0, W.b1, world, rank)
@@ -420,6 +438,8 @@ def main():
     ap.add_argument("--config", choices=list(WORKLOADS), default="mul_relin_rescale")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--batch", type=int, default=0, help="operand-0 batch: per GPU (weak) or global (strong); 0: the configuration's own")
+    ap.add_argument("--b1", type=int, default=0, help="operand-1 batch of the HEBench outer product (results = batch x b1; operand 1 is replicated on every rank); 0: the "
+                                                      "configuration's own (1).  `--config eltwise_mul --batch 16 --b1 16` is the 16 x 16 shape of configs[1] (SURVEY.md 8d cfg2)")
     ap.add_argument("--chunk", type=int, default=0, help="ops per kernel sequence (0: library default)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="results in the CPU-baseline sample (-1: the configuration's own, 0: skip)")
     ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of the CPU baseline (median reported)")
@@ -459,6 +479,10 @@ def main():
     be = importlib.import_module("reference-seal-backend_amd")
     sharding = load_sharding()
     W = WORKLOADS[args.config]
+    if args.b1 > 0:
+        if args.config in ("bfv_matmul",):
+            raise SystemExit("--b1 applies to the outer-product workloads only")
+        W = type(W.__name__ + f"_b1_{args.b1}", (W,), {"b1": args.b1})
     bits = W.bits or be.chain_bits(W.depth, W.coeff_bits)
     ctx = be.Context(be.SCHEME_CKKS if W.scheme == "ckks" else be.SCHEME_BFV, W.N, bit_sizes=bits, plain_bits=W.plain_bits, device=device)
     if args.chunk:
@@ -494,6 +518,18 @@ def main():
         elapsed = float(t.item())
     total_results = global_b0 * W.b1 * args.steps
     value = total_results / elapsed
+
+    # ---- shader clock held under this load: one extra untimed step (same schedule as the timed ones) with a one-wave probe beside it that
+    # samples s_memtime against the 100 MHz counter for ~80 % of a step (he355_clock_probe_begin; MI355X_MICROARCH.md "DVFS give-back") ----
+    clock = None
+    if n > 0 and not args.profile_mode:
+        step_us = elapsed / args.steps * 1e6
+        ctx.clock_probe_begin(max(200, int(step_us * 0.8)))
+        wl.step()
+        ctx.sync()
+        mhz, covered = ctx.clock_probe_end()
+        clock = {"sustained_mhz": round(mhz, 1), "seconds_covered": round(covered, 6),
+                 "source": "in-run: d(s_memtime) / d(s_memrealtime) x 100 MHz of one probe wave running beside one extra untimed step"}
 
     # ---- dominant kernel, single stream: one extra untimed step with the two-stream schedule off, HIP events around each launch ----
     k3 = None
@@ -583,23 +619,48 @@ def main():
         # SURVEY.md 8d prices every result with both operands read; in a b0 x 1 outer product operand 1 is ONE ciphertext that stays in
         # cache, so the bytes that must cross HBM are fewer: operands read once per batch, results written once
         comp_op = wl.compulsory_bytes_per_op(global_b0, W.b1)
-        tref = None
-        for tname in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):  # the newest committed PMC figure of this command
-            tpath = os.path.join(ROOT, "profiles", tname)
-            if args.config == "mul_relin_rescale" and os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                tref = {"file": "profiles/" + tname, "hbm_bytes_per_op": tj.get("hbm_bytes_per_op"),
-                        "note": "PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate runs) of an earlier invocation of this command (tools/profile_round.sh): "
-                                "not measured in this run"}
-                break
-        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5),
-                "traffic": None, "traffic_source": tref,
+        # The newest committed counter file of THIS configuration (tools/profile_cfg.sh -> tools/kernel_bounds.py --json: PMC passes of one bench
+        # step, each in its own rocprofv3 run): HBM bytes and VALU wave-instructions per result.  Not measured in this run -- PMC passes cannot
+        # run inside it -- so the file is named next to every number taken from it.
+        prof = committed_counters(args.config, W.b1, n)
+        ops_per_gpu_s = total_results / elapsed / world
+        traffic, traffic_src, valu = None, None, None
+        hbm_traffic_frac = None
+        if prof:
+            pj, pfile = prof
+            traffic = pj["hbm_bytes_per_op"] * n  # HBM bytes of one step's kernel sequence on one GPU (PMC: FETCH_SIZE x 2 + WRITE_SIZE)
+            hbm_traffic_frac = pj["hbm_bytes_per_op"] * ops_per_gpu_s / HBM_PEAK
+            traffic_src = {"file": pfile, "hbm_bytes_per_op": pj["hbm_bytes_per_op"], "ratio_to_algorithmic": round(pj["hbm_bytes_per_op"] / bytes_op, 2),
+                           "hbm_GBps_of_real_bytes": round(pj["hbm_bytes_per_op"] * ops_per_gpu_s / 1e9, 1), "frac_of_8TBps": round(hbm_traffic_frac, 4),
+                           "note": "PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 runs of one step of this command, tools/profile_cfg.sh): bytes per "
+                                   "result from that file x the results of one step here; not measured in this run"}
+            mhz = clock["sustained_mhz"] if clock and clock["sustained_mhz"] > 100 else pj.get("sustained_mhz_time_weighted")
+            if mhz and pj.get("valu_wave_instr_per_op"):
+                issue_peak = N_SIMD * mhz * 1e6 / 4  # a wave64 VALU instruction holds its 16-lane SIMD for 4 cycles
+                winstr_s = pj["valu_wave_instr_per_op"] * ops_per_gpu_s
+                valu = {"wave_instr_per_op": pj["valu_wave_instr_per_op"], "source": pfile + " (SQ_INSTS_VALU summed over the step's kernels / results)",
+                        "sustained_mhz": mhz, "sustained_mhz_source": clock["source"] if clock and clock["sustained_mhz"] > 100 else pfile + " (GRBM_GUI_ACTIVE / 8 / kernel time)",
+                        "issue_peak_wave_instr_per_s": round(issue_peak, 0), "achieved_wave_instr_per_s": round(winstr_s, 0),
+                        "frac": round(winstr_s / issue_peak, 4),
+                        "note": "1024 SIMDs x clock / 4 cycles per wave64 instruction; the fraction of VALU issue slots the step's kernels fill at the clock the chip "
+                                "held in this run"}
+        fr_valu = valu["frac"] if valu else None
+        if fr_valu is not None and hbm_traffic_frac is not None:
+            bound = "valu-issue" if fr_valu >= hbm_traffic_frac else "hbm"
+            bound_why = (f"VALU issue {fr_valu:.3f} of peak vs HBM (real bytes) {hbm_traffic_frac:.3f} of 8 TB/s: the larger fraction names the binding resource")
+        else:
+            bound = "hbm"
+            bound_why = "no committed counter file for this configuration: HBM is the roofline SURVEY.md 8d assigns it"
+        roof = {"bound": bound, "bound_why": bound_why,
+                "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5),
+                "traffic": traffic, "traffic_unit": "bytes per step per GPU" if traffic is not None else None, "traffic_source": traffic_src,
+                "valu": valu, "clock_probe": clock,
                 "algorithmic_bytes_per_op": round(bytes_op, 1),
                 "compulsory_bytes_per_op": round(comp_op, 1), "frac_of_compulsory": round(comp_op * total_results / elapsed / world / HBM_PEAK, 5),
                 "kernel": "whole kernel sequence of the step (per GPU); the dominant kernel's own figures are under dominant_kernel",
                 "gpu_ms_per_step_hip_events": round(gpu_ms / args.steps, 3),
-                "note": "algorithmic bytes (SURVEY.md 8d) x results / time / 8 TB/s, per GPU.  Key switching is bound by VALU issue (64-bit modular "
-                        "butterflies), not HBM: SURVEY.md 0.6, DESIGN.md 5"}
+                "note": "achieved / peak / frac: algorithmic bytes (SURVEY.md 8d) x results / time against 8 TB/s, per GPU.  `valu` prices the same run against the "
+                        "VALU issue rate (64-bit modular butterflies: SURVEY.md 0.6, DESIGN.md 5); `bound` names the larger fraction"}
         if k3 is not None and k3[1] > 0:
             k3_ms, k3_launches, k3_ops, ss_ms = k3
             L, K, N = wl.L, wl.K, W.N
@@ -627,7 +688,9 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": args.scaling,
-            "vs_baseline": None,
+            "vs_baseline": round(value / cpu["value"], 2) if cpu and cpu.get("value") else None,
+            "vs_baseline_note": ("value / cpu_baseline.value: the in-repo CPU port of the reference's algorithm timed in this run on this box's cores -- NOT a published "
+                                 "number (BASELINE.md holds none; SEAL itself is unavailable offline)") if cpu and cpu.get("value") else None,
             "dtype": "u64 (exact fp64-FMA engine for primes < 2^47, u64 Harvey/Shoup for the 60-bit primes)",
             "data": "synthetic (uniform residues generated in HBM; synthetic evaluation keys; the same global batch at every world size)",
             "config": {"workload": wl.describe(), "poly_modulus_degree": W.N, "coeff_modulus_bits": bits,

@@ -229,6 +229,12 @@ int he355_timer_end(he355_ctx *ctx, float *elapsed_ms);
 /* HIP events around every launch of the dominant kernel (k_k3, fp64-engine primes: the key-product kernel of the key switch)
  * between he355_timer_begin and he355_timer_end: summed duration, number of launches and ops they covered */
 int he355_probe_dominant_kernel(he355_ctx *ctx, float *total_ms, uint64_t *launches, uint64_t *ops);
+/* Shader clock held while a region runs: he355_clock_probe_begin launches one 64-lane wave on a stream of its own that samples the
+ * shader-cycle counter against the constant 100 MHz counter for `duration_us` of real time (a bound it always reaches) while whatever
+ * is queued next runs beside it; he355_clock_probe_end waits for it: *mhz = cycles / real time, *seconds = the time it covered.
+ * (bench.py: the VALU-issue roofline needs the clock the chip held under THIS load, not a nominal one.) */
+int he355_clock_probe_begin(he355_ctx *ctx, uint64_t duration_us);
+int he355_clock_probe_end(he355_ctx *ctx, double *mhz, double *seconds);
 /* ---- tuning ---- */
 int he355_set_dual_stream(he355_ctx *ctx, int on); /* chunks alternate between two HIP streams (default 1; HE355_DUAL_STREAM=0); 0: per-kernel timings without overlap */
 /* Key switches over at most n ciphertexts take the latency shape (serial loops of the throughput kernels dealt to more blocks; HEBench's

@@ -120,6 +120,7 @@ def lib():
             "he355_ntt_inverse": (i32, [vp, vp, u64, u8p, u32]),
             "he355_timer_begin": (i32, [vp]), "he355_timer_end": (i32, [vp, C.POINTER(C.c_float)]),
             "he355_probe_dominant_kernel": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+            "he355_clock_probe_begin": (i32, [vp, u64]), "he355_clock_probe_end": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
             "he355_set_chunk": (i32, [vp, u64]),
             "he355_set_latency_max": (i32, [vp, u64]),
             "he355_set_level_walk": (i32, [vp, i32]),
@@ -146,7 +147,7 @@ C_ABI_SYMBOLS = [
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_bfv_multiply_relin_accumulate", "he355_multiply_plain", "he355_add_plain",
     "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_keygen_relin", "he355_keygen_galois", "he355_ckks_encode", "he355_ckks_decode",
     "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_rotate_each", "he355_rotate_sum", "he355_accumulate", "he355_encrypt_zero", "he355_set_zero_stream",
-    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_set_chunk", "he355_set_latency_max", "he355_set_level_walk", "he355_mem_info", "he355_alloc_stats", "he355_pool_trim", "he355_bridge_abi", "he355_bridge_group_load_bytes",
+    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_clock_probe_begin", "he355_clock_probe_end", "he355_set_chunk", "he355_set_latency_max", "he355_set_level_walk", "he355_mem_info", "he355_alloc_stats", "he355_pool_trim", "he355_bridge_abi", "he355_bridge_group_load_bytes",
 ]
 
 
@@ -444,6 +445,16 @@ class Context:
         ms, n, ops = C.c_float(), C.c_uint64(), C.c_uint64()
         _check(lib().he355_probe_dominant_kernel(self.h, C.byref(ms), C.byref(n), C.byref(ops)))
         return float(ms.value), int(n.value), int(ops.value)
+
+    def clock_probe_begin(self, duration_us: int):
+        """one wave on its own stream samples shader cycles against the 100 MHz counter for `duration_us` while what is queued next runs"""
+        _check(lib().he355_clock_probe_begin(self.h, int(duration_us)))
+
+    def clock_probe_end(self):
+        """(MHz held, seconds covered) of the probe started by clock_probe_begin"""
+        mhz, sec = C.c_double(0), C.c_double(0)
+        _check(lib().he355_clock_probe_end(self.h, C.byref(mhz), C.byref(sec)))
+        return mhz.value, sec.value
 
     def timer_end(self) -> float:
         ms = C.c_float()

@@ -119,6 +119,22 @@ static u64 os_seed()
     return ((u64)rd() << 32) ^ (u64)rd();
 }
 
+// In-run shader clock (bench.py's roofline.valu.sustained_mhz): ONE wave on a stream of its own reads the shader-cycle counter
+// (s_memtime) and the constant 100 MHz counter (s_memrealtime), sleeps until `ticks_100mhz` of real time have passed -- a bound every
+// path reaches, nothing else ends the loop -- and reads both again: clock = d(s_memtime) / d(s_memrealtime) x 100 MHz while the
+// evaluator kernels of the probed region run beside it (/opt/skills/guides/MI355X_MICROARCH.md, "DVFS give-back" (6)).
+__global__ void k_clock_probe(u64 ticks_100mhz, u64 *out)
+{
+    const u64 r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    u64 r = r0;
+    while (r - r0 < ticks_100mhz) {
+        __builtin_amdgcn_s_sleep(127);
+        r = __builtin_amdgcn_s_memrealtime();
+    }
+    const u64 c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r - r0; }
+}
+
 class DeviceContext {
 public:
     DeviceContext(const Params &p, int device) : P(p), device_(device)
@@ -218,6 +234,7 @@ public:
         pool_.raw_free(d_floor_);
         pool_.raw_free(d_relin_);
         pool_.raw_free(d_relin_scaled_);
+        pool_.raw_free(d_clock_);
         for (auto &kv : d_galois_) pool_.raw_free(kv.second);
         for (auto &kv : d_perm_) pool_.raw_free(kv.second);
         (void)hipStreamSynchronize(stream2_);
@@ -234,6 +251,7 @@ public:
         (void)hipEventDestroy(ev_fork_);
         (void)hipEventDestroy(ev_join_);
         (void)hipStreamDestroy(stream2_);
+        if (probe_stream_) { (void)hipStreamSynchronize(probe_stream_); (void)hipStreamDestroy(probe_stream_); }
         (void)hipEventDestroy(ev0_);
         (void)hipEventDestroy(ev1_);
         (void)hipStreamDestroy(stream_);
@@ -513,16 +531,15 @@ public:
     // The fused mod-down runs the special prime's tiles as a launch of their own, ahead of the data primes' (their epilogue needs its
     // result): n1 rows x nc / 8 op-groups of blocks.  With a handful of ciphertexts at a small ring that launch is a few dozen blocks
     // on 256 CUs -- as long as the data primes' launch and nearly idle -- and the unfused sequence (every prime's tiles in ONE launch,
-    // then the two floor kernels) is the shorter chain.  HE355_FUSE_MIN_BLOCKS=<n>: fuse from n such blocks up.
+    // then the two floor kernels) is the shorter chain: fused from 128 such blocks up (HE355_K3_FUSE=all: always).
     bool fuse_pays(const KernelEnv &e, u64 nc) const
     {
-        static const u64 min_blocks = getenv("HE355_FUSE_MIN_BLOCKS") ? (u64)atoll(getenv("HE355_FUSE_MIN_BLOCKS")) : 128;
+        const u64 min_blocks = k3_fuse_policy() == 2 ? 0 : 128;
         return ((u64)1 << e.logn1) * ((nc + 7) / 8) >= min_blocks;
     }
     bool tensor_in_k3(const KernelEnv &env_, int L, u64 nc, const KsBuffers &B) const
     {
-        static const bool on = !(getenv("HE355_C01_RECOMPUTE") && getenv("HE355_C01_RECOMPUTE")[0] == '0');
-        return on && !latency_shape_env(env_, nc) && k3_can_fuse(env_) && fuse_pays(env_, nc) && B.c01_item_stride == 2 * (size_t)L * P.N;
+        return !latency_shape_env(env_, nc) && k3_can_fuse(env_) && fuse_pays(env_, nc) && B.c01_item_stride == 2 * (size_t)L * P.N;
     }
     // groups (grouped rotations, fused path only): per-group keys; g_off: index of the chunk's first op in the grouped batch
     bool key_switch_tail(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail,
@@ -616,11 +633,10 @@ public:
     // digit groups per fp64-engine tile (480 tiles x 4 single-wave blocks fill the chip once at batch 1), per u64-engine tile (64 tiles, rows
     // 2.5x as long), blocks per column for the targets of k_k2n / k_floor_colsn
     static constexpr int kLatTargets = 8;
-    // Digit groups per tile of the latency shape (HE355_LAT_SPLIT / HE355_LAT_SPLIT_U64; n_split > 1 is what selects the shape).  fp64-engine
+    // Digit groups per tile of the latency shape (n_split > 1 is what selects the shape).  fp64-engine
     // tiles: 480 x 2 single-wave blocks are ONE round of the chip's 1024 one-wave slots, 480 x 4 were two rounds of half the work each with
     // twice the start-ups and partial sums (batch 1: 0.326 -> 0.312 ms, batch 8: 0.98 -> 0.91 ms; 3 and 8 groups measured slower).
-    const int kLatSplit = getenv("HE355_LAT_SPLIT") && atoi(getenv("HE355_LAT_SPLIT")) > 1 ? atoi(getenv("HE355_LAT_SPLIT")) : 2;
-    const int kLatSplitU64 = getenv("HE355_LAT_SPLIT_U64") && atoi(getenv("HE355_LAT_SPLIT_U64")) > 1 ? atoi(getenv("HE355_LAT_SPLIT_U64")) : 8;
+    static constexpr int kLatSplit = 2, kLatSplitU64 = 8;
     bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
     // ... for a given kernel environment (a BFV context runs its rotation chains in the NTT domain on the CKKS pipeline: ntt_env)
     bool latency_shape_env(const KernelEnv &e, u64 nc) const { return e.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
@@ -666,14 +682,10 @@ public:
         // The second stream starts half a pipeline late (after the first chunk's K1+K2 on the first stream): from then on
         // one stream's ALU-bound kernels (K3, floor column pass) run beside the other's HBM-bound ones (K1, K2, floor row pass)
         // instead of beside their own kind.
-        static const bool stagger = !(getenv("HE355_STAGGER") && getenv("HE355_STAGGER")[0] == '0');
+        // (starting both streams together measured slower: HISTORY.md)
         if (dual) {
             (void)scratch(std::min<u64>(chunk, n), L, 0);
             (void)scratch(std::min<u64>(chunk, n), L, 1);
-            if (!stagger) {
-                HIPCHECK(hipEventRecord(ev_fork_, stream_));
-                HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
-            }
         }
         // k_k3 reads the operand rows while it writes results: only when `out` is a slab of its own (it always was meant to be)
         bool out_overlaps_operands = false;
@@ -698,7 +710,7 @@ public:
             TensorOperands ten;
             ten.a = a; ten.b = b; ten.ix = ix; ten.op_offset = off;
             launch_k1(env, L, K1_MUL, nc, off, a, b, ix, nullptr, B, nullptr, in_k3);
-            const bool fork_here = dual && stagger && ci == 0;
+            const bool fork_here = dual && ci == 0;
             u64 *ro = rescale ? out + off * 2 * (size_t)(L - 1) * N : nullptr;
             const bool done = key_switch_tail(env, L, nc, S, B, in_k3 ? relin_scaled() : d_relin_, rescale, fork_here ? ev_fork_ : nullptr, ro, in_k3 ? &ten : nullptr);
             if (fork_here) HIPCHECK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
@@ -1385,7 +1397,7 @@ public:
         // the terms of a matrix product) each is extended to Bsk and transformed ONCE (steps (1)-(3) per operand instead of per result:
         // SEAL's multiply recomputes them for every pair, the values are the same), and a result costs its dyadic tensor, three inverse
         // transforms and steps (6)-(8).
-        static const bool hoist_on = [] { const char *e = std::getenv("HE355_BEHZ_HOIST"); return !(e && e[0] == '0'); }();
+        const bool hoist_on = (behz_fuse_mask() & 2) != 0;
         const u64 gsz = std::min<u64>(ix.gs, n), G = ix.gs >= n ? 1 : (n + ix.gs - 1) / ix.gs;
         src.I = (gsz + ix.b1 - 1) / ix.b1; src.J = std::min<u64>(ix.b1, gsz); src.na = G * src.I;
         const u64 n_cts = src.na + G * src.J;
@@ -1768,6 +1780,27 @@ public:
         return ms;
     }
     void sync() { use(); HIPCHECK(hipStreamSynchronize(stream_)); HIPCHECK(hipStreamSynchronize(stream2_)); }
+    // clock probe: started BEFORE the region it measures (the wave takes its slot first), bounded by `duration_us` of real time
+    void clock_probe_begin(u64 duration_us)
+    {
+        use();
+        if (duration_us == 0 || duration_us > 10000000) throw std::invalid_argument("clock probe duration must be in (0, 10 s]");
+        if (!probe_stream_) HIPCHECK(hipStreamCreateWithFlags(&probe_stream_, hipStreamNonBlocking));
+        if (!d_clock_) dmalloc(d_clock_, 2 * sizeof(u64));
+        HIPCHECK(hipMemsetAsync(d_clock_, 0, 2 * sizeof(u64), probe_stream_));
+        hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, probe_stream_, duration_us * 100, d_clock_);
+        HIPCHECK(hipGetLastError());
+    }
+    void clock_probe_end(double *mhz, double *seconds)
+    {
+        use();
+        if (!probe_stream_ || !d_clock_) throw std::logic_error("clock probe not started");
+        u64 h[2] = {0, 0};
+        HIPCHECK(hipMemcpyAsync(h, d_clock_, sizeof h, hipMemcpyDeviceToHost, probe_stream_));
+        HIPCHECK(hipStreamSynchronize(probe_stream_));
+        if (mhz) *mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+        if (seconds) *seconds = (double)h[1] / 1e8;
+    }
 
 private:
     KernelProbe probe_;
@@ -1799,6 +1832,8 @@ private:
     u64 *scratch_ = nullptr, *scratch2_ = nullptr;
     size_t scratch_bytes_ = 0, scratch2_bytes_ = 0;
     hipStream_t stream2_ = nullptr;
+    hipStream_t probe_stream_ = nullptr; // clock_probe_begin's own stream
+    u64 *d_clock_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     bool dual_stream_ = true;
     u64 *rot_tmp_ = nullptr;
@@ -2213,6 +2248,8 @@ int he355_probe_dominant_kernel(he355_ctx *c, float *total_ms, uint64_t *launche
         if (ops) *ops = o;
     });
 }
+int he355_clock_probe_begin(he355_ctx *c, uint64_t duration_us) { return guarded([&] { dev(c).clock_probe_begin(duration_us); }); }
+int he355_clock_probe_end(he355_ctx *c, double *mhz, double *seconds) { return guarded([&] { dev(c).clock_probe_end(mhz, seconds); }); }
 int he355_set_chunk(he355_ctx *c, uint64_t ops)
 {
     return guarded([&] { dev(c).set_chunk((size_t)ops); });

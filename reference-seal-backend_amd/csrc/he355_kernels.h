@@ -123,6 +123,8 @@ struct K3Fuse {
     const u64 *c1_src = nullptr;
 };
 bool k3_can_fuse(const KernelEnv &env);
+int k3_fuse_policy(); // HE355_K3_FUSE: 0 never, 1 where it pays + small-grid rules (default), 2 always, no small-grid rules
+int behz_fuse_mask();  // HE355_BEHZ_FUSE: bit 0 column-pass fusion, bit 1 operands transformed once
 // n_split > 1 (latency shape, unfused only): the digits of every tile are cut into n_split groups, one single-wave block per (tile, op,
 // group), canonical partial sums -> split_part [n_split][n_ops * 2][L + 1][N]; launch_k3_combine then leaves t / tpr as the unsplit launch
 void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part = K3_ALL, const K3Fuse *fuse = nullptr,

@@ -1180,6 +1180,15 @@ __device__ __forceinline__ void k3_body_fn(ARGS A, const PrimeDev *primes, const
 #undef K3_BID_Y
 #undef K3_LDS_DECL
 }
+// the body's early-exit test (k3_body.inc: `if (tile >= total_tiles) return;`) for a block of WAVES waves
+template <int WAVES> __device__ __forceinline__ bool k3_block_has_tile(const K3Args &A, unsigned bid_x)
+{
+    const u64 n_og = (A.n_ops + WAVES - 1) / WAVES;
+    const u64 n_ogb = (n_og + A.og_per_block - 1) / A.og_per_block;
+    const u64 total_tiles = (u64)A.n_tt << A.logn1;
+    const u64 s = bid_x >> 3, xcd = bid_x & 7;
+    return (s / n_ogb) * 8 + xcd < total_tiles;
+}
 __global__ void __launch_bounds__(64) k_k3_dual(K3Args AF, K3Args AU, unsigned n_u, const PrimeDev *primes)
 {
     __shared__ u64 lds[1][kLdsRow];
@@ -1202,7 +1211,12 @@ __global__ void __launch_bounds__(512) k_k3_dual8(K3Args AF, K3Args AU, unsigned
     __shared__ __attribute__((aligned(16))) u64 stage[8][kRowN];
     __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kRowTw * 16];
     if (blockIdx.x < n_u) {
-        if (UW == 4 && threadIdx.x >= 256) return; // (wave-uniform: whole waves leave before any barrier)
+        if (UW == 4 && threadIdx.x >= 256) {
+            // waves 4-7 of a four-wave block do no work, but every wave of the block meets the body's one workgroup barrier (the
+            // twiddle staging) -- or none does, when the block has no tile
+            if (k3_block_has_tile<4>(AU, blockIdx.x)) __syncthreads();
+            return;
+        }
         k3_body_fn<ArU64, UW, FUSE, TENSOR, GROUPED, const K3Args>(AU, primes, blockIdx.x, 0, lds, stage, twl_raw);
     } else {
         k3_body_fn<ArF64, 8, FUSE, TENSOR, GROUPED, const K3Args>(AF, primes, blockIdx.x - n_u, 0, lds, stage, twl_raw);
@@ -2169,11 +2183,8 @@ static bool dual_engine_launches()
     return !off;
 }
 // ... also for small grids of the throughput shape: up to this many blocks for both engines together (four per CU; profiles/r04_dual_engine_latency.txt)
-static unsigned dual_max_blocks()
-{
-    static const unsigned v = getenv("HE355_DUAL_MAX_BLOCKS") ? (unsigned)atoi(getenv("HE355_DUAL_MAX_BLOCKS")) : 1024u;
-    return v;
-}
+int k3_fuse_policy();
+static unsigned dual_max_blocks() { return k3_fuse_policy() == 2 ? 0u : 1024u; }
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
                const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1, const KsGroups *groups)
 {
@@ -2237,11 +2248,9 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     // that fills the rounds of blocks better -- 512 blocks run at a time (two per CU); a block pays the digit's inverse column
     // pass once and a forward column pass + stores per target.  64 BFV ciphertexts at L = 3: 768 blocks = 1.5 rounds of all four
     // targets, or 3 full rounds of two targets each.  Only taken for a modelled gain of 5 % or more (the headline's 61440 blocks
-    // stay whole); HE355_K2_TSPLIT=<n> fixes it.
-    static const int ts_env = getenv("HE355_K2_TSPLIT") ? atoi(getenv("HE355_K2_TSPLIT")) : 0;
+    // stay whole).
     auto target_split = [&](unsigned gw) {
         if (tsplit > 1) return tsplit;
-        if (ts_env > 0) return ts_env;
         int ts = 1;
         const int n_tgt = L + 1 - (A.ckks ? 1 : 0);
         auto cost = [&](int c) { return (double)(((u64)gw * c + 511) / 512) * (1.0 + 1.2 * ((n_tgt + c - 1) / c)); };
@@ -2285,11 +2294,22 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     }
 }
 
-bool k3_can_fuse(const KernelEnv &env)
+// HE355_K3_FUSE: "0" = the unfused sequence everywhere (k_floor_rows finishes the mod-down); unset / "1" = fused where it pays, with the
+// small-grid rules (both engines in one launch, four-wave u64-engine blocks, unfused below a minimum of special-prime blocks); "all" =
+// fused for every throughput-shape batch and none of the small-grid rules (the schedule before those rules existed).  Thresholds are
+// constants (profiles/r04_dual_engine_latency.txt: swept on one box).
+int k3_fuse_policy()
 {
-    static const bool off = getenv("HE355_K3_FUSE") && getenv("HE355_K3_FUSE")[0] == '0'; // the unfused sequence (k_floor_rows finishes the mod-down)
-    return !off && env.scheme == 2 && env.K >= 2;
+    static const int v = [] {
+        const char *e = getenv("HE355_K3_FUSE");
+        if (!e) return 1;
+        if (e[0] == '0') return 0;
+        if (e[0] == 'a' || e[0] == 'A') return 2;
+        return 1;
+    }();
+    return v;
 }
+bool k3_can_fuse(const KernelEnv &env) { return k3_fuse_policy() != 0 && env.scheme == 2 && env.K >= 2; }
 
 void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part, const K3Fuse *fuse, int n_split, u64 *split_part,
                int n_split_u64, const KsGroups *groups, u64 g_op_offset)
@@ -2334,22 +2354,21 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         int waves = A.n_split > 1 ? 1 : 8; // latency shape: one wave per block, one (tile, op, digit group) each; else the 8-wave shape
         const u64 tiles = (u64)A.n_tt << env.logn1;
         // enough blocks to keep every CU busy for several rounds, few enough that start-up costs are amortised
-        static const u32 og_env = getenv("HE355_K3_OG") ? (u32)atoi(getenv("HE355_K3_OG")) : 0;
         // Op-groups per block: more of them amortise the block's start-up (twiddle staging, ~4 us) over more work, fewer of them give the
         // dispatcher more blocks to fill the 256 CUs with.  What counts for small grids is the number of ROUNDS of blocks: 64 tiles x 8
         // op-groups (BFV, 64 ciphertexts, L = 3) are two rounds of 256 one-group blocks or ONE round of two-group blocks, the same work
         // with half the start-ups (configs[4]: 65.3 -> 63.4 ms).  So: the candidate sizes from the shape's maximum down, each priced as
         // rounds x (groups x work per group + start-up), ties to the larger.  (Maximum for the 8-wave shape: 4 once a tile has 128
         // op-groups -- chunks of 1024 ciphertexts: 50.3 vs 50.9 ms per step with 2 -- and 2 below that, where 4 measured slower;
-        // profiles/r03_chunk_sweep.txt.)  HE355_K3_OG=<n> fixes the size.
+        // profiles/r03_chunk_sweep.txt.)
         u64 n_og = 0;
         u32 ogpb = 1;
         unsigned g = 0;
         auto size_grid = [&](int w) {
             n_og = (n_ops + w - 1) / w;
             const u32 og_max = w == 8 ? (n_og >= 128 ? 4 : 2) : 4;
-            ogpb = og_env ? og_env : og_max;
-            if (!og_env) {
+            ogpb = og_max;
+            {
                 const double work = (pass == 0 ? 7.0 : 14.0) * (L + 2) * (w == 4 ? 0.5 : 1.0), startup = 4.0; // us per op-group (one row step per digit + epilogue), per block
                 double best = 0;
                 for (u32 c = og_max; c >= 1; c >>= 1) {
@@ -2364,7 +2383,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         size_grid(waves);
         // u64-engine tiles of a small grid (at most half the CUs busy with 8-wave blocks): FOUR waves per block -- one per SIMD, each at
         // the full issue rate instead of half of it, and twice the blocks; the serial digit loop of a tile is what such a launch lasts
-        static const unsigned four_max = getenv("HE355_K3_FOUR_WAVES_MAX") ? (unsigned)atoi(getenv("HE355_K3_FOUR_WAVES_MAX")) : 128u;
+        const unsigned four_max = k3_fuse_policy() == 2 ? 0u : 128u;
         if (pass == 1 && waves == 8 && g <= four_max) {
             size_grid(4);
             // (a CU holds ONE block of either shape -- the LDS arrays -- so the four-wave blocks must still fit one round together with the
@@ -2536,10 +2555,16 @@ void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, const BehzSrc &
     else
         hipLaunchKernelGGL((k_behz_extend<kBehzMaxL, kBehzMaxB>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, src, xq, xbsk, n_cts * 2, logN);
 }
+// HE355_BEHZ_FUSE=<mask>: bit 0 = extension / floor fused with the column passes, bit 1 = operands shared by several results extended and
+// transformed once (he355_api.hip: bfv_multiply3); default 3.
+int behz_fuse_mask()
+{
+    static const int v = [] { const char *e = std::getenv("HE355_BEHZ_FUSE"); return e ? atoi(e) & 3 : 3; }();
+    return v;
+}
 bool behz_cols_fusable(const KernelEnv &env, const BehzDev &bz)
 {
-    static const bool on = [] { const char *e = std::getenv("HE355_BEHZ_FUSE"); return !(e && e[0] == '0'); }();
-    return on && bz.L <= 4 && bz.nB <= 6 && env.logn1 >= 1 && env.logn1 <= 4;
+    return (behz_fuse_mask() & 1) && bz.L <= 4 && bz.nB <= 6 && env.logn1 >= 1 && env.logn1 <= 4;
 }
 void launch_behz_extend_cols(const KernelEnv &env, const BehzDev &bz, const BehzSrc &src, u64 n_cts, u64 *xq, u64 *xbsk)
 {
