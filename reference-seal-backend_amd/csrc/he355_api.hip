@@ -91,14 +91,17 @@ __global__ void k_key_scaled_copy(const u64 *key, u64 *out, u64 n_polys, int log
             c.d = ar.canon2(ar.mulmod_c(c.d, fc.inv_d, fc.inv_i));
             v = c.u;
         } else {
-            v = mul_shoup(v, fc.inv, fc.inv_shoup, P.q);
+            ModU64 m; // (Barrett: this file is compiled once, whatever companion words the context's tables hold)
+            m.q = P.q; m.cr0 = P.cr0; m.cr1 = P.cr1;
+            v = mulmod(v, fc.inv, m);
         }
     }
     out[gid] = v;
 }
 
-// Shoup quotients of the key residues under the u64-engine primes, appended to the key: [L_top][2][n_q][N]
-__global__ void k_key_quotients(const u64 *key, u64 *keyq, u64 n_dk, int logN, const PrimeDev *primes, int K, int n_q, PrimeMap qmap)
+// Companion words of the key residues under the u64-engine primes, appended to the key: [L_top][2][n_q][N] -- their Shoup quotients, or
+// (fold: the context's u64-engine primes are 2^60 - c, modarith.h) the residues times 2^32
+__global__ void k_key_quotients(const u64 *key, u64 *keyq, u64 n_dk, int logN, const PrimeDev *primes, int K, int n_q, PrimeMap qmap, int fold)
 {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 poly = gid >> logN; // (digit*2 + k) * n_q + slot
@@ -107,7 +110,8 @@ __global__ void k_key_quotients(const u64 *key, u64 *keyq, u64 n_dk, int logN, c
     const u64 dk = poly / n_q;
     ArU64 ar;
     ar.q = primes[t].q; ar.two_q = 2 * ar.q; ar.cr0 = primes[t].cr0; ar.cr1 = primes[t].cr1; ar.ninv = ar.ninv_q = 0;
-    keyq[gid] = ar.shoup_quotient(key[((dk * K + t) << logN) + (gid & (((u64)1 << logN) - 1))]); // exact: k_k3's lazy runs rely on it
+    const u64 kv = key[((dk * K + t) << logN) + (gid & (((u64)1 << logN) - 1))];
+    keyq[gid] = fold ? barrett128((u128)kv << 32, ar.mod()) : ar.shoup_quotient(kv); // (exact quotient: k_k3's lazy runs rely on it)
 }
 
 } // namespace
@@ -155,7 +159,7 @@ public:
         const size_t N = P.N, K = P.K;
         // BFV: the BEHZ auxiliary primes follow the key chain, then the plain modulus t (BatchEncoder's NTT mod t)
         const bool with_t = P.scheme == kSchemeBFV && P.plain_modulus > 2 && (P.plain_modulus - 1) % (2 * N) == 0;
-        if (with_t) plain_tables_ = Params::make_prime_tables(P.plain_modulus, N, P.logn, false);
+        if (with_t) plain_tables_ = Params::make_prime_tables(P.plain_modulus, N, P.logn, true); // t < 2^32: the fp64 engine's
         t_index_ = with_t ? (int)(K + P.aux.size()) : -1;
         const size_t n_all = K + P.aux.size() + (with_t ? 1 : 0);
         std::vector<PrimeDev> pd(n_all);
@@ -206,7 +210,7 @@ public:
                 const u64 qi = P.primes[i].q, qs = P.primes[s].q;
                 const u64 inv = Params::invmod(qs % qi, qi);
                 f.inv = inv;
-                f.inv_shoup = (u64)(((u128)inv << 64) / qi);
+                f.inv_shoup = pre_word(inv, qi, P.primes[i].fold); // the u64 engine's companion word (Shoup quotient, or inv 2^32 mod q_i)
                 f.inv_d = (double)inv;
                 f.inv_i = (double)inv / (double)qi;
                 f.half_mod = (qs >> 1) % qi;
@@ -218,6 +222,7 @@ public:
         env_.floor_consts = d_floor_;
         env_.N = (int)N; env_.logn1 = P.logn1; env_.K = (int)K; env_.Ltop = (int)P.Ltop; env_.scheme = P.scheme;
         env_.stream = stream_;
+        env_.u64_fold = P.u64_fold;
         const char *ds = std::getenv("HE355_DUAL_STREAM");
         if (ds) dual_stream_ = ds[0] != '0';
         const char *lm = std::getenv("HE355_LATENCY_MAX");
@@ -344,7 +349,7 @@ public:
                 if (!env_.prime_f64[i]) qm.prime_of[k++] = (unsigned char)i;
             const u64 n_dk = P.Ltop * 2, tq = n_dk * n_q * P.N;
             hipLaunchKernelGGL(k_key_quotients, dim3((unsigned)((tq + 255) / 256)), dim3(256), 0, stream_, d_key, d_key + key_elems(), n_dk, P.logn, d_primes_,
-                               (int)P.K, n_q, qm);
+                               (int)P.K, n_q, qm, P.u64_fold ? 1 : 0);
         }
     }
     u64 **relin_slot() { return &d_relin_; }

@@ -26,7 +26,11 @@
 #include "client/multiword.h"
 #include "client/sampler.h"
 
+#if !defined(HE355_KNS) || !defined(HE355_U64_FOLD)
+#error "he355_kernels.hip is compiled once per form of the u64 engine: -DHE355_KNS=ks_shoup -DHE355_U64_FOLD=0 and -DHE355_KNS=ks_fold -DHE355_U64_FOLD=1 (Makefile)"
+#endif
 namespace he355 {
+namespace HE355_KNS {
 namespace {
 
 constexpr int kBlock = 256;
@@ -1492,7 +1496,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_floor_colsn(FloorColsArgs A, cons
             for (int a = 0; a < N1; ++a) {
                 const u64 v2 = park[a][threadIdx.x];
                 const u64 d1 = submod(qs2 > qi ? barrett64(v2, mi) : v2, f2.half_mod, qi);
-                dl[a] += mul_shoup(d1, f2.inv, f2.inv_shoup, qi);
+                dl[a] += mul_pre(d1, f2.inv, f2.inv_shoup, qi);
             }
         }
         col_fwd<ArU64, LOGN1>(ar, dl, ctw(Pi.fwd));
@@ -2053,7 +2057,7 @@ k_bfv_tail_fin(const u64 *t, const u64 *rp, u64 *c01, u64 c01_item_stride, const
     for (int a = 0; a < N1; ++a) {
         const u64 r = rp[ok * N + (a << kRowLog) + col];
         const u64 delta = submod(qs > qi ? barrett64(r, mi) : r, fc.half_mod, qi);
-        const u64 res = mul_shoup(submod(c[a], delta, qi), fc.inv, fc.inv_shoup, qi);
+        const u64 res = mulmod(submod(c[a], delta, qi), fc.inv, mi); // (a prime of either engine: Barrett)
         const u64 idx = (a << kRowLog) + col;
         dst[idx] = addmod(add[idx], res, qi);
     }
@@ -2183,7 +2187,6 @@ static bool dual_engine_launches()
     return !off;
 }
 // ... also for small grids of the throughput shape: up to this many blocks for both engines together (four per CU; profiles/r04_dual_engine_latency.txt)
-int k3_fuse_policy();
 static unsigned dual_max_blocks() { return k3_fuse_policy() == 2 ? 0u : 1024u; }
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
                const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1, const KsGroups *groups)
@@ -2294,22 +2297,6 @@ void launch_k2(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
     }
 }
 
-// HE355_K3_FUSE: "0" = the unfused sequence everywhere (k_floor_rows finishes the mod-down); unset / "1" = fused where it pays, with the
-// small-grid rules (both engines in one launch, four-wave u64-engine blocks, unfused below a minimum of special-prime blocks); "all" =
-// fused for every throughput-shape batch and none of the small-grid rules (the schedule before those rules existed).  Thresholds are
-// constants (profiles/r04_dual_engine_latency.txt: swept on one box).
-int k3_fuse_policy()
-{
-    static const int v = [] {
-        const char *e = getenv("HE355_K3_FUSE");
-        if (!e) return 1;
-        if (e[0] == '0') return 0;
-        if (e[0] == 'a' || e[0] == 'A') return 2;
-        return 1;
-    }();
-    return v;
-}
-bool k3_can_fuse(const KernelEnv &env) { return k3_fuse_policy() != 0 && env.scheme == 2 && env.K >= 2; }
 
 void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, const u64 *key, K3Part part, const K3Fuse *fuse, int n_split, u64 *split_part,
                int n_split_u64, const KsGroups *groups, u64 g_op_offset)
@@ -2555,13 +2542,6 @@ void launch_behz_extend(const KernelEnv &env, const BehzDev &bz, const BehzSrc &
     else
         hipLaunchKernelGGL((k_behz_extend<kBehzMaxL, kBehzMaxB>), dim3(grid_for(threads, kBlock)), dim3(kBlock), 0, env.stream, bz, env.primes, src, xq, xbsk, n_cts * 2, logN);
 }
-// HE355_BEHZ_FUSE=<mask>: bit 0 = extension / floor fused with the column passes, bit 1 = operands shared by several results extended and
-// transformed once (he355_api.hip: bfv_multiply3); default 3.
-int behz_fuse_mask()
-{
-    static const int v = [] { const char *e = std::getenv("HE355_BEHZ_FUSE"); return e ? atoi(e) & 3 : 3; }();
-    return v;
-}
 bool behz_cols_fusable(const KernelEnv &env, const BehzDev &bz)
 {
     return (behz_fuse_mask() & 1) && bz.L <= 4 && bz.nB <= 6 && env.logn1 >= 1 && env.logn1 <= 4;
@@ -2742,4 +2722,5 @@ void launch_bfv_tail_fin(const KernelEnv &env, int L, u64 n_ops, const u64 *t, c
 }
 
 // (the client-side kernels -- encryption, decryption, encoders, key generation -- and their launchers: he355_kernels_client.hip)
+} // namespace HE355_KNS
 } // namespace he355

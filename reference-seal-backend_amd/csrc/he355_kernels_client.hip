@@ -13,7 +13,11 @@
 #include "client/multiword.h"
 #include "client/sampler.h"
 
+#if !defined(HE355_KNS) || !defined(HE355_U64_FOLD)
+#error "he355_kernels_client.hip is compiled once per form of the u64 engine (Makefile)"
+#endif
 namespace he355 {
+namespace HE355_KNS {
 namespace {
 
 constexpr int kBlock = 256;
@@ -82,7 +86,7 @@ __global__ void __launch_bounds__(kBlock) k_divround_last_coeff(const u64 *z, u6
         const FloorConst f = fc[(K - 1) * K + i];
         const u64 ri = qs > Pi.q ? barrett64(r, make_modu(Pi)) : r;
         const u64 delta = submod(ri, f.half_mod, Pi.q);
-        out[((poly * L + i) << logN) + n] = mul_shoup(submod(z[((poly * K + i) << logN) + n], delta, Pi.q), f.inv, f.inv_shoup, Pi.q);
+        out[((poly * L + i) << logN) + n] = mulmod(submod(z[((poly * K + i) << logN) + n], delta, Pi.q), f.inv, make_modu(Pi)) /* any prime: Barrett */;
     }
 }
 // BFV: c0 += round(q*m/t) (util/scalingvariant.cpp multiply_add_plain_with_scaling_variant); plain [n][N] mod t.
@@ -377,4 +381,5 @@ void launch_keygen_kswitch(const KernelEnv &env, u64 *key, u64 *e_scratch, u64 *
                        logN, Ld);
 }
 
+} // namespace HE355_KNS
 } // namespace he355

@@ -89,7 +89,7 @@ int Params::tc128_max_bits(size_t N)
     }
 }
 
-Params *Params::create(int scheme, size_t N, const std::vector<int> &bit_sizes, int plain_bits, bool sec128)
+Params *Params::create(int scheme, size_t N, const std::vector<int> &bit_sizes, int plain_bits, bool sec128, bool allow_fold)
 {
     if (bit_sizes.empty() || bit_sizes.size() >= (size_t)kMaxPrimes) throw std::invalid_argument("invalid coefficient modulus count");
     if (sec128) {
@@ -111,14 +111,14 @@ Params *Params::create(int scheme, size_t N, const std::vector<int> &bit_sizes, 
     }
     u64 t = 0;
     if (scheme == kSchemeBFV) t = get_primes(2 * (u64)N, plain_bits, 1)[0];
-    return create_primes(scheme, N, chain, t);
+    return create_primes(scheme, N, chain, t, allow_fold);
 }
 
-Params *Params::create_primes(int scheme, size_t N, const std::vector<u64> &primes, u64 plain_modulus)
+Params *Params::create_primes(int scheme, size_t N, const std::vector<u64> &primes, u64 plain_modulus, bool allow_fold)
 {
     Params *p = new Params();
     try {
-        p->build(scheme, N, primes, plain_modulus);
+        p->build(scheme, N, primes, plain_modulus, allow_fold);
     } catch (...) {
         delete p;
         throw;
@@ -146,7 +146,7 @@ static u64 minimal_primitive_root(u64 two_n, u64 q)
     return best;
 }
 
-static Tw16 make_tw(u64 w, u64 q, bool f64)
+static Tw16 make_tw(u64 w, u64 q, bool f64, bool fold)
 {
     Tw16 t;
     if (f64) {
@@ -155,7 +155,7 @@ static Tw16 make_tw(u64 w, u64 q, bool f64)
         std::memcpy(&t.b, &wi, 8);
     } else {
         t.a = w;
-        t.b = (u64)(((u128)w << 64) / q);
+        t.b = pre_word(w, q, fold);
     }
     return t;
 }
@@ -166,7 +166,7 @@ ArU64 PrimeTables::aru() const
     a.q = q;
     a.two_q = 2 * q;
     a.ninv = ninv;
-    a.ninv_q = (u64)(((u128)ninv << 64) / q);
+    a.ninv_q = pre_word(ninv, q, fold);
     a.cr0 = mod.cr0;
     a.cr1 = mod.cr1;
     return a;
@@ -181,7 +181,7 @@ ArF64 PrimeTables::arf() const
     return a;
 }
 
-void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t)
+void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t, bool allow_fold)
 {
     if (scheme_ != kSchemeBFV && scheme_ != kSchemeCKKS) throw std::invalid_argument("unsupported scheme");
     int ln = 0;
@@ -197,7 +197,9 @@ void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t)
     plain_modulus = t;
     if (scheme == kSchemeBFV && t < 2) throw std::invalid_argument("BFV needs a plain modulus");
     const char *force = std::getenv("HE355_FORCE_U64");
-    const bool force_u64 = force && force[0] == '1';
+    const bool force_u64 = force && force[0] == '1', force_shoup = force && force[0] == 's';
+    const char *base = std::getenv("HE355_BEHZ_BASE");
+    aux_seal_base = scheme == kSchemeBFV && base && std::string(base) == "seal";
     primes.resize(K);
     for (size_t i = 0; i < K; ++i) {
         const u64 q = chain[i];
@@ -205,7 +207,7 @@ void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t)
             if (chain[k] == q) throw std::invalid_argument("coefficient moduli must be distinct");
         // SEAL's user moduli are at most 60 bits (SEAL_USER_MOD_BIT_COUNT_MAX); the u64 engine's wide lazy row pass needs 16 q <= 2^64
         if (q >> 60 || !is_prime(q)) throw std::invalid_argument("coefficient modulus must be a prime below 2^60");
-        primes[i] = make_prime_tables(q, N, logn, !force_u64 && (q >> 47) == 0);
+        primes[i].q = q; // (behz_base_suffices below reads the moduli; the tables follow once the form of their constants is known)
     }
     if (scheme == kSchemeBFV) {
         if (t >= ((u64)1 << 32)) throw std::invalid_argument("plain modulus too large for the BEHZ base");
@@ -213,26 +215,35 @@ void Params::build(int scheme_, size_t N_, const std::vector<u64> &chain, u64 t)
         // (the +1 case needs 32 + bits(t) + bits(q) >= 61|q| + 61, impossible for user primes <= 60 bits)
         const std::vector<u64> ap = get_primes(2 * (u64)N, 61, Ltop + 2);
         gamma = ap[1];
-        const char *base = std::getenv("HE355_BEHZ_BASE");
-        aux_seal_base = base && std::string(base) == "seal";
-        if (aux_seal_base) {
-            aux.push_back(make_prime_tables(ap[0], N, logn, false));
-            for (size_t i = 0; i < Ltop; ++i) aux.push_back(make_prime_tables(ap[2 + i], N, logn, false));
-        } else {
+        if (!aux_seal_base) {
             // the device's own base (he_params.h, Params::aux): kAuxBits-bit primes 1 (mod 2N), none of them a coefficient modulus,
-            // as many as the Shenoy-Kumaresan bound asks for at the first level (behz_base_suffices)
+            // as many as the Shenoy-Kumaresan bound asks for at the first level (behz_base_suffices).  It needs about 1.3 |q| primes
+            // where SEAL's needs |q| + 1: a chain so long that they no longer fit the device prime table (or the kernels' base-B
+            // limit), or that exhausts the candidates, takes SEAL's base instead.
             std::vector<u64> cand = get_primes(2 * (u64)N, kAuxBits, 3 * K + 16);
             cand.erase(std::remove_if(cand.begin(), cand.end(), [&](u64 v) { return std::find(chain.begin(), chain.end(), v) != chain.end(); }), cand.end());
             size_t next = 0;
-            aux.push_back(make_prime_tables(cand[next++], N, logn, !force_u64)); // m_sk
-            do {
-                if (next == cand.size()) throw std::logic_error("auxiliary BEHZ base: candidate primes exhausted");
+            bool ok = !cand.empty();
+            if (ok) aux.push_back(make_prime_tables(cand[next++], N, logn, !force_u64)); // m_sk
+            while (ok) {
+                if (next == cand.size() || aux.size() > (size_t)kBehzMaxB || K + aux.size() + 2 > (size_t)kMaxPrimes) { ok = false; break; }
                 aux.push_back(make_prime_tables(cand[next++], N, logn, !force_u64));
-            } while (!behz_base_suffices((int)Ltop, aux.size() - 1));
+                if (behz_base_suffices((int)Ltop, aux.size() - 1)) break;
+            }
+            if (!ok) { aux.clear(); aux_seal_base = true; }
+        }
+        if (aux_seal_base) {
+            aux.push_back(make_prime_tables(ap[0], N, logn, false));
+            for (size_t i = 0; i < Ltop; ++i) aux.push_back(make_prime_tables(ap[2 + i], N, logn, false));
         }
         // + 1: the plain modulus rides along in the device prime array
         if (K + aux.size() + 1 > (size_t)kMaxPrimes) throw std::invalid_argument("too many primes for the device prime table");
     }
+    // the form of the u64 engine's constants (he_params.h, u64_fold), then the chain's tables
+    u64_fold = allow_fold && !force_u64 && !force_shoup && !aux_seal_base;
+    for (size_t i = 0; i < K && u64_fold; ++i)
+        if ((chain[i] >> 47) != 0 && !fold_prime_ok(chain[i])) u64_fold = false;
+    for (size_t i = 0; i < K; ++i) primes[i] = make_prime_tables(chain[i], N, logn, !force_u64 && (chain[i] >> 47) == 0, u64_fold);
 }
 
 namespace {
@@ -459,9 +470,11 @@ BehzDev BehzHost::view(const u64 *w, const double *d, size_t K) const
     return Z;
 }
 
-PrimeTables Params::make_prime_tables(u64 q, size_t N, int logn, bool f64)
+PrimeTables Params::make_prime_tables(u64 q, size_t N, int logn, bool f64, bool fold)
 {
+    if (fold && !f64 && !fold_prime_ok(q)) throw std::logic_error("fold tables asked for a prime that is not 2^60 - c");
     PrimeTables pt;
+    pt.fold = fold && !f64;
     pt.q = q;
     pt.bits = 64 - __builtin_clzll(q);
     pt.mod = make_mod(q);
@@ -478,12 +491,12 @@ PrimeTables Params::make_prime_tables(u64 q, size_t N, int logn, bool f64)
         const uint32_t k = bitrev((uint32_t)e, logn);
         pt.fwd_u64[k] = pw;
         pt.inv_u64[k] = ipw;
-        pt.fwd[k] = make_tw(pw, q, pt.f64);
-        pt.inv[k] = make_tw(ipw, q, pt.f64);
+        pt.fwd[k] = make_tw(pw, q, pt.f64, pt.fold);
+        pt.inv[k] = make_tw(ipw, q, pt.f64, pt.fold);
         pw = mm(pw, pt.root, q);
         ipw = mm(ipw, iroot, q);
     }
-    pt.inv_w0_scaled = make_tw(mm(pt.inv_u64[1], pt.ninv, q), q, pt.f64);
+    pt.inv_w0_scaled = make_tw(mm(pt.inv_u64[1], pt.ninv, q), q, pt.f64, pt.fold);
     return pt;
 }
 

@@ -25,6 +25,7 @@ struct PrimeTables {
     ModU64 mod{};
     u64 root = 0;       // minimal primitive 2N-th root of unity
     bool f64 = false;   // true: ArF64 engine (q < 2^47), false: ArU64
+    bool fold = false;  // u64 engine: the companion word of every constant is w * 2^32 mod q (fold build, modarith.h), not the Shoup quotient
     u64 ninv = 0;       // N^-1 mod q
     std::vector<Tw16> fwd; // N entries, engine format, index = bit-reversed exponent
     std::vector<Tw16> inv; // inverse of fwd entry-wise, same indexing
@@ -74,8 +75,9 @@ struct BehzHost {
 class Params {
 public:
     // bit_sizes is the key-level chain; sec128 enforces SEAL's tc128 cap.  Throws std::invalid_argument.
-    static Params *create(int scheme, size_t N, const std::vector<int> &bit_sizes, int plain_bits, bool sec128);
-    static Params *create_primes(int scheme, size_t N, const std::vector<u64> &primes, u64 plain_modulus);
+    // allow_fold = false: the Shoup form of the u64 engine's constants whatever the primes (u64_fold below; the lane simulator's Shoup build)
+    static Params *create(int scheme, size_t N, const std::vector<int> &bit_sizes, int plain_bits, bool sec128, bool allow_fold = true);
+    static Params *create_primes(int scheme, size_t N, const std::vector<u64> &primes, u64 plain_modulus, bool allow_fold = true);
 
     int scheme = 0;
     size_t N = 0;
@@ -85,6 +87,11 @@ public:
     size_t Ltop = 0;    // data residues at the first level
     u64 plain_modulus = 0;
     std::vector<PrimeTables> primes;
+    // Every prime the u64 engine owns in this context (chain and auxiliary base) is 2^60 - c with c < 2^26 (fold_prime_ok): the tables
+    // hold fold companion words and the device runs the HE355_U64_FOLD build of the kernels.  False as soon as one such prime is of
+    // another shape (coefficient bits 47..59, SEAL's 61-bit auxiliary base, HE355_FORCE_U64): then every u64-engine prime takes the
+    // Shoup form.  HE355_FORCE_U64=shoup: the Shoup form with the default engine assignment (A/B and the test matrix).
+    bool u64_fold = false;
     // BFV only: auxiliary BEHZ base: m_sk, then B_0..B_{nB(Ltop)-1}.  Device prime index of m_sk is K, of B_i is K + 1 + i.
     // SEAL's RNSTool takes 61-bit primes (get_primes(2N, 61, |q| + 2) -> m_sk, gamma, B...; |B| = |q|).  The product of the
     // multiply does not depend on that choice: every step up to the fast floor is a modular identity in each auxiliary prime
@@ -119,11 +126,11 @@ public:
     static u64 invmod(u64 a, u64 q) { return powmod(a, q - 2, q); }
     static int tc128_max_bits(size_t N);
     // NTT tables of one prime q = 1 (mod 2N) (also used for the BFV plain modulus on the client side)
-    static PrimeTables make_prime_tables(u64 q, size_t N, int logn, bool f64);
+    static PrimeTables make_prime_tables(u64 q, size_t N, int logn, bool f64, bool fold = false);
 
 private:
     Params() = default;
-    void build(int scheme, size_t N, const std::vector<u64> &primes, u64 plain_modulus);
+    void build(int scheme, size_t N, const std::vector<u64> &primes, u64 plain_modulus, bool allow_fold);
 };
 
 ModU64 make_mod(u64 q);

@@ -82,34 +82,136 @@ HE_HD u64 mul_shoup(u64 x, u64 w, u64 wq, u64 q)
     return r >= q ? r - q : r;
 }
 
+// ---- fold reduction for q = 2^60 - c (round 5) -----------------------------------------------------------------------------------
+// Every 60-bit prime the reference's parameter rule produces (seal_context.cpp:79-82,107-110: the largest primes 1 (mod 2N) below
+// 2^60) is 2^60 - c with c < 2^24, so 2^60 == c (mod q) and a product is reduced by folding its high part back in -- no quotient.
+// A constant w travels with w2 = w * 2^32 mod q (the 16-byte entry that holds {w, Shoup quotient} for other primes):
+//     x * w == x0 * w + x1 * w2 = S < 2^93      (x = x1 2^32 + x0 ANY 64-bit value: four 32 x 32 -> 64 multiply-adds)
+//     tight: r = lo60(S) + (S >> 61) * 2c + bit60(S) * c   < 2^60 + 2^33 c   (< 1.13 q for c < 2^24; 6 multiplier ops)
+//     wide : r = lo61(S) + (S >> 61) * 2c                  < 2^61 + 2^33 c   (< 2.13 q; 5 multiplier ops)
+// against 10 multiplier ops of x * w - floor(x * wq / 2^64) * q.  Measured (tools/micro/u64_fold.hip, profiles/r05_micro_u64_fold.txt):
+// the wide lazy butterfly 26.6 ns against Shoup's 40.7 per wave and SIMD slot.  A context whose u64-engine primes all qualify
+// (Params::u64_fold) runs the HE355_U64_FOLD=1 build of the kernels (Makefile: every device file is compiled for both forms).
+constexpr u64 kFoldMask60 = 0x0FFFFFFFFFFFFFFFull, kFoldMask61 = 0x1FFFFFFFFFFFFFFFull;
+constexpr u32 kFoldMaxC = 1u << 26; // c below this: every bound used here holds with room (see the bounds at each function)
+HE_HD bool fold_prime_ok(u64 q) { return (q >> 59) == 1 && (q >> 60) == 0 && ((u64)1 << 60) - q < kFoldMaxC; }
+HE_HD u32 fold_c(u64 q) { return (u32)(((u64)1 << 60) - q); }
+// S = x0 * w + x1 * w2 as (up, low 32 bits): S = up * 2^32 + lo
+HE_HD u64 fold_sum(u64 x, u64 w, u64 w2, u32 &lo)
+{
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+    const u64 u = (u64)x0 * (u32)w;
+    const u64 u2 = (u64)x1 * (u32)w2 + (u32)u;
+    const u64 m1 = (u64)x0 * (u32)(w >> 32) + (u >> 32);
+    const u64 m2 = (u64)x1 * (u32)(w2 >> 32) + (u2 >> 32);
+    lo = (u32)u2;
+    return m1 + m2; // < 2^61 + 2^33 (w, w2 < 2^60)
+}
+// x * w mod q in [0, 2^60 + 2^33 c), any 64-bit x; w, w2 = w 2^32 mod q canonical
+HE_HD u64 fold_mul_tight(u64 x, u64 w, u64 w2, u32 c)
+{
+    u32 lo;
+    const u64 up = fold_sum(x, w, w2, lo);
+    const u32 h = (u32)(up >> 29), b = (u32)(up >> 28) & 1u; // S >> 61 (S < 2^93: fits 32 bits) and bit 60 of S
+    const u64 lo60 = ((up & 0x0FFFFFFFull) << 32) | lo;
+    return (u64)h * (2 * c) + ((u64)b * c + lo60);
+}
+// ... in [0, 2^61 + 2^33 c): bit 60 stays in the low part
+HE_HD u64 fold_mul_wide(u64 x, u64 w, u64 w2, u32 c)
+{
+    u32 lo;
+    const u64 up = fold_sum(x, w, w2, lo);
+    const u32 h = (u32)(up >> 29);
+    const u64 lo61 = ((up & 0x1FFFFFFFull) << 32) | lo;
+    return (u64)h * (2 * c) + lo61;
+}
+// any 64-bit x -> the same residue below 2^61 + 14 c (three instructions: the top three bits folded back in)
+HE_HD u64 fold_red2q(u64 x, u32 c) { return (x & kFoldMask61) + (u64)(u32)(x >> 61) * (2 * c); }
+// any 128-bit sum -> canonical residue
+HE_HD u64 fold_acc128(u128 acc, u64 q, u32 c)
+{
+    const u64 lo = (u64)acc & kFoldMask60;
+    const u128 hc = (acc >> 60) * c;                   // < 2^68 c  (< 2^94)
+    const u64 l2 = (u64)hc & kFoldMask60, h2 = (u64)(hc >> 60); // h2 < 2^34
+    u64 r = h2 * c + lo + l2;                          // < 2^60 + 2^61
+    r = (r & kFoldMask60) + (r >> 60) * c;             // < 2^60 + 3 c < 2 q
+    return r >= q ? r - q : r;
+}
+
 // One twiddle-table entry is 16 bytes for both engines (one dwordx4 / one s_load_dwordx4).
 struct alignas(16) Tw16 {
     u64 a, b;
 };
 
+#ifndef HE355_U64_FOLD
+#define HE355_U64_FOLD 0
+#endif
+// x * w mod q, lazy in [0, 2q) / canonical, for a constant w with its companion word w2: the Shoup quotient floor(w 2^64 / q), or
+// (HE355_U64_FOLD build: every u64-engine prime is 2^60 - c) w * 2^32 mod q.  Which one a table holds is the context's choice
+// (Params::u64_fold), and a context only ever runs the build that matches its tables.
+#if HE355_U64_FOLD
+HE_HD u64 mul_pre_lazy(u64 x, u64 w, u64 w2, u64 q) { return fold_mul_tight(x, w, w2, fold_c(q)); }
+#else
+HE_HD u64 mul_pre_lazy(u64 x, u64 w, u64 w2, u64 q) { return mul_shoup_lazy(x, w, w2, q); }
+#endif
+HE_HD u64 mul_pre(u64 x, u64 w, u64 w2, u64 q)
+{
+    const u64 r = mul_pre_lazy(x, w, w2, q);
+    return r >= q ? r - q : r;
+}
+// the companion word of a canonical constant (host side: tables, floor constants)
+HE_HD u64 pre_word(u64 w, u64 q, bool fold) { return fold ? (u64)(((u128)w << 32) % q) : (u64)(((u128)w << 64) / q); }
+
 // ====================================================================================================
 // ArU64 — Harvey lazy butterflies, values in [0,4q) forward / [0,2q) inverse
+// Two builds of the same engine (HE355_U64_FOLD): products by constants through Shoup quotients (any prime below 2^61), or through the
+// fold reduction above (primes 2^60 - c).  Every bound of the Shoup form holds for the fold form as it stands -- its lazy product is
+// below 1.13 q where Shoup's is below 2q -- except in the two places that are written for it: the wide lazy row pass (fold_mul_wide,
+// below 2.13 q, offsets of 3q, fold_red2q between the phases) and the key multiply-accumulate (128-bit sums, one reduction per 16).
 // ====================================================================================================
 struct ArU64 {
     typedef u64 T;
     u64 q, two_q;
-    u64 ninv, ninv_q; // N^-1 and its Shoup quotient (inverse transform scaling)
+    u64 ninv, ninv_q; // N^-1 and its companion word (inverse transform scaling)
     u64 cr0, cr1;     // Barrett constant floor(2^128/q)
+    static constexpr bool kFold = HE355_U64_FOLD != 0;
+    HE_HD u32 c() const { return fold_c(q); }
 
     HE_HD ModU64 mod() const { ModU64 m; m.q = q; m.cr0 = cr0; m.cr1 = cr1; return m; }
     // ---- dyadic domain: canonical in, canonical out ----
-    typedef u64 Acc;
     HE_HD T dy_in(u64 c) const { return c; }
     HE_HD T dy_mul(T x, T y) const { return barrett128((u128)x * y, mod()); }
     HE_HD T dy_add(T x, T y) const { return addmod(x, y, q); }
     HE_HD u64 dy_out(T x) const { return x; }
     HE_HD T key_in(u64 bits) const { return bits; }
+    typedef u64 Acc;
+#if HE355_U64_FOLD
+    // Key products through the wide fold product (below 2^61 + 2^33 c <= 2.5 * 2^60), the key's companion word key * 2^32 mod q where the
+    // Shoup build keeps the key's quotient: a sum that starts below 2^61 + 14c takes kAccRun = 5 products (2 + 12.5 < 16, times 2^60)
+    // before acc_reduce (three instructions) brings it back.  (128-bit sums reduced once per 16 products cost the same instructions
+    // and no companion table, but 64 more registers per wave: 95-235 spilled registers in the 8-wave k_k3 -- built and dropped.)
+    static constexpr bool kKeyQuotient = true;
+    static constexpr int kAccRun = 5;
+    HE_HD void acc_mac_lazy(Acc &acc, T x, T key, u64 key2) const
+    {
+        const u64 v = fold_mul_wide(x, key, key2, c());
+#if defined(HE355_LANE_SIM)
+        if (acc > ~(u64)0 - v) he355_sim_overflow = 1;
+#endif
+        acc += v;
+    }
+    HE_HD void acc_mac(Acc &acc, T x, T key, u64 key2) const { acc = fold_red2q(acc + fold_mul_wide(x, key, key2, c()), c()); } // acc below 2^61 + 14c stays there
+    HE_HD Acc acc_reduce(Acc acc) const { return fold_red2q(acc, c()); }
+    HE_HD u64 acc_canon(Acc acc) const { return to_canon(fold_red2q(acc, c())); } // below 2q + 16c < 4q
+    HE_HD Acc acc_from_canon(u64 v) const { return v; }
+    HE_HD Acc acc_from_lazy(T v) const { return v; }
+#else
     // acc += x*key, x lazy (< 4q), key canonical, keyq = its Shoup quotient floor(key*2^64/q) or up to 2 below it
     // (shoup_quotient_est).  The product term lands in [0,3q), the sum stays in [0,4q): 7q < 2^63 for q < 2^60.
     static constexpr bool kKeyQuotient = true;
     HE_HD void acc_mac(Acc &acc, T x, T key, u64 keyq) const
     {
-        const u64 s = acc + mul_shoup_lazy_uq(x, key, keyq, q);
+        const u64 s = acc + mul_pre_lazy(x, key, keyq, q);
         acc = s >= 2 * two_q ? s - 2 * two_q : s;
     }
     // The same without the conditional subtraction, for runs of products between two acc_reduce calls.  With the EXACT quotient
@@ -119,7 +221,7 @@ struct ArU64 {
     static constexpr int kAccRun = 6;
     HE_HD void acc_mac_lazy(Acc &acc, T x, T key, u64 keyq) const
     {
-        const u64 v = mul_shoup_lazy_uq(x, key, keyq, q);
+        const u64 v = mul_pre_lazy(x, key, keyq, q);
 #if defined(HE355_LANE_SIM)
         if (acc > ~(u64)0 - v) he355_sim_overflow = 1;
 #endif
@@ -129,6 +231,7 @@ struct ArU64 {
     HE_HD u64 acc_canon(Acc acc) const { return to_canon(acc); }
     HE_HD Acc acc_from_canon(u64 v) const { return v; }
     HE_HD Acc acc_from_lazy(T v) const { return v; } // a dy_mul result (canonical here) as the start of a sum
+#endif
     // floor(w * 2^64 / q) from the Barrett constant floor(2^128/q) = cr1:cr0, at most 2 too small (never too large)
     HE_HD u64 shoup_quotient_est(u64 w) const { return w * cr1 + mulhi64(w, cr0); }
     // floor(w * 2^64 / q) exactly, w < q: the estimate, then the remainder w * 2^64 - est * q (below 3q, so its low 64 bits are all
@@ -144,20 +247,20 @@ struct ArU64 {
     // (t - x) * inv (+ addend): t, addend canonical, x lazy < 4q; inv given as Shoup pair
     HE_HD u64 floor_fin(u64 t, T x, u64 inv, u64 inv_shoup, double, double, u64 addend) const
     {
-        u64 r = mul_shoup(t + 2 * two_q - x, inv, inv_shoup, q);
+        u64 r = mul_pre(t + 2 * two_q - x, inv, inv_shoup, q);
         return addmod(r, addend, q);
     }
 
     // two floor steps with one combined correction x: ((t * inv1 + addend) - x) * inv2; t, addend canonical, x lazy < 4q
     template <class FC> HE_HD u64 floor_fin2(u64 t, T x, const FC &f1, const FC &f2, u64 addend) const
     {
-        const u64 r1 = mul_shoup(t, f1.inv, f1.inv_shoup, q);
-        return mul_shoup(r1 + addend + 2 * two_q - x, f2.inv, f2.inv_shoup, q);
+        const u64 r1 = mul_pre(t, f1.inv, f1.inv_shoup, q);
+        return mul_pre(r1 + addend + 2 * two_q - x, f2.inv, f2.inv_shoup, q);
     }
     // The same two floor steps for sums that were formed with key residues scaled by s^-1 (k_k3<TENSOR>: t stands for t * inv already,
     // and the addend is inside it): t - x * inv, and (t - x) * inv2.  t canonical, x lazy < 4q.
-    HE_HD u64 floor_fin_s(u64 t, T x, u64 inv, u64 inv_shoup, double, double) const { return submod(t, mul_shoup(x, inv, inv_shoup, q), q); }
-    template <class FC> HE_HD u64 floor_fin2_s(u64 t, T x, const FC &f2) const { return mul_shoup(t + 2 * two_q - x, f2.inv, f2.inv_shoup, q); }
+    HE_HD u64 floor_fin_s(u64 t, T x, u64 inv, u64 inv_shoup, double, double) const { return submod(t, mul_pre(x, inv, inv_shoup, q), q); }
+    template <class FC> HE_HD u64 floor_fin2_s(u64 t, T x, const FC &f2) const { return mul_pre(t + 2 * two_q - x, f2.inv, f2.inv_shoup, q); }
     HE_HD T from_canon(u64 x) const { return x; }
     HE_HD T from_raw(u64 bits) const { return bits; }
     HE_HD u64 to_raw(T x) const { return x; }
@@ -173,7 +276,7 @@ struct ArU64 {
     template <bool SW = false> HE_HD void bfly_fwd(T &X, T &Y, const Tw16 &w) const
     {
         u64 u = X >= two_q ? X - two_q : X;
-        u64 v = mul_shoup_lazy_uq(Y, w.a, w.b, q);
+        u64 v = mul_pre_lazy(Y, w.a, w.b, q);
         X = u + v;
         Y = u + two_q - v;
     }
@@ -190,16 +293,28 @@ struct ArU64 {
     // may run six such stages (16 q), is brought back under 4q once (two conditional subtractions per element), and runs its last
     // four stages to values below 12 q, which the key multiply-accumulate accepts as they are (acc_mac's bound holds for any 64-bit
     // x).  Per 1024-point row and lane: 80 x 4 instructions saved, 16 x 8 spent.
+    // Fold build: the product is fold_mul_wide's, below 2^61 + 2^33 c <= 3q, so the offset is 3q and a stage adds at most 3q: a row
+    // entering below 4q runs phase A's four stages to below 16q <= 2^64 - 16c, lazy_reduce (three instructions: the top three bits
+    // folded back in) brings it below 2^61 + 14c before each of the next two phases, phase B ends below 14q + 16c and phase C below
+    // 8q + 16c (ntt_core.h: row_fwd_B_lazy / row_fwd_C_lazy).
     HE_HD void bfly_fwd_lazy(T &X, T &Y, const Tw16 &w) const
     {
+#if HE355_U64_FOLD
+        const u64 v = fold_mul_wide(Y, w.a, w.b, c());
+        const u64 off = two_q + q;
+#else
         const u64 v = mul_shoup_lazy_uq(Y, w.a, w.b, q);
+        const u64 off = two_q;
+#endif
 #if defined(HE355_LANE_SIM)
-        if (X > ~(u64)0 - v || X + two_q < v) he355_sim_overflow = 1;
+        if (X > ~(u64)0 - v || X > ~(u64)0 - off || X + off < v) he355_sim_overflow = 1;
 #endif
         const u64 x = X;
         X = x + v;
-        Y = x + two_q - v;
+        Y = x + off - v;
     }
+    // between the phases of the wide lazy row pass (fold build; the Shoup build reduces once, inside phase B: reduce16_to_4q)
+    HE_HD T lazy_reduce(T x) const { return fold_red2q(x, c()); }
     // SW: the twiddles are wave-uniform (they may stay in scalar registers)
     template <int G, bool SW = false> HE_HD void bfly_fwd_lazy_g(T (&X)[G], T (&Y)[G], const Tw16 (&w)[G]) const
     {
@@ -218,7 +333,7 @@ struct ArU64 {
     HE_HD u64 to_canon16(T x) const { return to_canon(reduce16_to_4q(x)); }
     template <bool SW = false> HE_HD u64 mul_tw(u64 x, u64 w, u64 wq) const
     {
-        return mul_shoup_lazy_uq(x, w, wq, q);
+        return mul_pre_lazy(x, w, wq, q);
     }
     template <bool SW = false> HE_HD void bfly_inv(T &X, T &Y, const Tw16 &w) const
     {
@@ -238,7 +353,7 @@ struct ArU64 {
         Y = mul_tw<SW>(d, w_scaled.a, w_scaled.b);
     }
     // scale by N^-1 only (N1 == 1 rings have no column pass)
-    HE_HD T scale_ninv(T x) const { return mul_shoup_lazy_uq(x, ninv, ninv_q, q); }
+    HE_HD T scale_ninv(T x) const { return mul_pre_lazy(x, ninv, ninv_q, q); }
     // bring a forward-lazy value into the inverse-lazy range (and vice versa these are no-ops)
     HE_HD T renorm(T x) const { return x >= two_q ? x - two_q : x; }
     static constexpr bool kNeedsRenormInv = false;
@@ -423,6 +538,8 @@ struct ArF64 {
     }
     template <int G, bool SW = false> HE_HD void bfly_fwd_lazy_g(T (&X)[G], T (&Y)[G], const Tw16 (&w)[G]) const { bfly_fwd_g<G>(X, Y, w); } // the fp64 engine is lazy anyway
     HE_HD T reduce16_to_4q(T x) const { return x; }
+    static constexpr bool kFold = false;
+    HE_HD T lazy_reduce(T x) const { return x; }
     template <bool SW = false> HE_HD void bfly_inv(T &X, T &Y, const Tw16 &w) const
     {
         double s = X + Y;

@@ -240,7 +240,8 @@ template <int U, class Ar> HE_HD void row_fwd_C(const Ar &ar, typename Ar::T (*x
     row_fwd_stage<U, 0>(ar, x, w, [](int r) { return 4 + 2 * (r >> 2) + ((r >> 1) & 1); });      // stage 9: pairs (r, r|1), twiddle (c, h = bit 1 of r)
 }
 // The same three phases over the wide lazy range of the u64 engine (ArU64::bfly_fwd_lazy; q < 2^60): in below 4q, A to 12q, B runs two
-// stages (16q), comes back under 4q, runs two more (8q), C to 12q.  The fp64 engine's instantiations are the plain phases.
+// stages (16q), comes back under 4q, runs two more (8q), C to 12q.  Fold build of the engine (stages of 3q): A to 16q, reduce, B to
+// 14q, reduce, C to 8q.  The fp64 engine's instantiations are the plain phases.
 // SW: w[] is wave-uniform (a caller that keeps phase A's twiddles in scalar registers)
 template <int U, bool SW = false, class Ar> HE_HD void row_fwd_A_lazy(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwA])
 {
@@ -249,19 +250,30 @@ template <int U, bool SW = false, class Ar> HE_HD void row_fwd_A_lazy(const Ar &
     row_fwd_stage_x<U, 1, true, SW>(ar, x, w, [](int r) { return 3 + (r >> 2); });
     row_fwd_stage_x<U, 0, true, SW>(ar, x, w, [](int r) { return 7 + (r >> 1); });
 }
-template <int U, class Ar> HE_HD void row_fwd_B_lazy(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwB])
+template <int U, class Ar> HE_HD void row_fwd_lazy_reduce_all(const Ar &ar, typename Ar::T (*x)[kRowE])
 {
-    row_fwd_stage_x<U, 3, true>(ar, x, w, [](int r) { return 0 + (r >> 4); });
-    row_fwd_stage_x<U, 2, true>(ar, x, w, [](int r) { return 1 + (r >> 3); });
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int r = 0; r < kRowE; ++r) x[u][r] = ar.reduce16_to_4q(x[u][r]);
+        for (int r = 0; r < kRowE; ++r) x[u][r] = ar.lazy_reduce(x[u][r]);
+}
+template <int U, class Ar> HE_HD void row_fwd_B_lazy(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwB])
+{
+    if constexpr (Ar::kFold) row_fwd_lazy_reduce_all<U>(ar, x); // fold build: below 16q -> below 2q + 16c, then four stages of 3q
+    row_fwd_stage_x<U, 3, true>(ar, x, w, [](int r) { return 0 + (r >> 4); });
+    row_fwd_stage_x<U, 2, true>(ar, x, w, [](int r) { return 1 + (r >> 3); });
+    if constexpr (!Ar::kFold) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < kRowE; ++r) x[u][r] = ar.reduce16_to_4q(x[u][r]);
+    }
     row_fwd_stage_x<U, 1, true>(ar, x, w, [](int r) { return 3 + (r >> 2); });
     row_fwd_stage_x<U, 0, true>(ar, x, w, [](int r) { return 7 + (r >> 1); });
 }
 template <int U, class Ar> HE_HD void row_fwd_C_lazy(const Ar &ar, typename Ar::T (*x)[kRowE], const Tw16 w[kTwC])
 {
+    if constexpr (Ar::kFold) row_fwd_lazy_reduce_all<U>(ar, x); // below 14q + 16c -> below 2q + 16c, two stages: below 8q + 16c
     row_fwd_stage_x<U, 1, true>(ar, x, w, [](int r) { return r >> 2; });
     row_fwd_stage_x<U, 0, true>(ar, x, w, [](int r) { return 4 + 2 * (r >> 2) + ((r >> 1) & 1); });
 }

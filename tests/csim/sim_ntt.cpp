@@ -3,6 +3,7 @@
 // so that the index maps, twiddle addressing and fp64 magnitude bounds can be checked against the oracle
 // without a GPU.  It is compiled only into tests/csim/_build/libcsim.so; the product never contains it.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <type_traits>
@@ -111,8 +112,10 @@ template <class Ar> static void rows_fwd(const Ar &ar, const PrimeTables &pt, in
                 for (int lane = 0; lane < 64; ++lane) {
                     Tw16 w[kTwC]; gather_C(twt, lane, w); row_fwd_C_lazy<1>(ar, lz[lane], w);
                     for (int r = 0; r < kRowE; ++r) {
-                        if (lz[lane][0][r] >= 12 * pt.q) throw std::runtime_error("wide-lazy row pass: a result is not below 12 q");
-                        lazy_ref[elemC(lane, r)] = ar.to_canon16(lz[lane][0][r]);
+                        // Shoup build: below 12 q; fold build: below 8 q + 16 c (modarith.h, bfly_fwd_lazy)
+                        const u64 bound = ArU64::kFold ? 8 * pt.q + 16 * (u64)fold_c(pt.q) : 12 * pt.q;
+                        if (lz[lane][0][r] >= bound) throw std::runtime_error("wide-lazy row pass: a result is not below its bound");
+                        lazy_ref[elemC(lane, r)] = ArU64::kFold ? ar.to_canon(ar.lazy_reduce(lz[lane][0][r])) : ar.to_canon16(lz[lane][0][r]);
                     }
                 }
                 if (he355_sim_overflow) throw std::runtime_error("wide-lazy row pass: a sum left 64 bits");
@@ -122,16 +125,19 @@ template <class Ar> static void rows_fwd(const Ar &ar, const PrimeTables &pt, in
                 const u64 ks[3] = {pt.q - 1, pt.q / 2 + 1, 1};
                 for (u64 xv : xs)
                     for (u64 kv : ks) {
-                        const u64 kq = ar.shoup_quotient(kv);
-                        if ((u128)kq * pt.q > ((u128)kv << 64) || (u128)(kq + 1) * pt.q <= ((u128)kv << 64)) throw std::runtime_error("shoup_quotient is not floor(w * 2^64 / q)");
-                        u64 acc = 4 * pt.q - 1, want = (u64)(((u128)(4 * pt.q - 1)) % pt.q);
+                        // the key's companion word: its exact Shoup quotient, or (fold build) the key times 2^32
+                        const u64 kq = ArU64::kFold ? pre_word(kv, pt.q, true) : ar.shoup_quotient(kv);
+                        if (!ArU64::kFold && ((u128)kq * pt.q > ((u128)kv << 64) || (u128)(kq + 1) * pt.q <= ((u128)kv << 64))) throw std::runtime_error("shoup_quotient is not floor(w * 2^64 / q)");
+                        // the largest accumulator a run may start from: just below 4q, or (fold build) what acc_reduce leaves, below 2^61 + 14c
+                        const u64 start = ArU64::kFold ? ((u64)1 << 61) + 14 * (u64)fold_c(pt.q) - 1 : 4 * pt.q - 1;
+                        u64 acc = start, want = (u64)(((u128)start) % pt.q);
                         for (int k = 0; k < ArU64::kAccRun; ++k) {
                             ar.acc_mac_lazy(acc, xv, kv, kq);
                             want = (u64)((want + (u128)(xv % pt.q) * kv) % pt.q);
                         }
                         if (he355_sim_overflow) throw std::runtime_error("lazy accumulation run: a sum left 64 bits");
                         acc = ar.acc_reduce(acc);
-                        if (acc >= 4 * pt.q || ar.acc_canon(acc) != want) throw std::runtime_error("lazy accumulation run: wrong residue");
+                        if (acc > start || ar.acc_canon(acc) != want) throw std::runtime_error("lazy accumulation run: wrong residue");
                     }
             }
         }
@@ -212,10 +218,53 @@ extern "C" {
 void *sim_params_create(int scheme, size_t N, const int *bits, size_t n, int plain_bits, int sec128)
 {
     try {
-        return Params::create(scheme, N, std::vector<int>(bits, bits + n), plain_bits, sec128 != 0);
+        // this library runs ONE form of the u64 engine's arithmetic: the tables must be made for it.  Shoup build: never fold tables;
+        // fold build: a parameter set whose u64-engine primes are not all 2^60 - c has no fold form (null: the caller skips it)
+        Params *p = Params::create(scheme, N, std::vector<int>(bits, bits + n), plain_bits, sec128 != 0, ArU64::kFold);
+        bool has_u64 = false;
+        for (const PrimeTables &pt : p->primes) has_u64 |= !pt.f64;
+        if (has_u64 && p->u64_fold != ArU64::kFold) {
+            delete p;
+            return nullptr;
+        }
+        return p;
     } catch (std::exception &) {
         return nullptr;
     }
+}
+int sim_u64_fold_build(void) { return ArU64::kFold ? 1 : 0; }
+// explicit primes (the ends of the fold form's range of c, long chains of 60-bit primes)
+void *sim_params_create_primes(int scheme, size_t N, const uint64_t *primes, size_t n, uint64_t plain_modulus)
+{
+    try {
+        Params *p = Params::create_primes(scheme, N, std::vector<u64>(primes, primes + n), plain_modulus, ArU64::kFold);
+        bool has_u64 = false;
+        for (const PrimeTables &pt : p->primes) has_u64 |= !pt.f64;
+        if (has_u64 && p->u64_fold != ArU64::kFold) {
+            delete p;
+            return nullptr;
+        }
+        return p;
+    } catch (std::exception &) {
+        return nullptr;
+    }
+}
+// The row pass of prime i on rows whose every element is `value`, taken as a RAW lazy input (what the column pass may hand over: anything
+// below 4q).  0: the wide-lazy pass stayed inside 64 bits and its bounds and agreed with the Harvey pass; 1: it did not.
+int sim_row_pass_extreme(void *p, size_t i, uint64_t value)
+{
+    const Params &P = *(Params *)p;
+    const PrimeTables &pt = P.primes[i];
+    if (pt.f64) return 0;
+    const int n1 = 1 << P.logn1;
+    std::vector<u64> in((size_t)n1 * kRowN, value), out((size_t)n1 * kRowN);
+    try {
+        rows_fwd(pt.aru(), pt, n1, true, in.data(), out.data());
+    } catch (std::exception &e) {
+        std::fprintf(stderr, "sim_row_pass_extreme: %s\n", e.what());
+        return 1;
+    }
+    return 0;
 }
 void sim_params_destroy(void *p) { delete (Params *)p; }
 uint64_t sim_modulus(void *p, size_t i) { return ((Params *)p)->primes[i].q; }

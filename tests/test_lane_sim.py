@@ -11,10 +11,13 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def sim():
+# both builds of the u64 engine (csrc/modarith.h): Shoup quotients, and the fold reduction for primes 2^60 - c
+@pytest.fixture(scope="module", params=["shoup", "fold"])
+def sim(request):
     subprocess.run(["make", "-C", os.path.join(HERE, "csim"), "-s"], check=True)
-    L = C.CDLL(os.path.join(HERE, "csim", "_build", "libcsim.so"))
+    L = C.CDLL(os.path.join(HERE, "csim", "_build", "libcsim.so" if request.param == "shoup" else "libcsim_fold.so"))
+    L.sim_u64_fold_build.restype = C.c_int
+    assert L.sim_u64_fold_build() == (request.param == "fold")
     u64p = C.POINTER(C.c_uint64)
     L.sim_params_create.restype = C.c_void_p
     L.sim_params_create.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_int), C.c_size_t, C.c_int, C.c_int]
@@ -45,6 +48,8 @@ def _mk(sim, N, bits, force_u64=False):
         h = sim.sim_params_create(2, N, arr, len(bits), 0, 0)
     finally:
         os.environ.pop("HE355_FORCE_U64", None)
+    if not h and sim.sim_u64_fold_build():
+        pytest.skip("this parameter set puts a prime that is not 2^60 - c on the u64 engine: no fold form")
     assert h
     return h
 
@@ -95,5 +100,49 @@ def test_galois_rules_match_oracle(sim, oracle):
             sim.sim_galois_perm(h, elt, perm)
             got = a[np.frombuffer(perm, dtype=np.uint32)]
             assert np.array_equal(got, ctx.apply_galois_poly(0, elt, True, a))
+    finally:
+        sim.sim_params_destroy(h)
+
+
+def _ntt_primes(N, lo, hi, count):
+    """`count` primes 1 (mod 2N) in [lo, hi), largest first"""
+    from sympy import isprime
+    out, v = [], (hi - 2) // (2 * N) * (2 * N) + 1
+    while v >= lo and len(out) < count:
+        if isprime(v):
+            out.append(v)
+        v -= 2 * N
+    return out
+
+
+@pytest.mark.parametrize("N", [1024, 4096, 32768])
+def test_fold_form_at_the_ends_of_its_range(sim, oracle, N):
+    """Fold build of the u64 engine (q = 2^60 - c): primes with the largest c the form admits (just below 2^26) and the smallest, rows
+    whose every element sits at the top of the lazy input range (4q - 1) and at q - 1: no sum leaves 64 bits, every phase stays
+    inside its bound, and the wide-lazy row pass agrees with the Harvey row pass (the simulator throws otherwise); transforms of
+    random data equal the oracle's.  The Shoup build runs the same primes through its own bounds."""
+    sim.sim_params_create_primes.restype = C.c_void_p
+    sim.sim_params_create_primes.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint64]
+    sim.sim_row_pass_extreme.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+    big_c = _ntt_primes(N, 2 ** 60 - 2 ** 26 + 1, 2 ** 60 - 2 ** 26 + 2 ** 24, 2)
+    small_c = _ntt_primes(N, 2 ** 59, 2 ** 60, 2)
+    primes = big_c + small_c
+    assert len(primes) == 4 and all(2 ** 60 - p < 2 ** 26 for p in primes)
+    arr = (C.c_uint64 * len(primes))(*primes)
+    h = sim.sim_params_create_primes(2, N, arr, len(primes), 0)
+    assert h
+    ctx = oracle.Context(oracle.SCHEME_CKKS, N, primes=primes)
+    rng = np.random.default_rng(N)
+    try:
+        for i, q in enumerate(primes):
+            for value in (4 * q - 1, 2 * q, q - 1, 0):
+                assert sim.sim_row_pass_extreme(h, i, value) == 0, (hex(q), value)
+            a = rng.integers(0, q, N, dtype=np.uint64)
+            f = a.copy()
+            sim.sim_ntt_forward(h, i, oracle._p(f))
+            assert np.array_equal(f, ctx.ntt(i, a))
+            g = f.copy()
+            sim.sim_ntt_inverse(h, i, oracle._p(g))
+            assert np.array_equal(g, a)
     finally:
         sim.sim_params_destroy(h)
