@@ -512,7 +512,27 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tdev = "cuda" if backend == "nccl" else "cpu"
+    # what a reader of the N > 1 line needs to see that the ranks really met over the collective backend and which card each one drove:
+    # an all-reduce of one 1 per rank (must equal the world size), every rank's own time and its device's PCI bus id
+    props = torch.cuda.get_device_properties(device)
+    bus = (f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', -1):02x}:{getattr(props, 'pci_device_id', 0):02x}"
+           if hasattr(props, "pci_bus_id") else None)
+    my_ms = elapsed / args.steps * 1e3
+    collective = None
+    per_rank_ms, per_rank_device = [round(my_ms, 3)], [{"rank": 0, "local_device": device, "pci_bus_id": bus, "name": props.name}]
     if world > 1:
+        ones = torch.ones(1, dtype=torch.float64, device=tdev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        tm = torch.tensor([my_ms], dtype=torch.float64, device=tdev)
+        allt = [torch.zeros_like(tm) for _ in range(world)]
+        dist.all_gather(allt, tm)
+        per_rank_ms = [round(float(x.item()), 3) for x in allt]
+        objs = [None] * world
+        dist.all_gather_object(objs, {"rank": rank, "local_device": device, "pci_bus_id": bus, "name": props.name})
+        per_rank_device = objs
+        collective = {"backend": dist.get_backend() + (" (RCCL)" if backend == "nccl" else ""), "world_size": dist.get_world_size(),
+                      "allreduce_of_ones": float(ones.item()),
+                      "note": "rendezvous, barriers, MAX-over-ranks and this all-reduce only: no collective inside the timed region (SURVEY.md 8e)"}
         t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -588,7 +608,8 @@ def main():
             cpu = {"value": best["ops_per_sec"], "unit": "ciphertext-ops/sec", "cores": best["threads"], "kind": "port",
                    "nproc": os.cpu_count(), "cpu_share": cpus, "scaling": scaling,
                    "one_thread_ops_per_sec": scaling[0]["ops_per_sec"] if scaling[0]["threads"] == 1 else None,
-                   "built_for_host": open(os.path.join(ROOT, "oracle", "_build", "host.sig")).read().strip()
+                   "built_for_host": "portable x86-64-v2 fallback (the in-tree -march=native build failed: oracle.build)" if ho.portable_build else
+                   open(os.path.join(ROOT, "oracle", "_build", "host.sig")).read().strip()
                    if os.path.exists(os.path.join(ROOT, "oracle", "_build", "host.sig")) else None,
                    "sample": f"thread counts {counts}; per count a sample of the first rows of the resident batch (>= 2 results per thread, same parameters and "
                              f"keys as the GPU step), median of the timed passes after one warm-up; value = the best count ({best['threads']} threads, "
@@ -702,6 +723,9 @@ def main():
                                  + "; rank r owns a contiguous block of operand-0 rows (sharding.shard_outer_product)"),
                        "batch_per_gpu": n, "global_batch": global_b0 * W.b1,
                        "parallelism": f"batch-sharded x{world}, keys and operand 1 replicated (built per device from the shared seed), no data-path collective"},
+            "collective": collective,
+            "per_rank_ms": per_rank_ms,
+            "per_rank_device": per_rank_device,
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity": {"checked_in_run": all_ok if any(p[1] for p in per_rank) else None,

@@ -64,22 +64,41 @@ def build(force: bool = False) -> str:
             return True
 
     if stale():
-        os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
-        with open(os.path.join(_HERE, "_build", ".lock"), "w") as lock:
-            fcntl.flock(lock, fcntl.LOCK_EX)
-            try:
-                if stale():  # somebody else may have built it while we waited
-                    try:
+        try:
+            os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+            with open(os.path.join(_HERE, "_build", ".lock"), "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    if stale():  # somebody else may have built it while we waited
                         subprocess.run(["make", "-C", _HERE, "-s", "-B"], check=True)
                         with open(sig_path, "w") as f:
                             f.write(sig + "\n")
-                    except (subprocess.CalledProcessError, OSError):
-                        if not os.path.exists(_LIB_PATH):
-                            raise
-                        import sys
-                        print("oracle: rebuild for this host failed, using the library that travelled with the tree", file=sys.stderr)
-            finally:
-                fcntl.flock(lock, fcntl.LOCK_UN)
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
+        except (subprocess.CalledProcessError, OSError) as e:
+            # The tree is read-only, or the rebuild failed.  A library that is present but was built `-march=native` on ANOTHER host may
+            # hold instructions this host cannot execute: it is never loaded.  Fall back to a portable build (x86-64-v2) outside the tree.
+            _portable_fallback(srcs, e)
+    return _LIB_PATH
+
+
+portable_build = False  # True: the library in use is the x86-64-v2 fallback (bench.py records it next to the CPU baseline)
+
+
+def _portable_fallback(srcs, why):
+    global _LIB_PATH, portable_build
+    import sys
+    import tempfile
+    out_dir = os.path.join(tempfile.gettempdir(), f"he_oracle_{os.getuid()}")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libhe_oracle_portable.so")
+    if not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs):
+        tmp = out + f".{os.getpid()}.tmp"
+        subprocess.run(["gcc", "-O3", "-march=x86-64-v2", "-fopenmp", "-fPIC", "-std=c11", "-shared", "-o", tmp, os.path.join(_HERE, "he_oracle.c"), "-lm"], check=True)
+        os.replace(tmp, out)
+    print(f"oracle: build in the tree failed ({why}); using a portable build at {out}", file=sys.stderr)
+    _LIB_PATH = out
+    portable_build = True
     return _LIB_PATH
 
 

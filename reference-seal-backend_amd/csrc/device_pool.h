@@ -24,6 +24,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace he355 {
@@ -97,6 +98,7 @@ public:
             if (it != free_.end() && !it->second.empty()) {
                 void *p = it->second.back();
                 it->second.pop_back();
+                cached_.erase(p);
                 st_.cached_bytes -= cls;
                 st_.live_bytes += cls;
                 ++st_.pool_hits;
@@ -113,19 +115,23 @@ public:
         live_[p] = cls;
         return p;
     }
-    // true: the block was one of this pool's and is back on its list
-    bool release(void *p)
+    // kReleased: the block was handed out by this pool and is back on its list.  kCached: it already IS on a list -- a second free of
+    // the same pointer (it must not be hipFree'd: the list still holds it and would hand freed memory to the next allocation).
+    // kUnknown: never issued by this pool (another context's block, or not a device allocation of this library at all).
+    enum Release { kReleased, kCached, kUnknown };
+    Release release(void *p)
     {
-        if (!p) return true;
+        if (!p) return kReleased;
         std::lock_guard<std::mutex> g(mu_);
         auto it = live_.find(p);
-        if (it == live_.end()) return false;
+        if (it == live_.end()) return cached_.count(p) ? kCached : kUnknown;
         const size_t cls = it->second;
         live_.erase(it);
         st_.live_bytes -= cls;
         st_.cached_bytes += cls;
         free_[cls].push_back(p);
-        return true;
+        cached_.insert(p);
+        return kReleased;
     }
     // hipFree every cached block; returns the bytes given back.  hipFree waits for the device, so work in flight on a cached block
     // (released with kernels still queued behind it) has drained before the memory goes.
@@ -139,6 +145,7 @@ public:
                 for (void *p : kv.second) blocks.push_back(p);
                 kv.second.clear();
             }
+            cached_.clear();
             bytes = st_.cached_bytes;
             st_.cached_bytes = 0;
             st_.raw_frees += blocks.size();
@@ -173,6 +180,7 @@ private:
     mutable std::mutex mu_;
     std::map<size_t, std::vector<void *>> free_;
     std::unordered_map<void *, size_t> live_;
+    std::unordered_set<void *> cached_; // the blocks on the free lists (release() tells a second free from a foreign pointer)
     Stats st_;
 };
 

@@ -275,10 +275,16 @@ public:
     }
     void pool_free(void *p)
     {
-        if (pool_on_ && pool_.release(p)) return;
-        // not one of the pool's blocks (a pointer the caller made some other way): the old contract, drain and free
-        sync();
-        pool_.raw_free(p);
+        if (!pool_on_) { // HE355_POOL=0: every block is a raw allocation, freed as before the pool existed
+            sync();
+            pool_.raw_free(p);
+            return;
+        }
+        switch (pool_.release(p)) {
+        case DevicePool::kReleased: return;
+        case DevicePool::kCached: throw std::invalid_argument("he355_free: this block was freed already");
+        default: throw std::invalid_argument("he355_free: not a block this context allocated (he355_malloc of another context?)");
+        }
     }
     DevicePool::Stats alloc_stats() const { return pool_.stats(); }
     size_t pool_trim() { sync(); return pool_.trim(); }
@@ -1091,15 +1097,25 @@ public:
         PolyView pv{};
         pv.polys_per_item = 2 * L; pv.item_stride = per;
         for (int p2 = 0; p2 < 2 * L; ++p2) pv.prime_of[p2] = (unsigned char)(p2 % L);
+        // every level's keys before anything is allocated: a missing key must not leave blocks behind
+        for (size_t lv = 1; lv <= depth; ++lv)
+            for (int id : levels[lv])
+                if (!galois_key(trie[(size_t)id].elt)) throw std::invalid_argument("Galois key not present");
+        // the one block this walk holds at a time (the previous level's ciphertexts): back to the pool however the walk ends
+        struct Held {
+            DevicePool &pool;
+            u64 *p = nullptr;
+            ~Held() { if (p) pool.release(p); }
+            void reset(u64 *q) { if (p) pool.release(p); p = q; } // (stream-ordered reuse: whatever takes the block next is queued behind these kernels)
+        } held{pool_};
         // level 0: the input in NTT form (BFV: a transformed copy), the running sum starts as (1 + steps of 0) x input
         const u64 *src = in;
-        u64 *owned_src = nullptr;
         if (bfv) {
-            owned_src = static_cast<u64 *>(pool_.alloc(bytes));
-            HIPCHECK(hipMemcpyAsync(owned_src, in, bytes, hipMemcpyDeviceToDevice, stream_));
-            pv.base = owned_src;
+            held.reset(static_cast<u64 *>(pool_.alloc(bytes)));
+            HIPCHECK(hipMemcpyAsync(held.p, in, bytes, hipMemcpyDeviceToDevice, stream_));
+            pv.base = held.p;
             launch_ntt_forward(env_, pv, (u32)n);
-            src = owned_src;
+            src = held.p;
         }
         HIPCHECK(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToDevice, stream_));
         Indexer ixp{};
@@ -1117,20 +1133,20 @@ public:
                 const RotNode &nd = trie[(size_t)nodes[g]];
                 perms[g] = perm(nd.elt);
                 keys[g] = galois_key(nd.elt);
-                if (!keys[g]) throw std::invalid_argument("Galois key not present");
                 src_block[g] = (u32)trie[(size_t)nd.parent].pos;
                 mult[g] = (u32)nd.ends;
             }
             const GroupTables gt = upload_groups(perms, keys, src_block, mult, (u32)n);
-            u64 *cur = static_cast<u64 *>(pool_.alloc(G * bytes));
-            apply_galois_grouped(L, G, n, src, gt.g, cur);
-            launch_sum_groups(env_, L, n, (u32)G, cur, gt.d_mult, out);
-            if (owned_src) pool_.release(owned_src); // (stream-ordered reuse: whatever takes the block next is queued behind these kernels)
-            owned_src = cur;
-            src = cur;
+            Held cur{pool_};
+            cur.reset(static_cast<u64 *>(pool_.alloc(G * bytes)));
+            apply_galois_grouped(L, G, n, src, gt.g, cur.p);
+            launch_sum_groups(env_, L, n, (u32)G, cur.p, gt.d_mult, out);
+            held.reset(cur.p);
+            cur.p = nullptr;
+            src = held.p;
             switches += G;
         }
-        if (owned_src) pool_.release(owned_src);
+        held.reset(nullptr);
         if (bfv) {
             pv.base = out;
             launch_ntt_inverse(env_, pv, (u32)n);

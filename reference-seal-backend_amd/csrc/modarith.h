@@ -335,6 +335,34 @@ struct ArU64 {
     {
         return mul_pre_lazy(x, w, wq, q);
     }
+#if HE355_U64_FOLD
+    // Fold build: values of the inverse transform stay below B = 2^61 + 2^33 c (<= 2.5 * 2^60 <= 3q - 2^58): the sum (below 2B < 2^64)
+    // comes back under 2^61 + 14c by fold_red2q, the difference takes the offset 3q >= B and goes through the wide product (below B).
+    // The last stage multiplies both outputs (tight products, below 1.5 * 2^60 < 2q), so what leaves a pass is as small as in the Shoup
+    // form; what passes BETWEEN the row pass and the column pass (raw rows) is below B, which the next bfly_inv accepts.
+    template <bool SW = false> HE_HD void bfly_inv(T &X, T &Y, const Tw16 &w) const
+    {
+#if defined(HE355_LANE_SIM)
+        const u64 B = ((u64)1 << 61) + ((u64)c() << 33);
+        if (X >= B || Y >= B) he355_sim_overflow = 1;
+#endif
+        const u64 s = X + Y;
+        const u64 d = X + (two_q + q) - Y;
+        X = fold_red2q(s, c());
+        Y = fold_mul_wide(d, w.a, w.b, c());
+    }
+    template <bool SW = false> HE_HD void bfly_inv_last(T &X, T &Y, const Tw16 &w_scaled) const
+    {
+#if defined(HE355_LANE_SIM)
+        const u64 B = ((u64)1 << 61) + ((u64)c() << 33);
+        if (X >= B || Y >= B) he355_sim_overflow = 1;
+#endif
+        const u64 s = X + Y;
+        const u64 d = X + (two_q + q) - Y;
+        X = mul_tw<SW>(s, ninv, ninv_q);
+        Y = mul_tw<SW>(d, w_scaled.a, w_scaled.b);
+    }
+#else
     template <bool SW = false> HE_HD void bfly_inv(T &X, T &Y, const Tw16 &w) const
     {
         u64 s = X + Y;
@@ -352,6 +380,7 @@ struct ArU64 {
         X = mul_tw<SW>(s, ninv, ninv_q);
         Y = mul_tw<SW>(d, w_scaled.a, w_scaled.b);
     }
+#endif
     // scale by N^-1 only (N1 == 1 rings have no column pass)
     HE_HD T scale_ninv(T x) const { return mul_pre_lazy(x, ninv, ninv_q, q); }
     // bring a forward-lazy value into the inverse-lazy range (and vice versa these are no-ops)

@@ -272,6 +272,8 @@ uint64_t sim_root(void *p, size_t i) { return ((Params *)p)->primes[i].root; }
 int sim_is_f64(void *p, size_t i) { return ((Params *)p)->primes[i].f64; }
 size_t sim_K(void *p) { return ((Params *)p)->K; }
 double sim_maxmag_reset(void) { double m = g_maxmag; g_maxmag = 0; return m; }
+// the bound / overflow flag of the u64 engine's lazy forms (modarith.h, HE355_LANE_SIM), read and cleared
+int sim_overflow_reset(void) { const int f = he355_sim_overflow; he355_sim_overflow = 0; return f; }
 void sim_ntt_forward(void *p, size_t i, uint64_t *poly)
 {
     const Params &P = *(Params *)p;

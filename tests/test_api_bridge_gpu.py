@@ -292,6 +292,57 @@ def test_operate_spread_over_a_device_group(backend, monkeypatch, ndev):
         backend.destroy(hb)
 
 
+def test_two_physical_devices(backend, monkeypatch):
+    """The first box with two GPUs that runs `pytest -m gpu` covers the cross-device paths: he355_copy_peer in both directions between two
+    PHYSICAL devices (a round trip of random bytes), and one operate() of every vector workload spread over a two-device group without
+    HE355_LOGICAL_DEVICES -- contexts on devices 0 and 1, keys generated per device from the shared seed, hipMemcpyPeer at load(),
+    parts gathered at store() (csrc/bridge/multi_device.cpp) -- equal to the single-device run and the cleartext.  Skipped on a
+    one-GPU box (where the logical-device tests above run the same code on one card)."""
+    be = importlib.import_module("reference-seal-backend_amd")
+    if be.device_count() < 2:
+        pytest.skip("needs two physical GPUs")
+    monkeypatch.delenv("HE355_LOGICAL_DEVICES", raising=False)
+    # he355_copy_peer, both directions
+    g0 = be.Context(be.SCHEME_CKKS, 4096, bit_sizes=[60, 45, 60], sec128=False, device=0)
+    g1 = be.Context(be.SCHEME_CKKS, 4096, bit_sizes=[60, 45, 60], sec128=False, device=1)
+    rng = np.random.default_rng(77)
+    x = rng.integers(0, 2 ** 63, 1 << 16, dtype=np.uint64)
+    d0, d1, back = g0.to_device(x), g1.alloc(x.size), g0.alloc(x.size)
+    lib = be.lib()
+    assert lib.he355_copy_peer(g1.h, d1.ptr, g0.h, d0.ptr, x.nbytes) == 0
+    g1.sync()
+    assert np.array_equal(d1.download(x.shape), x)
+    assert lib.he355_copy_peer(g0.h, back.ptr, g1.h, d1.ptr, x.nbytes) == 0
+    g0.sync()
+    assert np.array_equal(back.download(x.shape), x)
+    g0.close(); g1.close()
+    # one operate() over two physical devices, against one device and the cleartext
+    n = 64
+    a, b = rng.uniform(-1, 1, (5, n)), rng.uniform(-1, 1, (2, n))
+    for w, want, tol in ((W_ADD, (a[:, None, :] + b[None, :, :]).reshape(10, n), 1e-4), (W_MUL, (a[:, None, :] * b[None, :, :]).reshape(10, n), 1e-4)):
+        got = []
+        for ndev in (1, 2):
+            hb = backend.create(backend.find(w, SCHEME_CKKS, OFFLINE), ckks_params(n) + [("NumDevices", ndev)], (5, 2))
+            got.append(backend.run(hb, [a, b], n, np.float64))
+            backend.destroy(hb)
+            assert np.allclose(got[-1], want, atol=tol), (w, ndev)
+    hb = backend.create(backend.find(W_DOT, SCHEME_CKKS, OFFLINE), ckks_params(n, bits=40, scale=40) + [("NumDevices", 2)], (2, 2))
+    res = backend.run(hb, [a[:2], b], 1, np.float64)
+    assert np.allclose(res, (a[:2] @ b.T).reshape(4, 1), atol=1e-3)
+    backend.destroy(hb)
+    x, y = rng.integers(-500, 500, (4, n)), rng.integers(-500, 500, (3, n))
+    bfv = [("n", n), ("PolyModulusDegree", 8192), ("MultiplicativeDepth", 2), ("CoefficientModulusBits", 40), ("PlainModulusBits", 20), ("NumThreads", 0),
+           ("NumDevices", 2)]
+    hb = backend.create(backend.find(W_MUL, SCHEME_BFV, OFFLINE), bfv, (4, 3))
+    res = backend.run(hb, [x, y], n, np.int64)
+    assert np.array_equal(res, (x[:, None, :] * y[None, :, :]).reshape(12, n))
+    backend.destroy(hb)
+    moved = backend.L.he355_bridge_group_load_bytes
+    moved.restype, moved.argtypes = C.c_uint64, [C.c_int, C.c_int]
+    ct = 2 * 2 * 8192 * 8
+    assert moved(1, 0) == 2 * ct and moved(1, 1) == 3 * ct  # device 1 received its block of operand-0 rows and all of operand 1
+
+
 @pytest.mark.parametrize("ndev", [2, 3])
 def test_matmult_row_spread_over_a_device_group(backend, monkeypatch, ndev):
     """MatMultRow's row(-pair) ciphertexts are independent (bfv row .cpp:512-533): HE355_NUM_DEVICES spreads them over a device
@@ -392,3 +443,30 @@ def test_pool_reuses_and_trims():
     s2 = g.alloc_stats()
     assert s2["cached_bytes"] == 0 and s2["raw_frees"] == s1["raw_frees"] + 1
     g.close()
+
+
+def test_double_free_and_foreign_pointers_are_rejected():
+    """he355_free of a block that already sits on the pool's free list, or that another context allocated, is an argument error -- it
+    must not be hipFree'd while the list still holds it (the next allocation of that class would receive freed memory)."""
+    if os.environ.get("HE355_POOL", "1")[:1] == "0":
+        pytest.skip("HE355_POOL=0 selects the pre-pool allocation behaviour on purpose")
+    be = importlib.import_module("reference-seal-backend_amd")
+    g = be.Context(be.SCHEME_CKKS, 4096, bit_sizes=[60, 45, 60], sec128=False, device=0)
+    g2 = be.Context(be.SCHEME_CKKS, 4096, bit_sizes=[60, 45, 60], sec128=False, device=0)
+    lib = be.lib()
+    a = g.alloc(1 << 14)
+    p = a.ptr
+    assert lib.he355_free(g.h, p) == 0
+    a.ptr = None
+    s0 = g.alloc_stats()
+    assert lib.he355_free(g.h, p) == be.E_INVALID_ARGS           # freed twice
+    b = g2.alloc(1 << 14)
+    assert lib.he355_free(g.h, b.ptr) == be.E_INVALID_ARGS       # another context's block
+    s1 = g.alloc_stats()
+    assert s1["raw_frees"] == s0["raw_frees"] and s1["cached_bytes"] == s0["cached_bytes"]
+    c = g.alloc(1 << 14)                                               # the cached block is still good
+    assert c.ptr.value == p.value
+    x = np.arange(1 << 14, dtype=np.uint64)
+    c.upload(x)
+    assert np.array_equal(c.download(), x)
+    g.close(); g2.close()

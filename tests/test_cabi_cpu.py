@@ -121,3 +121,39 @@ def test_product_never_touches_oracle():
                     if lines:
                         bad.append((f, lines[:2]))
     assert not bad, bad
+
+
+def test_long_bfv_chain_falls_back_to_seals_auxiliary_base(be):
+    """The device's own BEHZ base (46-bit primes of the fp64 engine) needs about 1.3 |q| primes; a chain so long that they no longer
+    fit the device prime table (64 entries) or the kernels' base-B limit takes SEAL's 61-bit base (|q| + 1 primes) instead of
+    failing at context creation (he_params.cpp, Params::build).  28 primes of 60 bits: 27 data primes -> 36 auxiliary primes of 46
+    bits would make 28 + 37 + 1 = 66 entries; SEAL's base makes 28 + 28 + 1 = 57."""
+    ctx = be.Context(be.SCHEME_BFV, 32768, bit_sizes=[60] * 28, plain_bits=20, sec128=False)
+    base = ctx.bfv_aux_base()
+    assert len(base) == 1 + 27 and all(q.bit_length() == 61 for q in base)
+    ctx.close()
+    # a short chain keeps the 46-bit base
+    ctx = be.Context(be.SCHEME_BFV, 8192, bit_sizes=[60, 40, 60], plain_bits=20)
+    assert all(q.bit_length() == 46 for q in ctx.bfv_aux_base())
+    ctx.close()
+
+
+def test_oracle_falls_back_to_a_portable_build_when_the_tree_build_fails(monkeypatch):
+    """oracle.build(): when the in-tree `-march=native` build cannot be made (read-only tree, failed rebuild on another host) the
+    checker is compiled for x86-64-v2 outside the tree -- a library built for another host's instruction set is never loaded."""
+    import subprocess
+    import oracle
+    real = subprocess.run
+
+    def failing_make(cmd, *a, **k):
+        if cmd and cmd[0] == "make":
+            raise subprocess.CalledProcessError(2, cmd)
+        return real(cmd, *a, **k)
+
+    monkeypatch.setattr(subprocess, "run", failing_make)
+    monkeypatch.setattr(oracle, "_LIB_PATH", oracle._LIB_PATH)
+    monkeypatch.setattr(oracle, "portable_build", False)
+    path = oracle.build(force=True)
+    assert oracle.portable_build and "portable" in path and os.path.exists(path)
+    L = C.CDLL(path)
+    assert L.ho_max_threads() >= 1

@@ -73,8 +73,10 @@ def test_lane_program_matches_oracle(sim, oracle, N, force_u64):
                 sim.sim_ntt_forward(h, i, oracle._p(f))
                 assert np.array_equal(f, ctx.ntt(i, a)), (N, i, "forward")
                 g = f.copy()
+                sim.sim_overflow_reset()
                 sim.sim_ntt_inverse(h, i, oracle._p(g))
                 assert np.array_equal(g, a), (N, i, "inverse")
+                assert sim.sim_overflow_reset() == 0, (N, i, "a value of the inverse transform left its bound")
         mag = sim.sim_maxmag_reset()
         if not force_u64:
             assert 0 < mag < 2.0 ** 52, mag  # exactness bound of the fp64 engine (integers < 2^53)
@@ -141,8 +143,11 @@ def test_fold_form_at_the_ends_of_its_range(sim, oracle, N):
             f = a.copy()
             sim.sim_ntt_forward(h, i, oracle._p(f))
             assert np.array_equal(f, ctx.ntt(i, a))
-            g = f.copy()
-            sim.sim_ntt_inverse(h, i, oracle._p(g))
-            assert np.array_equal(g, a)
+            for b in (a, np.full(N, q - 1, dtype=np.uint64)):
+                g = ctx.ntt(i, b)
+                sim.sim_overflow_reset()
+                sim.sim_ntt_inverse(h, i, oracle._p(g))
+                assert np.array_equal(g, b)
+                assert sim.sim_overflow_reset() == 0
     finally:
         sim.sim_params_destroy(h)

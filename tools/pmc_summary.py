@@ -8,8 +8,10 @@ from collections import defaultdict
 
 def short(name):
     name = name.replace("he355::", "").replace("(anonymous namespace)::", "")
+    build = "F:" if "ks_fold::" in name else "S:" if "ks_shoup::" in name else ""  # which build of the device code (fold / Shoup form of the u64 engine)
+    name = name.replace("ks_fold::", "").replace("ks_shoup::", "")
     m = re.search(r"(k_\w+)(<[^(]*>)?", name)
-    return (m.group(1) + (m.group(2) or "")).replace(" ", "").replace(",", ";") if m else name[:40]
+    return build + (m.group(1) + (m.group(2) or "")).replace(" ", "").replace(",", ";") if m else name[:40]
 
 
 def main(d):
