@@ -225,6 +225,22 @@ AB::Handle LogRegHornerBenchmark::load(const AB::Handle *p_h_local_data, std::ui
     r.zero = m_p_ctx_wrapper->upload(std::vector<Cipher>{m_p_ctx_wrapper->encrypt(m_p_ctx_wrapper->encodeVector(std::vector<double>(1, 0.0)))});
     r.coeff = uploadPlains(m_plain_coeff);
     r.coeff3 = m_p_ctx_wrapper->upload(std::vector<Cipher>{m_p_ctx_wrapper->encrypt(m_plain_coeff.back())});
+    // ... and switched down to the levels operate() uses them at (RemoteOpParams)
+    const int L = r.W->L;
+    if (L >= 6) {
+        r.identity1 = dropTo(r.identity, L - 1);
+        r.tail2 = m_p_ctx_wrapper->allocResult(2, 2, L - 2, m_p_ctx_wrapper->scale());
+        const std::uint64_t per2 = 2 * (std::uint64_t)(L - 2) * m_p_ctx_wrapper->params().N;
+        HeContextWrapper::check(he355_mod_switch_drop(m_p_ctx_wrapper->raw(), r.zero->L, L - 2, 2, r.zero->d, r.tail2->d), "matchLevel");
+        HeContextWrapper::check(he355_mod_switch_drop(m_p_ctx_wrapper->raw(), r.b->L, L - 2, 2, r.b->d, r.tail2->d + per2), "matchLevel");
+        r.coeff3_2 = dropTo(r.coeff3, L - 2);
+        const std::uint64_t coeffN = (std::uint64_t)r.coeff->L * m_p_ctx_wrapper->params().N;
+        for (int k = 0; k < 3; ++k) {
+            r.coeff_at[k] = m_p_ctx_wrapper->allocResult(1, 1, L - 5 + k, m_p_ctx_wrapper->scale());
+            HeContextWrapper::check(he355_mod_switch_drop(m_p_ctx_wrapper->raw(), r.coeff->L, L - 5 + k, 1, r.coeff->d + (std::uint64_t)k * coeffN, r.coeff_at[k]->d),
+                                    "mod_switch_to");
+        }
+    }
     m_p_ctx_wrapper->needRelinKey();
     m_p_ctx_wrapper->needDefaultGaloisKeys(); // accumulateCKKS steps 2^k and the collapse's rotations by -i (NAF terms of -i)
     return this->getEngine().createHandle<decltype(r)>(sizeof(r), EncryptedOpParamsTag, std::move(r));
@@ -286,19 +302,23 @@ AB::Handle LogRegHornerBenchmark::operate(AB::Handle h_remote_packed, const AB::
         for (std::uint64_t i = 0; i < batch; ++i) steps[i] = -(std::int32_t)i;
         chk(he355_rotate_each(ctx, L1, batch, dots1->d, steps.data(), rot->d), "rotate_vector");
     }
-    std::shared_ptr<DeviceCiphers> id1 = dropTo(in.identity, L1);                         // mod_switch_to_inplace(plain, tmp.parms_id())
+    std::shared_ptr<DeviceCiphers> id1 = in.identity1 ? in.identity1 : dropTo(in.identity, L1); // mod_switch_to_inplace(plain, tmp.parms_id()): prepared at load()
     chk(he355_multiply_plain(ctx, L1, 2, batch, rot->d, id1->d, pairwise, rot->d), "multiply_plain"); // relinearize_inplace: size 2, nothing to do
     // terms [0, batch) = rescaled masked rotations, term batch = Enc(0), term batch+1 = bias; all at level L2, scales pinned to `scale`
     std::shared_ptr<DeviceCiphers> terms = cw.allocResult(batch + 2, 2, L2, scale);
     const std::uint64_t per2 = 2 * (std::uint64_t)L2 * N;
     chk(he355_rescale(ctx, L1, 2, batch, rot->d, terms->d), "rescale");
-    chk(he355_mod_switch_drop(ctx, in.zero->L, L2, 2, in.zero->d, terms->d + batch * per2), "matchLevel");       // retval: encrypt_zero, switched down
-    chk(he355_mod_switch_drop(ctx, in.b->L, L2, 2, in.b->d, terms->d + (batch + 1) * per2), "matchLevel");       // bias (.cpp:452-456)
+    if (in.tail2) { // both constants sit side by side at level L2 already (load()): one copy instead of two residue-dropping kernels
+        chk(he355_copy(ctx, terms->d + batch * per2, in.tail2->d, 2 * per2 * 8), "matchLevel"); // retval: encrypt_zero, and the bias (.cpp:452-456)
+    } else {
+        chk(he355_mod_switch_drop(ctx, in.zero->L, L2, 2, in.zero->d, terms->d + batch * per2), "matchLevel");
+        chk(he355_mod_switch_drop(ctx, in.b->L, L2, 2, in.b->d, terms->d + (batch + 1) * per2), "matchLevel");
+    }
     std::shared_ptr<DeviceCiphers> lr = cw.allocResult(1, 2, L2, scale);
     chk(he355_sum(ctx, L2, 2, batch + 2, terms->d, lr->d), "add");
 
     // ---- evaluatePolynomial (seal_context.cpp:417-457), Horner: ((c3 x + c2) x + c1) x + c0 ----------------------------
-    std::shared_ptr<DeviceCiphers> x = lr, acc = in.coeff3;
+    std::shared_ptr<DeviceCiphers> x = lr, acc = in.coeff3_2 ? in.coeff3_2 : in.coeff3;
     const std::uint64_t coeffN = (std::uint64_t)in.coeff->L * N;
     for (int k = 2; k >= 0; --k) {
         const int lvl = std::min(x->L, acc->L); // matchLevel: the higher operand is switched down
@@ -306,8 +326,11 @@ AB::Handle LogRegHornerBenchmark::operate(AB::Handle h_remote_packed, const AB::
         acc = dropTo(acc, lvl);
         std::shared_ptr<DeviceCiphers> nxt = cw.allocResult(1, 2, lvl - 1, scale); // scale pinned to the coefficient's (:452)
         chk(he355_multiply_relin(ctx, lvl, 1, acc->d, x->d, pairwise, 1, nxt->d), "multiply+relinearize+rescale");
-        std::shared_ptr<DeviceCiphers> ck = cw.allocResult(1, 1, lvl - 1, scale);
-        chk(he355_mod_switch_drop(ctx, in.coeff->L, lvl - 1, 1, in.coeff->d + k * coeffN, ck->d), "mod_switch_to");
+        std::shared_ptr<DeviceCiphers> ck = in.coeff_at[k] && in.coeff_at[k]->L == lvl - 1 ? in.coeff_at[k] : nullptr;
+        if (!ck) {
+            ck = cw.allocResult(1, 1, lvl - 1, scale);
+            chk(he355_mod_switch_drop(ctx, in.coeff->L, lvl - 1, 1, in.coeff->d + k * coeffN, ck->d), "mod_switch_to");
+        }
         chk(he355_add_plain(ctx, lvl - 1, 2, 1, nxt->d, ck->d, pairwise, nxt->d), "add_plain");
         // the temporaries of this step go back to the pool: reuse is stream-ordered, no synchronisation needed
         acc = nxt;

@@ -53,6 +53,10 @@ private:
         std::shared_ptr<DeviceCiphers> zero;     // Enc(0), top level (collapseCKKS's encrypt_zero)
         std::shared_ptr<DeviceCiphers> coeff;    // [4] sigmoid coefficients, plaintexts, top level
         std::shared_ptr<DeviceCiphers> coeff3;   // Enc(coeff[3]), top level (evaluatePolynomial's first encrypt)
+        // The same constants at the levels operate() meets them at (mod_switch_to / matchLevel of a constant drops residues: a function
+        // of the parameters alone, prepared at load() like the constants themselves): identity at L-1, Enc(0) / bias / Enc(coeff[3]) at
+        // L-2, coeff[k] at L-5+k (the level of Horner step k's product after its rescale)
+        std::shared_ptr<DeviceCiphers> identity1, tail2 /* {Enc(0), bias} side by side at L-2 */, coeff3_2, coeff_at[3];
     };
     static const hebench::APIBridge::DataPack &findDataPack(const hebench::APIBridge::DataPackCollection &c, std::uint64_t pos);
     std::shared_ptr<DeviceCiphers> uploadPlains(const std::vector<Plain> &p);

@@ -537,6 +537,10 @@ public:
         // this chunk) and is taken from there by the fused k_k3 instead of being written into c01 by k_k1
         int c1_mode = 0;
         const u64 *c1_src = nullptr;
+        // c1_mode 4: the rotation's input and its permutation (K3Fuse::gsrc): k_k3 gathers the permuted c0 and c1 itself
+        const u64 *gsrc = nullptr;
+        const uint32_t *gperm = nullptr;
+        u64 gsrc_op_offset = 0;
     };
     // true when key_switch_tail will take a fused path for this batch, i.e. when k_k3's epilogue is where c0, c1 are consumed
     // The fused mod-down runs the special prime's tiles as a launch of their own, ahead of the data primes' (their epilogue needs its
@@ -561,7 +565,7 @@ public:
             throw std::logic_error("key_switch_tail: grouped keys are for plain rotations into a ciphertext slab");
         const bool lat = !groups && latency_shape_env(env_, nc); // (a grouped launch always takes the throughput shape)
         auto with_operands = [&](K3Fuse f) {
-            if (ten) { f.ta = ten->a; f.tb = ten->b; f.tix = ten->ix; f.t_op_offset = ten->op_offset; f.c1_mode = ten->c1_mode; f.c1_src = ten->c1_src; }
+            if (ten) { f.ta = ten->a; f.tb = ten->b; f.tix = ten->ix; f.t_op_offset = ten->op_offset; f.c1_mode = ten->c1_mode; f.c1_src = ten->c1_src; f.gsrc = ten->gsrc; f.gperm = ten->gperm; f.gsrc_op_offset = ten->gsrc_op_offset; }
             return f;
         };
         const size_t N = P.N, LN = (size_t)L * N;
@@ -878,9 +882,15 @@ public:
             // from where it is (the addend may be `out`: the wave that reads a row is the one that writes it, afterwards)
             const bool c1_in_k3 = tensor_in_k3(env, L, nc, B);
             TensorOperands ten;
-            ten.c1_mode = addend ? 2 : 1;
+            ten.c1_mode = addend ? 2 : 4; // (4: k_k3 gathers the permuted c0 from `in` itself -- k_k1 writes two rows instead of three)
             ten.c1_src = addend ? addend + off * 2 * LN : nullptr;
+            ten.gsrc = in; ten.gperm = pm; ten.gsrc_op_offset = off;
+#if defined(HE355_NO_C0_GATHER) // A/B builds only (make VARIANT=...): k_k1 writes the permuted c0 as before round 5
+            if (!addend) ten.c1_mode = 1;
             launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend, false, c1_in_k3);
+#else
+            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend, false, c1_in_k3, nullptr, c1_in_k3 && !addend);
+#endif
             key_switch_tail(env, L, nc, S, B, key, false, nullptr, nullptr, c1_in_k3 ? &ten : nullptr);
         }
         HIPCHECK(hipGetLastError());
@@ -1063,9 +1073,15 @@ public:
             KsBuffers B = S.ks;
             B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
             TensorOperands ten;
-            ten.c1_mode = 1; // polynomial 1 of the rotated ciphertext is zero: the fused k_k3 starts it from there ...
+            ten.c1_mode = 4; // polynomial 1 of the rotated ciphertext is zero: the fused k_k3 starts it from there, and gathers the permuted c0 from `in` ...
+            ten.gsrc = in; ten.gsrc_op_offset = 0; // (grouped: the op's group names its source block; g_op_offset carries the chunk offset)
             const bool fused = fuse_pays(env, nc); // ... (small grids take the unfused sequence: k_k1 writes the zero polynomial, k_floor_rows adds into it)
+#if defined(HE355_NO_C0_GATHER)
+            ten.c1_mode = 1;
             launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, nullptr, B, nullptr, false, fused, &groups);
+#else
+            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, nullptr, B, nullptr, false, fused, &groups, fused);
+#endif
             key_switch_tail(env, L, nc, S, B, nullptr, false, nullptr, nullptr, fused ? &ten : nullptr, &groups, off);
         }
     }

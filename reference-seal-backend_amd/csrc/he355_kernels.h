@@ -92,8 +92,18 @@ struct K3Fuse {
     // rotations: polynomial 1 of the ciphertext the switched key part is added into is zero, or polynomial 1 of the rotation's addend --
     // k_k1 neither writes nor copies it.  c1_mode 0: read from c01 (as polynomial 0 always is); 1: zero; 2: row of c1_src [n_ops][2][L][N];
     // 3 (relinearize of size-3 ciphertexts): polynomials 0 AND 1, and the NTT-form own digit, are rows of c1_src [n_ops][3][L][N], the input
+    // 4 (a rotation without addend, round 5): polynomial 1 is zero, and polynomial 0 -- the Galois-permuted c0 -- is GATHERED by k_k3's
+    // epilogue from the rotation's input (gsrc [.][2][L][N], op reads ciphertext gsrc_op_offset + op through the NTT-domain permutation
+    // gperm; grouped launches take both from the op's group) behind the correction row's transform: k_k1 does not write it (no_c0n).
+    // A row of the permuted polynomial is a permutation of ONE row of the source (the low bits of the evaluation point's exponent
+    // depend on the row alone), so the gather touches the 8 KiB it needs and no more.  (The own digit -- the permuted c1 in NTT form --
+    // stays a row k_k1 writes: gathered here it sat in front of the first products with two dependent loads, and pulled through the
+    // landing buffer it delayed the first digit row; both measured slower than the row they saved, profiles/r05_rotation_gather.txt.)
     int c1_mode = 0;
     const u64 *c1_src = nullptr;
+    const u64 *gsrc = nullptr;
+    const uint32_t *gperm = nullptr;
+    u64 gsrc_op_offset = 0;
 };
 // HE355_K3_FUSE: "0" = the unfused sequence everywhere (k_floor_rows finishes the mod-down); unset / "1" = fused where it pays, with the
 // small-grid rules (both engines in one launch, four-wave u64-engine blocks, unfused below a minimum of special-prime blocks); "all" =

@@ -598,6 +598,7 @@ struct K1Args {
     u64 n_ops, op_offset;
     int L, logn1, mode;
     int no_c1;                 // K1_GALOIS: polynomial 1 of c01 (zeros / the addend's) is left to the fused k_k3 (K3Fuse::c1_mode)
+    int no_c0n;                // K1_GALOIS, no addend: the permuted c0 is not written either (the fused k_k3 gathers it from the input: c1_mode 4)
     int n_i;                   // residues handled by this launch (one arithmetic engine per launch)
     unsigned char i_list[64];
     KsGroups groups;           // K1_GALOIS, grouped launch (group_size > 0): op's source ciphertext and permutation table come from its group
@@ -668,7 +669,7 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
 #pragma unroll
         for (int r2 = 0; r2 < kRowE; ++r2) {
             const uint32_t src = pm[elemC(lane, r2)];
-            v0[r2] = p0[src];
+            v0[r2] = A.no_c0n ? 0 : p0[src];
             v2[r2] = p0[P1 + src];
             v1[r2] = 0;
             x[r2] = ar.from_canon(v2[r2]);
@@ -682,7 +683,7 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
             for (int r2 = 0; r2 < kRowE; ++r2) v0[r2] = addmod(v0[r2], a0[r2], P.q);
         }
         if (valid) {
-            store_rowC(c0p, lane, v0);
+            if (!A.no_c0n) store_rowC(c0p, lane, v0);
             if (!A.no_c1) store_rowC(c1p, lane, v1);
             store_rowC(c2np, lane, v2);
         }
@@ -828,9 +829,15 @@ __device__ __forceinline__ void store_pattern_rows_wide(__amdgpu_buffer_rsrc_t d
 #pragma unroll
     for (int k = 0; k < N1 / 4; ++k) // 4 rows x 256 bytes per instruction
         __builtin_amdgcn_raw_buffer_store_b128(vl[k], dst, (int)lane_lo, k * 4 * (int)kSlotBytes, 0);
+#if defined(HE355_ROW5_PROBE) // TIMING PROBE ONLY (wrong results): the high plane as if it were 8 bits per element -- 5-byte rows
+#pragma unroll
+    for (int k = 0; k < N1 / 16; ++k)
+        __builtin_amdgcn_raw_buffer_store_b128(vh[k], dst, (int)lane_hi, k * 8 * (int)kSlotBytes, 0);
+#else
 #pragma unroll
     for (int k = 0; k < N1 / 8; ++k) // 8 rows x 128 bytes per instruction
         __builtin_amdgcn_raw_buffer_store_b128(vh[k], dst, (int)lane_hi, k * 8 * (int)kSlotBytes, 0);
+#endif
     HE_WAVE_SYNC(); // the tile is free again for the next target
 }
 // worst-case magnitude after the forward column pass of the fp64 engine from inputs |x| < m0 (ArF64::bfly_fwd: m -> m + q (1/2 + m 2^-51))
@@ -1121,6 +1128,7 @@ struct K3Args {
     const FloorConst *fc;          // FUSE: floor constants [K][K]
     const u64 *cols2; u64 *out2;   // FUSE + rescale: second correction slab [n_ops*2][L-1][N] and the final output [n_ops][2][L-1][N]
     int c1_mode; const u64 *c1_src; // FUSE, rotations: the floor step's addend of polynomial 1 is zero (1) / a row of c1_src (2) instead of a c01 row (0)
+    const u64 *gsrc; const uint32_t *gperm; u64 gsrc_op_offset; // c1_mode 4: the rotation's input, gathered here (K3Fuse::gsrc)
     const u64 *ta, *tb; Indexer tix; u64 t_op_offset; // FUSE, ct x ct multiply: the floor step's addend is a0 b0 / a0 b1 + a1 b0 of these operands (K3Fuse::ta); ta null: read from c01
     KsGroups groups; u64 g_op_offset; u64 keyq_offset; // GROUPED: op (g_op_offset + op) takes its key from groups.key[group]; its quotients follow at keyq_offset
     const u64 *keyq;   // Shoup quotients of the key residues under the u64-engine primes: [L_top][2][n_q][N]
@@ -2186,10 +2194,21 @@ static bool dual_engine_launches()
     static const bool off = getenv("HE355_DUAL_ENGINE") && getenv("HE355_DUAL_ENGINE")[0] == '0';
     return !off;
 }
-// ... also for small grids of the throughput shape: up to this many blocks for both engines together (four per CU; profiles/r04_dual_engine_latency.txt)
-static unsigned dual_max_blocks() { return k3_fuse_policy() == 2 ? 0u : 1024u; }
+// ... also for small grids of the throughput shape: up to this many blocks for both engines together (profiles/r04_dual_engine_latency.txt)
+#if defined(HE355_DUAL_MAX_ENV) // sweep builds only (make VARIANT=...): the threshold from the environment
+static unsigned dual_max_blocks()
+{
+    static const unsigned v = getenv("HE355_DUAL_MAX_BLOCKS") ? (unsigned)atoi(getenv("HE355_DUAL_MAX_BLOCKS")) : 4096u;
+    return k3_fuse_policy() == 2 ? 0u : v;
+}
+#else
+// (4096 since round 5: with the fold form of the u64 engine its blocks are no longer 2.5 times as long as the fp64 engine's, and grids of
+// a few thousand blocks gain from the shared launch too -- LogReg offline 5.72 -> 5.38 ms, the other descriptors unchanged within noise:
+// profiles/r05_dual_threshold_sweep.txt)
+static unsigned dual_max_blocks() { return k3_fuse_policy() == 2 ? 0u : 4096u; }
+#endif
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
-               const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1, const KsGroups *groups)
+               const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1, const KsGroups *groups, bool no_c0n)
 {
     if (!n_ops) return;
     if (groups && (mode != K1_GALOIS || addend)) throw std::runtime_error("grouped launch: rotations without addend only");
@@ -2197,6 +2216,8 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
     if (no_c1 && mode != K1_GALOIS && mode != K1_CT3) throw std::runtime_error("no_c1: rotations and size-3 inputs only");
     K1Args A;
     A.no_c1 = no_c1 ? 1 : 0;
+    if (no_c0n && (mode != K1_GALOIS || addend || !no_c1)) throw std::runtime_error("no_c0n: rotations without addend whose polynomial 1 is left to k_k3 only");
+    A.no_c0n = no_c0n ? 1 : 0;
     A.groups = groups ? *groups : KsGroups{};
     A.a = a; A.b = b; A.ix = ix; A.perm = perm; A.addend = addend;
     A.c01 = buf.c01; A.c01_item_stride = buf.c01_item_stride; A.c2n = buf.c2n; A.c2r = buf.c2r;
@@ -2316,6 +2337,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.cols = fuse ? fuse->cols : nullptr; A.c01 = fuse ? fuse->c01 : nullptr; A.c01_item_stride = fuse ? fuse->c01_item_stride : 0;
         A.cols2 = fuse ? fuse->cols2 : nullptr; A.out2 = fuse ? fuse->out : nullptr;
         A.c1_mode = fuse ? fuse->c1_mode : 0; A.c1_src = fuse ? fuse->c1_src : nullptr;
+        A.gsrc = fuse ? fuse->gsrc : nullptr; A.gperm = fuse ? fuse->gperm : nullptr; A.gsrc_op_offset = fuse ? fuse->gsrc_op_offset : 0;
+        if (A.c1_mode == 4 && (!A.gsrc || (!groups && !A.gperm))) throw std::runtime_error("gathered rotation: the input slab and its permutation are needed");
         A.ta = fuse ? fuse->ta : nullptr; A.tb = fuse ? fuse->tb : nullptr; A.tix = fuse ? fuse->tix : Indexer{}; A.t_op_offset = fuse ? fuse->t_op_offset : 0;
         if (fuse && fuse->cols2 && fuse->tt_hi > L - 1) throw std::runtime_error("fused rescale: only primes below the one divided out");
         A.fc = env.floor_consts;

@@ -368,6 +368,30 @@ template <class Ar, bool LAST, class TW> HE_HD void row_inv_A(const Ar &ar, type
 template <class Ar, int LOGN1, class TW> HE_HD void col_fwd(const Ar &ar, typename Ar::T x[1 << LOGN1], TW tw)
 {
     constexpr int N1 = 1 << LOGN1;
+    if constexpr (Ar::kFold) {
+        // Fold build of the u64 engine: the wide lazy butterfly (no conditional subtraction, the five-multiplier product; a stage adds at
+        // most 3q).  In below 4q: four stages reach 16q <= 2^64 - 16c, so a fifth stage is preceded by lazy_reduce (three instructions
+        // per element); one more lazy_reduce leaves every output below 2q + 16c -- inside the [0, 4q) every consumer of a column pass reads.
+#pragma unroll
+        for (int s = 0; s < LOGN1; ++s) {
+            if (s == 4) {
+#pragma unroll
+                for (int a = 0; a < N1; ++a) x[a] = ar.lazy_reduce(x[a]);
+            }
+            const int gap = N1 >> (s + 1);
+#pragma unroll
+            for (int a = 0; a < N1; ++a) {
+                if (a & gap) continue;
+                const Tw16 w = tw_load(tw, (u32)((1 << s) + (a / (2 * gap))));
+                ar.bfly_fwd_lazy(x[a], x[a + gap], w);
+            }
+        }
+        if (LOGN1 > 0) {
+#pragma unroll
+            for (int a = 0; a < N1; ++a) x[a] = ar.lazy_reduce(x[a]);
+        }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < LOGN1; ++s) {
         const int gap = N1 >> (s + 1);

@@ -214,6 +214,21 @@ template <class Ar> static void inv_any(const Ar &ar, const Params &P, const Pri
     std::memcpy(poly, out.data(), P.N * 8);
 }
 
+// the forward column pass of prime i on a column whose every element is `value` (any lazy input below 4q): no sum leaves 64 bits, every
+// output is below 4q, and the residues equal those of the same column entered canonically.  0: ok.
+template <int LOGN1> static int col_extreme(const ArU64 &ar, const PrimeTables &pt, u64 value)
+{
+    constexpr int N1 = 1 << LOGN1;
+    u64 x[N1], y[N1];
+    for (int a = 0; a < N1; ++a) { x[a] = value; y[a] = value % pt.q; }
+    he355_sim_overflow = 0;
+    col_fwd<ArU64, LOGN1>(ar, x, pt.fwd.data());
+    col_fwd<ArU64, LOGN1>(ar, y, pt.fwd.data());
+    if (he355_sim_overflow) return 1;
+    for (int a = 0; a < N1; ++a)
+        if (x[a] >= 4 * pt.q || ar.to_canon(x[a]) != ar.to_canon(y[a])) return 1;
+    return 0;
+}
 extern "C" {
 void *sim_params_create(int scheme, size_t N, const int *bits, size_t n, int plain_bits, int sec128)
 {
@@ -287,6 +302,21 @@ void sim_ntt_inverse(void *p, size_t i, uint64_t *poly)
     const PrimeTables &pt = P.primes[i];
     if (pt.f64) inv_any(pt.arf(), P, pt, poly);
     else inv_any(pt.aru(), P, pt, poly);
+}
+int sim_col_pass_extreme(void *p, size_t i, uint64_t value)
+{
+    const Params &P = *(Params *)p;
+    const PrimeTables &pt = P.primes[i];
+    if (pt.f64) return 0;
+    const ArU64 ar = pt.aru();
+    switch (P.logn1) {
+    case 1: return col_extreme<1>(ar, pt, value);
+    case 2: return col_extreme<2>(ar, pt, value);
+    case 3: return col_extreme<3>(ar, pt, value);
+    case 4: return col_extreme<4>(ar, pt, value);
+    case 5: return col_extreme<5>(ar, pt, value);
+    default: return 0;
+    }
 }
 uint32_t sim_galois_elt(void *p, int step) { return ((Params *)p)->galois_elt_from_step(step); }
 size_t sim_galois_elts_all(void *p, uint32_t *out)

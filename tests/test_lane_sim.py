@@ -126,6 +126,7 @@ def test_fold_form_at_the_ends_of_its_range(sim, oracle, N):
     sim.sim_params_create_primes.restype = C.c_void_p
     sim.sim_params_create_primes.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint64]
     sim.sim_row_pass_extreme.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+    sim.sim_col_pass_extreme.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
     big_c = _ntt_primes(N, 2 ** 60 - 2 ** 26 + 1, 2 ** 60 - 2 ** 26 + 2 ** 24, 2)
     small_c = _ntt_primes(N, 2 ** 59, 2 ** 60, 2)
     primes = big_c + small_c
@@ -139,6 +140,7 @@ def test_fold_form_at_the_ends_of_its_range(sim, oracle, N):
         for i, q in enumerate(primes):
             for value in (4 * q - 1, 2 * q, q - 1, 0):
                 assert sim.sim_row_pass_extreme(h, i, value) == 0, (hex(q), value)
+                assert sim.sim_col_pass_extreme(h, i, value) == 0, (hex(q), value)
             a = rng.integers(0, q, N, dtype=np.uint64)
             f = a.copy()
             sim.sim_ntt_forward(h, i, oracle._p(f))
