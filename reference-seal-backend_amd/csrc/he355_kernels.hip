@@ -2195,17 +2195,23 @@ static bool dual_engine_launches()
     return !off;
 }
 // ... also for small grids of the throughput shape: up to this many blocks for both engines together (profiles/r04_dual_engine_latency.txt)
-#if defined(HE355_DUAL_MAX_ENV) // sweep builds only (make VARIANT=...): the threshold from the environment
-static unsigned dual_max_blocks()
+// (round 5: per kernel.  k_k3's shared launch pays up to a few thousand blocks since the fold form of the u64 engine brought its blocks
+// close to the fp64 engine's in length; the others -- whose dual kernels are the latency shape's, behind a function boundary -- keep
+// the 1024 they were swept at.  profiles/r05_dual_threshold_sweep.txt)
+#if defined(HE355_DUAL_MAX_ENV) // sweep builds only (make VARIANT=...): the thresholds from the environment
+static unsigned dual_max_blocks_k3()
 {
     static const unsigned v = getenv("HE355_DUAL_MAX_BLOCKS") ? (unsigned)atoi(getenv("HE355_DUAL_MAX_BLOCKS")) : 4096u;
     return k3_fuse_policy() == 2 ? 0u : v;
 }
+static unsigned dual_max_blocks()
+{
+    static const unsigned v = getenv("HE355_DUAL_MAX_OTHER") ? (unsigned)atoi(getenv("HE355_DUAL_MAX_OTHER")) : 1024u;
+    return k3_fuse_policy() == 2 ? 0u : v;
+}
 #else
-// (4096 since round 5: with the fold form of the u64 engine its blocks are no longer 2.5 times as long as the fp64 engine's, and grids of
-// a few thousand blocks gain from the shared launch too -- LogReg offline 5.72 -> 5.38 ms, the other descriptors unchanged within noise:
-// profiles/r05_dual_threshold_sweep.txt)
-static unsigned dual_max_blocks() { return k3_fuse_policy() == 2 ? 0u : 4096u; }
+static unsigned dual_max_blocks_k3() { return k3_fuse_policy() == 2 ? 0u : 4096u; }
+static unsigned dual_max_blocks() { return k3_fuse_policy() == 2 ? 0u : 1024u; }
 #endif
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
                const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1, const KsGroups *groups, bool no_c0n)
@@ -2413,7 +2419,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         return;
     }
     // throughput shape, small grids (up to two blocks per CU for both engines together): both engines in one launch
-    if (n_pend == 2 && pend[0].waves == 8 && pend[0].g + pend[1].g <= dual_max_blocks() && dual_engine_launches()) {
+    if (n_pend == 2 && pend[0].waves == 8 && pend[0].g + pend[1].g <= dual_max_blocks_k3() && dual_engine_launches()) {
         const dim3 gd(pend[0].g + pend[1].g);
 #define HE355_K3D8(F, T, G)                                                                                                                     \
     do {                                                                                                                                        \

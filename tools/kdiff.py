@@ -11,7 +11,7 @@ def load(d):
     f = max(glob.glob(d + '/**/*kernel_stats.csv', recursive=True), key=os.path.getmtime)
     out = {}
     for r in csv.DictReader(open(f)):
-        n = r['Name'].replace('he355::(anonymous namespace)::', '').replace('he355::', '').split('(')[0]
+        n = r['Name'].replace('(anonymous namespace)::', '').replace('he355::', '').replace('ks_fold::', 'F:').replace('ks_shoup::', 'S:').replace('void ', '').split('(')[0]
         c, t = out.get(n, (0, 0.0))
         out[n] = (c + int(r['Calls']), t + float(r['TotalDurationNs']))
     return out
