@@ -209,6 +209,7 @@ __device__ __forceinline__ void wave_rows_inv(const Ar &ar, const PrimeDev &P, b
     T *lds = reinterpret_cast<T *>(lds_w);
     const auto itw = tw_table(gtw(P.inv), rowbase);
     row_inv_C(ar, x, itw, lane);
+#if defined(HE355_NO_INV_PREFETCH) // A/B builds only: every phase loads its twiddles after the exchange, as before round 5
     lds_store_C(lds, lane, x);
     HE_WAVE_SYNC();
     lds_load_B(lds, lane, x);
@@ -220,6 +221,27 @@ __device__ __forceinline__ void wave_rows_inv(const Ar &ar, const PrimeDev &P, b
     HE_WAVE_SYNC();
     if (last) row_inv_A<Ar, true>(ar, x, itw, P.inv_w0_scaled);
     else row_inv_A<Ar, false>(ar, x, itw, P.inv_w0_scaled);
+    return;
+#endif
+    // the twiddles of the next phase are requested before the exchange that precedes it (round 5; the forward pass always did): they land
+    // while the exchange round-trips through LDS instead of behind it -- phase A's are lane-uniform, scalar loads
+    Tw16 wb[kTwInvB];
+    gather_inv_B(itw, lane, wb);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_store_C(lds, lane, x);
+    HE_WAVE_SYNC();
+    lds_load_B(lds, lane, x);
+    HE_WAVE_SYNC();
+    row_inv_B_w(ar, x, wb);
+    Tw16 wa[kTwInvA];
+    gather_inv_A(tw_table(ctw(P.inv), rowbase), wa);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_store_B(lds, lane, x);
+    HE_WAVE_SYNC();
+    lds_load_A(lds, lane, x);
+    HE_WAVE_SYNC();
+    if (last) row_inv_A_w<Ar, true>(ar, x, wa, P.inv_w0_scaled);
+    else row_inv_A_w<Ar, false>(ar, x, wa, P.inv_w0_scaled);
 }
 
 // =======================================================================================================

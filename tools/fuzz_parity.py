@@ -71,6 +71,8 @@ def main():
             N = int(rng.choice([1024, 2048, 4096, 8192, 16384], p=[0.25, 0.25, 0.2, 0.15, 0.15]))
             K = int(rng.integers(2, 6))
             bits = [int(x) for x in rng.integers(35, 61, K)]
+            if rng.random() < 0.5:  # the reference's shape {60, small ..., 60}: every u64-engine prime is 2^60 - c, the context takes the fold build
+                bits = [60 if (i in (0, K - 1) or rng.random() < 0.2) else int(rng.integers(35, 47)) for i in range(K)]
             pb = int(rng.integers(16, 23))
             seal_base = bool(rng.random() < 0.2)  # SEAL's 61-bit auxiliary base instead of the device's 46-bit one (same bits out)
             if seal_base:
@@ -148,6 +150,8 @@ def main():
         N = int(rng.choice([1024, 2048, 4096, 8192, 16384], p=[0.3, 0.25, 0.2, 0.15, 0.1]))
         n_data = int(rng.integers(1, 6 if N <= 4096 else 4))
         bits = [int(rng.choice([36, 40, 44, 45, 46, 47, 50, 52, 55, 60])) for _ in range(n_data)]
+        if rng.random() < 0.5:  # fold build of the u64 engine: only 60-bit primes above 2^47 (the reference's {60, b ..., 60})
+            bits = [int(rng.choice([36, 40, 44, 45, 46, 60], p=[0.15, 0.2, 0.1, 0.2, 0.1, 0.25])) for _ in range(n_data)]
         bits.append(int(rng.choice([45, 47, 50, 58, 60])))  # the special prime
         force = bool(rng.random() < 0.15)
         if force:
