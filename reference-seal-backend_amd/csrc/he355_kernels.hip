@@ -202,6 +202,33 @@ __device__ __forceinline__ void wave_rows_fwd(const Ar &ar, const TW &tw, int la
 {
     wave_rows_fwd_n(ar, tw, lane, lds_w, reinterpret_cast<typename Ar::T(*)[kRowE]>(x));
 }
+// The inverse row pass on a row-local copy of the row's inverse twiddles (TwRow / TwRowF64, staged in LDS by the block: k_k1's
+// throughput shape, where the four waves of a block work on the same (prime, row) of four ciphertexts): every phase's twiddles are
+// LDS reads of this wave's own block instead of 46 scattered 16-byte loads per lane from the 512 KiB table in L2.
+template <class Ar, class TW>
+__device__ __forceinline__ void wave_rows_inv_tw(const Ar &ar, const TW &itw, const Tw16 &w0_scaled, bool last, int lane, u64 *lds_w, typename Ar::T x[kRowE])
+{
+    typedef typename Ar::T T;
+    T *lds = reinterpret_cast<T *>(lds_w);
+    row_inv_C(ar, x, itw, lane);
+    Tw16 wb[kTwInvB];
+    gather_inv_B(itw, lane, wb);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_store_C(lds, lane, x);
+    HE_WAVE_SYNC();
+    lds_load_B(lds, lane, x);
+    HE_WAVE_SYNC();
+    row_inv_B_w(ar, x, wb);
+    Tw16 wa[kTwInvA];
+    gather_inv_A(itw, wa);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_store_B(lds, lane, x);
+    HE_WAVE_SYNC();
+    lds_load_A(lds, lane, x);
+    HE_WAVE_SYNC();
+    if (last) row_inv_A_w<Ar, true>(ar, x, wa, w0_scaled);
+    else row_inv_A_w<Ar, false>(ar, x, wa, w0_scaled);
+}
 template <class Ar>
 __device__ __forceinline__ void wave_rows_inv(const Ar &ar, const PrimeDev &P, bool last, u32 rowbase, int lane, u64 *lds_w, typename Ar::T x[kRowE])
 {
@@ -606,6 +633,40 @@ __global__ void __launch_bounds__(kBlock) k_mul3_acc(const u64 *a, const u64 *b,
     reinterpret_cast<ulonglong2 *>(po + 2 * P1)[e2] = s2;
 }
 
+// Stage the 1023 forward twiddles of row `rowbase` of prime P in LDS (one copy per block): every wave, digit and op
+// of a (prime, row) tile reads them from there (ds_read, lane-dependent index) instead of L2.  fp64 engine: w only.
+// The caller synchronises the block before the first use.
+template <class Ar, int BLOCK>
+__device__ __forceinline__ typename std::conditional<std::is_same<Ar, ArF64>::value, TwRowF64, TwRow>::type
+stage_row_twiddles(const PrimeDev &P, const Ar &ar, u32 rowbase, unsigned char *twl_raw, bool inverse = false)
+{
+    constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
+    typename std::conditional<kF64, TwRowF64, TwRow>::type twr;
+    const gtw_t gf = gtw(inverse ? P.inv : P.fwd); // (the two tables share their indexing: entry (rowbase << s) + g of stage s)
+    constexpr int kIter = (kRowTw + BLOCK - 1) / BLOCK;
+    Tw16 tmp[kIter];
+#pragma unroll
+    for (int k = 0; k < kIter; ++k) { // all loads in flight together
+        const u32 i = threadIdx.x + k * BLOCK;
+        tmp[k] = tw_load(gf, tw_row_source(rowbase, i + 1 < (u32)kRowTw ? i : 0));
+    }
+    if constexpr (kF64) {
+        double *twl = reinterpret_cast<double *>(twl_raw);
+#pragma unroll
+        for (int k = 0; k < kIter; ++k)
+            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[threadIdx.x + k * BLOCK] = ArF64::tw_w(tmp[k]);
+        twr.t = twl;
+        twr.qinv = ar.qinv;
+    } else {
+        Tw16 *twl = reinterpret_cast<Tw16 *>(twl_raw);
+#pragma unroll
+        for (int k = 0; k < kIter; ++k)
+            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[threadIdx.x + k * BLOCK] = tmp[k];
+        twr.t = twl;
+    }
+    return twr;
+}
+
 // =======================================================================================================
 // K1: (multiply | take ct3 | Galois-permute) + inverse row pass of the key-switch target
 // =======================================================================================================
@@ -626,8 +687,8 @@ struct K1Args {
     KsGroups groups;           // K1_GALOIS, grouped launch (group_size > 0): op's source ciphertext and permutation table come from its group
 };
 
-template <class Ar, int MODE>
-__device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 op, int i, u32 a_row, int lane, u64 *lds, bool valid)
+template <class Ar, int MODE, class ITW = int>
+__device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 op, int i, u32 a_row, int lane, u64 *lds, bool valid, const ITW *staged = nullptr)
 {
     typedef typename Ar::T T;
     const Ar ar = make_ar(P, (Ar *)nullptr);
@@ -711,27 +772,54 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
         }
     }
     const bool last = A.logn1 == 0;
-    wave_rows_inv(ar, P, last, n1 + a_row, lane, lds, x);
+    if constexpr (std::is_same<ITW, int>::value) wave_rows_inv(ar, P, last, n1 + a_row, lane, lds, x);
+    else wave_rows_inv_tw(ar, *staged, P.inv_w0_scaled, last, lane, lds, x); // the row's inverse twiddles, staged in LDS by the block
 #pragma unroll
     for (int r2 = 0; r2 < kRowE; ++r2) v0[r2] = last ? ar.to_canon(x[r2]) : ar.to_raw(x[r2]);
     if (valid) store_rowA(c2rp, lane, v0);
 }
 
+// Throughput shape (round 5): a block's four waves take the SAME (residue, row) of four consecutive ciphertexts, so the block stages that
+// row's 1023 inverse twiddles in LDS once (8 KiB as doubles for the fp64 engine, 16 KiB for the u64 engine) and every phase of the
+// four inverse row passes reads them from there -- before, each wave fetched its 46 entries per lane from the prime's 512 KiB table
+// in L2, twice the bytes of the row it transformed, with the latency in front of every phase.  Blocks of one tile are consecutive
+// (the tile's twiddle rows and, for rotations, its permutation rows stay in L2).  Grid: n_i * n1 * ceil(n_ops / 4).
 template <int MODE, class Ar>
 __global__ void __launch_bounds__(kBlock) k_k1(K1Args A, const PrimeDev *primes)
 {
     __shared__ u64 lds[kWaves][kLdsRow];
+#if defined(HE355_K1_UNSTAGED) // A/B builds only: one (op, residue, row) job per wave in job order, twiddles from the table in L2 (rounds 1-4)
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const u32 n1 = 1u << A.logn1;
+        const u64 total = A.n_ops * A.n_i * n1;
+        u64 job = (u64)blockIdx.x * kWaves + wave;
+        const bool valid = job < total;
+        if (!valid) job = total - 1;
+        const u32 a_row = (u32)(job & (n1 - 1));
+        const u64 oi = job >> A.logn1;
+        const int i = A.i_list[oi % A.n_i];
+        const u64 op = oi / A.n_i;
+        k1_job<Ar, MODE>(A, primes[i], op, i, a_row, lane, lds[wave], valid);
+        return;
+    }
+#endif
+    constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
+    __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 n1 = 1u << A.logn1;
-    const u64 total = A.n_ops * A.n_i * n1;
-    u64 job = (u64)blockIdx.x * kWaves + wave;
-    const bool valid = job < total;
-    if (!valid) job = total - 1;
-    const u32 a_row = (u32)(job & (n1 - 1));
-    const u64 oi = job >> A.logn1;
-    const int i = A.i_list[oi % A.n_i];
-    const u64 op = oi / A.n_i;
-    k1_job<Ar, MODE>(A, primes[i], op, i, a_row, lane, lds[wave], valid);
+    const u64 n_opg = (A.n_ops + kWaves - 1) / kWaves;
+    const u64 tile = blockIdx.x / n_opg, opg = blockIdx.x % n_opg; // (grid = tiles * n_opg exactly)
+    const u32 a_row = (u32)(tile & (n1 - 1));
+    const int i = A.i_list[tile >> A.logn1];
+    u64 op = opg * kWaves + wave;
+    const bool valid = op < A.n_ops;
+    if (!valid) op = A.n_ops - 1;
+    const PrimeDev &P = primes[i];
+    const Ar ar = make_ar(P, (Ar *)nullptr);
+    const auto itw = stage_row_twiddles<Ar, kBlock>(P, ar, n1 + a_row, twl_raw, true);
+    __syncthreads();
+    k1_job<Ar, MODE>(A, P, op, i, a_row, lane, lds[wave], valid, &itw);
 }
 // Latency shape: the fp64-engine residues (blocks 0 .. n_f - 1) and the u64-engine residues of one key switch in ONE launch (see k_k3_dual)
 template <int MODE, class Ar>
@@ -1109,40 +1197,6 @@ __global__ void __launch_bounds__(kBlock) k_k2n_dual(K2Args AN, K2Args AW, unsig
 // =======================================================================================================
 // K3: per (op, key prime tt, row): sum over digits j of NTT_tt(digit j) * key_j[k][tt]
 // =======================================================================================================
-// Stage the 1023 forward twiddles of row `rowbase` of prime P in LDS (one copy per block): every wave, digit and op
-// of a (prime, row) tile reads them from there (ds_read, lane-dependent index) instead of L2.  fp64 engine: w only.
-// The caller synchronises the block before the first use.
-template <class Ar, int BLOCK>
-__device__ __forceinline__ typename std::conditional<std::is_same<Ar, ArF64>::value, TwRowF64, TwRow>::type
-stage_row_twiddles(const PrimeDev &P, const Ar &ar, u32 rowbase, unsigned char *twl_raw)
-{
-    constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
-    typename std::conditional<kF64, TwRowF64, TwRow>::type twr;
-    const gtw_t gf = gtw(P.fwd);
-    constexpr int kIter = (kRowTw + BLOCK - 1) / BLOCK;
-    Tw16 tmp[kIter];
-#pragma unroll
-    for (int k = 0; k < kIter; ++k) { // all loads in flight together
-        const u32 i = threadIdx.x + k * BLOCK;
-        tmp[k] = tw_load(gf, tw_row_source(rowbase, i + 1 < (u32)kRowTw ? i : 0));
-    }
-    if constexpr (kF64) {
-        double *twl = reinterpret_cast<double *>(twl_raw);
-#pragma unroll
-        for (int k = 0; k < kIter; ++k)
-            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[threadIdx.x + k * BLOCK] = ArF64::tw_w(tmp[k]);
-        twr.t = twl;
-        twr.qinv = ar.qinv;
-    } else {
-        Tw16 *twl = reinterpret_cast<Tw16 *>(twl_raw);
-#pragma unroll
-        for (int k = 0; k < kIter; ++k)
-            if (threadIdx.x + k * BLOCK < (u32)kRowTw) twl[threadIdx.x + k * BLOCK] = tmp[k];
-        twr.t = twl;
-    }
-    return twr;
-}
-
 struct K3Args {
     const u64 *d, *c2n, *key;
     const u64 *cols;   // FUSE: mod-down corrections after the forward column pass [n_ops*2][L][N] (raw of prime tt)
@@ -2259,6 +2313,7 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
         AP[pass] = A;
         gp[pass] = A.n_i ? grid_for((n_ops * A.n_i) << env.logn1, kWaves) : 0;
     }
+    // (k_k1 proper -- the throughput shape -- maps a block onto one (residue, row) tile and four consecutive ops: its own grid below)
     const hipStream_t st = env.stream;
     if (gp[0] && gp[1] && (n_ops <= 8 || gp[0] + gp[1] <= dual_max_blocks()) && mode != K1_MUL_C2 && !(mode == K1_MUL && no_c01) &&
         dual_engine_launches()) { // latency shape / small grids: one launch for both engines
@@ -2270,8 +2325,12 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
     }
     for (int pass = 0; pass < 2; ++pass) {
         if (!gp[pass]) continue;
-        const dim3 grid(gp[pass]);
         const K1Args &AA = AP[pass];
+#if defined(HE355_K1_UNSTAGED)
+        const dim3 grid(gp[pass]);
+#else
+        const dim3 grid((unsigned)((((u64)AA.n_i) << env.logn1) * ((n_ops + kWaves - 1) / kWaves)));
+#endif
         if (pass == 0) {
             if (mode == K1_MUL && no_c01) hipLaunchKernelGGL((k_k1<K1_MUL_C2, ArF64>), grid, dim3(kBlock), 0, st, AA, env.primes);
             else if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArF64>), grid, dim3(kBlock), 0, st, AA, env.primes);

@@ -1,12 +1,14 @@
 #!/bin/bash
-# same-box A/B: inverse row-pass twiddles requested before the exchange (product) vs after it (lib/alt_noprefetch.so)
+# same-box A/B: k_k1 tile-mapped with LDS-staged inverse twiddles (product) vs one job per wave, twiddles from L2 (lib/alt_k1flat.so)
 set -e
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r5m; mkdir -p $O
+O=gpurun_out/r5p; mkdir -p $O
 L=$PWD/reference-seal-backend_amd/lib
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_bfv.py tests/test_api_bridge_gpu.py tests/test_gpu_code_paths.py -m gpu -x -q > $O/pytest.log 2>&1 || { tail -30 $O/pytest.log; exit 1; }
+tail -2 $O/pytest.log
 for rep in 1 2 3; do
-for arm in prefetch noprefetch; do
-  if [ $arm = noprefetch ]; then export HE355_LIB_PATH=$L/alt_noprefetch.so; else unset HE355_LIB_PATH; fi
+for arm in k1staged k1flat; do
+  if [ $arm = k1flat ]; then export HE355_LIB_PATH=$L/alt_k1flat.so; else unset HE355_LIB_PATH; fi
   for cfg in bfv_matmul dot mul_relin_rescale; do
     timeout -k 10 300 python3 bench.py --config $cfg --steps 5 --warmup 1 --cpu-sample 0 --parity-sample 1 > $O/${cfg}_${arm}_$rep.json 2> $O/${cfg}_${arm}_$rep.err
     python3 -c "import json;j=json.load(open('$O/${cfg}_${arm}_$rep.json'));print('$cfg $arm $rep', j['ms_per_step'], j['parity']['checked_in_run'])"
