@@ -712,7 +712,7 @@ def main():
             "vs_baseline": round(value / cpu["value"], 2) if cpu and cpu.get("value") else None,
             "vs_baseline_note": ("value / cpu_baseline.value: the in-repo CPU port of the reference's algorithm timed in this run on this box's cores -- NOT a published "
                                  "number (BASELINE.md holds none; SEAL itself is unavailable offline)") if cpu and cpu.get("value") else None,
-            "dtype": "u64 (exact fp64-FMA engine for primes < 2^47, u64 Harvey/Shoup for the 60-bit primes)",
+            "dtype": "u64 (exact residues; fp64-FMA engine for primes < 2^47, u64 Harvey engine with the fold reduction for the 60-bit primes)",
             "data": "synthetic (uniform residues generated in HBM; synthetic evaluation keys; the same global batch at every world size)",
             "config": {"workload": wl.describe(), "poly_modulus_degree": W.N, "coeff_modulus_bits": bits,
                        "batch": (f"{global_b0} x {W.b1} results globally; scaling = {args.scaling}: "
