@@ -137,6 +137,8 @@ def test_oracle_build_is_locked_and_host_stamped(tmp_path):
     import subprocess
     import sys
     import oracle
+    if os.environ.get("HE_ORACLE_LIB_PATH"):
+        pytest.skip("HE_ORACLE_LIB_PATH names the library (tools/asan_oracle.sh): oracle.build() does not build")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sig = os.path.join(root, "oracle", "_build", "host.sig")
     oracle.build()
