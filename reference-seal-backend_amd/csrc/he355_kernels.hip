@@ -2481,6 +2481,12 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         // u64-engine tiles of a small grid (at most half the CUs busy with 8-wave blocks): FOUR waves per block -- one per SIMD, each at
         // the full issue rate instead of half of it, and twice the blocks; the serial digit loop of a tile is what such a launch lasts
         const unsigned four_max = k3_fuse_policy() == 2 ? 0u : 128u;
+#if defined(HE355_U64_FOUR_WAVES_ALWAYS) // A/B builds only: the u64 engine's tiles as four-wave blocks whatever the grid
+        if (pass == 1 && waves == 8) {
+            size_grid(4);
+            waves = 4;
+        } else
+#endif
         if (pass == 1 && waves == 8 && g <= four_max) {
             size_grid(4);
             // (a CU holds ONE block of either shape -- the LDS arrays -- so the four-wave blocks must still fit one round together with the
