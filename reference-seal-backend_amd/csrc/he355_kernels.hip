@@ -133,7 +133,13 @@ __device__ __forceinline__ void dma_row_to_lds(const u64 *grow, u64 *lds_row, in
     const u64 *g = grow + (lane << 1);
 #pragma unroll
     for (int k = 0; k < PIECES; ++k)
+#if defined(HE355_DMA_DEFAULT_POLICY) // A/B builds only: the default cache policy, as before round 5
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lbase + (u32)(k << 10)), "v"(g + (k << 7)) : "memory");
+#else
+        // non-temporal (round 5): a row is read once, by this wave -- served from L2 past the L1, which the block's eight waves share for the
+        // key rows of the digit step (headline -0.7 %, configs[3] / [4] -1 %: profiles/r05_small_ab.txt)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lbase + (u32)(k << 10)), "v"(g + (k << 7)) : "memory");
+#endif
 }
 __device__ __forceinline__ void lds_rowA(const u64 *lds_row, int lane, u64 v[kRowE])
 {
