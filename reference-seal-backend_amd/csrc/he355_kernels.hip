@@ -942,6 +942,9 @@ __device__ __forceinline__ void store_pattern_rows_wide(__amdgpu_buffer_rsrc_t d
 #pragma unroll
     for (int k = 0; k < N1 / 8; ++k) vh[k] = hi4[k * 64 + lane];
     __builtin_amdgcn_sched_barrier(0);
+#if defined(HE355_K2N_ABL_NOSTORE) // DIAGNOSTIC builds only (wrong results): everything but the store instructions themselves (the condition is true at run time)
+    if (__builtin_amdgcn_s_memtime() != 0) { HE_WAVE_SYNC(); return; } // (opaque to the compiler: nothing upstream is dead code)
+#endif
 #pragma unroll
     for (int k = 0; k < N1 / 4; ++k) // 4 rows x 256 bytes per instruction
         __builtin_amdgcn_raw_buffer_store_b128(vl[k], dst, (int)lane_lo, k * 4 * (int)kSlotBytes, 0);
