@@ -882,14 +882,19 @@ public:
             // from where it is (the addend may be `out`: the wave that reads a row is the one that writes it, afterwards)
             const bool c1_in_k3 = tensor_in_k3(env, L, nc, B);
             TensorOperands ten;
-            ten.c1_mode = addend ? 2 : 4; // (4: k_k3 gathers the permuted c0 from `in` itself -- k_k1 writes two rows instead of three)
+            // (4 / 5: k_k3's epilogue gathers the permuted c0 from `in` itself -- and adds the addend's polynomial 0 to it -- so k_k1 writes two
+            // rows instead of three and reads neither c0 nor the addend)
+            ten.c1_mode = addend ? 5 : 4;
             ten.c1_src = addend ? addend + off * 2 * LN : nullptr;
             ten.gsrc = in; ten.gperm = pm; ten.gsrc_op_offset = off;
-#if defined(HE355_NO_C0_GATHER) // A/B builds only (make VARIANT=...): k_k1 writes the permuted c0 as before round 5
-            if (!addend) ten.c1_mode = 1;
+#if defined(HE355_NO_C0_GATHER) // A/B builds only (make VARIANT=...): k_k1 writes the permuted c0 (+ addend0) as before round 5
+            ten.c1_mode = addend ? 2 : 1;
             launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend, false, c1_in_k3);
-#else
+#elif defined(HE355_NO_ADDEND_GATHER) // A/B builds only: the gather for rotations without addend only
+            if (addend) ten.c1_mode = 2;
             launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend, false, c1_in_k3, nullptr, c1_in_k3 && !addend);
+#else
+            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend, false, c1_in_k3, nullptr, c1_in_k3);
 #endif
             key_switch_tail(env, L, nc, S, B, key, false, nullptr, nullptr, c1_in_k3 ? &ten : nullptr);
         }

@@ -99,6 +99,8 @@ struct K3Fuse {
     // depend on the row alone), so the gather touches the 8 KiB it needs and no more.  (The own digit -- the permuted c1 in NTT form --
     // stays a row k_k1 writes: gathered here it sat in front of the first products with two dependent loads, and pulled through the
     // landing buffer it delayed the first digit row; both measured slower than the row they saved, profiles/r05_rotation_gather.txt.)
+    // 5: the same for a rotation WITH addend (he355_rotate_add, accumulate): polynomial 0 = the addend's polynomial 0 (row of c1_src) + the gathered
+    // permuted c0, polynomial 1 = the addend's (as mode 2); k_k1 reads neither c0 nor the addend and writes neither.
     int c1_mode = 0;
     const u64 *c1_src = nullptr;
     const u64 *gsrc = nullptr;

@@ -763,7 +763,7 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
             v1[r2] = 0;
             x[r2] = ar.from_canon(v2[r2]);
         }
-        if (A.addend) { // out = addend + rotate(in): the ciphertext the key-switched result is added into starts from the addend
+        if (A.addend && !A.no_c0n) { // out = addend + rotate(in): the ciphertext the key-switched result is added into starts from the addend
             const u64 *ad = A.addend + (A.op_offset + op) * 2 * P1 + roff;
             u64 a0[kRowE];
             load_rowC(ad, lane, a0);
@@ -2307,7 +2307,7 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
     if (no_c1 && mode != K1_GALOIS && mode != K1_CT3) throw std::runtime_error("no_c1: rotations and size-3 inputs only");
     K1Args A;
     A.no_c1 = no_c1 ? 1 : 0;
-    if (no_c0n && (mode != K1_GALOIS || addend || !no_c1)) throw std::runtime_error("no_c0n: rotations without addend whose polynomial 1 is left to k_k3 only");
+    if (no_c0n && (mode != K1_GALOIS || !no_c1 || (addend && groups))) throw std::runtime_error("no_c0n: rotations whose polynomial 1 is left to k_k3 only");
     A.no_c0n = no_c0n ? 1 : 0;
     A.groups = groups ? *groups : KsGroups{};
     A.a = a; A.b = b; A.ix = ix; A.perm = perm; A.addend = addend;
@@ -2434,7 +2434,8 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         A.cols2 = fuse ? fuse->cols2 : nullptr; A.out2 = fuse ? fuse->out : nullptr;
         A.c1_mode = fuse ? fuse->c1_mode : 0; A.c1_src = fuse ? fuse->c1_src : nullptr;
         A.gsrc = fuse ? fuse->gsrc : nullptr; A.gperm = fuse ? fuse->gperm : nullptr; A.gsrc_op_offset = fuse ? fuse->gsrc_op_offset : 0;
-        if (A.c1_mode == 4 && (!A.gsrc || (!groups && !A.gperm))) throw std::runtime_error("gathered rotation: the input slab and its permutation are needed");
+        if ((A.c1_mode == 4 || A.c1_mode == 5) && (!A.gsrc || (!groups && !A.gperm))) throw std::runtime_error("gathered rotation: the input slab and its permutation are needed");
+        if (A.c1_mode == 5 && !A.c1_src) throw std::runtime_error("gathered rotation with addend: the addend rows are needed");
         A.ta = fuse ? fuse->ta : nullptr; A.tb = fuse ? fuse->tb : nullptr; A.tix = fuse ? fuse->tix : Indexer{}; A.t_op_offset = fuse ? fuse->t_op_offset : 0;
         if (fuse && fuse->cols2 && fuse->tt_hi > L - 1) throw std::runtime_error("fused rescale: only primes below the one divided out");
         A.fc = env.floor_consts;
