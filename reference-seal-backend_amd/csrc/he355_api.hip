@@ -887,15 +887,7 @@ public:
             ten.c1_mode = addend ? 5 : 4;
             ten.c1_src = addend ? addend + off * 2 * LN : nullptr;
             ten.gsrc = in; ten.gperm = pm; ten.gsrc_op_offset = off;
-#if defined(HE355_NO_C0_GATHER) // A/B builds only (make VARIANT=...): k_k1 writes the permuted c0 (+ addend0) as before round 5
-            ten.c1_mode = addend ? 2 : 1;
-            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend, false, c1_in_k3);
-#elif defined(HE355_NO_ADDEND_GATHER) // A/B builds only: the gather for rotations without addend only
-            if (addend) ten.c1_mode = 2;
-            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend, false, c1_in_k3, nullptr, c1_in_k3 && !addend);
-#else
             launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, pm, B, addend, false, c1_in_k3, nullptr, c1_in_k3);
-#endif
             key_switch_tail(env, L, nc, S, B, key, false, nullptr, nullptr, c1_in_k3 ? &ten : nullptr);
         }
         HIPCHECK(hipGetLastError());
@@ -1081,12 +1073,7 @@ public:
             ten.c1_mode = 4; // polynomial 1 of the rotated ciphertext is zero: the fused k_k3 starts it from there, and gathers the permuted c0 from `in` ...
             ten.gsrc = in; ten.gsrc_op_offset = 0; // (grouped: the op's group names its source block; g_op_offset carries the chunk offset)
             const bool fused = fuse_pays(env, nc); // ... (small grids take the unfused sequence: k_k1 writes the zero polynomial, k_floor_rows adds into it)
-#if defined(HE355_NO_C0_GATHER)
-            ten.c1_mode = 1;
-            launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, nullptr, B, nullptr, false, fused, &groups);
-#else
             launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, nullptr, B, nullptr, false, fused, &groups, fused);
-#endif
             key_switch_tail(env, L, nc, S, B, nullptr, false, nullptr, nullptr, fused ? &ten : nullptr, &groups, off);
         }
     }

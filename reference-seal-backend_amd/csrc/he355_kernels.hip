@@ -133,13 +133,9 @@ __device__ __forceinline__ void dma_row_to_lds(const u64 *grow, u64 *lds_row, in
     const u64 *g = grow + (lane << 1);
 #pragma unroll
     for (int k = 0; k < PIECES; ++k)
-#if defined(HE355_DMA_DEFAULT_POLICY) // A/B builds only: the default cache policy, as before round 5
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lbase + (u32)(k << 10)), "v"(g + (k << 7)) : "memory");
-#else
         // non-temporal (round 5): a row is read once, by this wave -- served from L2 past the L1, which the block's eight waves share for the
         // key rows of the digit step (headline -0.7 %, configs[3] / [4] -1 %: profiles/r05_small_ab.txt)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lbase + (u32)(k << 10)), "v"(g + (k << 7)) : "memory");
-#endif
 }
 __device__ __forceinline__ void lds_rowA(const u64 *lds_row, int lane, u64 v[kRowE])
 {
@@ -242,20 +238,6 @@ __device__ __forceinline__ void wave_rows_inv(const Ar &ar, const PrimeDev &P, b
     T *lds = reinterpret_cast<T *>(lds_w);
     const auto itw = tw_table(gtw(P.inv), rowbase);
     row_inv_C(ar, x, itw, lane);
-#if defined(HE355_NO_INV_PREFETCH) // A/B builds only: every phase loads its twiddles after the exchange, as before round 5
-    lds_store_C(lds, lane, x);
-    HE_WAVE_SYNC();
-    lds_load_B(lds, lane, x);
-    HE_WAVE_SYNC();
-    row_inv_B(ar, x, itw, lane);
-    lds_store_B(lds, lane, x);
-    HE_WAVE_SYNC();
-    lds_load_A(lds, lane, x);
-    HE_WAVE_SYNC();
-    if (last) row_inv_A<Ar, true>(ar, x, itw, P.inv_w0_scaled);
-    else row_inv_A<Ar, false>(ar, x, itw, P.inv_w0_scaled);
-    return;
-#endif
     // the twiddles of the next phase are requested before the exchange that precedes it (round 5; the forward pass always did): they land
     // while the exchange round-trips through LDS instead of behind it -- phase A's are lane-uniform, scalar loads
     Tw16 wb[kTwInvB];
@@ -794,22 +776,6 @@ template <int MODE, class Ar>
 __global__ void __launch_bounds__(kBlock) k_k1(K1Args A, const PrimeDev *primes)
 {
     __shared__ u64 lds[kWaves][kLdsRow];
-#if defined(HE355_K1_UNSTAGED) // A/B builds only: one (op, residue, row) job per wave in job order, twiddles from the table in L2 (rounds 1-4)
-    {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const u32 n1 = 1u << A.logn1;
-        const u64 total = A.n_ops * A.n_i * n1;
-        u64 job = (u64)blockIdx.x * kWaves + wave;
-        const bool valid = job < total;
-        if (!valid) job = total - 1;
-        const u32 a_row = (u32)(job & (n1 - 1));
-        const u64 oi = job >> A.logn1;
-        const int i = A.i_list[oi % A.n_i];
-        const u64 op = oi / A.n_i;
-        k1_job<Ar, MODE>(A, primes[i], op, i, a_row, lane, lds[wave], valid);
-        return;
-    }
-#endif
     constexpr bool kF64 = std::is_same<Ar, ArF64>::value;
     __shared__ __attribute__((aligned(16))) unsigned char twl_raw[kF64 ? kRowTw * 8 : kRowTw * 16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -942,21 +908,12 @@ __device__ __forceinline__ void store_pattern_rows_wide(__amdgpu_buffer_rsrc_t d
 #pragma unroll
     for (int k = 0; k < N1 / 8; ++k) vh[k] = hi4[k * 64 + lane];
     __builtin_amdgcn_sched_barrier(0);
-#if defined(HE355_K2N_ABL_NOSTORE) // DIAGNOSTIC builds only (wrong results): everything but the store instructions themselves (the condition is true at run time)
-    if (__builtin_amdgcn_s_memtime() != 0) { HE_WAVE_SYNC(); return; } // (opaque to the compiler: nothing upstream is dead code)
-#endif
 #pragma unroll
     for (int k = 0; k < N1 / 4; ++k) // 4 rows x 256 bytes per instruction
         __builtin_amdgcn_raw_buffer_store_b128(vl[k], dst, (int)lane_lo, k * 4 * (int)kSlotBytes, 0);
-#if defined(HE355_ROW5_PROBE) // TIMING PROBE ONLY (wrong results): the high plane as if it were 8 bits per element -- 5-byte rows
-#pragma unroll
-    for (int k = 0; k < N1 / 16; ++k)
-        __builtin_amdgcn_raw_buffer_store_b128(vh[k], dst, (int)lane_hi, k * 8 * (int)kSlotBytes, 0);
-#else
 #pragma unroll
     for (int k = 0; k < N1 / 8; ++k) // 8 rows x 128 bytes per instruction
         __builtin_amdgcn_raw_buffer_store_b128(vh[k], dst, (int)lane_hi, k * 8 * (int)kSlotBytes, 0);
-#endif
     HE_WAVE_SYNC(); // the tile is free again for the next target
 }
 // worst-case magnitude after the forward column pass of the fp64 engine from inputs |x| < m0 (ArF64::bfly_fwd: m -> m + q (1/2 + m 2^-51))
@@ -2283,21 +2240,8 @@ static bool dual_engine_launches()
 // (round 5: per kernel.  k_k3's shared launch pays up to a few thousand blocks since the fold form of the u64 engine brought its blocks
 // close to the fp64 engine's in length; the others -- whose dual kernels are the latency shape's, behind a function boundary -- keep
 // the 1024 they were swept at.  profiles/r05_dual_threshold_sweep.txt)
-#if defined(HE355_DUAL_MAX_ENV) // sweep builds only (make VARIANT=...): the thresholds from the environment
-static unsigned dual_max_blocks_k3()
-{
-    static const unsigned v = getenv("HE355_DUAL_MAX_BLOCKS") ? (unsigned)atoi(getenv("HE355_DUAL_MAX_BLOCKS")) : 4096u;
-    return k3_fuse_policy() == 2 ? 0u : v;
-}
-static unsigned dual_max_blocks()
-{
-    static const unsigned v = getenv("HE355_DUAL_MAX_OTHER") ? (unsigned)atoi(getenv("HE355_DUAL_MAX_OTHER")) : 1024u;
-    return k3_fuse_policy() == 2 ? 0u : v;
-}
-#else
 static unsigned dual_max_blocks_k3() { return k3_fuse_policy() == 2 ? 0u : 4096u; }
 static unsigned dual_max_blocks() { return k3_fuse_policy() == 2 ? 0u : 1024u; }
-#endif
 void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offset, const u64 *a, const u64 *b, Indexer ix, const uint32_t *perm,
                const KsBuffers &buf, const u64 *addend, bool no_c01, bool no_c1, const KsGroups *groups, bool no_c0n)
 {
@@ -2335,11 +2279,7 @@ void launch_k1(const KernelEnv &env, int L, K1Mode mode, u64 n_ops, u64 op_offse
     for (int pass = 0; pass < 2; ++pass) {
         if (!gp[pass]) continue;
         const K1Args &AA = AP[pass];
-#if defined(HE355_K1_UNSTAGED)
-        const dim3 grid(gp[pass]);
-#else
         const dim3 grid((unsigned)((((u64)AA.n_i) << env.logn1) * ((n_ops + kWaves - 1) / kWaves)));
-#endif
         if (pass == 0) {
             if (mode == K1_MUL && no_c01) hipLaunchKernelGGL((k_k1<K1_MUL_C2, ArF64>), grid, dim3(kBlock), 0, st, AA, env.primes);
             else if (mode == K1_MUL) hipLaunchKernelGGL((k_k1<K1_MUL, ArF64>), grid, dim3(kBlock), 0, st, AA, env.primes);
@@ -2491,12 +2431,6 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
         // u64-engine tiles of a small grid (at most half the CUs busy with 8-wave blocks): FOUR waves per block -- one per SIMD, each at
         // the full issue rate instead of half of it, and twice the blocks; the serial digit loop of a tile is what such a launch lasts
         const unsigned four_max = k3_fuse_policy() == 2 ? 0u : 128u;
-#if defined(HE355_U64_FOUR_WAVES_ALWAYS) // A/B builds only: the u64 engine's tiles as four-wave blocks whatever the grid
-        if (pass == 1 && waves == 8) {
-            size_grid(4);
-            waves = 4;
-        } else
-#endif
         if (pass == 1 && waves == 8 && g <= four_max) {
             size_grid(4);
             // (a CU holds ONE block of either shape -- the LDS arrays -- so the four-wave blocks must still fit one round together with the

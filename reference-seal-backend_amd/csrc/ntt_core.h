@@ -320,48 +320,6 @@ template <class Ar, class TW> HE_HD void row_inv_C(const Ar &ar, typename Ar::T 
         }
     }
 }
-template <class Ar, class TW> HE_HD void row_inv_B(const Ar &ar, typename Ar::T x[kRowE], const TW &itw, int lane)
-{
-    const u32 hi4 = (u32)lane >> 2;
-    if (Ar::kNeedsRenormInv) {
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) x[r] = ar.renorm(x[r]);
-    }
-#pragma unroll
-    for (int s = 7; s >= 4; --s) {
-        const int bit = 7 - s;
-        Tw16 w[8];
-#pragma unroll
-        for (int g = 0; g < (1 << (s - 4)); ++g) w[g] = itw.get(s, (hi4 << (s - 4)) | (u32)g);
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) {
-            if (r & (1 << bit)) continue;
-            ar.bfly_inv(x[r], x[r | (1 << bit)], w[r >> (8 - s)]);
-        }
-    }
-}
-// LAST = this is the final stage of the whole transform (N1 == 1): fold N^-1 using itw_scaled for stage 0
-template <class Ar, bool LAST, class TW> HE_HD void row_inv_A(const Ar &ar, typename Ar::T x[kRowE], const TW &itw, const Tw16 &w0_scaled)
-{
-    if (Ar::kNeedsRenormInv) {
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) x[r] = ar.renorm(x[r]);
-    }
-#pragma unroll
-    for (int s = 3; s >= 0; --s) {
-        const int bit = 3 - s;
-        Tw16 w[8];
-#pragma unroll
-        for (int g = 0; g < (1 << s); ++g) w[g] = itw.get(s, (u32)g);
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) {
-            if (r & (1 << bit)) continue;
-            if (LAST && s == 0) ar.bfly_inv_last(x[r], x[r | (1 << bit)], w0_scaled);
-            else ar.bfly_inv(x[r], x[r | (1 << bit)], w[r >> (4 - s)]);
-        }
-    }
-}
-
 // Phases B and A of the inverse row pass on twiddles gathered up front (as the forward phases take them): a kernel issues the loads
 // BEFORE the LDS exchange that precedes the phase, so they land while the exchange is in flight instead of behind it.  wb: stage s
 // (7..4) entry g at (1 << (s - 4)) - 1 + g; wa: stage s (3..0) entry g at (1 << s) - 1 + g (lane-uniform: scalar loads through ctw_t).
@@ -421,7 +379,6 @@ template <class Ar, bool LAST> HE_HD void row_inv_A_w(const Ar &ar, typename Ar:
 template <class Ar, int LOGN1, class TW> HE_HD void col_fwd(const Ar &ar, typename Ar::T x[1 << LOGN1], TW tw)
 {
     constexpr int N1 = 1 << LOGN1;
-#if !defined(HE355_NO_LAZY_COL) // (A/B builds only: the standard butterflies in the fold build's column pass)
     if constexpr (Ar::kFold) {
         // Fold build of the u64 engine: the wide lazy butterfly (no conditional subtraction, the five-multiplier product; a stage adds at
         // most 3q).  In below 4q: four stages reach 16q <= 2^64 - 16c, so a fifth stage is preceded by lazy_reduce (three instructions
@@ -446,7 +403,6 @@ template <class Ar, int LOGN1, class TW> HE_HD void col_fwd(const Ar &ar, typena
         }
         return;
     }
-#endif
 #pragma unroll
     for (int s = 0; s < LOGN1; ++s) {
         const int gap = N1 >> (s + 1);

@@ -171,12 +171,19 @@ template <class Ar> static void rows_inv(const Ar &ar, const PrimeTables &pt, in
             track(x, kRowE);
         }
         xchg(2, 1, lds, regs);
-        for (int lane = 0; lane < 64; ++lane) { row_inv_B(ar, regs[lane], itw, lane); track(regs[lane], kRowE); }
+        for (int lane = 0; lane < 64; ++lane) { // (as the kernels run it: the phase's twiddles gathered up front)
+            Tw16 wb[kTwInvB];
+            gather_inv_B(itw, lane, wb);
+            row_inv_B_w(ar, regs[lane], wb);
+            track(regs[lane], kRowE);
+        }
         xchg(1, 0, lds, regs);
         for (int lane = 0; lane < 64; ++lane) {
             T *x = regs[lane];
-            if (n1 == 1) row_inv_A<Ar, true>(ar, x, itw, pt.inv_w0_scaled);
-            else row_inv_A<Ar, false>(ar, x, itw, pt.inv_w0_scaled);
+            Tw16 wa[kTwInvA];
+            gather_inv_A(itw, wa);
+            if (n1 == 1) row_inv_A_w<Ar, true>(ar, x, wa, pt.inv_w0_scaled);
+            else row_inv_A_w<Ar, false>(ar, x, wa, pt.inv_w0_scaled);
             track(x, kRowE);
             for (int r = 0; r < kRowE; ++r) out[(size_t)a * kRowN + elemA(lane, r)] = (n1 == 1) ? ar.to_canon(x[r]) : ar.to_raw(x[r]);
         }
