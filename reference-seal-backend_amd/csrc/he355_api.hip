@@ -226,7 +226,7 @@ public:
         const char *ds = std::getenv("HE355_DUAL_STREAM");
         if (ds) dual_stream_ = ds[0] != '0';
         const char *lm = std::getenv("HE355_LATENCY_MAX");
-        if (lm) lat_max_ = (u64)std::max(0, std::atoi(lm));
+        if (lm) set_latency_max((u64)std::max(0, std::atoi(lm)));
         const char *ch = std::getenv("HE355_CHUNK");
         if (ch && std::atoi(ch) > 0) chunk_ = (size_t)std::atoi(ch);
     }
@@ -292,7 +292,7 @@ public:
     int device() const { return device_; }
     const KernelEnv &env() const { return env_; }
     void set_chunk(size_t c) { chunk_ = c ? c : 1; }
-    void set_latency_max(u64 n) { lat_max_ = n; }
+    void set_latency_max(u64 n) { lat_max_ = n; lat_auto_ = false; }
     void set_level_walk(bool on) { level_walk_ = on; }
 
     size_t key_elems() const { return P.Ltop * 2 * P.K * P.N; }
@@ -652,9 +652,13 @@ public:
     // tiles: 480 x 2 single-wave blocks are ONE round of the chip's 1024 one-wave slots, 480 x 4 were two rounds of half the work each with
     // twice the start-ups and partial sums (batch 1: 0.326 -> 0.312 ms, batch 8: 0.98 -> 0.91 ms; 3 and 8 groups measured slower).
     static constexpr int kLatSplit = 2, kLatSplitU64 = 8;
-    bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
+    // Where the latency shape stops paying is a matter of rows, not of ciphertexts: the throughput kernels fill the chip from about 2^17
+    // coefficients per residue on (profiles/r05_latency_boundary.txt: N = 2^15 crosses between 4 and 5 ciphertexts at depth 6 and 16, 2^14
+    // between 6 and 8, 2^13 at 12), so the default limit is 2^17 / N ciphertexts, at most 12; he355_set_latency_max replaces it.
+    u64 lat_limit() const { return lat_auto_ ? std::min<u64>(12, std::max<u64>(1, ((u64)1 << 17) / P.N)) : lat_max_; }
+    bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_limit() && P.K >= 2; }
     // ... for a given kernel environment (a BFV context runs its rotation chains in the NTT domain on the CKKS pipeline: ntt_env)
-    bool latency_shape_env(const KernelEnv &e, u64 nc) const { return e.scheme == kSchemeCKKS && nc <= lat_max_ && P.K >= 2; }
+    bool latency_shape_env(const KernelEnv &e, u64 nc) const { return e.scheme == kSchemeCKKS && nc <= lat_limit() && P.K >= 2; }
     // the kernel environment of a batch on stream `which`
     // ntt: the NTT-domain (CKKS) pipeline whatever the context's scheme (ntt_env)
     KernelEnv batch_env(u64 /*nc*/, int which = 0, bool ntt = false) const
@@ -1297,7 +1301,7 @@ public:
             // latency shape (1 ciphertext at N = 2^14: 2.02 -> 1.59 ms) -- and in the throughput regime (1024 ciphertexts at N = 2^14:
             // 44.1 -> 38.9 ms); in between (64-80 ciphertexts at N <= 2^14) the BFV kernels' launches fill the chip better: 1.47 -> 1.77 ms.
             const int n_steps = rot + (count > half ? 1 : 0);
-            const bool ntt_chain = level_walk_ && n_steps >= 2 && k3_can_fuse(ntt_env()) && (n <= lat_max_ || n * P.N >= ((u64)1 << 23));
+            const bool ntt_chain = level_walk_ && n_steps >= 2 && k3_can_fuse(ntt_env()) && (n <= lat_limit() || n * P.N >= ((u64)1 << 23));
             PolyView pv{};
             pv.base = inout; pv.polys_per_item = 2 * L; pv.item_stride = 2 * (u64)L * P.N;
             for (int p2 = 0; p2 < 2 * L; ++p2) pv.prime_of[p2] = (unsigned char)(p2 % L);
@@ -1841,7 +1845,8 @@ private:
     PrimeDev *d_primes_ = nullptr;
     u64 *lat_part_[2] = {nullptr, nullptr}; // partial sums of the digit-split K3 (latency shape), one per stream
     size_t lat_part_bytes_[2] = {0, 0};
-    u64 lat_max_ = 8;              // largest batch that takes the latency shape (HE355_LATENCY_MAX; 0: never)
+    u64 lat_max_ = 0;              // largest batch that takes the latency shape once set (HE355_LATENCY_MAX; 0: never) ...
+    bool lat_auto_ = true;         // ... until then lat_limit()'s rule
     FloorConst *d_floor_ = nullptr;
     std::vector<void *> owned_;
     u64 *d_relin_ = nullptr;

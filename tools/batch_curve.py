@@ -20,12 +20,16 @@ ap.add_argument("--config", nargs="+", default=["mul_relin_rescale", "dot"])
 ap.add_argument("--batches", nargs="+", type=int, default=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024])
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--N", type=int, default=0, help="ring degree in place of the configuration's (CKKS chains {60, 45 x (depth-1), 60})")
+ap.add_argument("--depth", type=int, default=0, help="chain depth in place of the configuration's")
 args = ap.parse_args()
 
 be = importlib.import_module("reference-seal-backend_amd")
 sharding = bench.load_sharding()
 for cfg in args.config:
     W = bench.WORKLOADS[cfg]
+    if args.N or args.depth:
+        W = type(W.__name__, (W,), {"N": args.N or W.N, "depth": args.depth or W.depth, "bits": None})
     bits = W.bits or be.chain_bits(W.depth, W.coeff_bits)
     rows = []
     for b in args.batches:
