@@ -239,7 +239,7 @@ int he355_clock_probe_end(he355_ctx *ctx, double *mhz, double *seconds);
 int he355_set_dual_stream(he355_ctx *ctx, int on); /* chunks alternate between two HIP streams (default 1; HE355_DUAL_STREAM=0); 0: per-kernel timings without overlap */
 /* Key switches over at most n ciphertexts take the latency shape (serial loops of the throughput kernels dealt to more blocks; HEBench's
  * Latency category is batch 1: src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:138-141).  Default: 2^17 / N ciphertexts, at most 12 -- where the throughput kernels start filling the chip (4 at N = 2^15, 8 at 2^14);
- * a call (or HE355_LATENCY_MAX) replaces the rule by n; 0: never.
+ * a call (or HE355_LATENCY_MAX) replaces the rule by n; 0: never; UINT64_MAX: the rule again.
  * Results are bit-identical either way. */
 int he355_set_latency_max(he355_ctx *ctx, uint64_t n);
 /* he355_rotate_sum walks its NAF-prefix trie level by level, all nodes of a level in one grouped key-switch sequence (default 1;

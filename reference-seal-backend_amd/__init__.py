@@ -395,8 +395,9 @@ class Context:
         arr = (C.c_int32 * n)(*[int(v) for v in steps])
         _check(lib().he355_rotate_each(self.h, L, n, inp.ptr, arr, out.ptr))
 
-    def set_latency_max(self, n):
-        _check(lib().he355_set_latency_max(self.h, n))
+    def set_latency_max(self, n=None):
+        """largest batch whose key switches take the latency shape; None: the library's rule (batch * N <= 2^17, at most 12)"""
+        _check(lib().he355_set_latency_max(self.h, 2 ** 64 - 1 if n is None else n))
 
     def set_level_walk(self, on: bool):
         _check(lib().he355_set_level_walk(self.h, int(on)))

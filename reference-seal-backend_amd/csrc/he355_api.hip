@@ -292,7 +292,7 @@ public:
     int device() const { return device_; }
     const KernelEnv &env() const { return env_; }
     void set_chunk(size_t c) { chunk_ = c ? c : 1; }
-    void set_latency_max(u64 n) { lat_max_ = n; lat_auto_ = false; }
+    void set_latency_max(u64 n) { lat_auto_ = n == ~(u64)0; lat_max_ = lat_auto_ ? 0 : n; } // ~0: back to lat_limit()'s rule
     void set_level_walk(bool on) { level_walk_ = on; }
 
     size_t key_elems() const { return P.Ltop * 2 * P.K * P.N; }

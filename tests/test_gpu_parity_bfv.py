@@ -423,5 +423,5 @@ def test_rotate_sum_shares_naf_prefixes_bit_for_bit(pair, be, walk):
             want = o.add(want, o.rotate(a[r], s, keys))
         assert np.array_equal(got[r], want), r
     g.set_level_walk(True)  # the context is shared by the module's tests: back to the defaults
-    g.set_latency_max(8)
+    g.set_latency_max(None)
     g.set_chunk(1024)
