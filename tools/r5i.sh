@@ -20,3 +20,6 @@ python3 tools/bench_bridge.py --sizes both --reps 20 --out $O/bridge_phases.json
 echo "== test matrix"
 bash tools/test_matrix.sh > $O/test_matrix.txt 2>&1 || true
 cat $O/test_matrix.txt
+echo "== batch curve"
+python3 tools/batch_curve.py > $O/batch_curve.txt 2>&1 || true
+grep "^#" $O/batch_curve.txt
