@@ -737,13 +737,36 @@ __device__ __forceinline__ void k1_job(const K1Args &A, const PrimeDev &P, u64 o
         const u64 *p0 = A.a + src_ct * 2 * P1 + (u64)i * N;
         const uint32_t *pm = perm + ((u64)a_row << kRowLog);
         u64 v2[kRowE];
+        // The permutation of an NTT-form polynomial maps a row ONTO one source row (the low logn1 + 1 bits of an element's exponent are its
+        // row's alone, and so are those of g times it: Params::galois_perm_ntt checks it), so the wave reads that row the way it reads any
+        // row -- 16 bytes per lane, every line once -- into its exchange buffer and permutes there: sixteen 8-byte reads per lane at
+        // addresses of its own were sixty-four cache lines per instruction for the texture path, and what k_k1 spent its time on.
+        {
+            const u64 *srow = p0 + (u64)(__builtin_amdgcn_readfirstlane(pm[0]) & ~(u32)(kRowN - 1));
+            u32 pl[kRowE];
 #pragma unroll
-        for (int r2 = 0; r2 < kRowE; ++r2) {
-            const uint32_t src = pm[elemC(lane, r2)];
-            v0[r2] = A.no_c0n ? 0 : p0[src];
-            v2[r2] = p0[P1 + src];
-            v1[r2] = 0;
-            x[r2] = ar.from_canon(v2[r2]);
+            for (int r2 = 0; r2 < kRowE; ++r2) pl[r2] = lds_pad((int)(pm[elemC(lane, r2)] & (u32)(kRowN - 1)));
+            u64 t[kRowE];
+            load_rowC(srow + P1, lane, t);
+            lds_store_C(lds, lane, t);
+            HE_WAVE_SYNC();
+#pragma unroll
+            for (int r2 = 0; r2 < kRowE; ++r2) v2[r2] = lds[pl[r2]];
+            if (!A.no_c0n) {
+                load_rowC(srow, lane, t);
+                HE_WAVE_SYNC();
+                lds_store_C(lds, lane, t);
+                HE_WAVE_SYNC();
+#pragma unroll
+                for (int r2 = 0; r2 < kRowE; ++r2) v0[r2] = lds[pl[r2]];
+            }
+            HE_WAVE_SYNC(); // (the inverse row pass writes the buffer next)
+#pragma unroll
+            for (int r2 = 0; r2 < kRowE; ++r2) {
+                if (A.no_c0n) v0[r2] = 0;
+                v1[r2] = 0;
+                x[r2] = ar.from_canon(v2[r2]);
+            }
         }
         if (A.addend && !A.no_c0n) { // out = addend + rotate(in): the ciphertext the key-switched result is added into starts from the addend
             const u64 *ad = A.addend + (A.op_offset + op) * 2 * P1 + roff;

@@ -535,6 +535,9 @@ std::vector<uint32_t> Params::galois_perm_ntt(uint32_t elt) const
         const u64 odd = 2 * (u64)bitrev((uint32_t)i, logn) + 1; // exponent of psi evaluated at slot i
         const u64 src = ((odd * elt) & (2 * N - 1)) >> 1;
         perm[i] = bitrev((uint32_t)src, logn);
+        // A row of 1024 slots has ONE source row: the row index of slot i is the low logn1 bits of its exponent's upper part, and
+        // odd * elt keeps low bits low.  The rotation kernels read the source row as a whole on the strength of this (k_k1, K1_GALOIS).
+        if ((perm[i] >> 10) != (perm[i & ~(size_t)1023] >> 10)) throw std::logic_error("galois_perm_ntt: a row with two source rows");
     }
     return perm;
 }
