@@ -552,6 +552,14 @@ public:
         const u64 min_blocks = k3_fuse_policy() == 2 ? 0 : 128;
         return ((u64)1 << e.logn1) * ((nc + 7) / 8) >= min_blocks;
     }
+    // he355_rotate_sum: the level's sum formed by k_k3 itself (KsGroups::sum_out).  The launch then has (tiles x n / 8) blocks however many
+    // groups the level has, so it needs enough of them to fill the chip, groups of a multiple of eight ciphertexts, the fused path for
+    // every chunk, and counts that leave bit 31 free.
+    bool level_sum_pays(const KernelEnv &e, int L, u64 n) const
+    {
+        if (n % 8 || !k3_can_fuse(e) || !fuse_pays(e, n) || (u64)chunk_ < n) return false; // (a launch holds whole groups, and takes the fused path)
+        return (((u64)L << e.logn1) * (n / 8)) >= 512;                                      // blocks of the data-prime launch
+    }
     bool tensor_in_k3(const KernelEnv &env_, int L, u64 nc, const KsBuffers &B) const
     {
         return !latency_shape_env(env_, nc) && k3_can_fuse(env_) && fuse_pays(env_, nc) && B.c01_item_stride == 2 * (size_t)L * P.N;
@@ -1061,13 +1069,19 @@ public:
         return e;
     }
     // NTT-form ciphertexts: out[g * gs + c] = apply_galois(in[src_block[g] * gs + c], element / key of group g), c < gs, g < G
-    void apply_galois_grouped(int L, u64 G, u64 gs, const u64 *in, const KsGroups &groups, u64 *out)
+    // groups.sum_out (level_sum_pays): k_k3 adds every group's ciphertext into the sum itself; chunks are then whole groups
+    // (returns false where it could not: the scratch arenas hold less than one group per launch -- the caller then sums the groups itself)
+    bool apply_galois_grouped(int L, u64 G, u64 gs, const u64 *in, KsGroups groups, u64 *out)
     {
         const KernelEnv env = ntt_env();
         const size_t N = P.N, LN = (size_t)L * N;
         const u64 n = G * gs;
         Indexer ix{};
-        const size_t chunk = chunk_ops(n, L, false);
+        size_t chunk = chunk_ops(n, L, false);
+        if (groups.sum_out) {
+            if (chunk < gs || !fuse_pays(env, gs)) groups.sum_out = nullptr;
+            else chunk -= chunk % gs;
+        }
         for (u64 off = 0; off < n; off += chunk) {
             const u64 nc = std::min<u64>(chunk, n - off);
             Scratch S = scratch(std::min<u64>(chunk, n), L);
@@ -1077,9 +1091,11 @@ public:
             ten.c1_mode = 4; // polynomial 1 of the rotated ciphertext is zero: the fused k_k3 starts it from there, and gathers the permuted c0 from `in` ...
             ten.gsrc = in; ten.gsrc_op_offset = 0; // (grouped: the op's group names its source block; g_op_offset carries the chunk offset)
             const bool fused = fuse_pays(env, nc); // ... (small grids take the unfused sequence: k_k1 writes the zero polynomial, k_floor_rows adds into it)
+            if (groups.sum_out && !fused) throw std::logic_error("level sum: the fused key switch only"); // (fuse_pays grows with the chunk)
             launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, nullptr, B, nullptr, false, fused, &groups, fused);
             key_switch_tail(env, L, nc, S, B, nullptr, false, nullptr, nullptr, fused ? &ten : nullptr, &groups, off);
         }
+        return groups.sum_out != nullptr;
     }
     u64 rotate_sum(int L, u64 n, const u64 *in, const int *steps, u64 n_steps, u64 *out)
     {
@@ -1141,18 +1157,23 @@ public:
             std::vector<const uint32_t *> perms(G);
             std::vector<const u64 *> keys(G);
             std::vector<u32> src_block(G), mult(G);
+            // The level's sum inside k_k3 (KsGroups::sum_out) where its grid shape fills the chip -- one block per (tile, eight ciphertexts),
+            // each walking the level's groups -- and every chunk takes the fused path: the groups' ciphertexts that nothing starts from are
+            // then never written, and k_sum_groups' pass over all of them (an HBM stream of its own, 6 % of configs[4]) is gone.
+            const bool in_k3 = level_sum_pays(nenv, L, n) && n_steps < kGroupKeepBit;
             for (size_t g = 0; g < G; ++g) {
                 const RotNode &nd = trie[(size_t)nodes[g]];
                 perms[g] = perm(nd.elt);
                 keys[g] = galois_key(nd.elt);
                 src_block[g] = (u32)trie[(size_t)nd.parent].pos;
                 mult[g] = (u32)nd.ends;
+                if (in_k3 && !nd.kids.empty()) mult[g] |= kGroupKeepBit;
             }
-            const GroupTables gt = upload_groups(perms, keys, src_block, mult, (u32)n);
+            GroupTables gt = upload_groups(perms, keys, src_block, mult, (u32)n);
             Held cur{pool_};
             cur.reset(static_cast<u64 *>(pool_.alloc(G * bytes)));
-            apply_galois_grouped(L, G, n, src, gt.g, cur.p);
-            launch_sum_groups(env_, L, n, (u32)G, cur.p, gt.d_mult, out);
+            if (in_k3) { gt.g.sum_out = out; gt.g.count = gt.d_mult; }
+            if (!apply_galois_grouped(L, G, n, src, gt.g, cur.p)) launch_sum_groups(env_, L, n, (u32)G, cur.p, gt.d_mult, out);
             held.reset(cur.p);
             cur.p = nullptr;
             src = held.p;

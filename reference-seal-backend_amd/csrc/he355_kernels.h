@@ -64,7 +64,14 @@ struct KsGroups {
     const u64 *const *key = nullptr;
     const u32 *src_block = nullptr;
     u32 group_size = 0;
+    // Level sum inside the fused k_k3 (he355_rotate_sum, round 5): sum_out [group_size][2][L][N] += (count[g] & 0x7fffffff) x the group's
+    // rotated ciphertext, added by the wave that formed it; a group's own ciphertext is written only where bit 31 of count[g] says some
+    // group of the next level starts from it.  Race-free because the launch then gives a block ONE (tile, eight ciphertexts) and lets it
+    // walk the groups one after the other (launch_k3 sizes the grid so: needs group_size % 8 == 0 and whole groups per launch).
+    u64 *sum_out = nullptr;
+    const u32 *count = nullptr;
 };
+constexpr u32 kGroupKeepBit = 0x80000000u;
 constexpr int kMoveListCap = 64;
 enum K1Mode { K1_MUL = 0, K1_CT3 = 1, K1_GALOIS = 2 };
 // K3: forward row pass of every (tt, j) + multiply-accumulate with the key -> t (data primes) / tpr (special)

@@ -517,11 +517,21 @@ __global__ void __launch_bounds__(kBlock) k_sum_groups(const u64 *in, u64 *out, 
     const u64 ctn = (u64)polys << logN;
     ulonglong2 *po = reinterpret_cast<ulonglong2 *>(out + c * ctn + ((u64)p << logN)) + e2;
     ulonglong2 s = *po;
-    for (u32 g = 0; g < n_groups; ++g) {
-        const u32 m = mult[g];
-        if (!m) continue;
-        const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(in + ((u64)g * n_cts + c) * ctn + ((u64)p << logN))[e2];
-        for (u32 r = 0; r < m; ++r) { s.x = addmod(s.x, x.x, q); s.y = addmod(s.y, x.y, q); }
+    // four groups' loads in flight per lane (the counts are wave-uniform: scalar loads, uniform branches); every word is read once: non-temporal
+    typedef unsigned long long v2u __attribute__((ext_vector_type(2)));
+    const v2u *pin = reinterpret_cast<const v2u *>(in + c * ctn + ((u64)p << logN)) + e2;
+    const u64 gstride = (n_cts * ctn) >> 1;
+    for (u32 g = 0; g < n_groups; g += 4) {
+        u32 m[4];
+        v2u x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = g + k < n_groups ? mult[g + k] & ~kGroupKeepBit : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (m[k]) x[k] = __builtin_nontemporal_load(pin + (u64)(g + k) * gstride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            for (u32 r = 0; r < m[k]; ++r) { s.x = addmod(s.x, x[k].x, q); s.y = addmod(s.y, x[k].y, q); }
     }
     *po = s;
 }
@@ -1204,6 +1214,7 @@ struct K3Args {
     int L, K, logn1, ckks;
     int n_tt;
     u32 og_per_block; // consecutive op-groups one block handles on its tile
+    u32 og_stride;    // 1; level-sum launches (KsGroups::sum_out): the block's op-groups are n_ogb apart -- the same eight ciphertexts of every group
     // latency shape (few ops): the digits of a tile are cut into n_split groups, one block each (blockIdx.y); group g writes its canonical
     // partial sums to part[g][op * 2 + k][L + 1][N] and k_k3_combine adds them up (and runs the special prime's inverse row pass)
     int n_split;
@@ -2451,10 +2462,19 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             g = (unsigned)(((tiles + 7) / 8) * 8 * n_ogb);
         };
         size_grid(waves);
+        const bool level_sum = groups && groups->sum_out && fuse; // (the special prime's launch ahead of it writes no ciphertext rows)
+        if (level_sum) {
+            // one block per (tile, eight ciphertexts), walking this launch's groups in turn (see KsGroups::sum_out)
+            const u64 gs8 = groups->group_size / 8;
+            if (waves != 8 || groups->group_size % 8 || n_ops % groups->group_size || g_op_offset % groups->group_size)
+                throw std::runtime_error("level sum in k_k3: fused 8-wave launches over whole groups of a multiple of eight ciphertexts");
+            ogpb = (u32)(n_og / gs8);
+            g = (unsigned)(((tiles + 7) / 8) * 8 * gs8);
+        }
         // u64-engine tiles of a small grid (at most half the CUs busy with 8-wave blocks): FOUR waves per block -- one per SIMD, each at
         // the full issue rate instead of half of it, and twice the blocks; the serial digit loop of a tile is what such a launch lasts
         const unsigned four_max = k3_fuse_policy() == 2 ? 0u : 128u;
-        if (pass == 1 && waves == 8 && g <= four_max) {
+        if (pass == 1 && waves == 8 && g <= four_max && !level_sum) {
             size_grid(4);
             // (a CU holds ONE block of either shape -- the LDS arrays -- so the four-wave blocks must still fit one round together with the
             // fp64-engine blocks they may share the launch with)
@@ -2462,6 +2482,7 @@ void launch_k3(const KernelEnv &env, int L, u64 n_ops, const KsBuffers &buf, con
             else size_grid(8);
         }
         A.og_per_block = ogpb;
+        A.og_stride = level_sum ? (u32)(groups->group_size / 8) : 1u;
         pend[n_pend].A = A; pend[n_pend].g = g; pend[n_pend].f64 = pass == 0; pend[n_pend].waves = waves;
         ++n_pend;
     }

@@ -425,3 +425,46 @@ def test_rotate_sum_shares_naf_prefixes_bit_for_bit(pair, be, walk):
     g.set_level_walk(True)  # the context is shared by the module's tests: back to the defaults
     g.set_latency_max(None)
     g.set_chunk(1024)
+
+
+@pytest.mark.parametrize("scheme", ["bfv", "ckks"])
+def test_rotate_sum_level_sum_inside_the_key_switch(be, oracle, scheme):
+    """From batches whose grid fills the chip (eight-ciphertext groups x tiles >= 512 blocks) he355_rotate_sum's level walk lets the fused
+    k_k3 add every node's ciphertext into the sum itself -- one block per (tile, eight ciphertexts) walking the level's nodes, nodes
+    nothing starts from never written (KsGroups::sum_out) -- instead of k_sum_groups' pass over them.  Same bits as that pass (forced by a
+    chunk below the batch, which rules the in-kernel sum out) and as the reference's unshared loop on sampled ciphertexts; steps with
+    repeats (a node several steps end at), inner nodes that are ends themselves, a zero step."""
+    N, bits = 8192, [60, 40, 40, 60]
+    n = 176  # 3 primes x 8 rows x 22 eight-ciphertext groups = 528 blocks
+    sch_g, sch_o = (be.SCHEME_BFV, oracle.SCHEME_BFV) if scheme == "bfv" else (be.SCHEME_CKKS, oracle.SCHEME_CKKS)
+    kw = dict(plain_bits=20) if scheme == "bfv" else {}
+    g = be.Context(sch_g, N, bit_sizes=bits, sec128=False, device=0, **kw)
+    o = oracle.Context(sch_o, N, bit_sizes=bits, sec128=False, **kw)
+    rng = np.random.default_rng(77)
+    L = g.L
+    try:
+        keys = {}
+        k = 0
+        while (1 << k) < N // 2:
+            for s in (1 << k, -(1 << k)):
+                e = o.galois_elt(s)
+                keys[e] = o.random_kswitch_key(rng)
+                g.set_galois_key(e, keys[e])
+            k += 1
+        a = rand_cts(o, rng, n, L)
+        da = g.to_device(a)
+        steps = [1, 2, 3, 3, 5, 6, 7, 0, 1, 11, -3, 96]
+        out, out2 = g.alloc(n * 2 * L * N), g.alloc(n * 2 * L * N)
+        g.set_latency_max(0)
+        issued = g.rotate_sum(L, n, da, steps, out)
+        got = out.download((n, 2, L, N))
+        g.set_chunk(n - 8)  # a launch no longer holds whole groups: every level through k_sum_groups
+        assert g.rotate_sum(L, n, da, steps, out2) == issued
+        assert np.array_equal(out2.download((n, 2, L, N)), got)
+        for r in (0, 7, 8, 100, n - 1):
+            want = a[r].copy()
+            for s in steps:
+                want = o.add(want, o.rotate(a[r], s, keys) if s else a[r])
+            assert np.array_equal(got[r], want), r
+    finally:
+        g.close()
