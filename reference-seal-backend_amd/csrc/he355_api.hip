@@ -547,22 +547,26 @@ public:
     // result): n1 rows x nc / 8 op-groups of blocks.  With a handful of ciphertexts at a small ring that launch is a few dozen blocks
     // on 256 CUs -- as long as the data primes' launch and nearly idle -- and the unfused sequence (every prime's tiles in ONE launch,
     // then the two floor kernels) is the shorter chain: fused from 128 such blocks up (HE355_K3_FUSE=all: always).
-    bool fuse_pays(const KernelEnv &e, u64 nc) const
+    bool fuse_pays(const KernelEnv &e, u64 nc, int L) const
     {
-        const u64 min_blocks = k3_fuse_policy() == 2 ? 0 : 128;
-        return ((u64)1 << e.logn1) * ((nc + 7) / 8) >= min_blocks;
+        if (k3_fuse_policy() == 2) return true;
+        // ... or from 1536 (tile, op-group) units of the data primes' launch up: at L = 16 that launch is 16 times the special prime's, and what
+        // the fused epilogue saves (the sums' trip through HBM, k_floor_rows) outweighs the idle launch ahead of it from 17 ciphertexts on at
+        // N = 2^15 instead of 25 (batch 20 / 24 of the headline shape: 1.64 -> 1.45 / 1.79 -> 1.52 ms, DotProduct -9 %; profiles/r05_latency_boundary.txt)
+        const u64 sp_blocks = ((u64)1 << e.logn1) * ((nc + 7) / 8);
+        return sp_blocks >= 128 || sp_blocks * (u64)L >= 1536;
     }
     // he355_rotate_sum: the level's sum formed by k_k3 itself (KsGroups::sum_out).  The launch then has (tiles x n / 8) blocks however many
     // groups the level has, so it needs enough of them to fill the chip, groups of a multiple of eight ciphertexts, the fused path for
     // every chunk, and counts that leave bit 31 free.
     bool level_sum_pays(const KernelEnv &e, int L, u64 n) const
     {
-        if (n % 8 || !k3_can_fuse(e) || !fuse_pays(e, n) || (u64)chunk_ < n) return false; // (a launch holds whole groups, and takes the fused path)
+        if (n % 8 || !k3_can_fuse(e) || !fuse_pays(e, n, L) || (u64)chunk_ < n) return false; // (a launch holds whole groups, and takes the fused path)
         return (((u64)L << e.logn1) * (n / 8)) >= 512;                                      // blocks of the data-prime launch
     }
     bool tensor_in_k3(const KernelEnv &env_, int L, u64 nc, const KsBuffers &B) const
     {
-        return !latency_shape_env(env_, nc) && k3_can_fuse(env_) && fuse_pays(env_, nc) && B.c01_item_stride == 2 * (size_t)L * P.N;
+        return !latency_shape_env(env_, nc) && k3_can_fuse(env_) && fuse_pays(env_, nc, L) && B.c01_item_stride == 2 * (size_t)L * P.N;
     }
     // groups (grouped rotations, fused path only): per-group keys; g_off: index of the chunk's first op in the grouped batch
     bool key_switch_tail(const KernelEnv &env_, int L, u64 nc, const Scratch &S, const KsBuffers &B, const u64 *key, bool with_tail,
@@ -593,7 +597,7 @@ public:
         }
         launch_k2(env_, L, nc, B);
         if (after_k2) HIPCHECK(hipEventRecord(after_k2, env_.stream));
-        if (k3_can_fuse(env_) && B.c01_item_stride == 2 * LN && fuse_pays(env_, nc)) {
+        if (k3_can_fuse(env_) && B.c01_item_stride == 2 * LN && fuse_pays(env_, nc, L)) {
             // special prime first, its correction through the column pass, then the data primes with the mod-down finished
             // inside K3 (the sums never go to HBM)
             launch_k3(env_, L, nc, B, key, K3_SPECIAL_ONLY, nullptr, 1, nullptr, 0, groups, g_off);
@@ -1079,7 +1083,7 @@ public:
         Indexer ix{};
         size_t chunk = chunk_ops(n, L, false);
         if (groups.sum_out) {
-            if (chunk < gs || !fuse_pays(env, gs)) groups.sum_out = nullptr;
+            if (chunk < gs || !fuse_pays(env, gs, L)) groups.sum_out = nullptr;
             else chunk -= chunk % gs;
         }
         for (u64 off = 0; off < n; off += chunk) {
@@ -1090,7 +1094,7 @@ public:
             TensorOperands ten;
             ten.c1_mode = 4; // polynomial 1 of the rotated ciphertext is zero: the fused k_k3 starts it from there, and gathers the permuted c0 from `in` ...
             ten.gsrc = in; ten.gsrc_op_offset = 0; // (grouped: the op's group names its source block; g_op_offset carries the chunk offset)
-            const bool fused = fuse_pays(env, nc); // ... (small grids take the unfused sequence: k_k1 writes the zero polynomial, k_floor_rows adds into it)
+            const bool fused = fuse_pays(env, nc, L); // ... (small grids take the unfused sequence: k_k1 writes the zero polynomial, k_floor_rows adds into it)
             if (groups.sum_out && !fused) throw std::logic_error("level sum: the fused key switch only"); // (fuse_pays grows with the chunk)
             launch_k1(env, L, K1_GALOIS, nc, off, in, nullptr, ix, nullptr, B, nullptr, false, fused, &groups, fused);
             key_switch_tail(env, L, nc, S, B, nullptr, false, nullptr, nullptr, fused ? &ten : nullptr, &groups, off);
