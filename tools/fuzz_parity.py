@@ -3,7 +3,7 @@
 fp64-/u64-engine primes, forced-u64 contexts), levels, batch sizes on both sides of the latency-shape boundary, chunk sizes with
 ragged tails; CKKS multiply -> relinearize (-> rescale), relinearize of size-3 ciphertexts, rotations and rotate_add; BFV (30 % of the
 cases) BEHZ multiply, relinearize and a row or column rotation; and for both schemes the rotation chains of round 4 -- he355_rotate_sum
-(NAF-prefix trie, walked node by node or level by level with grouped key switches), he355_rotate_each, he355_accumulate -- every result
+(NAF-prefix trie, walked node by node or level by level with grouped key switches, now and then at a batch that sums the level inside k_k3), he355_rotate_each, he355_accumulate -- every result
 compared bit for bit.  usage: tools/fuzz_parity.py <seconds> [seed]   (prints one line per case; exit 1 on the first mismatch)"""
 import importlib
 import os
@@ -39,6 +39,18 @@ def chains(be, g, o, rng, L, n, a, da):
             want = o.add(want, o.rotate(a[r], st, keys) if st else a[r])
         ok = ok and np.array_equal(got[r], want)
     what.append(f"rotsum{len(steps)}")
+    # now and then a batch whose level walk sums inside k_k3 (KsGroups::sum_out: groups of a multiple of eight ciphertexts, at least 512
+    # blocks in the data primes' launch): the input repeated to that size, a sample of the results against the rows checked above
+    n1 = max(1, N // 1024)
+    big = 8 * -(-512 // (8 * L * n1)) * 8
+    if ok and walk and n >= 1 and big * 2 * L * N * 8 <= (1 << 28) and rng.random() < 0.25:
+        reps = -(-big // n)
+        tiled = np.concatenate([a] * reps)[:big]
+        dbig, obig = g.to_device(tiled), g.alloc(big * 2 * L * N)
+        g.rotate_sum(L, big, dbig, steps, obig)
+        gotb = obig.download((big, 2, L, N))
+        ok = all(np.array_equal(gotb[r], got[r % n]) for r in range(big))
+        what.append(f"levelsum{big}")
     if ok and g.scheme == be.SCHEME_CKKS:
         each = [int(x) for x in rng.integers(-15, 16, n)]
         g.rotate_each(L, n, da, each, out)
