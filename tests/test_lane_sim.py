@@ -106,6 +106,29 @@ def test_galois_rules_match_oracle(sim, oracle):
         sim.sim_params_destroy(h)
 
 
+@pytest.mark.parametrize("N", [1024, 2048, 8192, 32768])
+def test_every_default_rotation_maps_a_row_onto_one_source_row(sim, N):
+    """k_k1 (K1_GALOIS) reads the source row of a rotated row WHOLE and permutes it in LDS, and k_k3 gathers the permuted c0 from one
+    8 KiB row: both rest on the NTT-domain permutation of every Galois element mapping each row of 1024 slots onto one row of the source.
+    Params::galois_perm_ntt throws otherwise; here for every element of the default key set and the conjugation, and the map is checked
+    to be a bijection of the rows."""
+    bits = [50, 40, 50]
+    h = _mk(sim, N, bits)
+    try:
+        buf = (C.c_uint32 * 64)()
+        n = sim.sim_galois_elts_all(h, buf)
+        perm = (C.c_uint32 * N)()
+        for elt in list(buf[:n]) + [2 * N - 1, 3, 5 ** 3 % (2 * N)]:
+            sim.sim_galois_perm(h, elt, perm)  # (throws -> a null table / abort would fail the test)
+            p = np.frombuffer(perm, dtype=np.uint32).reshape(N // 1024, 1024)
+            rows = p >> 10
+            assert (rows == rows[:, :1]).all(), elt
+            assert sorted(rows[:, 0].tolist()) == list(range(N // 1024)), elt
+            assert all(sorted((r & 1023).tolist()) == list(range(1024)) for r in p), elt
+    finally:
+        sim.sim_params_destroy(h)
+
+
 def _ntt_primes(N, lo, hi, count):
     """`count` primes 1 (mod 2N) in [lo, hi), largest first"""
     from sympy import isprime
