@@ -8,8 +8,13 @@ element with the HEBench outer-product indexing of seal_ckks_element_wise_benchm
 that pipeline over the rank's resident shard of the batch.
 
   --config mul_relin_rescale | eltwise_mul | dot | bfv_matmul | bfv_add     (BASELINE.json configs[2], [1], [3], [4], [0])
-  --scaling weak | strong      weak (default): --batch results PER GPU, global batch = batch x N;  strong: --batch is the GLOBAL
-                               batch, cut into contiguous blocks of operand 0 (reference-seal-backend_amd/sharding.py)
+  --scaling weak | strong      weak: --batch results PER GPU, global batch = batch x N;  strong: --batch is the GLOBAL batch, cut into
+                               contiguous blocks of operand 0 (reference-seal-backend_amd/sharding.py).  Not given (how the driver runs it):
+                               N = 1 is one run (the two coincide); N > 1 times BOTH in the one invocation -- `value` / `scaling` = strong
+                               at the global batch `metric` names (north_star: "batch = 1024 ... >= 6x at 8 GPUs"), and a `weak` block
+                               (value, ms_per_step, per_rank_ms) for --batch results per GPU beside it
+  --force-dist                 (or HE355_BENCH_FORCE_DIST=1) at --gpus 1: start the one rank under torch.distributed.run and initialise the
+                               collective backend (nccl = RCCL) anyway -- the multi-GPU branch as far as a 1-GPU box can take it
 One process per GPU (torch.distributed.run), no data-path collective: results are independent.  Every rank
 builds the same evaluation keys on its own device from the shared seed (the generators are counter-based: a pure function of
 seed and index) and fills its shard of the global operand array with the values the whole array holds there
@@ -80,12 +85,23 @@ class Workload:
         c.fill_uniform(self.d_b, self.b1 * size * L, self.pm, SEED_B)
         self.ix = self.be.Context.outer(0, self.rows, 0, self.b1)
 
+    first_row = 0  # checker legs: the operand-0 row the sample starts at (0: the head of the shard; tests also hold the LAST rows to the oracle)
+
     def host_operands(self, rows, size=2):
-        """the first `rows` rows of this rank's operand 0 and all of operand 1, as numpy arrays (checker input)"""
+        """`rows` rows of this rank's operand 0 starting at self.first_row, and all of operand 1, as numpy arrays (checker input)"""
         L, N = self.L, self.N
-        a = self.d_a.download_head((rows, size, L, N))
+        a = self.d_a.download_range(self.first_row * size * L * N, (rows, size, L, N))
         b = self.d_b.download_head((self.b1, size, L, N))
         return a, b
+
+    def result_slab(self):
+        """(device slab of the step's results, u64 words per result)"""
+        raise NotImplementedError
+
+    def result_rows(self, k):
+        """k results starting at result self.first_row * b1"""
+        buf, per = self.result_slab()
+        return buf.download_range(self.first_row * self.b1 * per[0] * per[1] * self.N, (k,) + per + (self.N,))
 
     def key_bytes(self):
         return self.L * 2 * self.K * self.N * 8
@@ -123,8 +139,8 @@ class MulRelinRescale(Workload):
         L, N = self.L, self.N
         return 2 * (2 * L * N * 8) + 2 * (L - 1) * N * 8 + self.key_bytes() / global_batch
 
-    def result_rows(self, k):
-        return self.d_out.download_head((k, 2, self.L - 1, self.N))
+    def result_slab(self):
+        return self.d_out, (2, self.L - 1)
 
     def checker(self, ho, o, rows, threads, passes):
         """oracle on the first `rows` rows of the shard; returns (seconds per pass list, expected results)"""
@@ -160,8 +176,8 @@ class MulRelin(MulRelinRescale):
         L, N = self.L, self.N
         return 3 * (2 * L * N * 8) + self.key_bytes() / global_batch  # read 2 cts, write 1 at the same level, the key once per batch
 
-    def result_rows(self, k):
-        return self.d_out.download_head((k, 2, self.L, self.N))
+    def result_slab(self):
+        return self.d_out, (2, self.L)
 
     def checker(self, ho, o, rows, threads, passes):
         a, b = self.host_operands(rows)
@@ -196,8 +212,8 @@ class EltwiseMul(Workload):
     def bytes_per_op(self, global_batch):
         return 7 * self.L * self.N * 8  # read 4 polys, write 3 = 7,340,032 B
 
-    def result_rows(self, k):
-        return self.d_out.download_head((k, 3, self.L, self.N))
+    def result_slab(self):
+        return self.d_out, (3, self.L)
 
     def checker(self, ho, o, rows, threads, passes):
         a, b = self.host_operands(rows)
@@ -241,8 +257,8 @@ class DotProduct(Workload):
         L, N = self.L, self.N
         return 2 * (2 * L * N * 8) + 2 * L * N * 8 + 13 * self.key_bytes() / global_batch
 
-    def result_rows(self, k):
-        return self.d_out.download_head((k, 2, self.L, self.N))
+    def result_slab(self):
+        return self.d_out, (2, self.L)
 
     def checker(self, ho, o, rows, threads, passes):
         a, b = self.host_operands(rows)
@@ -303,8 +319,8 @@ class BfvMatMul(Workload):
         ct = 2 * L * N * 8
         return 2 * ct + (ct + (1 + len(self.gk_steps)) * self.key_bytes()) / global_batch
 
-    def result_rows(self, k):
-        return self.result.download_head((k, 2, self.L, self.N))
+    def result_slab(self):
+        return self.result, (2, self.L)
 
     def checker(self, ho, o, rows, threads, passes):
         a, b = self.host_operands(rows)
@@ -343,8 +359,8 @@ class BfvAdd(Workload):
     def bytes_per_op(self, global_batch):
         return 3 * 2 * self.L * self.N * 8  # read 2 cts (operand 1 from cache after the first result), write 1
 
-    def result_rows(self, k):
-        return self.d_out.download_head((k, 2, self.L, self.N))
+    def result_slab(self):
+        return self.d_out, (2, self.L)
 
     def checker(self, ho, o, rows, threads, passes):
         a, b = self.host_operands(rows)
@@ -405,27 +421,41 @@ def self_launch(n_gpus: int) -> int:
     return proc.returncode
 
 
+def scalings_of(args, world):
+    """The scalings one invocation times, primary first.  N = 1: one run (both scalings are the same job).  N > 1 without --scaling: BOTH --
+    `value` answers north_star's strong question (the GLOBAL batch is --batch, 1024 for the headline, at every N: ">= 6x at 8 GPUs"), and a
+    `weak` block beside it times --batch results PER GPU (the 1-GPU load on every GPU).  --scaling weak|strong times that one only."""
+    if args.scaling:
+        return [args.scaling]
+    return ["weak"] if world == 1 else ["strong", "weak"]
+
+
 def dry_run(args, rank, world, dist, torch) -> int:
-    """The N>1 path without a GPU: rendezvous over gloo, the shard every rank would own, one JSON line from rank 0."""
-    if world > 1:
+    """The N>1 path without a GPU: rendezvous over gloo, the shard every rank would own under every scaling the real run would time, one
+    JSON line from rank 0 (the primary scaling's shards at the top level, every scaling under `runs`)."""
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         dist.init_process_group(backend="gloo")
     W = WORKLOADS[args.config]
     if args.b1 > 0:
         W = type(W.__name__ + f"_b1_{args.b1}", (W,), {"b1": args.b1})
     batch = args.batch or W.default_batch
-    global_b0 = batch * world if args.scaling == "weak" else batch
-    sh = load_sharding().shard_outer_product(global_b0, W.b1, world, rank)
-    mine = torch.tensor([rank, sh.a_base, sh.a_count, sh.n_results], dtype=torch.int64)
-    rows = [mine]
-    if world > 1:
-        rows = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(rows, mine)
-        dist.barrier()
+    runs = []
+    for scaling in scalings_of(args, world):
+        global_b0 = batch * world if scaling == "weak" else batch
+        sh = load_sharding().shard_outer_product(global_b0, W.b1, world, rank)
+        mine = torch.tensor([rank, sh.a_base, sh.a_count, sh.n_results], dtype=torch.int64)
+        rows = [mine]
+        if use_dist:
+            rows = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(rows, mine)
+            dist.barrier()
+        runs.append({"scaling": scaling, "global_b0": global_b0,
+                     "shards": [{"rank": int(r[0]), "a_base": int(r[1]), "a_count": int(r[2]), "n_results": int(r[3])} for r in rows]})
     if rank == 0:
-        shards = [{"rank": int(r[0]), "a_base": int(r[1]), "a_count": int(r[2]), "n_results": int(r[3])} for r in rows]
-        print(json.dumps({"dry_run": True, "n_gpus": world, "config": args.config, "scaling": args.scaling, "global_b0": global_b0, "b1": W.b1,
-                          "shards": shards}))
-    if world > 1:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "config": args.config, "scaling": runs[0]["scaling"], "global_b0": runs[0]["global_b0"],
+                          "b1": W.b1, "shards": runs[0]["shards"], "runs": runs}))
+    if use_dist:
         dist.destroy_process_group()
     return 0
 
@@ -436,7 +466,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=list(WORKLOADS), default="mul_relin_rescale")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="weak: --batch results PER GPU; strong: --batch is the GLOBAL batch.  Not given: N = 1 runs the batch once (the two are the same job); "
+                         "N > 1 times BOTH in one invocation -- `value` = strong (north_star: batch 1024 over the GPUs of the node), a `weak` block beside it")
     ap.add_argument("--batch", type=int, default=0, help="operand-0 batch: per GPU (weak) or global (strong); 0: the configuration's own")
     ap.add_argument("--b1", type=int, default=0, help="operand-1 batch of the HEBench outer product (results = batch x b1; operand 1 is replicated on every rank); 0: the "
                                                       "configuration's own (1).  `--config eltwise_mul --batch 16 --b1 16` is the 16 x 16 shape of configs[1] (SURVEY.md 8d cfg2)")
@@ -448,17 +480,21 @@ def main():
                                                            "the global batch, rank 0 prints them; no GPU is touched (what the CPU test of the N>1 path runs)")
     ap.add_argument("--profile-mode", action="store_true", help="only warm-up + timed steps on the GPU (no CPU baseline, no parity sample, no extra "
                                                                 "single-stream step): what rocprofv3 traces and PMC passes should see")
+    ap.add_argument("--force-dist", action="store_true", default=os.environ.get("HE355_BENCH_FORCE_DIST", "0") not in ("", "0"),
+                    help="take the N > 1 branch at --gpus 1 too (also HE355_BENCH_FORCE_DIST=1): the one rank is started under torch.distributed.run, initialises the "
+                         "collective backend (nccl = RCCL) on its device, and the line carries `collective` -- what a 1-GPU box can check of the multi-GPU path")
     args = ap.parse_args()
     if args.profile_mode:
         args.cpu_sample, args.parity_sample = 0, 0
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))  # plain `python bench.py --gpus N`: this process becomes the launcher
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    use_dist = world > 1 or args.force_dist
 
     import torch
     import torch.distributed as dist
@@ -470,11 +506,12 @@ def main():
     backend = os.environ.get("HE355_BENCH_BACKEND", "nccl")
     device = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
-    if world > 1:
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend=backend)
+    tdev = "cuda" if backend == "nccl" else "cpu"
 
     be = importlib.import_module("reference-seal-backend_amd")
     sharding = load_sharding()
@@ -489,55 +526,83 @@ def main():
         ctx.set_chunk(args.chunk)
 
     batch = args.batch or W.default_batch
-    global_b0 = batch * world if args.scaling == "weak" else batch
-    shard = sharding.shard_outer_product(global_b0, W.b1, world, rank)  # contiguous block of operand-0 rows; operand 1 and keys replicated
-    wl = W(be, ctx, shard, args)
-    wl.setup()
-    n = wl.n
 
     def barrier():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        wl.step()
-    barrier()
-    ctx.timer_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    gpu_ms = ctx.timer_end()  # HIP events on the stream the kernels run on
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tdev = "cuda" if backend == "nccl" else "cpu"
+    def timed_run(scaling):
+        """One complete measurement under `scaling`: this rank's shard of the global batch resident in HBM, W warm-up steps, barrier + synchronize,
+        K timed steps, barrier + synchronize, MAX over ranks.  Returns the workload (its buffers still resident) and the figures."""
+        global_b0 = batch * world if scaling == "weak" else batch
+        shard = sharding.shard_outer_product(global_b0, W.b1, world, rank)  # contiguous block of operand-0 rows; operand 1 and keys replicated
+        first_buf = len(ctx._bufs)
+        wl = W(be, ctx, shard, args)
+        wl.setup()
+        for _ in range(args.warmup):
+            wl.step()
+        barrier()
+        ctx.timer_begin()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step()
+        gpu_ms = ctx.timer_end()  # HIP events on the stream the kernels run on
+        barrier()
+        elapsed = time.perf_counter() - t0
+        my_ms = elapsed / args.steps * 1e3
+        per_rank_ms = [round(my_ms, 3)]
+        if use_dist:
+            tm = torch.tensor([my_ms], dtype=torch.float64, device=tdev)
+            allt = [torch.zeros_like(tm) for _ in range(world)]
+            dist.all_gather(allt, tm)
+            per_rank_ms = [round(float(x.item()), 3) for x in allt]
+            t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        total_results = global_b0 * W.b1 * args.steps
+        return {"wl": wl, "scaling": scaling, "global_b0": global_b0, "elapsed": elapsed, "gpu_ms": gpu_ms, "per_rank_ms": per_rank_ms,
+                "total_results": total_results, "value": total_results / elapsed, "bufs": (first_buf, len(ctx._bufs))}
+
+    def release(run):
+        """hand a finished run's slabs back to the context's pool before the next run is set up"""
+        lo, hi = run["bufs"]
+        for b in ctx._bufs[lo:hi]:
+            b.free()
+        del ctx._bufs[lo:hi]
+        run["wl"] = None
+
+    # secondary runs first (their slabs are released), the primary last: the probes and checker legs below work on its resident shard
+    plan = scalings_of(args, world)
+    secondary = []
+    for sc in plan[1:]:
+        r = timed_run(sc)
+        n_sec = r["wl"].n
+        release(r)
+        secondary.append({"scaling": sc, "value": round(r["value"], 2), "unit": "ciphertext-ops/sec", "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 3),
+                          "per_rank_ms": r["per_rank_ms"], "global_batch": r["global_b0"] * W.b1, "batch_per_gpu_rank0": n_sec,
+                          "batch": (f"{batch} operand-0 rows PER GPU x {world} GPUs" if sc == "weak" else f"global batch {batch} cut over {world} GPUs")})
+    run = timed_run(plan[0])
+    wl, n = run["wl"], run["wl"].n
+    scaling_kind, global_b0, elapsed, gpu_ms, per_rank_ms, total_results, value = (run[k] for k in ("scaling", "global_b0", "elapsed", "gpu_ms", "per_rank_ms",
+                                                                                                "total_results", "value"))
     # what a reader of the N > 1 line needs to see that the ranks really met over the collective backend and which card each one drove:
     # an all-reduce of one 1 per rank (must equal the world size), every rank's own time and its device's PCI bus id
     props = torch.cuda.get_device_properties(device)
     bus = (f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', -1):02x}:{getattr(props, 'pci_device_id', 0):02x}"
            if hasattr(props, "pci_bus_id") else None)
-    my_ms = elapsed / args.steps * 1e3
     collective = None
-    per_rank_ms, per_rank_device = [round(my_ms, 3)], [{"rank": 0, "local_device": device, "pci_bus_id": bus, "name": props.name}]
-    if world > 1:
+    per_rank_device = [{"rank": 0, "local_device": device, "pci_bus_id": bus, "name": props.name}]
+    if use_dist:
         ones = torch.ones(1, dtype=torch.float64, device=tdev)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-        tm = torch.tensor([my_ms], dtype=torch.float64, device=tdev)
-        allt = [torch.zeros_like(tm) for _ in range(world)]
-        dist.all_gather(allt, tm)
-        per_rank_ms = [round(float(x.item()), 3) for x in allt]
         objs = [None] * world
         dist.all_gather_object(objs, {"rank": rank, "local_device": device, "pci_bus_id": bus, "name": props.name})
         per_rank_device = objs
         collective = {"backend": dist.get_backend() + (" (RCCL)" if backend == "nccl" else ""), "world_size": dist.get_world_size(),
                       "allreduce_of_ones": float(ones.item()),
                       "note": "rendezvous, barriers, MAX-over-ranks and this all-reduce only: no collective inside the timed region (SURVEY.md 8e)"}
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    total_results = global_b0 * W.b1 * args.steps
-    value = total_results / elapsed
 
     # ---- shader clock held under this load: one extra untimed step (same schedule as the timed ones) with a one-wave probe beside it that
     # samples s_memtime against the 100 MHz counter for ~80 % of a step (he355_clock_probe_begin; MI355X_MICROARCH.md "DVFS give-back") ----
@@ -574,7 +639,7 @@ def main():
         assert [int(q) for q in o.moduli] == [int(q) for q in ctx.moduli]
         cpus = ho.effective_cpus()  # affinity mask and cgroup quota: omp_get_max_threads() sees neither a quota nor a CPU share
         cores = max(1, min(ho.lib().ho_max_threads(), cpus["affinity"] or 1 << 30))
-        threads = cores if world == 1 else max(1, cores // world)
+        threads = cores if world == 1 else max(1, min(cores, cpus["effective"] or cores) // world)  # the ranks of a node share its CPU quota
         res_wanted = csample if do_cpu else psample
         rows_checked = min(wl.rows, max(1, -(-res_wanted // W.b1)))  # whole operand-0 rows
         wl.step()  # (the extra single-stream step above left the same results; this keeps the legs independent of it)
@@ -625,7 +690,7 @@ def main():
 
     # every rank's verdict reaches rank 0
     flags = [1 if parity is None else int(parity), rows_checked * W.b1]
-    if world > 1:
+    if use_dist:
         t = torch.tensor(flags, dtype=torch.int64, device=tdev)
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
@@ -708,22 +773,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": scaling_kind,
             "vs_baseline": round(value / cpu["value"], 2) if cpu and cpu.get("value") else None,
             "vs_baseline_note": ("value / cpu_baseline.value: the in-repo CPU port of the reference's algorithm timed in this run on this box's cores -- NOT a published "
                                  "number (BASELINE.md holds none; SEAL itself is unavailable offline)") if cpu and cpu.get("value") else None,
             "dtype": "u64 (exact residues; fp64-FMA engine for primes < 2^47, u64 Harvey engine with the fold reduction for the 60-bit primes)",
             "data": "synthetic (uniform residues generated in HBM; synthetic evaluation keys; the same global batch at every world size)",
             "config": {"workload": wl.describe(), "poly_modulus_degree": W.N, "coeff_modulus_bits": bits,
-                       "batch": (f"{global_b0} x {W.b1} results globally; scaling = {args.scaling}: "
+                       "batch": (f"{global_b0} x {W.b1} results globally; scaling = {scaling_kind}: "
                                  + (f"{batch} operand-0 rows PER GPU x {world} GPU(s) -- per-GPU work is the batch `metric` names at every N, so the line "
-                                    "answers `ciphertext-ops/sec at N GPUs` with each GPU as loaded as the 1-GPU run" if args.scaling == "weak" else
+                                    "answers `ciphertext-ops/sec at N GPUs` with each GPU as loaded as the 1-GPU run" if scaling_kind == "weak" else
                                     f"the GLOBAL batch is {batch} at every N ({n} results on rank 0) -- answers north_star's `batch = 1024 ... >= 6x at 8 GPUs` "
-                                    "(run with --scaling strong --batch 1024)")
+                                    "(the default at N > 1; the `weak` block beside it times the same batch PER GPU)")
                                  + "; rank r owns a contiguous block of operand-0 rows (sharding.shard_outer_product)"),
                        "batch_per_gpu": n, "global_batch": global_b0 * W.b1,
                        "parallelism": f"batch-sharded x{world}, keys and operand 1 replicated (built per device from the shared seed), no data-path collective"},
             "collective": collective,
+            "weak": next((b for b in secondary if b["scaling"] == "weak"), None),
+            "other_scalings": secondary or None,
             "per_rank_ms": per_rank_ms,
             "per_rank_device": per_rank_device,
             "roofline": roof,
@@ -734,7 +801,7 @@ def main():
             "results_checksum_rank0": checksum,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     ctx.close()
     if not all_ok:

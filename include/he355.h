@@ -94,6 +94,9 @@ int he355_device_init(he355_ctx *ctx, int device_ordinal); /* uploads tables; cr
  * he355_device_init (its tables, keys and scratch arenas included); he355_pool_trim drains the streams and hipFree()s the cached
  * blocks (also done by itself when the device runs out of memory). */
 int he355_malloc(he355_ctx *ctx, uint64_t bytes, void **d_ptr);
+/* he355_free takes ONLY pointers this context's he355_malloc returned and has not freed yet: a block freed twice, a pointer of another
+ * context or one from hipMalloc is refused with HE355_E_INVALID_ARGS and left untouched (since round 5; before, a foreign pointer was
+ * drained and hipFree()d).  A host that allocates device memory by other means must release it by the same means. */
 int he355_free(he355_ctx *ctx, void *d_ptr);
 typedef struct {
     uint64_t raw_mallocs, raw_frees; /* hipMalloc / hipFree calls            */
@@ -102,6 +105,20 @@ typedef struct {
 } he355_alloc_stats_t;
 int he355_alloc_stats(he355_ctx *ctx, he355_alloc_stats_t *out); /* ctx == NULL: totals over every context of the process (byte fields 0) */
 int he355_pool_trim(he355_ctx *ctx, uint64_t *released_bytes);
+/* Which shape / schedule the context's key switches took since he355_device_init (or the last call with reset != 0).  The choice is the
+ * library's (batch, ring size, level: DESIGN.md 5.2-5.3) and never changes a result bit; tests use the counters to prove that the shape they
+ * mean to hold to the oracle is the one that ran (tests/test_gpu_bench_shapes.py).  A "sequence" is the kernel sequence of one chunk of a batch. */
+typedef struct {
+    uint64_t ks_fused;      /* throughput shape, mod-down finished inside k_k3                          */
+    uint64_t ks_unfused;    /* throughput shape, separate floor kernels (small grids)                   */
+    uint64_t ks_latency;    /* latency shape (digit-split tiles, batch x N <= 2^17)                     */
+    uint64_t ks_lds;        /* ring-in-LDS shape (N <= 8192, few ciphertexts): one workgroup per residue polynomial */
+    uint64_t level_sums_in_k3;         /* he355_rotate_sum levels whose sum was formed by k_k3 itself   */
+    uint64_t level_sums_by_kernel;     /* ... by k_sum_groups                                            */
+    uint64_t level_sum_launches_in_k3; /* fused sequences that carried a level sum (several per level when HE355_CHUNK cuts it) */
+    uint64_t reserved;
+} he355_path_stats_t;
+int he355_path_stats(he355_ctx *ctx, he355_path_stats_t *out, int reset);
 int he355_upload(he355_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int he355_download(he355_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
 int he355_copy(he355_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes); /* device to device, on the context's stream */
@@ -219,6 +236,16 @@ int he355_ckks_encode(he355_ctx *ctx, uint64_t n, const double *d_values, uint64
 int he355_ckks_decode(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_plain, double scale, double *d_out);
 int he355_bfv_encode(he355_ctx *ctx, uint64_t n, const int64_t *d_values, uint64_t count, uint64_t *d_plain);
 int he355_bfv_decode(he355_ctx *ctx, uint64_t n, const uint64_t *d_plain, int64_t *d_out);
+/* The same decoders writing only the slots a caller reads: `ranges` = n_ranges (1..4) HOST pairs {first_slot, count}; d_out is
+ * [n][sum of counts], the ranges one after the other.  A workload's decode() copies the first n (vectors) or dim3 (matrix rows) slots of
+ * each result (src/benchmarks/ckks/seal_ckks_element_wise_benchmark.cpp:214-226; both batching rows for the BFV row-major product,
+ * bfv/seal_bfv_matmult_row_benchmark.cpp:339-369), so the device writes and the host downloads n x count values instead of n x N/2 (N). */
+int he355_ckks_decode_slots(he355_ctx *ctx, int L, uint64_t n, const uint64_t *d_plain, double scale, const uint64_t *ranges, uint64_t n_ranges, double *d_out);
+int he355_bfv_decode_slots(he355_ctx *ctx, uint64_t n, const uint64_t *d_plain, const uint64_t *ranges, uint64_t n_ranges, int64_t *d_out);
+/* Page-locked host memory (hipHostMalloc) for he355_upload / he355_download of small, frequent transfers (the bridge's decode results and
+ * encode inputs live in one such buffer per benchmark object). */
+int he355_host_alloc(he355_ctx *ctx, uint64_t bytes, void **h_ptr);
+int he355_host_free(he355_ctx *ctx, void *h_ptr);
 /* transforms of n_polys residue polynomials, polynomial p under prime prime_of[p % period] (test / client use) */
 int he355_ntt_forward(he355_ctx *ctx, uint64_t *d_polys, uint64_t n_polys, const uint8_t *prime_of, uint32_t period);
 int he355_ntt_inverse(he355_ctx *ctx, uint64_t *d_polys, uint64_t n_polys, const uint8_t *prime_of, uint32_t period);

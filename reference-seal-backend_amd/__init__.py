@@ -39,6 +39,11 @@ class AllocStats(C.Structure):
                 ("cached_bytes", C.c_uint64), ("live_bytes", C.c_uint64)]
 
 
+class PathStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("ks_fused", "ks_unfused", "ks_latency", "ks_lds", "level_sums_in_k3", "level_sums_by_kernel",
+                                           "level_sum_launches_in_k3", "reserved")]
+
+
 def build(force: bool = False) -> str:
     """Compile the backend for gfx950 with hipcc (csrc/Makefile)."""
     csrc = os.path.join(_HERE, "csrc")
@@ -100,6 +105,9 @@ def lib():
             "he355_ckks_decode": (i32, [vp, i32, u64, vp, C.c_double, vp]),
             "he355_bfv_encode": (i32, [vp, u64, vp, u64, vp]),
             "he355_bfv_decode": (i32, [vp, u64, vp, vp]),
+            "he355_ckks_decode_slots": (i32, [vp, i32, u64, vp, C.c_double, _u64p, u64, vp]),
+            "he355_bfv_decode_slots": (i32, [vp, u64, vp, _u64p, u64, vp]),
+            "he355_host_alloc": (i32, [vp, u64, vpp]), "he355_host_free": (i32, [vp, vp]),
             "he355_decrypt": (i32, [vp, i32, i32, u64, vp, vp]),
             "he355_multiply_plain": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
             "he355_add_plain": (i32, [vp, i32, i32, u64, vp, vp, Indexer, vp]),
@@ -127,6 +135,7 @@ def lib():
             "he355_mem_info": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
             "he355_alloc_stats": (i32, [vp, C.POINTER(AllocStats)]),
             "he355_pool_trim": (i32, [vp, C.POINTER(C.c_uint64)]),
+            "he355_path_stats": (i32, [vp, C.POINTER(PathStats), i32]),
             "he355_bridge_abi": (u64, [C.c_char_p, u64]),
             "he355_bridge_group_load_bytes": (u64, [i32, i32]),
         }
@@ -146,8 +155,8 @@ C_ABI_SYMBOLS = [
     "he355_set_galois_key_synthetic", "he355_add", "he355_sub", "he355_multiply", "he355_bfv_multiply", "he355_multiply_relin",
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_bfv_multiply_relin_accumulate", "he355_multiply_plain", "he355_add_plain",
     "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_keygen_relin", "he355_keygen_galois", "he355_ckks_encode", "he355_ckks_decode",
-    "he355_bfv_encode", "he355_bfv_decode", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_rotate_each", "he355_rotate_sum", "he355_accumulate", "he355_encrypt_zero", "he355_set_zero_stream",
-    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_clock_probe_begin", "he355_clock_probe_end", "he355_set_chunk", "he355_set_latency_max", "he355_set_level_walk", "he355_mem_info", "he355_alloc_stats", "he355_pool_trim", "he355_bridge_abi", "he355_bridge_group_load_bytes",
+    "he355_bfv_encode", "he355_bfv_decode", "he355_ckks_decode_slots", "he355_bfv_decode_slots", "he355_host_alloc", "he355_host_free", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_rotate_each", "he355_rotate_sum", "he355_accumulate", "he355_encrypt_zero", "he355_set_zero_stream",
+    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_clock_probe_begin", "he355_clock_probe_end", "he355_set_chunk", "he355_set_latency_max", "he355_set_level_walk", "he355_mem_info", "he355_alloc_stats", "he355_pool_trim", "he355_path_stats", "he355_bridge_abi", "he355_bridge_group_load_bytes",
 ]
 
 
@@ -180,6 +189,15 @@ class DeviceBuffer:
         out = np.empty(self.n, dtype=np.uint64)
         _check(lib().he355_download(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes))
         return out.reshape(shape) if shape is not None else out
+
+    def download_range(self, offset_u64: int, shape) -> np.ndarray:
+        """prod(shape) elements starting at element offset_u64 (one row out of the middle or the end of a large slab)"""
+        k = int(np.prod(shape))
+        assert 0 <= offset_u64 and offset_u64 + k <= self.n, (offset_u64, k, self.n)
+        out = np.empty(k, dtype=np.uint64)
+        if k:
+            _check(lib().he355_download(self.ctx.h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr.value + int(offset_u64) * 8), out.nbytes))
+        return out.reshape(shape)
 
     def download_head(self, shape) -> np.ndarray:
         """the first prod(shape) elements only (a sample of a large slab without moving the whole slab over PCIe)"""
@@ -372,6 +390,20 @@ class Context:
     def bfv_decode(self, n, plain, out):
         _check(lib().he355_bfv_decode(self.h, n, plain.ptr, out.ptr))
 
+    @staticmethod
+    def _ranges(ranges):
+        flat = [int(v) for r in ranges for v in r]
+        return (C.c_uint64 * len(flat))(*flat), len(flat) // 2
+
+    def ckks_decode_slots(self, L, n, plain, scale, ranges, out):
+        """only the slots of `ranges` = [(first, count), ...]: out is [n][sum of counts]"""
+        arr, k = self._ranges(ranges)
+        _check(lib().he355_ckks_decode_slots(self.h, L, n, plain.ptr, scale, arr, k, out.ptr))
+
+    def bfv_decode_slots(self, n, plain, ranges, out):
+        arr, k = self._ranges(ranges)
+        _check(lib().he355_bfv_decode_slots(self.h, n, plain.ptr, arr, k, out.ptr))
+
     def relinearize_rescale(self, L, n, ct3, out):
         _check(lib().he355_relinearize_rescale(self.h, L, n, ct3.ptr, out.ptr))
 
@@ -413,6 +445,12 @@ class Context:
         st = AllocStats()
         _check(lib().he355_alloc_stats(self.h, C.byref(st)))
         return {k: int(getattr(st, k)) for k, _ in AllocStats._fields_}
+
+    def path_stats(self, reset: bool = False) -> dict:
+        """which key-switch shape / schedule ran (he355_path_stats): counts of kernel sequences since device_init or the last reset"""
+        st = PathStats()
+        _check(lib().he355_path_stats(self.h, C.byref(st), int(reset)))
+        return {k: int(getattr(st, k)) for k, _ in PathStats._fields_ if k != "reserved"}
 
     def pool_trim(self) -> int:
         b = C.c_uint64()

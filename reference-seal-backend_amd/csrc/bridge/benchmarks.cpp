@@ -110,6 +110,7 @@ VectorBenchmark::VectorBenchmark(hebench::cpp::BaseEngine &engine, const AB::Ben
         m_p_ctx_wrapper = HeContextWrapper::createCKKSContext(poly_modulus_degree, multiplicative_depth, (int)coeff_modulus_bits, (int)extra_bits);
     else
         m_p_ctx_wrapper = HeContextWrapper::createBFVContext(poly_modulus_degree, multiplicative_depth, (int)coeff_modulus_bits, (int)extra_bits);
+    m_p_ctx_wrapper->prepareClient(256);
     const std::size_t slot_count = m_p_ctx_wrapper->slot_count();
     if (m_w_params.n() > slot_count)
         throw HEBenchError(HEBERROR_MSG_CLASS("Vector size cannot be greater than " + std::to_string(slot_count) + "."), HEBENCH_ECODE_INVALID_ARGS);
@@ -153,18 +154,21 @@ void VectorBenchmark::decode(AB::Handle encoded_data, AB::DataPackCollection *p_
     const std::size_t out_n = dot ? 1 : m_w_params.n();
     const std::size_t n_res = std::min<std::size_t>(params.size(), p_native->p_data_packs[0].buffer_count);
     const std::vector<Plain> wanted(params.begin(), params.begin() + n_res);
+    // only the out_n slots the loop below copies are decoded to the host (the reference decodes all and copies the first n: .cpp:214-226)
+    const HeContextWrapper::SlotRanges head{{0, out_n}};
     if (m_scheme == Scheme::CKKS) {
-        const std::vector<std::vector<double>> vals = m_p_ctx_wrapper->decodeBatchCKKS(wanted);
+        const std::vector<double> vals = m_p_ctx_wrapper->decodeSlotsCKKS(wanted, head);
         for (std::size_t result_i = 0; result_i < n_res; ++result_i) {
             double *output_location = reinterpret_cast<double *>(p_native->p_data_packs[0].p_buffers[result_i].p);
+            const double *v = vals.data() + result_i * out_n;
             for (std::size_t x = 0; x < out_n; ++x) // same clamp as ckks eltwise .cpp:222-225
-                output_location[x] = std::abs(vals[result_i][x]) < 0.00005 ? 0 : vals[result_i][x];
+                output_location[x] = std::abs(v[x]) < 0.00005 ? 0 : v[x];
         }
     } else {
-        const std::vector<std::vector<std::int64_t>> vals = m_p_ctx_wrapper->decodeBatchBFV(wanted);
+        const std::vector<std::int64_t> vals = m_p_ctx_wrapper->decodeSlotsBFV(wanted, head);
         for (std::size_t result_i = 0; result_i < n_res; ++result_i) {
             std::int64_t *output_location = reinterpret_cast<std::int64_t *>(p_native->p_data_packs[0].p_buffers[result_i].p);
-            for (std::size_t x = 0; x < out_n; ++x) output_location[x] = vals[result_i][x];
+            std::copy(vals.begin() + result_i * out_n, vals.begin() + (result_i + 1) * out_n, output_location);
         }
     }
 }

@@ -39,7 +39,34 @@ DeviceCiphers::~DeviceCiphers()
 HeContextWrapper::~HeContextWrapper()
 {
     m_client.reset();
+    if (m_pinned) (void)he355_host_free(m_ctx, m_pinned);
     if (m_ctx) he355_ctx_destroy(m_ctx);
+}
+void *HeContextWrapper::pinned(std::uint64_t bytes)
+{
+    if (bytes > m_pinned_bytes) {
+        if (m_pinned) check(he355_host_free(m_ctx, m_pinned), "page-locked buffer");
+        m_pinned = nullptr; m_pinned_bytes = 0;
+        const std::uint64_t want = std::max<std::uint64_t>(bytes, (std::uint64_t)1 << 20);
+        check(he355_host_alloc(m_ctx, want, &m_pinned), "page-locked buffer");
+        m_pinned_bytes = want;
+    }
+    return m_pinned;
+}
+void HeContextWrapper::prepareClient(std::uint64_t batch_hint)
+{
+    if (!clientOnDevice()) return; // (no device: the host client needs nothing prepared)
+    (void)pinned((std::uint64_t)1 << 20);
+    // one throw-away encode -> decode of `batch_hint` empty vectors sizes the client scratch and the pool's size classes, builds the encoder
+    // and CRT tables and pages the kernels in: the first real encode() then costs what the second one does
+    const std::uint64_t n = std::max<std::uint64_t>(1, std::min<std::uint64_t>(batch_hint, 256));
+    if (isCKKS()) {
+        const std::vector<Plain> pl = encodeBatch(std::vector<std::vector<double>>(n, std::vector<double>(1, 0.0)));
+        (void)decodeSlotsCKKS(pl, SlotRanges{{0, 1}});
+    } else if (m_params->plain_modulus > 2 && (m_params->plain_modulus - 1) % (2 * m_params->N) == 0) {
+        const std::vector<Plain> pl = encodeBatch(std::vector<std::vector<std::int64_t>>(n, std::vector<std::int64_t>(1, 0)));
+        (void)decodeSlotsBFV(pl, SlotRanges{{0, 1}});
+    }
 }
 
 void HeContextWrapper::init(int scheme, std::size_t N, std::size_t depth, int bits, int plain_bits)
@@ -269,6 +296,70 @@ std::vector<std::vector<std::int64_t>> HeContextWrapper::decodeBatchBFV(const st
     check(he355_download(m_ctx, flat.get(), dv.p, n * N * 8), "download");
     out.reserve(n);
     for (std::uint64_t i = 0; i < n; ++i) out.emplace_back(flat.get() + i * N, flat.get() + (i + 1) * N);
+    return out;
+}
+static std::uint64_t ranges_total(const HeContextWrapper::SlotRanges &ranges, std::uint64_t slots, std::vector<std::uint64_t> &flat)
+{
+    std::uint64_t total = 0;
+    if (ranges.empty() || ranges.size() > 4) throw HEBenchError("decode: 1 to 4 slot ranges", HEBENCH_ECODE_INVALID_ARGS);
+    for (const auto &r : ranges) {
+        if (r.first > slots || r.second > slots - r.first) throw HEBenchError("decode: slot range outside the encoder's slots", HEBENCH_ECODE_INVALID_ARGS);
+        flat.push_back(r.first); flat.push_back(r.second);
+        total += r.second;
+    }
+    return total;
+}
+std::vector<double> HeContextWrapper::decodeSlotsCKKS(const std::vector<Plain> &plains, const SlotRanges &ranges)
+{
+    std::vector<std::uint64_t> flat;
+    const std::uint64_t total = ranges_total(ranges, slot_count(), flat), n = plains.size();
+    std::vector<double> out;
+    if (!n || !total) return out;
+    bool uniform = true;
+    for (const Plain &p : plains) uniform = uniform && p.L == plains[0].L && p.scale == plains[0].scale;
+    if (!clientOnDevice() || !uniform || plains[0].L > 16) { // host decoder: all slots, then the wanted ones
+        out.resize(n * total);
+        std::vector<double> all(slot_count());
+        for (std::size_t i = 0; i < n; ++i) {
+            m_client->ckks_decode(hostData(plains[i]), (size_t)plains[i].L, plains[i].scale, all.data());
+            double *dst = out.data() + i * total;
+            for (const auto &r : ranges) dst = std::copy(all.begin() + r.first, all.begin() + r.first + r.second, dst);
+        }
+        return out;
+    }
+    const int L = plains[0].L;
+    const std::uint64_t N = m_params->N, pl = (std::uint64_t)L * N, bytes = n * total * 8;
+    const Staged in = stage(plains, pl);
+    DevBuf dv(m_ctx, bytes);
+    check(he355_ckks_decode_slots(m_ctx, L, n, in.d, plains[0].scale, flat.data(), ranges.size(), dv.as<double>()), "decode");
+    double *host = static_cast<double *>(pinned(bytes));
+    check(he355_download(m_ctx, host, dv.p, bytes), "download"); // (stream-ordered behind the decode kernels; returns when the bytes are here)
+    out.assign(host, host + n * total);
+    return out;
+}
+std::vector<std::int64_t> HeContextWrapper::decodeSlotsBFV(const std::vector<Plain> &plains, const SlotRanges &ranges)
+{
+    std::vector<std::uint64_t> flat;
+    const std::uint64_t total = ranges_total(ranges, slot_count(), flat), n = plains.size();
+    std::vector<std::int64_t> out;
+    if (!n || !total) return out;
+    if (!clientOnDevice()) {
+        out.resize(n * total);
+        std::vector<std::int64_t> all(slot_count());
+        for (std::size_t i = 0; i < n; ++i) {
+            m_client->bfv_decode(hostData(plains[i]), all.data());
+            std::int64_t *dst = out.data() + i * total;
+            for (const auto &r : ranges) dst = std::copy(all.begin() + r.first, all.begin() + r.first + r.second, dst);
+        }
+        return out;
+    }
+    const std::uint64_t N = m_params->N, bytes = n * total * 8;
+    const Staged in = stage(plains, N);
+    DevBuf dv(m_ctx, bytes);
+    check(he355_bfv_decode_slots(m_ctx, n, in.d, flat.data(), ranges.size(), dv.as<std::int64_t>()), "decode");
+    std::int64_t *host = static_cast<std::int64_t *>(pinned(bytes));
+    check(he355_download(m_ctx, host, dv.p, bytes), "download");
+    out.assign(host, host + n * total);
     return out;
 }
 // Client side: on the MI355X when one is present (he355_encrypt / he355_decrypt: same bits as the host code below for the same

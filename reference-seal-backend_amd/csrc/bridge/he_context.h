@@ -95,6 +95,16 @@ public:
     std::vector<Plain> encodeBatch(const std::vector<std::vector<std::int64_t>> &rows);
     std::vector<std::vector<double>> decodeBatchCKKS(const std::vector<Plain> &plains);
     std::vector<std::vector<std::int64_t>> decodeBatchBFV(const std::vector<Plain> &plains);
+    // ... writing / downloading only the slots a workload's decode() reads: `ranges` = {first slot, count} (at most 4), the result is flat,
+    // [plains.size()][sum of counts] (ckks eltwise .cpp:214-226 copies the first n slots of a result; bfv row .cpp:339-369 the first dim3 of
+    // both batching rows).  The values land in a page-locked buffer the context owns and are copied out of it once.
+    typedef std::vector<std::pair<std::uint64_t, std::uint64_t>> SlotRanges;
+    std::vector<double> decodeSlotsCKKS(const std::vector<Plain> &plains, const SlotRanges &ranges);
+    std::vector<std::int64_t> decodeSlotsBFV(const std::vector<Plain> &plains, const SlotRanges &ranges);
+    // Everything the first encode() / encrypt() / decode() of a benchmark would otherwise pay for inside the call: device + streams, the
+    // client keys in HBM, the encoders' tables, the client scratch for `batch_hint` objects and the page-locked staging buffer.  Called by
+    // the benchmark constructors (createBenchmark is where the reference generates its keys: seal_context.cpp:46-70).
+    void prepareClient(std::uint64_t batch_hint = 1);
     Cipher encrypt(const Plain &plain);
     Plain decrypt(const Cipher &cipher);
     std::vector<Cipher> encryptBatch(const std::vector<Plain> &plains);   // one device call for the whole operand when a GPU is present
@@ -138,6 +148,9 @@ private:
     double m_scale = 1.0;
     bool m_device = false, m_relin = false;
     int m_client_dev = -1; // -1: not decided yet
+    void *m_pinned = nullptr; // page-locked staging of decode results / encode inputs (he355_host_alloc), grown on demand
+    std::uint64_t m_pinned_bytes = 0;
+    void *pinned(std::uint64_t bytes);
     std::map<uint32_t, bool> m_galois;
 };
 

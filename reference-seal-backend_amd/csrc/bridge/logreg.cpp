@@ -91,6 +91,7 @@ LogRegHornerBenchmark::LogRegHornerBenchmark(hebench::cpp::BaseEngine &engine, c
     const std::uint64_t scale_bits = bench_params.params[LogRegHornerBenchmarkDescription::Index_ScaleExponentBits].u_param;
     if (bits < 1) throw HEBenchError(HEBERROR_MSG_CLASS("Multiplicative depth must be greater than 0."), HEBENCH_ECODE_INVALID_ARGS);
     m_p_ctx_wrapper = HeContextWrapper::createCKKSContext(N, depth, (int)bits, (int)scale_bits);
+    m_p_ctx_wrapper->prepareClient(128);
     if (m_n > m_p_ctx_wrapper->slot_count())
         throw HEBenchError(HEBERROR_MSG_CLASS("Invalid workload parameter 'n'. Number of features must be under " + std::to_string(m_p_ctx_wrapper->slot_count()) + "."),
                            HEBENCH_ECODE_INVALID_ARGS);
@@ -173,8 +174,9 @@ void LogRegHornerBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackCollec
     const std::uint64_t min_count = std::min(result.buffer_count, batch);
     if (min_count == 0) return;
     const Plain &encoded = this->getEngine().retrieveFromHandle<Plain>(h_encoded_data, EncodedResultTag);
-    std::vector<double> v(m_p_ctx_wrapper->slot_count());
-    m_p_ctx_wrapper->client().ckks_decode(m_p_ctx_wrapper->hostData(encoded), (size_t)encoded.L, encoded.scale, v.data());
+    // the first min_count slots are the predictions (one per sample): decoded where the plaintext lies, only those come back
+    const std::uint64_t want = std::min<std::uint64_t>(min_count, m_p_ctx_wrapper->slot_count());
+    const std::vector<double> v = m_p_ctx_wrapper->decodeSlotsCKKS(std::vector<Plain>(1, encoded), HeContextWrapper::SlotRanges{{0, want}});
     for (std::uint64_t s = 0; s < min_count && s < v.size(); ++s)
         if (result.p_buffers[s].p && result.p_buffers[s].size >= sizeof(double))
             *reinterpret_cast<double *>(result.p_buffers[s].p) = std::abs(v[s]) < 0.00005 ? 0.0 : v[s];

@@ -82,6 +82,7 @@ MatMultCipherBatchAxisBenchmark::MatMultCipherBatchAxisBenchmark(hebench::cpp::B
     const int bits = (int)m_w[MatMultCipherBatchAxisBenchmarkDescription::Index_CoefficientModulusBits];
     const int extra = (int)m_w[MatMultCipherBatchAxisBenchmarkDescription::Index_ScaleExponentBits];
     m_p_ctx_wrapper = scheme == Scheme::CKKS ? HeContextWrapper::createCKKSContext(N, depth, bits, extra) : HeContextWrapper::createBFVContext(N, depth, bits, extra);
+    m_p_ctx_wrapper->prepareClient(256);
 }
 
 namespace {
@@ -110,7 +111,7 @@ AB::Handle MatMultCipherBatchAxisBenchmark::encode(const AB::DataPackCollection 
         if (dp->p_buffers[0].size < r * c * 8) throw HEBenchError(HEBERROR_MSG_CLASS("Insufficient data for matrix."), HEBENCH_ECODE_INVALID_ARGS);
         // storage order: M0 column-major, M1 row-major; encoded in groups by encodeBatch (same bits as one encodeVector per element)
         out.m[op].reserve(r * c);
-        const std::uint64_t kGroup = 256;
+        const std::uint64_t kGroup = 4096;
         for (std::uint64_t k0 = 0; k0 < r * c; k0 += kGroup) {
             const std::uint64_t k1 = std::min<std::uint64_t>(r * c, k0 + kGroup);
             std::vector<Plain> enc;
@@ -146,19 +147,19 @@ void MatMultCipherBatchAxisBenchmark::decode(AB::Handle h_encoded_data, AB::Data
     if (rc.p_buffers[0].size == 0) return;
     if (!rc.p_buffers[0].p) throw HEBenchError(HEBERROR_MSG_CLASS("Unexpected empty buffer in data pack."), HEBENCH_ECODE_CRITICAL_ERROR);
     const std::size_t room = rc.p_buffers[0].size / 8;
-    const std::size_t total = std::min(res.size(), room), kGroup = 256; // decode as much as fits (ckks .cpp:246-262), in groups
+    const std::size_t total = std::min(res.size(), room), kGroup = 4096; // decode as much as fits (ckks .cpp:246-262), in groups
     for (std::size_t k0 = 0; k0 < total; k0 += kGroup) {
         const std::size_t k1 = std::min(total, k0 + kGroup);
         const std::vector<Plain> group(res.begin() + k0, res.begin() + k1);
         if (m_scheme == Scheme::CKKS) {
-            const std::vector<std::vector<double>> vals = m_p_ctx_wrapper->decodeBatchCKKS(group);
+            const std::vector<double> vals = m_p_ctx_wrapper->decodeSlotsCKKS(group, HeContextWrapper::SlotRanges{{0, 1}}); // slot 0 is the entry
             for (std::size_t k = k0; k < k1; ++k) {
-                const double v0 = vals[k - k0][0];
+                const double v0 = vals[k - k0];
                 reinterpret_cast<double *>(rc.p_buffers[0].p)[k] = std::abs(v0) < 0.00005 ? 0.0 : v0;
             }
         } else {
-            const std::vector<std::vector<std::int64_t>> vals = m_p_ctx_wrapper->decodeBatchBFV(group);
-            for (std::size_t k = k0; k < k1; ++k) reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p)[k] = vals[k - k0][0];
+            const std::vector<std::int64_t> vals = m_p_ctx_wrapper->decodeSlotsBFV(group, HeContextWrapper::SlotRanges{{0, 1}});
+            for (std::size_t k = k0; k < k1; ++k) reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p)[k] = vals[k - k0];
         }
     }
 }

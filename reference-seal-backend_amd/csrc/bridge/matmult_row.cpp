@@ -88,6 +88,7 @@ MatMultRowLatencyBenchmark::MatMultRowLatencyBenchmark(hebench::cpp::BaseEngine 
     const std::uint64_t depth = m_w[MatMultRowBenchmarkDescription::Index_NumCoefficientModuli];
     const int bits = (int)m_w[MatMultRowBenchmarkDescription::Index_CoefficientModulusBits], extra = (int)m_w[MatMultRowBenchmarkDescription::Index_PlainModulusBits];
     m_p_ctx_wrapper = scheme == Scheme::CKKS ? HeContextWrapper::createCKKSContext(N, depth, bits, extra) : HeContextWrapper::createBFVContext(N, depth, bits, extra);
+    m_p_ctx_wrapper->prepareClient(256);
     m_num_devices = DeviceGroup::resolveCount(0); // HE355_NUM_DEVICES: the declared workload parameters stay the reference's
 }
 
@@ -178,9 +179,9 @@ void MatMultRowLatencyBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackC
     if (m_scheme == Scheme::CKKS) { // decodeResult, ckks row .cpp:330-356: row i = first dim3 slots of ciphertext i, |x| < 0.00005 -> 0
         double *raw = reinterpret_cast<double *>(rc.p_buffers[0].p);
         std::size_t room = rc.p_buffers[0].size / sizeof(double), pos = 0;
-        const std::vector<std::vector<double>> vals = m_p_ctx_wrapper->decodeBatchCKKS(enc.C);
-        for (std::size_t i = 0; i < enc.d.rows && i < vals.size() && pos < room; ++i) {
-            const std::vector<double> &v = vals[i];
+        const std::vector<double> vals = m_p_ctx_wrapper->decodeSlotsCKKS(enc.C, HeContextWrapper::SlotRanges{{0, enc.d.cols}});
+        for (std::size_t i = 0; i < enc.d.rows && i < enc.C.size() && pos < room; ++i) {
+            const double *v = vals.data() + i * enc.d.cols;
             for (std::size_t j = 0; j < enc.d.cols && pos < room; ++j) raw[pos++] = std::abs(v[j]) < 0.00005 ? 0.0 : v[j];
         }
         return;
@@ -189,12 +190,13 @@ void MatMultRowLatencyBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackC
     const std::size_t dim1 = enc.d.rows, dim3 = enc.d.cols, slots = m_p_ctx_wrapper->slot_count(), row_size = slots / 2;
     std::int64_t *raw = reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p);
     std::size_t room = rc.p_buffers[0].size / sizeof(std::int64_t), pos = 0;
-    const std::vector<std::vector<std::int64_t>> vals = m_p_ctx_wrapper->decodeBatchBFV(enc.C);
+    // the first dim3 slots of both batching rows of every ciphertext: [ciphertext][2][dim3]
+    const std::vector<std::int64_t> vals = m_p_ctx_wrapper->decodeSlotsBFV(enc.C, HeContextWrapper::SlotRanges{{0, dim3}, {row_size, dim3}});
     (void)slots;
     for (std::size_t i = 0; i < dim1 && pos < room; ++i) {
-        const std::vector<std::int64_t> &v = vals.at(i / 2);
-        const std::size_t off = (i & 1) ? row_size : 0;
-        for (std::size_t j = 0; j < dim3 && pos < room; ++j) raw[pos++] = v[off + j];
+        if (i / 2 >= enc.C.size()) throw std::out_of_range("MatMultRow decode: result row beyond the decrypted ciphertexts");
+        const std::int64_t *v = vals.data() + (i / 2) * 2 * dim3 + ((i & 1) ? dim3 : 0);
+        for (std::size_t j = 0; j < dim3 && pos < room; ++j) raw[pos++] = v[j];
     }
 }
 

@@ -84,6 +84,7 @@ MatMultValBenchmark::MatMultValBenchmark(hebench::cpp::BaseEngine &engine, const
     const std::uint64_t depth = m_w[MatMultValBenchmarkDescription::Index_NumCoefficientModuli];
     const int bits = (int)m_w[MatMultValBenchmarkDescription::Index_CoefficientModulusBits], extra = (int)m_w[MatMultValBenchmarkDescription::Index_ScaleExponentBits];
     m_p_ctx_wrapper = scheme == Scheme::CKKS ? HeContextWrapper::createCKKSContext(N, depth, bits, extra) : HeContextWrapper::createBFVContext(N, depth, bits, extra);
+    m_p_ctx_wrapper->prepareClient(256);
 }
 
 const AB::DataPack &MatMultValBenchmark::findDataPack(const AB::DataPackCollection &c, std::uint64_t pos)
@@ -139,19 +140,19 @@ void MatMultValBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackCollecti
     const AB::DataPack &rc = findDataPack(*p_native, 0);
     if (rc.buffer_count == 0 || !rc.p_buffers || !rc.p_buffers[0].p) return;
     const std::size_t room = rc.p_buffers[0].size / 8;
-    const std::size_t total = std::min<std::size_t>(rows_M0() * cols_M1(), room), kGroup = 256; // decoded in groups: bounded host memory
+    const std::size_t total = std::min<std::size_t>(rows_M0() * cols_M1(), room), kGroup = 4096; // decoded in groups: bounded host memory
     for (std::size_t k0 = 0; k0 < total; k0 += kGroup) {
         const std::size_t k1 = std::min(total, k0 + kGroup);
         const std::vector<Plain> group(res.begin() + k0, res.begin() + k1);
         if (m_scheme == Scheme::CKKS) {
-            const std::vector<std::vector<double>> vals = m_p_ctx_wrapper->decodeBatchCKKS(group);
+            const std::vector<double> vals = m_p_ctx_wrapper->decodeSlotsCKKS(group, HeContextWrapper::SlotRanges{{0, 1}}); // slot 0 is the entry
             for (std::size_t k = k0; k < k1; ++k) {
-                const double v0 = vals[k - k0][0];
+                const double v0 = vals[k - k0];
                 reinterpret_cast<double *>(rc.p_buffers[0].p)[k] = std::abs(v0) < 0.00005 ? 0.0 : v0; // ckks .cpp:356-359
             }
         } else {
-            const std::vector<std::vector<std::int64_t>> vals = m_p_ctx_wrapper->decodeBatchBFV(group);
-            for (std::size_t k = k0; k < k1; ++k) reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p)[k] = vals[k - k0][0];
+            const std::vector<std::int64_t> vals = m_p_ctx_wrapper->decodeSlotsBFV(group, HeContextWrapper::SlotRanges{{0, 1}});
+            for (std::size_t k = k0; k < k1; ++k) reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p)[k] = vals[k - k0];
         }
     }
 }

@@ -287,6 +287,13 @@ public:
         }
     }
     DevicePool::Stats alloc_stats() const { return pool_.stats(); }
+    // which shape / schedule the key switches of this context took (he355_path_stats): counted per kernel sequence (one chunk of a batch)
+    he355_path_stats_t path_stats(bool reset)
+    {
+        const he355_path_stats_t s = paths_;
+        if (reset) paths_ = he355_path_stats_t{};
+        return s;
+    }
     size_t pool_trim() { sync(); return pool_.trim(); }
     hipStream_t stream() const { return stream_; }
     int device() const { return device_; }
@@ -583,6 +590,7 @@ public:
         const size_t N = P.N, LN = (size_t)L * N;
         const int SP = (int)P.K - 1;
         if (lat) {
+            ++paths_.ks_latency;
             // Few ciphertexts (HEBench's Latency category is batch 1: ckks eltwise .cpp:138-141): the throughput shape would leave one
             // wave walking all digits of a tile and one lane walking all targets of a column while the chip idles.  Same kernels,
             // unfused, with the serial loops dealt to more blocks: targets of a column over kLatTargets blocks (k_k2n, k_floor_colsn),
@@ -600,6 +608,8 @@ public:
         if (k3_can_fuse(env_) && B.c01_item_stride == 2 * LN && fuse_pays(env_, nc, L)) {
             // special prime first, its correction through the column pass, then the data primes with the mod-down finished
             // inside K3 (the sums never go to HBM)
+            ++paths_.ks_fused;
+            if (groups && groups->sum_out) ++paths_.level_sum_launches_in_k3;
             launch_k3(env_, L, nc, B, key, K3_SPECIAL_ONLY, nullptr, 1, nullptr, 0, groups, g_off);
             if (rescale_out && L >= 2) {
                 // Mod-down + rescale with ONE column pass and ONE row transform per target: only the prime the rescale divides out needs
@@ -623,6 +633,7 @@ public:
             return false;
         }
         if (ten) throw std::logic_error("key_switch_tail: c0, c1 were left to a fused k_k3 that is not running");
+        ++paths_.ks_unfused;
         launch_k3(env_, L, nc, B, key, K3_ALL, nullptr, 1, nullptr, 0, groups, g_off);
         launch_floor_cols(env_, SP, L, nc * 2, B.tpr, B.e);
         return key_switch_floor_rows(env_, L, nc, S, B, with_tail);
@@ -1086,6 +1097,11 @@ public:
             if (chunk < gs || !fuse_pays(env, gs, L)) groups.sum_out = nullptr;
             else chunk -= chunk % gs;
         }
+        // A level sum is a read-modify-write of groups.sum_out WITHOUT atomics.  It is exact because (1) the launch shape gives one wave sole
+        // ownership of a (ciphertext, polynomial, tile, row) of the sum across all groups of the launch (launch_k3 checks the whole-group
+        // shape), and (2) every chunk of the level is queued on this ONE stream, in order: never alternate these chunks over stream2_ the way
+        // multiply_relin does, and never give grouped launches the four-wave or dual shapes.
+        if (groups.sum_out && env.stream != stream_) throw std::logic_error("level sum: the chunks of a level must stay on one stream");
         for (u64 off = 0; off < n; off += chunk) {
             const u64 nc = std::min<u64>(chunk, n - off);
             Scratch S = scratch(std::min<u64>(chunk, n), L);
@@ -1177,7 +1193,8 @@ public:
             Held cur{pool_};
             cur.reset(static_cast<u64 *>(pool_.alloc(G * bytes)));
             if (in_k3) { gt.g.sum_out = out; gt.g.count = gt.d_mult; }
-            if (!apply_galois_grouped(L, G, n, src, gt.g, cur.p)) launch_sum_groups(env_, L, n, (u32)G, cur.p, gt.d_mult, out);
+            if (apply_galois_grouped(L, G, n, src, gt.g, cur.p)) ++paths_.level_sums_in_k3;
+            else { ++paths_.level_sums_by_kernel; launch_sum_groups(env_, L, n, (u32)G, cur.p, gt.d_mult, out); }
             held.reset(cur.p);
             cur.p = nullptr;
             src = held.p;
@@ -1738,13 +1755,28 @@ public:
         HIPCHECK(hipStreamSynchronize(stream_));
         if (err) throw std::invalid_argument("encoded values are too large");
     }
-    // CKKSEncoder::decode: [n][L][N] NTT-form plaintexts -> [n][N/2] real slot values
-    void ckks_decode(int L, u64 n, const u64 *plain, double scale, double *out)
+    // the slot ranges of a decode call, checked against the encoder's slot count (ranges == null: every slot)
+    SlotRanges slot_ranges(const u64 *ranges, u64 n_ranges, u64 slots) const
+    {
+        SlotRanges sr{};
+        if (!ranges) { sr.n = 1; sr.first[0] = 0; sr.count[0] = sr.total = (u32)slots; return sr; }
+        if (n_ranges < 1 || n_ranges > (u64)kMaxSlotRanges) throw std::invalid_argument("decode: 1 to 4 slot ranges");
+        sr.n = (u32)n_ranges;
+        for (u64 g = 0; g < n_ranges; ++g) {
+            const u64 first = ranges[2 * g], count = ranges[2 * g + 1];
+            if (first > slots || count > slots - first) throw std::invalid_argument("decode: slot range outside the encoder's slots");
+            sr.first[g] = (u32)first; sr.count[g] = (u32)count; sr.total += (u32)count;
+        }
+        return sr;
+    }
+    // CKKSEncoder::decode: [n][L][N] NTT-form plaintexts -> [n][total] real slot values (ranges == null: all N/2)
+    void ckks_decode(int L, u64 n, const u64 *plain, double scale, double *out, const u64 *ranges = nullptr, u64 n_ranges = 0)
     {
         use();
         check_level(L);
         if (P.scheme != kSchemeCKKS) throw std::invalid_argument("he355_ckks_decode needs a CKKS context");
         if (L > 16) throw std::invalid_argument("decoding supports up to 16 data primes");
+        const SlotRanges sr = slot_ranges(ranges, n_ranges, P.N / 2);
         const EncTablesDev &T = enc_tables();
         const CrtTablesDev &crt = crt_tables(L);
         const size_t N = P.N;
@@ -1754,7 +1786,7 @@ public:
             const u64 c = std::min<u64>(cmax, n - off);
             HIPCHECK(hipMemcpyAsync(coeff, plain + off * L * N, c * L * N * 8, hipMemcpyDeviceToDevice, stream_));
             launch_ntt_inverse(env_, poly_view(coeff, L, N, L), (u32)c);
-            launch_ckks_decode(env_, c, coeff, scale, zbuf, out + off * (N / 2), T, crt);
+            launch_ckks_decode(env_, c, coeff, scale, zbuf, out + off * sr.total, T, crt, sr);
         }
         HIPCHECK(hipGetLastError());
     }
@@ -1772,10 +1804,11 @@ public:
         launch_ntt_inverse(env_, v, (u32)n);
         HIPCHECK(hipGetLastError());
     }
-    void bfv_decode(u64 n, const u64 *plain, long long *out)
+    void bfv_decode(u64 n, const u64 *plain, long long *out, const u64 *ranges = nullptr, u64 n_ranges = 0)
     {
         use();
         if (t_index_ < 0) throw std::invalid_argument("he355_bfv_decode needs a BFV context with a batching plain modulus");
+        const SlotRanges sr = slot_ranges(ranges, n_ranges, P.N);
         const EncTablesDev &T = enc_tables();
         const u64 cmax = 1024;
         u64 *ev = client_scratch(cmax * P.N);
@@ -1785,7 +1818,7 @@ public:
             PolyView v = poly_view(ev, 1, P.N, 1);
             v.prime_of[0] = (unsigned char)t_index_;
             launch_ntt_forward(env_, v, (u32)c);
-            launch_bfv_decode_gather(env_, c, ev, out + off * P.N, T.slot_index, P.plain_modulus);
+            launch_bfv_decode_gather(env_, c, ev, out + off * sr.total, T.slot_index, P.plain_modulus, sr);
         }
         HIPCHECK(hipGetLastError());
     }
@@ -1897,6 +1930,7 @@ private:
     bool dual_stream_ = true;
     u64 *rot_tmp_ = nullptr;
     size_t rot_tmp_bytes_ = 0;
+    he355_path_stats_t paths_{};
     bool level_walk_ = !(getenv("HE355_LEVEL_WALK") && getenv("HE355_LEVEL_WALK")[0] == '0'); // he355_rotate_sum: trie levels as grouped launches
     unsigned char *d_groups_ = nullptr; // group tables of the grouped key switches (upload_groups)
     size_t groups_bytes_ = 0, groups_next_ = 0;
@@ -2068,6 +2102,13 @@ int he355_alloc_stats(he355_ctx *c, he355_alloc_stats_t *out)
         out->raw_mallocs = st.raw_mallocs; out->raw_frees = st.raw_frees;
         out->pool_hits = st.pool_hits; out->pool_misses = st.pool_misses;
         out->cached_bytes = st.cached_bytes; out->live_bytes = st.live_bytes;
+    });
+}
+int he355_path_stats(he355_ctx *c, he355_path_stats_t *out, int reset)
+{
+    return guarded([&] {
+        if (!out) throw std::invalid_argument("null pointer");
+        *out = dev(c).path_stats(reset != 0);
     });
 }
 int he355_pool_trim(he355_ctx *c, uint64_t *released_bytes)
@@ -2297,6 +2338,37 @@ int he355_bfv_encode(he355_ctx *c, uint64_t n, const int64_t *d_values, uint64_t
 int he355_bfv_decode(he355_ctx *c, uint64_t n, const uint64_t *d_plain, int64_t *d_out)
 {
     return guarded([&] { dev(c).bfv_decode(n, d_plain, reinterpret_cast<long long *>(d_out)); });
+}
+int he355_ckks_decode_slots(he355_ctx *c, int L, uint64_t n, const uint64_t *d_plain, double scale, const uint64_t *ranges, uint64_t n_ranges, double *d_out)
+{
+    return guarded([&] {
+        if (!ranges) throw std::invalid_argument("null pointer");
+        dev(c).ckks_decode(L, n, d_plain, scale, d_out, ranges, n_ranges);
+    });
+}
+int he355_bfv_decode_slots(he355_ctx *c, uint64_t n, const uint64_t *d_plain, const uint64_t *ranges, uint64_t n_ranges, int64_t *d_out)
+{
+    return guarded([&] {
+        if (!ranges) throw std::invalid_argument("null pointer");
+        dev(c).bfv_decode(n, d_plain, reinterpret_cast<long long *>(d_out), ranges, n_ranges);
+    });
+}
+// Page-locked host memory for the small, frequent transfers of a harness run (decode results, encode inputs): a copy to or from it is one
+// DMA with no staging pass through the runtime's own pinned buffer
+int he355_host_alloc(he355_ctx *c, uint64_t bytes, void **h_ptr)
+{
+    return guarded([&] {
+        if (!h_ptr) throw std::invalid_argument("null pointer");
+        dev(c).use();
+        HIPCHECK(hipHostMalloc(h_ptr, bytes ? bytes : 8, hipHostMallocDefault));
+    });
+}
+int he355_host_free(he355_ctx *c, void *h_ptr)
+{
+    return guarded([&] {
+        dev(c).use();
+        if (h_ptr) HIPCHECK(hipHostFree(h_ptr));
+    });
 }
 int he355_probe_dominant_kernel(he355_ctx *c, float *total_ms, uint64_t *launches, uint64_t *ops)
 {

@@ -165,6 +165,15 @@ struct EncTablesDev { // device copies of the host client's encoder tables (clie
 };
 
 
+// the slots a decode writes per plaintext: up to kMaxSlotRanges ranges [first, first + count) of the slot vector, written one after the other
+// (out row = `total` values).  A workload's decode() reads the first n / dim3 slots of a result -- and BFV MatMultRow those of both batching rows
+// (bfv row .cpp:339-369) -- not the N/2 or N the encoder has
+constexpr int kMaxSlotRanges = 4;
+struct SlotRanges {
+    u32 n, total;
+    u32 first[kMaxSlotRanges], count[kMaxSlotRanges];
+};
+
 // ---- the launchers: two builds of the device code -----------------------------------------------------------------------
 namespace ks_shoup {
 #include "he355_launchers.inc"

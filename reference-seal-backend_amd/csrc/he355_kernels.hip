@@ -33,231 +33,7 @@ namespace he355 {
 namespace HE355_KNS {
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kWaves = 4;
-
-// Each wave exchanges data only inside its own LDS region: LDS instructions of one wave execute in
-// order, so a wavefront-scope release/acquire pair (compiler ordering only) is all the hand-off needs.
-// Every wave of a block still runs the same number of phases (invalid jobs are clamped, not skipped), so
-// building with -DHE355_BLOCK_SYNC (workgroup barriers instead, debug aid) stays legal.
-#if defined(HE355_BLOCK_SYNC)
-#define HE_WAVE_SYNC() __syncthreads()
-#else
-#define HE_WAVE_SYNC()                                             \
-    do {                                                           \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
-        __builtin_amdgcn_wave_barrier();                           \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
-    } while (0)
-#endif
-
-// Twiddle tables are reached through pointers stored in PrimeDev (HBM), which the compiler would treat as
-// generic (flat_load + full s_waitcnt per access).  They are always global memory: say so.
-__device__ __forceinline__ gtw_t gtw(const Tw16 *p) { return (gtw_t)p; }
-__device__ __forceinline__ ctw_t ctw(const Tw16 *p) { return (ctw_t)(unsigned long long)p; } // lane-uniform entries: scalar loads
-
-__device__ __forceinline__ ArU64 make_ar(const PrimeDev &p, ArU64 *)
-{
-    ArU64 a;
-    a.q = p.q; a.two_q = p.q * 2; a.ninv = p.ninv; a.ninv_q = p.ninv_q; a.cr0 = p.cr0; a.cr1 = p.cr1;
-    return a;
-}
-__device__ __forceinline__ ArF64 make_ar(const PrimeDev &p, ArF64 *)
-{
-    ArF64 a;
-    a.q = p.qd; a.qinv = p.qinv; a.ninv = p.ninv_d; a.ninv_i = p.ninv_i;
-    return a;
-}
-__device__ __forceinline__ ModU64 make_modu(const PrimeDev &p)
-{
-    ModU64 m;
-    m.q = p.q; m.cr0 = p.cr0; m.cr1 = p.cr1;
-    return m;
-}
-
-// ---- row <-> register moves ---------------------------------------------------------------------------
-__device__ __forceinline__ void load_rowA(const u64 *row, int lane, u64 v[kRowE])
-{
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r) v[r] = row[(r << 6) | lane];
-}
-__device__ __forceinline__ void store_rowA(u64 *row, int lane, const u64 v[kRowE])
-{
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r) row[(r << 6) | lane] = v[r];
-}
-// layout C (ntt_core.h elemC): registers 4c..4c+3 of a lane are 4 consecutive elements (32 bytes); the 4 lanes of a quad
-// cover 128 consecutive bytes per chunk c, quads are 512 bytes apart
-__device__ __forceinline__ void load_rowC(const u64 *row, int lane, u64 v[kRowE])
-{
-    const u64 *base = row + ((lane >> 2) << 6) + ((lane & 3) << 2);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(base + (c << 4));
-        const ulonglong2 lo = p[0], hi = p[1];
-        v[4 * c + 0] = lo.x; v[4 * c + 1] = lo.y; v[4 * c + 2] = hi.x; v[4 * c + 3] = hi.y;
-    }
-}
-__device__ __forceinline__ void store_rowC(u64 *row, int lane, const u64 v[kRowE])
-{
-    u64 *base = row + ((lane >> 2) << 6) + ((lane & 3) << 2);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        ulonglong2 *p = reinterpret_cast<ulonglong2 *>(base + (c << 4));
-        p[0] = make_ulonglong2(v[4 * c + 0], v[4 * c + 1]);
-        p[1] = make_ulonglong2(v[4 * c + 2], v[4 * c + 3]);
-    }
-}
-
-// Key products issued together in the fused fp64 k_k3 (2 polynomials x kMacG / 2 elements): interleaved chains, at two waves per
-// SIMD a serial chain issues at 3/4 of the pipe's rate.
-#ifndef HE355_MAC_G
-#define HE355_MAC_G 4
-#endif
-constexpr int kMacG = HE355_MAC_G;
-
-// ---- LDS-DMA: one 8 KiB row, HBM -> this wave's LDS staging buffer, no VGPRs, asynchronous -------------
-// Each global_load_lds_dwordx4 moves 64 x 16 B; the LDS image is the row in natural element order.
-// Completion is covered by the issuing wave's vmcnt (s_waitcnt vmcnt(0) before the first ds_read).
-typedef __attribute__((address_space(3))) void lds_void_t;
-// The instruction is issued from inline assembly, i.e. hidden from the compiler's wait-count insertion.
-// Through the builtin (__builtin_amdgcn_global_load_lds), every ds_read that follows a DMA in program order gets an s_waitcnt vmcnt(0) in front of it whenever the
-// compiler cannot rule out that it reads the landing buffer -- in k_k3 that is the first LDS exchange of the row transform, a third
-// of the way into the step the DMA was meant to hide behind (ISA of round 2's kernel).  The kernels wait for a landing buffer
-// themselves (asm volatile s_waitcnt vmcnt(0) before they read it); vector-memory results return in issue order, so the waits the
-// compiler places for its own, younger loads stay sufficient.  M0 (LDS base of the DMA) is used by nothing else in these kernels.
-template <int PIECES = 8> // 1 KiB pieces of the row slot that hold data (8: a row of 64-bit words; 6: a 48-bit packed digit row)
-__device__ __forceinline__ void dma_row_to_lds(const u64 *grow, u64 *lds_row, int lane)
-{
-    const u32 lbase = __builtin_amdgcn_readfirstlane((u32)(unsigned long long)(lds_void_t *)lds_row);
-    const u64 *g = grow + (lane << 1);
-#pragma unroll
-    for (int k = 0; k < PIECES; ++k)
-        // non-temporal (round 5): a row is read once, by this wave -- served from L2 past the L1, which the block's eight waves share for the
-        // key rows of the digit step (headline -0.7 %, configs[3] / [4] -1 %: profiles/r05_small_ab.txt)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lbase + (u32)(k << 10)), "v"(g + (k << 7)) : "memory");
-}
-__device__ __forceinline__ void lds_rowA(const u64 *lds_row, int lane, u64 v[kRowE])
-{
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r) v[r] = lds_row[(r << 6) | lane];
-}
-
-// ---- 48-bit digit rows (fp64-engine targets) -----------------------------------------------------------
-// The digit slab is the largest HBM stream of a key switch (written once by k_k2, read once by k_k3) and the chip's mixed
-// read/write bandwidth bounds the sequence, so a digit row of an fp64-engine prime is stored in 6 of the 8 KiB of its slot:
-// a plane of 1024 low 32-bit words, then a plane of 1024 high 16-bit words, of the bit pattern of (x + kPackBias), x an
-// integer with |x| < 2^47.  The pattern's top 16 bits are then always 0x4338, so 48 bits carry the value exactly.
-constexpr double kPackBias = 4503599627370496.0 + 2251799813685248.0 + 140737488355328.0; // 2^52 + 2^51 + 2^47
-constexpr int kPackHiOff = 4096;                                                          // byte offset of the high plane in the slot
-__device__ __forceinline__ double unpack48(u32 lo, u32 hi16)
-{
-    union { u64 u; double d; } c;
-    c.u = ((u64)(0x43380000u | hi16) << 32) | lo;
-    return c.d - kPackBias;
-}
-__device__ __forceinline__ void lds_rowA48(const u64 *lds_row, int lane, double x[kRowE])
-{
-    const u32 *lo = reinterpret_cast<const u32 *>(lds_row);
-    const unsigned short *hi = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(lds_row) + kPackHiOff);
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r) x[r] = unpack48(lo[(r << 6) | lane], hi[(r << 6) | lane]);
-}
-// ---- wave-level row transforms (x in: layout A for forward, layout C for inverse) ---------------------
-// lds_w: the wave's exchange buffer.  The twiddles of phase B / C are gathered BEFORE the exchange that precedes the phase and
-// pinned there with a scheduling barrier, so their loads are in flight while the exchange round-trips through LDS.
-struct NoHook {
-    __device__ __forceinline__ void operator()() const {}
-};
-// `before_c` runs after phase B's math and before the second exchange: a caller uses it to put global loads in flight
-// that it needs right after the transform (they then land during the exchange and phase C).
-// LAZY (u64 engine, q < 2^60, rows entering below 4q): the wide lazy range of ntt_core.h's row_fwd_*_lazy -- results below 12q, for
-// consumers that take any 64-bit lazy value (k_k3's key multiply-accumulate); ignored by the fp64 engine.
-template <class Ar, class TW, class Hook = NoHook, bool LAZY = false>
-__device__ __forceinline__ void wave_rows_fwd_n(const Ar &ar, const TW &tw, int lane, u64 *lds_w, typename Ar::T (*x)[kRowE], Hook before_c = Hook())
-{
-    typedef typename Ar::T T;
-    T *lds = reinterpret_cast<T *>(lds_w);
-    Tw16 wa[kTwA];
-    gather_A(tw, wa);
-    if constexpr (LAZY) row_fwd_A_lazy<1>(ar, x, wa); else row_fwd_A<1>(ar, x, wa);
-    Tw16 wb[kTwB];
-    gather_B(tw, lane, wb);
-    __builtin_amdgcn_sched_barrier(0);
-    lds_store_A(lds, lane, x[0]);
-    HE_WAVE_SYNC();
-    lds_load_B(lds, lane, x[0]);
-    HE_WAVE_SYNC();
-    if constexpr (LAZY) row_fwd_B_lazy<1>(ar, x, wb); else row_fwd_B<1>(ar, x, wb);
-    Tw16 wc[kTwC];
-    gather_C(tw, lane, wc);
-    before_c();
-    __builtin_amdgcn_sched_barrier(0);
-    lds_store_B(lds, lane, x[0]);
-    HE_WAVE_SYNC();
-    lds_load_C(lds, lane, x[0]);
-    HE_WAVE_SYNC();
-    if constexpr (LAZY) row_fwd_C_lazy<1>(ar, x, wc); else row_fwd_C<1>(ar, x, wc);
-}
-template <class Ar, class TW>
-__device__ __forceinline__ void wave_rows_fwd(const Ar &ar, const TW &tw, int lane, u64 *lds_w, typename Ar::T x[kRowE])
-{
-    wave_rows_fwd_n(ar, tw, lane, lds_w, reinterpret_cast<typename Ar::T(*)[kRowE]>(x));
-}
-// The inverse row pass on a row-local copy of the row's inverse twiddles (TwRow / TwRowF64, staged in LDS by the block: k_k1's
-// throughput shape, where the four waves of a block work on the same (prime, row) of four ciphertexts): every phase's twiddles are
-// LDS reads of this wave's own block instead of 46 scattered 16-byte loads per lane from the 512 KiB table in L2.
-template <class Ar, class TW>
-__device__ __forceinline__ void wave_rows_inv_tw(const Ar &ar, const TW &itw, const Tw16 &w0_scaled, bool last, int lane, u64 *lds_w, typename Ar::T x[kRowE])
-{
-    typedef typename Ar::T T;
-    T *lds = reinterpret_cast<T *>(lds_w);
-    row_inv_C(ar, x, itw, lane);
-    Tw16 wb[kTwInvB];
-    gather_inv_B(itw, lane, wb);
-    __builtin_amdgcn_sched_barrier(0);
-    lds_store_C(lds, lane, x);
-    HE_WAVE_SYNC();
-    lds_load_B(lds, lane, x);
-    HE_WAVE_SYNC();
-    row_inv_B_w(ar, x, wb);
-    Tw16 wa[kTwInvA];
-    gather_inv_A(itw, wa);
-    __builtin_amdgcn_sched_barrier(0);
-    lds_store_B(lds, lane, x);
-    HE_WAVE_SYNC();
-    lds_load_A(lds, lane, x);
-    HE_WAVE_SYNC();
-    if (last) row_inv_A_w<Ar, true>(ar, x, wa, w0_scaled);
-    else row_inv_A_w<Ar, false>(ar, x, wa, w0_scaled);
-}
-template <class Ar>
-__device__ __forceinline__ void wave_rows_inv(const Ar &ar, const PrimeDev &P, bool last, u32 rowbase, int lane, u64 *lds_w, typename Ar::T x[kRowE])
-{
-    typedef typename Ar::T T;
-    T *lds = reinterpret_cast<T *>(lds_w);
-    const auto itw = tw_table(gtw(P.inv), rowbase);
-    row_inv_C(ar, x, itw, lane);
-    // the twiddles of the next phase are requested before the exchange that precedes it (round 5; the forward pass always did): they land
-    // while the exchange round-trips through LDS instead of behind it -- phase A's are lane-uniform, scalar loads
-    Tw16 wb[kTwInvB];
-    gather_inv_B(itw, lane, wb);
-    __builtin_amdgcn_sched_barrier(0);
-    lds_store_C(lds, lane, x);
-    HE_WAVE_SYNC();
-    lds_load_B(lds, lane, x);
-    HE_WAVE_SYNC();
-    row_inv_B_w(ar, x, wb);
-    Tw16 wa[kTwInvA];
-    gather_inv_A(tw_table(ctw(P.inv), rowbase), wa);
-    __builtin_amdgcn_sched_barrier(0);
-    lds_store_B(lds, lane, x);
-    HE_WAVE_SYNC();
-    lds_load_A(lds, lane, x);
-    HE_WAVE_SYNC();
-    if (last) row_inv_A_w<Ar, true>(ar, x, wa, P.inv_w0_scaled);
-    else row_inv_A_w<Ar, false>(ar, x, wa, P.inv_w0_scaled);
-}
+#include "kernel_common.inc"
 
 // =======================================================================================================
 // Generic transforms over a PolyView

@@ -239,9 +239,9 @@ __global__ void __launch_bounds__(kEncBlock) k_ckks_encode(const double *values,
         }
     }
 }
-// coeff [n][L][N] coefficient-form plaintext -> out [n][N/2] slot values (real parts)
+// coeff [n][L][N] coefficient-form plaintext -> out [n][sr.total]: the real parts of the slots the ranges name (all N/2 by default)
 __global__ void __launch_bounds__(kEncBlock) k_ckks_decode(const u64 *coeff, double scale, client::Cplx *zbuf, double *out, EncTables T, const PrimeDev *primes,
-                                                           CrtDev c, int logN)
+                                                           CrtDev c, int logN, SlotRanges sr)
 {
     const u32 N = 1u << logN, half = N >> 1;
     const u64 r = blockIdx.x;
@@ -263,7 +263,12 @@ __global__ void __launch_bounds__(kEncBlock) k_ckks_decode(const u64 *coeff, dou
     }
     __syncthreads();
     fft_stages_block(z, T.W, N, true);
-    for (u32 i = threadIdx.x; i < half; i += kEncBlock) out[r * half + i] = z[T.slot_index[i]].re;
+    (void)half;
+    u32 base = 0;
+    for (u32 g = 0; g < sr.n; ++g) {
+        for (u32 i = threadIdx.x; i < sr.count[g]; i += kEncBlock) out[r * sr.total + base + i] = z[T.slot_index[sr.first[g] + i]].re;
+        base += sr.count[g];
+    }
 }
 // BatchEncoder::encode: values [n][count] int64 -> evaluations mod t at the bit-reversed slot positions (the caller applies the
 // inverse NTT mod t); BatchEncoder::decode: evaluations -> centred int64 slots
@@ -276,13 +281,17 @@ __global__ void __launch_bounds__(kBlock) k_bfv_encode_scatter(const long long *
     const u64 m = v >= 0 ? (u64)v % t : (u64)(-v) % t;
     ev[(r << logN) + client::bitrev_u32(slot_index[i], logN)] = (v >= 0 || m == 0) ? m : t - m;
 }
-__global__ void __launch_bounds__(kBlock) k_bfv_decode_gather(const u64 *ev, long long *out, const uint32_t *slot_index, u64 t, int logN, u64 n_vec)
+// one thread per wanted slot: gid = r * sr.total + position inside the concatenated ranges
+__global__ void __launch_bounds__(kBlock) k_bfv_decode_gather(const u64 *ev, long long *out, const uint32_t *slot_index, u64 t, int logN, u64 n_vec, SlotRanges sr)
 {
     const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
-    const u64 r = gid >> logN, i = gid & (((u64)1 << logN) - 1);
+    const u64 r = gid / sr.total;
     if (r >= n_vec) return;
+    u32 pos = (u32)(gid - r * sr.total), g = 0;
+    while (pos >= sr.count[g]) pos -= sr.count[g++];
+    const u32 i = sr.first[g] + pos;
     const u64 v = ev[(r << logN) + client::bitrev_u32(slot_index[i], logN)];
-    out[(r << logN) + i] = v > t / 2 ? (long long)v - (long long)t : (long long)v;
+    out[gid] = v > t / 2 ? (long long)v - (long long)t : (long long)v;
 }
 
 inline unsigned grid_for(u64 jobs, u64 per_block) { return (unsigned)((jobs + per_block - 1) / per_block); }
@@ -344,7 +353,8 @@ void launch_ckks_encode(const KernelEnv &env, u64 n_vec, const double *values, u
     hipLaunchKernelGGL(k_ckks_encode, dim3((unsigned)n_vec), dim3(kEncBlock), 0, env.stream, values, count, scale, static_cast<client::Cplx *>(zbuf), plain, T,
                        env.primes, env.Ltop, env.logn1 + kRowLog, err);
 }
-void launch_ckks_decode(const KernelEnv &env, u64 n_vec, const u64 *coeff, double scale, void *zbuf, double *out, const EncTablesDev &t, const CrtTablesDev &c)
+void launch_ckks_decode(const KernelEnv &env, u64 n_vec, const u64 *coeff, double scale, void *zbuf, double *out, const EncTablesDev &t, const CrtTablesDev &c,
+                        const SlotRanges &sr)
 {
     if (!n_vec) return;
     EncTables T;
@@ -353,7 +363,7 @@ void launch_ckks_decode(const KernelEnv &env, u64 n_vec, const u64 *coeff, doubl
     d.v.L = c.L; d.v.words = c.words; d.v.Q = c.Q; d.v.halfQ = c.halfQ; d.v.punct = c.punct; d.v.inv = c.inv;
     d.Qd = c.Qd; d.t = c.t;
     hipLaunchKernelGGL(k_ckks_decode, dim3((unsigned)n_vec), dim3(kEncBlock), 0, env.stream, coeff, scale, static_cast<client::Cplx *>(zbuf), out, T, env.primes, d,
-                       env.logn1 + kRowLog);
+                       env.logn1 + kRowLog, sr);
 }
 void launch_bfv_encode_scatter(const KernelEnv &env, u64 n_vec, const long long *values, u64 count, u64 *ev, const uint32_t *slot_index, u64 t)
 {
@@ -361,11 +371,11 @@ void launch_bfv_encode_scatter(const KernelEnv &env, u64 n_vec, const long long 
     const int logN = env.logn1 + kRowLog;
     hipLaunchKernelGGL(k_bfv_encode_scatter, dim3(grid_for(n_vec << logN, kBlock)), dim3(kBlock), 0, env.stream, values, count, ev, slot_index, t, logN, n_vec);
 }
-void launch_bfv_decode_gather(const KernelEnv &env, u64 n_vec, const u64 *ev, long long *out, const uint32_t *slot_index, u64 t)
+void launch_bfv_decode_gather(const KernelEnv &env, u64 n_vec, const u64 *ev, long long *out, const uint32_t *slot_index, u64 t, const SlotRanges &sr)
 {
-    if (!n_vec) return;
+    if (!n_vec || !sr.total) return;
     const int logN = env.logn1 + kRowLog;
-    hipLaunchKernelGGL(k_bfv_decode_gather, dim3(grid_for(n_vec << logN, kBlock)), dim3(kBlock), 0, env.stream, ev, out, slot_index, t, logN, n_vec);
+    hipLaunchKernelGGL(k_bfv_decode_gather, dim3(grid_for(n_vec * sr.total, kBlock)), dim3(kBlock), 0, env.stream, ev, out, slot_index, t, logN, n_vec, sr);
 }
 
 void launch_keygen_kswitch(const KernelEnv &env, u64 *key, u64 *e_scratch, u64 *target_scratch, const u64 *sk, const uint32_t *perm, u64 seed, u64 key_id)

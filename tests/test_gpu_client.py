@@ -247,6 +247,15 @@ def test_encoders_match_host_client_and_oracle(request, case, be, sim, oracle):
                     sim.simc_ckks_decode(c, oracle._p(np.ascontiguousarray(sub[r])), Ld, scale, want.ctypes.data_as(dp))
                     assert np.array_equal(vals[r], want), (count, Ld, r)
                     assert np.allclose(vals[r, :count], x[r], atol=1e-6) and np.allclose(vals[r, count:], 0, atol=1e-6)
+                # he355_ckks_decode_slots: only the slots a workload's decode() reads -- the same bits as those slots of the full decode
+                for ranges in ([(0, 1)], [(0, 5)], [(3, 4), (N // 2 - 2, 2)], [(0, N // 2)], [(0, 2), (7, 1), (N // 4, 3), (1, 2)]):
+                    tot = sum(cnt for _, cnt in ranges)
+                    outs = g.alloc(n * tot)
+                    g.ckks_decode_slots(Ld, n, dpl, scale, ranges, outs)
+                    part = outs.download().view(np.float64).reshape(n, tot)
+                    assert np.array_equal(part, np.concatenate([vals[:, f:f + cnt] for f, cnt in ranges], axis=1)), (Ld, ranges)
+                with pytest.raises(be.HE355Error):
+                    g.ckks_decode_slots(Ld, n, dpl, scale, [(N // 2 - 1, 2)], out)  # beyond the encoder's slots
     else:
         n = 3
         codec = ho.BatchCodec(N, o.t)
@@ -267,6 +276,15 @@ def test_encoders_match_host_client_and_oracle(request, case, be, sim, oracle):
             g.bfv_decode(n, plain, out)
             vals = out.download().view(np.int64).reshape(n, N)
             assert np.array_equal(vals[:, :count], x) and not vals[:, count:].any()
+            # he355_bfv_decode_slots: e.g. the first dim3 slots of both batching rows (the row-major product's decode, bfv row .cpp:339-369)
+            for ranges in ([(0, 1)], [(0, 7), (N // 2, 7)], [(N - 3, 3)], [(0, N)], [(5, 2), (0, 1), (N // 2 + 1, 4), (9, 9)]):
+                tot = sum(cnt for _, cnt in ranges)
+                outs = g.alloc(n * tot)
+                g.bfv_decode_slots(n, plain, ranges, outs)
+                part = outs.download().view(np.int64).reshape(n, tot)
+                assert np.array_equal(part, np.concatenate([vals[:, f:f + cnt] for f, cnt in ranges], axis=1)), ranges
+            with pytest.raises(be.HE355Error):
+                g.bfv_decode_slots(n, plain, [(N, 1)], out)
     sim.simc_destroy(c)
     sim.sim_params_destroy(p)
 

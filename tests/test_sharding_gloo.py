@@ -106,6 +106,23 @@ def test_bench_self_launches_its_ranks():
         assert sum(s["a_count"] for s in doc["shards"]) == b0  # the shards tile the global batch
 
 
+def test_bench_times_both_scalings_at_n_gt_1_by_default():
+    """`python bench.py --gpus N` with no --scaling (how the driver runs it): N > 1 plans BOTH scalings in the one invocation -- the primary
+    (`value`) is strong at the global batch `metric` names (north_star: batch 1024 over the GPUs), a weak run (1024 per GPU) beside it --
+    and N = 1 plans one run.  --force-dist takes the distributed branch with one rank."""
+    p, doc = _bench("--gpus", "2", "--dry-run", env={"HE355_BENCH_BACKEND": "gloo"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert [r["scaling"] for r in doc["runs"]] == ["strong", "weak"] and doc["scaling"] == "strong"
+    assert doc["runs"][0]["global_b0"] == 1024 and [s["a_count"] for s in doc["runs"][0]["shards"]] == [512, 512]
+    assert doc["runs"][1]["global_b0"] == 2048 and [s["a_count"] for s in doc["runs"][1]["shards"]] == [1024, 1024]
+    assert [s["a_base"] for s in doc["runs"][1]["shards"]] == [0, 1024]
+    p, doc = _bench("--gpus", "1", "--dry-run")
+    assert p.returncode == 0 and [r["scaling"] for r in doc["runs"]] == ["weak"] and doc["global_b0"] == 1024
+    p, doc = _bench("--gpus", "1", "--dry-run", "--force-dist", env={"HE355_BENCH_BACKEND": "gloo"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert doc["n_gpus"] == 1 and doc["shards"][0]["a_count"] == 1024
+
+
 def test_bench_self_launch_propagates_failure():
     """Without --dry-run the ranks need a GPU: on a box without one every rank exits loudly (no CPU fallback) and the launcher
     returns non-zero; on a GPU box two gloo ranks share the card and the run succeeds."""
@@ -127,8 +144,22 @@ def test_bench_two_ranks_share_the_gpu_through_the_self_launch_path():
     p, doc = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "6", "--scaling", "strong", "--cpu-sample", "0",
                     "--parity-sample", "1", env={"HE355_BENCH_BACKEND": "gloo"}, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
-    assert doc["n_gpus"] == 2 and doc["config"]["global_batch"] == 6
+    assert doc["n_gpus"] == 2 and doc["config"]["global_batch"] == 6 and doc["scaling"] == "strong"
     assert doc["parity"]["checked_in_run"] is True and [r["ok"] for r in doc["parity"]["per_rank"]] == [True, True]
+    assert doc["collective"]["world_size"] == 2 and doc["collective"]["allreduce_of_ones"] == 2.0 and len(doc["per_rank_ms"]) == 2
+
+
+@pytest.mark.gpu
+def test_bench_both_scalings_in_one_invocation_on_the_shared_gpu():
+    """The default N > 1 invocation on the one-GPU box (two gloo ranks share the card): the line's `value` is the strong run, the `weak`
+    block carries its own value / ms_per_step / per_rank_ms, and the CPU-thread list of the baseline never lands in `scaling`."""
+    p, doc = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "6", "--cpu-sample", "0", "--parity-sample", "1",
+                    env={"HE355_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert doc["scaling"] == "strong" and doc["config"]["global_batch"] == 6 and doc["config"]["batch_per_gpu"] == 3
+    w = doc["weak"]
+    assert w["scaling"] == "weak" and w["global_batch"] == 12 and w["batch_per_gpu_rank0"] == 6 and len(w["per_rank_ms"]) == 2 and w["value"] > 0
+    assert doc["parity"]["checked_in_run"] is True
 
 
 def test_oracle_build_is_locked_and_host_stamped(tmp_path):
