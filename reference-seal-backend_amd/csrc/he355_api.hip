@@ -4,6 +4,8 @@
 // entry point fails with HE355_E_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <array>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -301,6 +303,7 @@ public:
     void set_chunk(size_t c) { chunk_ = c ? c : 1; }
     void set_latency_max(u64 n) { lat_auto_ = n == ~(u64)0; lat_max_ = lat_auto_ ? 0 : n; } // ~0: back to lat_limit()'s rule
     void set_level_walk(bool on) { level_walk_ = on; }
+    void set_lds_max(u64 n) { lds_auto_ = n == ~(u64)0; lds_max_ = lds_auto_ ? 0 : n; }
 
     size_t key_elems() const { return P.Ltop * 2 * P.K * P.N; }
     size_t n_q_primes() const
@@ -397,6 +400,9 @@ public:
         dmalloc(d, P.N * 4);
         HIPCHECK(hipMemcpy(d, h.data(), P.N * 4, hipMemcpyHostToDevice));
         d_perm_[elt] = d;
+        std::array<unsigned char, 32> rows{};
+        for (size_t a = 0; a < ((size_t)1 << P.logn1) && a < rows.size(); ++a) rows[a] = (unsigned char)(h[a << kRowLog] >> kRowLog);
+        perm_rows_[elt] = rows; // the one source row of every row of the permuted polynomial (the ring-in-LDS kernels take it with their arguments)
         return d;
     }
 
@@ -682,6 +688,27 @@ public:
     bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_limit() && P.K >= 2; }
     // ... for a given kernel environment (a BFV context runs its rotation chains in the NTT domain on the CKKS pipeline: ntt_env)
     bool latency_shape_env(const KernelEnv &e, u64 nc) const { return e.scheme == kSchemeCKKS && nc <= lat_limit() && P.K >= 2; }
+    // Ring-in-LDS shape (he355_kernels_lds.hip): N <= 8192, NTT-domain pipeline, at most lds_limit() ciphertexts per sequence -- two
+    // launches of L^2 + 2L one-polynomial workgroups per ciphertext instead of six launches through HBM.  Where the throughput shape's
+    // better use of the chip overtakes it was measured (profiles/r06_lds_shape.txt); he355_set_lds_max / HE355_LDS_MAX replace the rule.
+    // The rule: as long as k_lds_digits' grid, (L + 1) L blocks per ciphertext, runs in ONE round of the chip -- 256 CUs, one 8-wave block each
+    // at N = 8192 (two, four, eight blocks per CU for the smaller rings): at {60, 40, 60} that is 42 ciphertexts (32: 61 against 78 us per key
+    // switch, 48: 76 against 86, 64: 88 against 95; profiles/r06_lds_shape.txt).
+    u64 lds_limit(const KernelEnv &e, int L) const
+    {
+        if (!lds_auto_) return lds_max_;
+        const u64 blocks = (u64)256 << (3 - std::min(3, e.logn1));
+        return std::max<u64>(1, blocks / ((u64)(L + 1) * (u64)L));
+    }
+    bool lds_shape(const KernelEnv &e, int L, u64 nc) const { return e.scheme == kSchemeCKKS && ks_lds_supported(e, L) && nc <= lds_limit(e, L); }
+    // scratch of the shape: the arena behind c01 (k_lds_digits' partial products; (2L + 2) L N words per ciphertext fit there for L <= 8)
+    u64 *lds_part(const Scratch &S, int L, u64 nc) const
+    {
+        const size_t need = (size_t)ks_lds_part_words(env_, L), have = scratch_words_per_op(L) - 2 * (size_t)L * P.N;
+        if (need > have) throw std::logic_error("ring-in-LDS key switch: the arena is too small for the partial products");
+        (void)nc;
+        return S.ks.c2n;
+    }
     // the kernel environment of a batch on stream `which`
     // ntt: the NTT-domain (CKKS) pipeline whatever the context's scheme (ntt_env)
     KernelEnv batch_env(u64 /*nc*/, int which = 0, bool ntt = false) const
@@ -746,6 +773,15 @@ public:
             Scratch S = scratch(std::min<u64>(chunk, n), L, which);
             KsBuffers B = S.ks;
             if (!rescale) { B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN; }
+            if (lds_shape(env, L, nc) && !out_overlaps_operands) {
+                // a ring that fits LDS: tensor product, key switch and the add in two launches (the operands are read where they lie)
+                ++paths_.ks_lds;
+                LdsKsOperands src;
+                src.mode = LDSKS_MUL; src.a = a; src.b = b; src.ix = ix; src.op_offset = off;
+                launch_ks_lds(env, L, nc, src, d_relin_, lds_part(S, L, nc), B.c01, B.c01_item_stride);
+                if (rescale) launch_rescale_lds(env, L, 2, nc, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N);
+                continue;
+            }
             // c0, c1 of the tensor product: written by k_k1, or (fused key switch) computed by k_k3 where it adds them in -- k_k1 is
             // HBM-bound and then reads half and writes a third of what it did, k_k3 is not and reads the operand rows instead of c01
             const bool in_k3 = tensor_in_k3(env, L, nc, B) && !out_overlaps_operands;
@@ -799,7 +835,18 @@ public:
             // on the fused path k_k3 reads c0, c1 and the NTT-form c2 from the size-3 input where it lies (k_k1 copies nothing: it only
             // sends c2 through the inverse row pass); `out` must then be a slab of its own
             auto overlap = [](const u64 *p, size_t np, const u64 *q, size_t nq) { return p < q + nq && q < p + np; };
-            const bool in_k3 = tensor_in_k3(env, L, nc, B) && !overlap(out, n * 2 * (size_t)(rescale ? L - 1 : L) * N, ct3, n * 3 * LN);
+            const bool out_apart = !overlap(out, n * 2 * (size_t)(rescale ? L - 1 : L) * N, ct3, n * 3 * LN);
+            if (lds_shape(env, L, nc) && out_apart) {
+                ++paths_.ks_lds;
+                LdsKsOperands src;
+                src.mode = LDSKS_PLAIN;
+                src.tgt = ct3 + off * 3 * LN + 2 * LN; src.tgt_op_stride = 3 * LN;
+                src.add = ct3 + off * 3 * LN; src.add_op_stride = 3 * LN;
+                launch_ks_lds(env, L, nc, src, d_relin_, lds_part(S, L, nc), B.c01, B.c01_item_stride);
+                if (rescale) launch_rescale_lds(env, L, 2, nc, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N);
+                continue;
+            }
+            const bool in_k3 = tensor_in_k3(env, L, nc, B) && out_apart;
             TensorOperands ten;
             ten.c1_mode = 3;
             ten.c1_src = ct3 + off * 3 * LN;
@@ -861,6 +908,10 @@ public:
             const u64 nc = std::min<u64>(chunk, n - off);
             Scratch S = scratch(std::min<u64>(chunk, n), L); // arena sized for the batch actually processed
             const u64 *src = in + off * size * LN;
+            if (lds_shape(env_, L, nc) && !ranges_overlap(in, n * size * LN, out, n * size * (size_t)(L - 1) * N)) { // (the blocks of an op read all of its input)
+                launch_rescale_lds(env_, L, size, nc, src, (u64)size * LN, out + off * size * (size_t)(L - 1) * N);
+                continue;
+            }
             launch_rows_inv_select(env_, L - 1, nc * size, src + (size_t)(L - 1) * N, LN, S.rlr);
             rescale_tail(env_, L, size, nc, S, src, (u64)size * LN, out + off * size * (size_t)(L - 1) * N);
         }
@@ -905,6 +956,18 @@ public:
             KsBuffers B = S.ks;
             B.c01 = out + off * 2 * LN; B.c01_item_stride = 2 * LN;
             const KernelEnv env = batch_env(nc, 0, true);
+            if (lds_shape(env, L, nc)) {
+                // a ring that fits LDS: permutation, key switch and the add in two launches (an addend may be `out`: the wave that reads a row
+                // of it is the one that writes that row of the result, afterwards)
+                ++paths_.ks_lds;
+                LdsKsOperands src;
+                src.mode = LDSKS_GALOIS; src.a = in; src.op_offset = off; src.perm = pm;
+                const std::array<unsigned char, 32> &rows = perm_rows_.at(elt);
+                std::copy(rows.begin(), rows.end(), src.perm_src_row);
+                src.add = addend ? addend + off * 2 * LN : nullptr; src.add_op_stride = 2 * LN;
+                launch_ks_lds(env, L, nc, src, key, lds_part(S, L, nc), B.c01, B.c01_item_stride);
+                continue;
+            }
             // polynomial 1 of the rotated ciphertext is zero (or the addend's): on the fused path k_k1 does not write it and k_k3 takes it
             // from where it is (the addend may be `out`: the wave that reads a row is the one that writes it, afterwards)
             const bool c1_in_k3 = tensor_in_k3(env, L, nc, B);
@@ -1930,7 +1993,10 @@ private:
     bool dual_stream_ = true;
     u64 *rot_tmp_ = nullptr;
     size_t rot_tmp_bytes_ = 0;
+    std::map<uint32_t, std::array<unsigned char, 32>> perm_rows_;
     he355_path_stats_t paths_{};
+    bool lds_auto_ = !getenv("HE355_LDS_MAX");
+    u64 lds_max_ = getenv("HE355_LDS_MAX") ? (u64)std::max(0, std::atoi(getenv("HE355_LDS_MAX"))) : 0;
     bool level_walk_ = !(getenv("HE355_LEVEL_WALK") && getenv("HE355_LEVEL_WALK")[0] == '0'); // he355_rotate_sum: trie levels as grouped launches
     unsigned char *d_groups_ = nullptr; // group tables of the grouped key switches (upload_groups)
     size_t groups_bytes_ = 0, groups_next_ = 0;
@@ -2163,6 +2229,10 @@ int he355_fill_uniform_at(he355_ctx *c, uint64_t *d_dst, uint64_t n_polys, const
 }
 int he355_set_dual_stream(he355_ctx *c, int on) { return guarded([&] { dev(c).set_dual_stream(on != 0); }); }
 int he355_set_latency_max(he355_ctx *c, uint64_t n) { return guarded([&] { dev(c).set_latency_max(n); }); }
+int he355_set_lds_max(he355_ctx *c, uint64_t n)
+{
+    return guarded([&] { dev(c).set_lds_max(n); });
+}
 int he355_set_level_walk(he355_ctx *c, int on) { return guarded([&] { dev(c).set_level_walk(on != 0); }); }
 int he355_set_relin_key(he355_ctx *c, const uint64_t *h_key)
 {

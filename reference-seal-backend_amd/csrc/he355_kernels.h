@@ -165,6 +165,24 @@ struct EncTablesDev { // device copies of the host client's encoder tables (clie
 };
 
 
+// ---- key switch for rings that fit one CU's LDS (he355_kernels_lds.hip): where the target polynomial and the ciphertext the switched key
+// part is added into come from.  The kernels read them where they lie -- nothing is staged in HBM for them.
+enum LdsKsMode {
+    LDSKS_PLAIN = 0,  // target: tgt + op * tgt_op_stride, [L][N] NTT form; addend: add + op * add_op_stride, [2][L][N] (null: zero) -- relinearize of size-3 inputs
+    LDSKS_MUL = 1,    // ct x ct multiply: target = a1 b1, addend = (a0 b0, a0 b1 + a1 b0); result r = op_offset + op takes a[idx_a(ix, r)], b[idx_b(ix, r)]
+    LDSKS_GALOIS = 2, // rotation: target = perm(c1), addend = (perm(c0), 0) [+ add]; a = the input slab [.][2][L][N], op reads ciphertext op_offset + op
+};
+struct LdsKsOperands {
+    int mode = LDSKS_PLAIN;
+    const u64 *tgt = nullptr; u64 tgt_op_stride = 0;
+    const u64 *add = nullptr; u64 add_op_stride = 0;
+    const u64 *a = nullptr, *b = nullptr;
+    Indexer ix{};
+    u64 op_offset = 0;
+    const uint32_t *perm = nullptr;
+    unsigned char perm_src_row[32] = {}; // LDSKS_GALOIS: the ONE source row row a of the permuted polynomial comes from (perm[a * 1024] >> 10; Params::galois_perm_ntt)
+};
+
 // the slots a decode writes per plaintext: up to kMaxSlotRanges ranges [first, first + count) of the slot vector, written one after the other
 // (out row = `total` values).  A workload's decode() reads the first n / dim3 slots of a result -- and BFV MatMultRow those of both batching rows
 // (bfv row .cpp:339-369) -- not the N/2 or N the encoder has
@@ -230,6 +248,10 @@ HE355_FWD(launch_ckks_decode)
 HE355_FWD(launch_bfv_encode_scatter)
 HE355_FWD(launch_bfv_decode_gather)
 HE355_FWD(launch_keygen_kswitch)
+HE355_FWD(launch_ks_lds)
+HE355_FWD(launch_rescale_lds)
+HE355_FWD(ks_lds_supported)
+HE355_FWD(ks_lds_part_words)
 #undef HE355_FWD
 #endif
 

@@ -320,6 +320,38 @@ template <class Ar, class TW> HE_HD void row_inv_C(const Ar &ar, typename Ar::T 
         }
     }
 }
+// Phase C of the inverse row pass on twiddles gathered up front (gather_inv_C: stage 9's eight entries, then stage 8's four -- the order
+// row_inv_C reads them in): a kernel whose row arrives behind other work requests them together with the row (he355_kernels_lds.hip).
+constexpr int kTwInvC = 12;
+template <class TW> HE_HD void gather_inv_C(const TW &itw, int lane, Tw16 w[kTwInvC])
+{
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) {
+        if (r & 1) continue;
+        w[n++] = itw.get(9, (u32)elemC(lane, r) >> 1);
+    }
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) {
+        if ((r & 2) || (r & 1)) continue;
+        w[n++] = itw.get(8, (u32)elemC(lane, r) >> 2);
+    }
+}
+template <class Ar> HE_HD void row_inv_C_w(const Ar &ar, typename Ar::T x[kRowE], const Tw16 w[kTwInvC])
+{
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) {
+        if (r & 1) continue;
+        ar.bfly_inv(x[r], x[r | 1], w[n++]);
+    }
+    n = 0;
+#pragma unroll
+    for (int r = 0; r < kRowE; ++r) {
+        if (r & 2) continue;
+        ar.bfly_inv(x[r], x[r | 2], w[8 + (n++ >> 1)]);
+    }
+}
 // Phases B and A of the inverse row pass on twiddles gathered up front (as the forward phases take them): a kernel issues the loads
 // BEFORE the LDS exchange that precedes the phase, so they land while the exchange is in flight instead of behind it.  wb: stage s
 // (7..4) entry g at (1 << (s - 4)) - 1 + g; wa: stage s (3..0) entry g at (1 << s) - 1 + g (lane-uniform: scalar loads through ctw_t).

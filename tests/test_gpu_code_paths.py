@@ -17,14 +17,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SETTINGS = {
     "defaults": {},
     "u64_engine_every_prime_shoup_form": {"HE355_FORCE_U64": "1"},
+    "u64_engine_every_prime_shoup_form_no_ring_in_lds": {"HE355_FORCE_U64": "1", "HE355_LDS_MAX": "0"},
     "u64_engine_shoup_form_default_assignment": {"HE355_FORCE_U64": "shoup"},
     "behz_seal_61bit_base": {"HE355_BEHZ_BASE": "seal"},
     "behz_unfused_no_hoist": {"HE355_BEHZ_FUSE": "0"},
-    "throughput_shape_for_every_batch": {"HE355_LATENCY_MAX": "0"},
-    "latency_shape_up_to_64": {"HE355_LATENCY_MAX": "64"},
-    "one_launch_per_engine": {"HE355_DUAL_ENGINE": "0"},
-    "unfused_mod_down": {"HE355_K3_FUSE": "0"},
-    "fused_everywhere_no_small_grid_rules": {"HE355_K3_FUSE": "all"},
+    # (the core's rings are N = 4096: without HE355_LDS_MAX=0 its small batches would all take the ring-in-LDS shape of round 6 and the
+    # settings below would select nothing)
+    "ring_in_lds_up_to_64": {"HE355_LDS_MAX": "64"},
+    "no_ring_in_lds": {"HE355_LDS_MAX": "0"},
+    "throughput_shape_for_every_batch": {"HE355_LATENCY_MAX": "0", "HE355_LDS_MAX": "0"},
+    "latency_shape_up_to_64": {"HE355_LATENCY_MAX": "64", "HE355_LDS_MAX": "0"},
+    "one_launch_per_engine": {"HE355_DUAL_ENGINE": "0", "HE355_LDS_MAX": "0"},
+    "unfused_mod_down": {"HE355_K3_FUSE": "0", "HE355_LDS_MAX": "0"},
+    "fused_everywhere_no_small_grid_rules": {"HE355_K3_FUSE": "all", "HE355_LDS_MAX": "0"},
     "node_by_node_walks": {"HE355_LEVEL_WALK": "0"},
     "device_pool_off": {"HE355_POOL": "0"},
     "single_stream_chunks_of_3": {"HE355_DUAL_STREAM": "0", "HE355_CHUNK": "3"},

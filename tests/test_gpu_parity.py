@@ -704,6 +704,7 @@ def test_latency_shape_equals_throughput_shape(pair, be, n):
     want_rl = [o.relinearize(o.multiply_ntt(a[r], b[r]), rk) for r in range(n)]
     want_rot = [o.add(b[r], o.apply_galois(a[r], e1, gk)) for r in range(n)]
     try:
+        g.set_lds_max(0)  # (rings up to N = 8192 would take the ring-in-LDS shape at these batches: test_lds_shape_* holds that one)
         for lat in (0, 16, None):  # throughput shape, latency shape, whichever the library's rule picks
             g.set_latency_max(lat)
             out = g.alloc(n * 2 * L * N)
@@ -723,6 +724,82 @@ def test_latency_shape_equals_throughput_shape(pair, be, n):
                 assert np.array_equal(got[r], want_rot[r]), (lat, r)
     finally:
         g.set_latency_max(None)
+        g.set_lds_max(None)
+
+
+@pytest.mark.parametrize("n", [1, 3, 20])
+def test_lds_shape_equals_the_other_shapes_and_the_oracle(pair, be, n):
+    """Rings that fit one CU's LDS (N <= 8192): key switches as two launches of one-polynomial workgroups (k_lds_digits, k_lds_moddown:
+    he355_set_lds_max).  Same bits as the oracle and as the HBM shapes for multiply -> relinearize (-> rescale), relinearize (-> rescale) of
+    size-3 ciphertexts, rotation, rotate_add (also adding in place) and a rotation through NAF steps; the path counters prove which ran."""
+    g, o, rng = pair
+    L, N = g.L, g.N
+    rk = o.random_kswitch_key(rng)
+    g.set_relin_key(rk)
+    e1, e3 = o.galois_elt(1), o.galois_elt(-2)
+    gk1, gk3 = o.random_kswitch_key(rng), o.random_kswitch_key(rng)
+    g.set_galois_key(e1, gk1)
+    g.set_galois_key(e3, gk3)
+    a, b = rand_cts(o, rng, n, L), rand_cts(o, rng, min(n, 2), L)
+    da, db = g.to_device(a), g.to_device(b)
+    ix = be.Context.outer(0, n, 0, 1)  # every a[r] times b[0]
+    c3 = np.stack([o.multiply_ntt(a[r], b[0]) for r in range(n)])
+    d3 = g.to_device(c3)
+    want_rl = [o.relinearize(c3[r], rk) for r in range(n)]
+    want_rot = [o.apply_galois(a[r], e1, gk1) for r in range(n)]
+    want_rot_add = [o.add(want_rl[r], o.apply_galois(a[r], e3, gk3)) for r in range(n)]
+    fits = N <= 8192 and L <= 8
+    try:
+        for lds in (64, 0):
+            g.set_lds_max(lds)
+            g.path_stats(reset=True)
+            out = g.alloc(n * 2 * L * N)
+            g.multiply_relin(L, n, da, db, ix, out)
+            got = out.download((n, 2, L, N))
+            for r in range(n):
+                assert np.array_equal(got[r], want_rl[r]), ("multiply_relin", lds, r)
+            g.relinearize(L, n, d3, out)
+            got = out.download((n, 2, L, N))
+            for r in range(n):
+                assert np.array_equal(got[r], want_rl[r]), ("relinearize", lds, r)
+            if L >= 2:
+                out2 = g.alloc(n * 2 * (L - 1) * N)
+                g.multiply_relin(L, n, da, db, ix, out2, rescale=True)
+                got = out2.download((n, 2, L - 1, N))
+                for r in range(n):
+                    assert np.array_equal(got[r], o.rescale(want_rl[r])), ("multiply_relin_rescale", lds, r)
+                g.relinearize_rescale(L, n, d3, out2)
+                got = out2.download((n, 2, L - 1, N))
+                for r in range(n):
+                    assert np.array_equal(got[r], o.rescale(want_rl[r])), ("relinearize_rescale", lds, r)
+                # he355_rescale by itself (the same floor kernel with the last data prime as its source), sizes 2 and 3
+                out3 = g.alloc(n * 3 * (L - 1) * N)
+                g.rescale(L, 3, n, d3, out3)
+                got = out3.download((n, 3, L - 1, N))
+                for r in range(n):
+                    assert np.array_equal(got[r], o.rescale(c3[r])), ("rescale size 3", lds, r)
+                g.rescale(L, 2, n, da, out2)
+                got = out2.download((n, 2, L - 1, N))
+                for r in range(n):
+                    assert np.array_equal(got[r], o.rescale(a[r])), ("rescale size 2", lds, r)
+            rot = g.alloc(n * 2 * L * N)
+            g.rotate(L, n, da, 1, rot)
+            got = rot.download((n, 2, L, N))
+            for r in range(n):
+                assert np.array_equal(got[r], want_rot[r]), ("rotate", lds, r)
+            # out = relinearized product; out += rotate(a, -2) IN PLACE (the addend is the output slab)
+            g.relinearize(L, n, d3, out)
+            g.rotate_add(L, n, da, -2, out, out)
+            got = out.download((n, 2, L, N))
+            for r in range(n):
+                assert np.array_equal(got[r], want_rot_add[r]), ("rotate_add in place", lds, r)
+            st = g.path_stats()
+            if lds and fits:
+                assert st["ks_lds"] == (7 if L >= 2 else 5) and st["ks_fused"] == st["ks_unfused"] == st["ks_latency"] == 0, st
+            else:
+                assert st["ks_lds"] == 0, st
+    finally:
+        g.set_lds_max(None)
 
 
 def test_pipeline_regression_fixture_gpu(be, oracle):
