@@ -239,31 +239,75 @@ __global__ void __launch_bounds__(kEncBlock) k_ckks_encode(const double *values,
         }
     }
 }
-// coeff [n][L][N] coefficient-form plaintext -> out [n][sr.total]: the real parts of the slots the ranges name (all N/2 by default)
-__global__ void __launch_bounds__(kEncBlock) k_ckks_decode(const u64 *coeff, double scale, client::Cplx *zbuf, double *out, EncTables T, const PrimeDev *primes,
-                                                           CrtDev c, int logN, SlotRanges sr)
+// CKKSEncoder::decode in two kernels.
+// (1) k_ckks_decode_compose<W>: ONE THREAD PER COEFFICIENT over the whole batch -- CRT composition of the L = W - 2 residues into a W-word
+//     integer, centred, divided by the scale and twisted into the transform's input.  The multiword arithmetic is client/multiword.h's
+//     (the host decoder's) with the word count a template parameter: fixed trip counts, so x[] lives in registers -- the run-time-sized
+//     version indexed a private array in scratch memory and ran as one 1024-thread block per plaintext (10 ms for ONE result at N = 2^15,
+//     L = 16; profiles/r05_bridge_phases.jsonl).  Same operations in the same order: the same doubles, bit for bit.
+// (2) k_ckks_decode_fft: one 1024-thread block per plaintext runs the N-point transform and writes the wanted slots.
+template <int W>
+__global__ void __launch_bounds__(kBlock) k_ckks_decode_compose(const u64 *coeff, double scale, client::Cplx *zbuf, EncTables T, const PrimeDev *primes, CrtDev c,
+                                                                int logN, u64 n_vec)
 {
-    const u32 N = 1u << logN, half = N >> 1;
+    constexpr int L = W - 2;
+    const u64 gid = (u64)blockIdx.x * kBlock + threadIdx.x;
+    const u64 r = gid >> logN;
+    const u32 n = (u32)(gid & (((u64)1 << logN) - 1));
+    if (r >= n_vec) return;
+    u64 x[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) x[k] = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) { // client::crt_compose: x += punct_i * ((res_i * inv_i) mod q_i)
+        const u64 f = barrett128((u128)coeff[((r * L + (u64)i) << logN) + n] * c.v.inv[i], make_modu(primes[i]));
+        const u64 *pu = c.v.punct + (u64)i * W;
+        u64 carry = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const u128 p = (u128)pu[k] * f + x[k] + carry;
+            x[k] = (u64)p;
+            carry = (u64)(p >> 64);
+        }
+    }
+    auto cmp = [&](const u64 *b) { // mw_cmp(x, b)
+        int res = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+            if (x[k] != b[k]) res = x[k] > b[k] ? 1 : -1; // (ascending: the most significant differing word decides last)
+        return res;
+    };
+    while (cmp(c.v.Q) >= 0) { // x -= Q (at most L times)
+        u64 borrow = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const u128 d = (u128)x[k] - c.v.Q[k] - borrow;
+            x[k] = (u64)d;
+            borrow = (u64)(d >> 64) & 1;
+        }
+    }
+    double v;
+    if (cmp(c.v.halfQ) > 0) { // centred representative: -(Q - x)
+        u64 y[W];
+        u64 borrow = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const u128 d = (u128)c.v.Q[k] - x[k] - borrow;
+            y[k] = (u64)d;
+            borrow = (u64)(d >> 64) & 1;
+        }
+        v = -client::mw_to_double(y, W);
+    } else {
+        v = client::mw_to_double(x, W);
+    }
+    zbuf[(r << logN) + client::bitrev_u32(n, logN)] = client::ckks_decode_coeff(v, T.Z[n], scale);
+}
+__global__ void __launch_bounds__(kEncBlock) k_ckks_decode_fft(client::Cplx *zbuf, double *out, EncTables T, int logN, SlotRanges sr)
+{
+    const u32 N = 1u << logN;
     const u64 r = blockIdx.x;
     client::Cplx *z = zbuf + r * N;
-    ModU64 mods[16];
-    for (int i = 0; i < c.v.L; ++i) mods[i] = make_modu(primes[i]);
-    for (u32 n = threadIdx.x; n < N; n += kEncBlock) {
-        u64 x[client::kMwWords], y[client::kMwWords];
-        client::crt_compose(c.v, mods, coeff + ((r * c.v.L) << logN) + n, (u64)1 << logN, x);
-        double v;
-        if (client::mw_cmp(x, c.v.halfQ, c.v.words) > 0) {
-            client::mw_copy(y, c.v.Q, c.v.words);
-            client::mw_sub(y, x, c.v.words);
-            v = -client::mw_to_double(y, c.v.words);
-        } else {
-            v = client::mw_to_double(x, c.v.words);
-        }
-        z[client::bitrev_u32(n, logN)] = client::ckks_decode_coeff(v, T.Z[n], scale);
-    }
-    __syncthreads();
     fft_stages_block(z, T.W, N, true);
-    (void)half;
     u32 base = 0;
     for (u32 g = 0; g < sr.n; ++g) {
         for (u32 i = threadIdx.x; i < sr.count[g]; i += kEncBlock) out[r * sr.total + base + i] = z[T.slot_index[sr.first[g] + i]].re;
@@ -362,8 +406,17 @@ void launch_ckks_decode(const KernelEnv &env, u64 n_vec, const u64 *coeff, doubl
     CrtDev d;
     d.v.L = c.L; d.v.words = c.words; d.v.Q = c.Q; d.v.halfQ = c.halfQ; d.v.punct = c.punct; d.v.inv = c.inv;
     d.Qd = c.Qd; d.t = c.t;
-    hipLaunchKernelGGL(k_ckks_decode, dim3((unsigned)n_vec), dim3(kEncBlock), 0, env.stream, coeff, scale, static_cast<client::Cplx *>(zbuf), out, T, env.primes, d,
-                       env.logn1 + kRowLog, sr);
+    const int logN = env.logn1 + kRowLog;
+    const unsigned grid = grid_for(n_vec << logN, kBlock);
+    client::Cplx *z = static_cast<client::Cplx *>(zbuf);
+#define HE355_COMPOSE(W) case W: hipLaunchKernelGGL(k_ckks_decode_compose<W>, dim3(grid), dim3(kBlock), 0, env.stream, coeff, scale, z, T, env.primes, d, logN, n_vec); break;
+    switch (c.words) { // words = L + 2 (DeviceContext::crt_tables), L <= 16
+        HE355_COMPOSE(3) HE355_COMPOSE(4) HE355_COMPOSE(5) HE355_COMPOSE(6) HE355_COMPOSE(7) HE355_COMPOSE(8) HE355_COMPOSE(9) HE355_COMPOSE(10)
+        HE355_COMPOSE(11) HE355_COMPOSE(12) HE355_COMPOSE(13) HE355_COMPOSE(14) HE355_COMPOSE(15) HE355_COMPOSE(16) HE355_COMPOSE(17) HE355_COMPOSE(18)
+    default: throw std::invalid_argument("launch_ckks_decode: CRT tables of 1 to 16 data primes");
+    }
+#undef HE355_COMPOSE
+    hipLaunchKernelGGL(k_ckks_decode_fft, dim3((unsigned)n_vec), dim3(kEncBlock), 0, env.stream, z, out, T, logN, sr);
 }
 void launch_bfv_encode_scatter(const KernelEnv &env, u64 n_vec, const long long *values, u64 count, u64 *ev, const uint32_t *slot_index, u64 t)
 {
