@@ -157,7 +157,7 @@ void VectorBenchmark::decode(AB::Handle encoded_data, AB::DataPackCollection *p_
     // only the out_n slots the loop below copies are decoded to the host (the reference decodes all and copies the first n: .cpp:214-226)
     const HeContextWrapper::SlotRanges head{{0, out_n}};
     if (m_scheme == Scheme::CKKS) {
-        const std::vector<double> vals = m_p_ctx_wrapper->decodeSlotsCKKS(wanted, head);
+        const auto vals = m_p_ctx_wrapper->decodeSlotsCKKS(wanted, head);
         for (std::size_t result_i = 0; result_i < n_res; ++result_i) {
             double *output_location = reinterpret_cast<double *>(p_native->p_data_packs[0].p_buffers[result_i].p);
             const double *v = vals.data() + result_i * out_n;
@@ -165,7 +165,7 @@ void VectorBenchmark::decode(AB::Handle encoded_data, AB::DataPackCollection *p_
                 output_location[x] = std::abs(v[x]) < 0.00005 ? 0 : v[x];
         }
     } else {
-        const std::vector<std::int64_t> vals = m_p_ctx_wrapper->decodeSlotsBFV(wanted, head);
+        const auto vals = m_p_ctx_wrapper->decodeSlotsBFV(wanted, head);
         for (std::size_t result_i = 0; result_i < n_res; ++result_i) {
             std::int64_t *output_location = reinterpret_cast<std::int64_t *>(p_native->p_data_packs[0].p_buffers[result_i].p);
             std::copy(vals.begin() + result_i * out_n, vals.begin() + (result_i + 1) * out_n, output_location);

@@ -42,21 +42,33 @@ HeContextWrapper::~HeContextWrapper()
     if (m_pinned) (void)he355_host_free(m_ctx, m_pinned);
     if (m_ctx) he355_ctx_destroy(m_ctx);
 }
+// The page-locked staging buffer: 1 MiB, allocated once (prepareClient, i.e. createBenchmark) -- page-locking memory costs milliseconds, so
+// it never grows inside a phase; transfers beyond it go to pageable memory, where the copy itself dominates anyway.
 void *HeContextWrapper::pinned(std::uint64_t bytes)
 {
-    if (bytes > m_pinned_bytes) {
-        if (m_pinned) check(he355_host_free(m_ctx, m_pinned), "page-locked buffer");
-        m_pinned = nullptr; m_pinned_bytes = 0;
-        const std::uint64_t want = std::max<std::uint64_t>(bytes, (std::uint64_t)1 << 20);
-        check(he355_host_alloc(m_ctx, want, &m_pinned), "page-locked buffer");
-        m_pinned_bytes = want;
+    if (!m_pinned) {
+        check(he355_host_alloc(m_ctx, (std::uint64_t)1 << 20, &m_pinned), "page-locked buffer");
+        m_pinned_bytes = (std::uint64_t)1 << 20;
     }
-    return m_pinned;
+    return bytes <= m_pinned_bytes ? m_pinned : nullptr;
+}
+template <class T> HeContextWrapper::Decoded<T> HeContextWrapper::fetchDecoded(const void *d_src, std::uint64_t count)
+{
+    Decoded<T> out;
+    out.count = count;
+    T *host = static_cast<T *>(pinned(count * sizeof(T)));
+    if (!host) {
+        out.heap.reset(new T[count]); // (not value-initialised: the download fills it)
+        host = out.heap.get();
+    }
+    check(he355_download(m_ctx, host, d_src, count * sizeof(T)), "download"); // (stream-ordered behind the decode kernels; returns when the bytes are here)
+    out.ptr = host;
+    return out;
 }
 void HeContextWrapper::prepareClient(std::uint64_t batch_hint)
 {
     if (!clientOnDevice()) return; // (no device: the host client needs nothing prepared)
-    (void)pinned((std::uint64_t)1 << 20);
+    (void)pinned(1);
     // one throw-away encode -> decode of `batch_hint` empty vectors sizes the client scratch and the pool's size classes, builds the encoder
     // and CRT tables and pages the kernels in: the first real encode() then costs what the second one does
     const std::uint64_t n = std::max<std::uint64_t>(1, std::min<std::uint64_t>(batch_hint, 256));
@@ -309,20 +321,21 @@ static std::uint64_t ranges_total(const HeContextWrapper::SlotRanges &ranges, st
     }
     return total;
 }
-std::vector<double> HeContextWrapper::decodeSlotsCKKS(const std::vector<Plain> &plains, const SlotRanges &ranges)
+HeContextWrapper::Decoded<double> HeContextWrapper::decodeSlotsCKKS(const std::vector<Plain> &plains, const SlotRanges &ranges)
 {
     std::vector<std::uint64_t> flat;
     const std::uint64_t total = ranges_total(ranges, slot_count(), flat), n = plains.size();
-    std::vector<double> out;
+    Decoded<double> out;
     if (!n || !total) return out;
     bool uniform = true;
     for (const Plain &p : plains) uniform = uniform && p.L == plains[0].L && p.scale == plains[0].scale;
     if (!clientOnDevice() || !uniform || plains[0].L > 16) { // host decoder: all slots, then the wanted ones
-        out.resize(n * total);
+        out.heap.reset(new double[n * total]);
+        out.ptr = out.heap.get(); out.count = n * total;
         std::vector<double> all(slot_count());
         for (std::size_t i = 0; i < n; ++i) {
             m_client->ckks_decode(hostData(plains[i]), (size_t)plains[i].L, plains[i].scale, all.data());
-            double *dst = out.data() + i * total;
+            double *dst = out.heap.get() + i * total;
             for (const auto &r : ranges) dst = std::copy(all.begin() + r.first, all.begin() + r.first + r.second, dst);
         }
         return out;
@@ -332,23 +345,21 @@ std::vector<double> HeContextWrapper::decodeSlotsCKKS(const std::vector<Plain> &
     const Staged in = stage(plains, pl);
     DevBuf dv(m_ctx, bytes);
     check(he355_ckks_decode_slots(m_ctx, L, n, in.d, plains[0].scale, flat.data(), ranges.size(), dv.as<double>()), "decode");
-    double *host = static_cast<double *>(pinned(bytes));
-    check(he355_download(m_ctx, host, dv.p, bytes), "download"); // (stream-ordered behind the decode kernels; returns when the bytes are here)
-    out.assign(host, host + n * total);
-    return out;
+    return fetchDecoded<double>(dv.p, n * total);
 }
-std::vector<std::int64_t> HeContextWrapper::decodeSlotsBFV(const std::vector<Plain> &plains, const SlotRanges &ranges)
+HeContextWrapper::Decoded<std::int64_t> HeContextWrapper::decodeSlotsBFV(const std::vector<Plain> &plains, const SlotRanges &ranges)
 {
     std::vector<std::uint64_t> flat;
     const std::uint64_t total = ranges_total(ranges, slot_count(), flat), n = plains.size();
-    std::vector<std::int64_t> out;
+    Decoded<std::int64_t> out;
     if (!n || !total) return out;
     if (!clientOnDevice()) {
-        out.resize(n * total);
+        out.heap.reset(new std::int64_t[n * total]);
+        out.ptr = out.heap.get(); out.count = n * total;
         std::vector<std::int64_t> all(slot_count());
         for (std::size_t i = 0; i < n; ++i) {
             m_client->bfv_decode(hostData(plains[i]), all.data());
-            std::int64_t *dst = out.data() + i * total;
+            std::int64_t *dst = out.heap.get() + i * total;
             for (const auto &r : ranges) dst = std::copy(all.begin() + r.first, all.begin() + r.first + r.second, dst);
         }
         return out;
@@ -357,10 +368,7 @@ std::vector<std::int64_t> HeContextWrapper::decodeSlotsBFV(const std::vector<Pla
     const Staged in = stage(plains, N);
     DevBuf dv(m_ctx, bytes);
     check(he355_bfv_decode_slots(m_ctx, n, in.d, flat.data(), ranges.size(), dv.as<std::int64_t>()), "decode");
-    std::int64_t *host = static_cast<std::int64_t *>(pinned(bytes));
-    check(he355_download(m_ctx, host, dv.p, bytes), "download");
-    out.assign(host, host + n * total);
-    return out;
+    return fetchDecoded<std::int64_t>(dv.p, n * total);
 }
 // Client side: on the MI355X when one is present (he355_encrypt / he355_decrypt: same bits as the host code below for the same
 // randomness counter — tests/test_gpu_client.py), on the host otherwise, as in the reference, whose Encryptor / Decryptor are

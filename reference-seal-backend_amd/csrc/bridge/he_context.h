@@ -99,8 +99,20 @@ public:
     // [plains.size()][sum of counts] (ckks eltwise .cpp:214-226 copies the first n slots of a result; bfv row .cpp:339-369 the first dim3 of
     // both batching rows).  The values land in a page-locked buffer the context owns and are copied out of it once.
     typedef std::vector<std::pair<std::uint64_t, std::uint64_t>> SlotRanges;
-    std::vector<double> decodeSlotsCKKS(const std::vector<Plain> &plains, const SlotRanges &ranges);
-    std::vector<std::int64_t> decodeSlotsBFV(const std::vector<Plain> &plains, const SlotRanges &ranges);
+    // the decoded values: in the context's page-locked buffer (small results: valid until the context's next decode) or in a heap block of
+    // their own that nobody zero-filled first (large ones) -- read once by the caller, never copied in between
+    template <class T> struct Decoded {
+        std::unique_ptr<T[]> heap;
+        const T *ptr = nullptr;
+        std::size_t count = 0;
+        const T *data() const { return ptr; }
+        const T *begin() const { return ptr; }
+        const T *end() const { return ptr + count; }
+        std::size_t size() const { return count; }
+        const T &operator[](std::size_t i) const { return ptr[i]; }
+    };
+    Decoded<double> decodeSlotsCKKS(const std::vector<Plain> &plains, const SlotRanges &ranges);
+    Decoded<std::int64_t> decodeSlotsBFV(const std::vector<Plain> &plains, const SlotRanges &ranges);
     // Everything the first encode() / encrypt() / decode() of a benchmark would otherwise pay for inside the call: device + streams, the
     // client keys in HBM, the encoders' tables, the client scratch for `batch_hint` objects and the page-locked staging buffer.  Called by
     // the benchmark constructors (createBenchmark is where the reference generates its keys: seal_context.cpp:46-70).
@@ -151,6 +163,7 @@ private:
     void *m_pinned = nullptr; // page-locked staging of decode results / encode inputs (he355_host_alloc), grown on demand
     std::uint64_t m_pinned_bytes = 0;
     void *pinned(std::uint64_t bytes);
+    template <class T> Decoded<T> fetchDecoded(const void *d_src, std::uint64_t count);
     std::map<uint32_t, bool> m_galois;
 };
 

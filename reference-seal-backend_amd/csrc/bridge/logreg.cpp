@@ -177,7 +177,7 @@ void LogRegHornerBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackCollec
     const Plain &encoded = this->getEngine().retrieveFromHandle<Plain>(h_encoded_data, EncodedResultTag);
     // the first min_count slots are the predictions (one per sample): decoded where the plaintext lies, only those come back
     const std::uint64_t want = std::min<std::uint64_t>(min_count, m_p_ctx_wrapper->slot_count());
-    const std::vector<double> v = m_p_ctx_wrapper->decodeSlotsCKKS(std::vector<Plain>(1, encoded), HeContextWrapper::SlotRanges{{0, want}});
+    const auto v = m_p_ctx_wrapper->decodeSlotsCKKS(std::vector<Plain>(1, encoded), HeContextWrapper::SlotRanges{{0, want}});
     for (std::uint64_t s = 0; s < min_count && s < v.size(); ++s)
         if (result.p_buffers[s].p && result.p_buffers[s].size >= sizeof(double))
             *reinterpret_cast<double *>(result.p_buffers[s].p) = std::abs(v[s]) < 0.00005 ? 0.0 : v[s];

@@ -179,7 +179,7 @@ void MatMultRowLatencyBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackC
     if (m_scheme == Scheme::CKKS) { // decodeResult, ckks row .cpp:330-356: row i = first dim3 slots of ciphertext i, |x| < 0.00005 -> 0
         double *raw = reinterpret_cast<double *>(rc.p_buffers[0].p);
         std::size_t room = rc.p_buffers[0].size / sizeof(double), pos = 0;
-        const std::vector<double> vals = m_p_ctx_wrapper->decodeSlotsCKKS(enc.C, HeContextWrapper::SlotRanges{{0, enc.d.cols}});
+        const auto vals = m_p_ctx_wrapper->decodeSlotsCKKS(enc.C, HeContextWrapper::SlotRanges{{0, enc.d.cols}});
         for (std::size_t i = 0; i < enc.d.rows && i < enc.C.size() && pos < room; ++i) {
             const double *v = vals.data() + i * enc.d.cols;
             for (std::size_t j = 0; j < enc.d.cols && pos < room; ++j) raw[pos++] = std::abs(v[j]) < 0.00005 ? 0.0 : v[j];
@@ -191,7 +191,7 @@ void MatMultRowLatencyBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackC
     std::int64_t *raw = reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p);
     std::size_t room = rc.p_buffers[0].size / sizeof(std::int64_t), pos = 0;
     // the first dim3 slots of both batching rows of every ciphertext: [ciphertext][2][dim3]
-    const std::vector<std::int64_t> vals = m_p_ctx_wrapper->decodeSlotsBFV(enc.C, HeContextWrapper::SlotRanges{{0, dim3}, {row_size, dim3}});
+    const auto vals = m_p_ctx_wrapper->decodeSlotsBFV(enc.C, HeContextWrapper::SlotRanges{{0, dim3}, {row_size, dim3}});
     (void)slots;
     for (std::size_t i = 0; i < dim1 && pos < room; ++i) {
         if (i / 2 >= enc.C.size()) throw std::out_of_range("MatMultRow decode: result row beyond the decrypted ciphertexts");

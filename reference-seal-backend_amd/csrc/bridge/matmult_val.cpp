@@ -145,13 +145,13 @@ void MatMultValBenchmark::decode(AB::Handle h_encoded_data, AB::DataPackCollecti
         const std::size_t k1 = std::min(total, k0 + kGroup);
         const std::vector<Plain> group(res.begin() + k0, res.begin() + k1);
         if (m_scheme == Scheme::CKKS) {
-            const std::vector<double> vals = m_p_ctx_wrapper->decodeSlotsCKKS(group, HeContextWrapper::SlotRanges{{0, 1}}); // slot 0 is the entry
+            const auto vals = m_p_ctx_wrapper->decodeSlotsCKKS(group, HeContextWrapper::SlotRanges{{0, 1}}); // slot 0 is the entry
             for (std::size_t k = k0; k < k1; ++k) {
                 const double v0 = vals[k - k0];
                 reinterpret_cast<double *>(rc.p_buffers[0].p)[k] = std::abs(v0) < 0.00005 ? 0.0 : v0; // ckks .cpp:356-359
             }
         } else {
-            const std::vector<std::int64_t> vals = m_p_ctx_wrapper->decodeSlotsBFV(group, HeContextWrapper::SlotRanges{{0, 1}});
+            const auto vals = m_p_ctx_wrapper->decodeSlotsBFV(group, HeContextWrapper::SlotRanges{{0, 1}});
             for (std::size_t k = k0; k < k1; ++k) reinterpret_cast<std::int64_t *>(rc.p_buffers[0].p)[k] = vals[k - k0];
         }
     }

@@ -18,7 +18,7 @@
 // ciphertext.  The inverse transform of digit j is repeated by the L blocks that lift it and the special prime's inverse transform by the L
 // blocks that consume it: on a chip that idles at these sizes the redundancy costs nothing, the dependent chain is what counts.
 // Same lane programs as every other kernel (ntt_core.h), same exact arithmetic, canonical outputs: bit-identical to the other shapes
-// (tests/test_gpu_parity.py::test_lds_shape_*), SEAL's switch_key_inplace step for step (oracle/he_oracle.c:506-568).
+// (tests/test_gpu_parity.py::test_lds_shape_*), SEAL's switch_key_inplace step for step.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -378,7 +378,7 @@ __device__ __forceinline__ u64 lazy_to_4q(const ArU64 &ar, u64 x) { if constexpr
 __device__ __forceinline__ double lazy_to_4q(const ArF64 &, double x) { return x; }
 
 // One RNS floor step (divide-and-round by prime s) with both transforms in LDS -- the mod-down of a key switch (s = the special prime) and
-// the CKKS rescale (s = the last data prime; SEAL divide_and_round_q_last_ntt_inplace, oracle/he_oracle.c:578-600) are the same step:
+// the CKKS rescale (s = the last data prime; SEAL divide_and_round_q_last_ntt_inplace) are the same step:
 //   out[op][k][i] = ((sum of a_terms rows under q_i) - NTT_i(delta)) s^-1 + addend,   delta = ((t + s/2) mod s  mod q_i) - (s/2 mod q_i),
 //   t = iNTT_s(sum of t_terms rows under s).   Block = (op, target prime i < n_tgt, polynomial k < n_polys).
 struct LdsFloorArgs {

@@ -146,6 +146,16 @@ struct alignas(16) Tw16 {
 #ifndef HE355_U64_FOLD
 #define HE355_U64_FOLD 0
 #endif
+// Everything whose BODY depends on HE355_U64_FOLD lives in an inline namespace named after the form: the two builds of the device code and
+// the host library (default form) are linked into one shared object, and without it `he355::mul_pre_lazy`, `he355::ArU64::bfly_inv` ... would
+// be one mangled name with two definitions -- harmless while only device code (per translation unit) uses them, a silent wrong-residue bug
+// the day a host function odr-uses one.  Name lookup is unchanged: `he355::ArU64` finds the form of the including build.
+#if HE355_U64_FOLD
+#define HE355_ARITH_NS u64_fold_form
+#else
+#define HE355_ARITH_NS u64_shoup_form
+#endif
+inline namespace HE355_ARITH_NS {
 // x * w mod q, lazy in [0, 2q) / canonical, for a constant w with its companion word w2: the Shoup quotient floor(w 2^64 / q), or
 // (HE355_U64_FOLD build: every u64-engine prime is 2^60 - c) w * 2^32 mod q.  Which one a table holds is the context's choice
 // (Params::u64_fold), and a context only ever runs the build that matches its tables.
@@ -387,6 +397,8 @@ struct ArU64 {
     HE_HD T renorm(T x) const { return x >= two_q ? x - two_q : x; }
     static constexpr bool kNeedsRenormInv = false;
 };
+
+} // inline namespace HE355_ARITH_NS
 
 // ====================================================================================================
 // ArF64 — exact arithmetic in doubles, centred lazy residues, q < 2^47

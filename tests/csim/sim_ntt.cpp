@@ -167,7 +167,15 @@ template <class Ar> static void rows_inv(const Ar &ar, const PrimeTables &pt, in
         for (int lane = 0; lane < 64; ++lane) {
             T *x = regs[lane];
             for (int r = 0; r < kRowE; ++r) x[r] = ar.from_canon(in[(size_t)a * kRowN + elemC(lane, r)]);
+            // phase C both ways: twiddles read where they are used (row_inv_C), and gathered up front (gather_inv_C + row_inv_C_w: what the
+            // ring-in-LDS kernels of he355_kernels_lds.hip run) -- the same registers, bit for bit
+            T y[kRowE];
+            for (int r = 0; r < kRowE; ++r) y[r] = x[r];
+            Tw16 wc[kTwInvC];
+            gather_inv_C(itw, lane, wc);
+            row_inv_C_w(ar, y, wc);
             row_inv_C(ar, x, itw, lane);
+            if (std::memcmp(x, y, sizeof(T) * kRowE) != 0) throw std::runtime_error("row_inv_C_w differs from row_inv_C");
             track(x, kRowE);
         }
         xchg(2, 1, lds, regs);
