@@ -17,7 +17,10 @@ set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 rc=0
 # Round 6: rings up to N = 8192 take the ring-in-LDS shape for small batches (HE355_LDS_MAX); the settings that select HBM shapes switch it off.
-for cfg in "HE355_NONE=1" "HE355_LDS_MAX=0" "HE355_LDS_MAX=64" "HE355_K3_FUSE=0 HE355_LDS_MAX=0" "HE355_K3_FUSE=all HE355_LDS_MAX=0" "HE355_DEVICE_CLIENT=0" "HE355_DUAL_STREAM=0 HE355_CHUNK=3" "HE355_LATENCY_MAX=0 HE355_LDS_MAX=0" "HE355_LATENCY_MAX=64 HE355_LDS_MAX=0" "HE355_CHUNK=256" "HE355_LEVEL_WALK=0" "HE355_POOL=0" "HE355_NUM_DEVICES=2 HE355_LOGICAL_DEVICES=2" "HE355_BEHZ_BASE=seal" "HE355_BEHZ_FUSE=2" "HE355_BEHZ_BASE=seal HE355_BEHZ_FUSE=0" "HE355_BEHZ_FUSE=1" "HE355_DUAL_ENGINE=0 HE355_LDS_MAX=0" "HE355_FORCE_U64=1" "HE355_FORCE_U64=shoup" "HE355_FORCE_U64=shoup HE355_LDS_MAX=0"; do
+# usage: tools/test_matrix.sh [first [count]] -- a slice of the settings (a gpurun call is capped at 20 minutes; the whole matrix takes about 30)
+CFGS=("HE355_NONE=1" "HE355_LDS_MAX=0" "HE355_LDS_MAX=64" "HE355_K3_FUSE=0 HE355_LDS_MAX=0" "HE355_K3_FUSE=all HE355_LDS_MAX=0" "HE355_DEVICE_CLIENT=0" "HE355_DUAL_STREAM=0 HE355_CHUNK=3" "HE355_LATENCY_MAX=0 HE355_LDS_MAX=0" "HE355_LATENCY_MAX=64 HE355_LDS_MAX=0" "HE355_CHUNK=256" "HE355_LEVEL_WALK=0" "HE355_POOL=0" "HE355_NUM_DEVICES=2 HE355_LOGICAL_DEVICES=2" "HE355_BEHZ_BASE=seal" "HE355_BEHZ_FUSE=2" "HE355_BEHZ_BASE=seal HE355_BEHZ_FUSE=0" "HE355_BEHZ_FUSE=1" "HE355_DUAL_ENGINE=0 HE355_LDS_MAX=0" "HE355_FORCE_U64=1" "HE355_FORCE_U64=shoup" "HE355_FORCE_U64=shoup HE355_LDS_MAX=0")
+FIRST=${1:-0}; COUNT=${2:-${#CFGS[@]}}
+for cfg in "${CFGS[@]:$FIRST:$COUNT}"; do
   echo "== $cfg"
   env $cfg timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -1 || rc=1
 done
