@@ -275,14 +275,9 @@ int he355_set_latency_max(he355_ctx *ctx, uint64_t n);
 int he355_set_level_walk(he355_ctx *ctx, int on);
 /* Rings that fit one CU's LDS (N <= 8192, at most 8 data primes): key switches over at most n ciphertexts per kernel sequence run as TWO
  * launches of one-polynomial workgroups whose transforms never leave LDS (csrc/he355_kernels_lds.hip; the reference's descriptors default
- * to N = 8192: src/benchmarks/ckks/seal_ckks_dot_product_benchmark.cpp:53-60).  Default: the library's rule (16); a call (or
+ * to N = 8192: src/benchmarks/ckks/seal_ckks_dot_product_benchmark.cpp:53-60).  Default: the library's rule (one and a half rounds of the chip for the first kernel's grid: 64 ciphertexts at {60, 40, 60}); a call (or
  * HE355_LDS_MAX) replaces it by n; 0: never; UINT64_MAX: the rule again.  Results are bit-identical either way. */
 int he355_set_lds_max(he355_ctx *ctx, uint64_t n);
-/* ... in one of two forms the library picks by the batch: target-major (a workgroup per (target prime, digit): two transforms per launch, the
- * shortest dependent chain; while the grid runs in one round of the chip) or source-major (a workgroup per digit / per polynomial that inverts
- * once and walks the target primes: no transform repeated; larger batches).  form 1 / 2 pins one of them wherever the shape is taken at all,
- * 0 gives the choice back (HE355_LDS_FORM=target|source).  Results are bit-identical. */
-int he355_set_lds_form(he355_ctx *ctx, int form);
 /* ops processed per kernel sequence: default 1024 (HE355_CHUNK), i.e. BASELINE configs[2]'s batch in one piece (scratch ~ 117 MiB/op at
  * N=2^15, L=16).  The size actually used is halved until the scratch arena(s) fit in the device memory that is free at the call. */
 int he355_set_chunk(he355_ctx *ctx, uint64_t ops_per_chunk);

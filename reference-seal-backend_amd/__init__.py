@@ -133,7 +133,6 @@ def lib():
             "he355_set_latency_max": (i32, [vp, u64]),
             "he355_set_level_walk": (i32, [vp, i32]),
             "he355_set_lds_max": (i32, [vp, u64]),
-            "he355_set_lds_form": (i32, [vp, i32]),
             "he355_mem_info": (i32, [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
             "he355_alloc_stats": (i32, [vp, C.POINTER(AllocStats)]),
             "he355_pool_trim": (i32, [vp, C.POINTER(C.c_uint64)]),
@@ -158,7 +157,7 @@ C_ABI_SYMBOLS = [
     "he355_relinearize", "he355_relinearize_rescale", "he355_multiply_accumulate", "he355_bfv_multiply_relin_accumulate", "he355_multiply_plain", "he355_add_plain",
     "he355_mod_switch_drop", "he355_sum", "he355_set_public_key", "he355_set_secret_key", "he355_encrypt", "he355_decrypt", "he355_keygen_relin", "he355_keygen_galois", "he355_ckks_encode", "he355_ckks_decode",
     "he355_bfv_encode", "he355_bfv_decode", "he355_ckks_decode_slots", "he355_bfv_decode_slots", "he355_host_alloc", "he355_host_free", "he355_rescale", "he355_apply_galois", "he355_rotate", "he355_rotate_add", "he355_rotate_each", "he355_rotate_sum", "he355_accumulate", "he355_encrypt_zero", "he355_set_zero_stream",
-    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_clock_probe_begin", "he355_clock_probe_end", "he355_set_chunk", "he355_set_latency_max", "he355_set_level_walk", "he355_set_lds_max", "he355_set_lds_form", "he355_mem_info", "he355_alloc_stats", "he355_pool_trim", "he355_path_stats", "he355_bridge_abi", "he355_bridge_group_load_bytes",
+    "he355_ntt_forward", "he355_ntt_inverse", "he355_timer_begin", "he355_timer_end", "he355_probe_dominant_kernel", "he355_clock_probe_begin", "he355_clock_probe_end", "he355_set_chunk", "he355_set_latency_max", "he355_set_level_walk", "he355_set_lds_max", "he355_mem_info", "he355_alloc_stats", "he355_pool_trim", "he355_path_stats", "he355_bridge_abi", "he355_bridge_group_load_bytes",
 ]
 
 
@@ -436,10 +435,6 @@ class Context:
     def set_lds_max(self, n=None):
         """largest batch whose key switches take the ring-in-LDS shape (N <= 8192); None: the library's rule; 0: never"""
         _check(lib().he355_set_lds_max(self.h, 2 ** 64 - 1 if n is None else n))
-
-    def set_lds_form(self, form=0):
-        """ring-in-LDS kernels: 0 the library's choice, 1 target-major, 2 source-major (one inverse transform, every target)"""
-        _check(lib().he355_set_lds_form(self.h, int(form)))
 
     def set_level_walk(self, on: bool):
         _check(lib().he355_set_level_walk(self.h, int(on)))

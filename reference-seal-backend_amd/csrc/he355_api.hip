@@ -304,7 +304,6 @@ public:
     void set_latency_max(u64 n) { lat_auto_ = n == ~(u64)0; lat_max_ = lat_auto_ ? 0 : n; } // ~0: back to lat_limit()'s rule
     void set_level_walk(bool on) { level_walk_ = on; }
     void set_lds_max(u64 n) { lds_auto_ = n == ~(u64)0; lds_max_ = lds_auto_ ? 0 : n; }
-    void set_lds_form(int form) { if (form < 0 || form > 2) throw std::invalid_argument("form: 0 (auto), 1 (target-major) or 2 (source-major)"); lds_form_pin_ = form; }
 
     size_t key_elems() const { return P.Ltop * 2 * P.K * P.N; }
     size_t n_q_primes() const
@@ -689,31 +688,21 @@ public:
     bool latency_shape(u64 nc) const { return P.scheme == kSchemeCKKS && nc <= lat_limit() && P.K >= 2; }
     // ... for a given kernel environment (a BFV context runs its rotation chains in the NTT domain on the CKKS pipeline: ntt_env)
     bool latency_shape_env(const KernelEnv &e, u64 nc) const { return e.scheme == kSchemeCKKS && nc <= lat_limit() && P.K >= 2; }
-    // Ring-in-LDS shape (he355_kernels_lds.hip): N <= 8192, NTT-domain pipeline, batches up to what lds_form() admits -- two
+    // Ring-in-LDS shape (he355_kernels_lds.hip): N <= 8192, NTT-domain pipeline, batches up to lds_limit() -- two
     // launches of L^2 + 2L one-polynomial workgroups per ciphertext instead of six launches through HBM.  Where the throughput shape's
     // better use of the chip overtakes it was measured (profiles/r06_lds_shape.txt); he355_set_lds_max / HE355_LDS_MAX replace the rule.
-    // Which form, if any (0: none; 1: target-major k_lds_digits / k_lds_floor; 2: source-major k_lds_digits_all / k_lds_floor_all):
-    //  * target-major while k_lds_digits' grid, (L + 1) L blocks per ciphertext, runs in ONE round of the chip -- 256 CUs, one 8-wave block each
-    //    at N = 8192 (two, four, eight blocks per CU for the smaller rings): 42 ciphertexts at {60, 40, 60} (32: 61 against 78 us per key
-    //    switch, 48: 76 against 86; profiles/r06_lds_shape.txt) -- the dependent chain is two transforms per launch;
-    //  * source-major beyond that, while ITS grids (2 L and 2 blocks per ciphertext) stay within kLdsSourceRounds rounds: a block inverts
-    //    once and walks the targets, no transform is repeated, L + 1 transforms per launch;
-    //  * the HBM shapes above that.  he355_set_lds_max / HE355_LDS_MAX cap the batch; HE355_LDS_FORM=target|source pins the form (A/B).
-    int lds_form(const KernelEnv &e, int L, u64 nc) const
+    // The rule: while k_lds_digits' grid, (L + 1) L blocks per ciphertext, runs in at most one and a half rounds of the chip -- 256 CUs, one
+    // 8-wave block each at N = 8192 (two, four, eight blocks per CU for the smaller rings): 64 ciphertexts at {60, 40, 60} (32: 61 against 78 us
+    // per key switch, 64: 89 against 95, 96: 131 against 113), 32 at {60, 40, 40, 60}; beyond that the HBM throughput shapes use the chip
+    // better (profiles/r06_lds_shape.txt; a "one inverse transform, every target" form of the kernels for larger batches was built, bit-exact,
+    // and lost everywhere: same file, tools/patches/r06_lds_source_major.patch).  he355_set_lds_max / HE355_LDS_MAX replace the rule.
+    u64 lds_limit(const KernelEnv &e, int L) const
     {
-        if (e.scheme != kSchemeCKKS || !ks_lds_supported(e, L)) return 0;
-        if (!lds_auto_) {
-            if (nc > lds_max_) return 0;
-            if (lds_form_pin_) return lds_form_pin_;
-        }
-        const u64 round = (u64)256 << (3 - std::min(3, e.logn1));
-        if (lds_form_pin_ == 1) return nc * (u64)(L + 1) * (u64)L <= round * kLdsSourceRounds ? 1 : 0;
-        if (lds_form_pin_ == 2) return nc * 2 * (u64)L <= round * kLdsSourceRounds ? 2 : 0;
-        if (nc * (u64)(L + 1) * (u64)L <= round) return 1;
-        if (nc * 2 * (u64)L <= round * kLdsSourceRounds) return 2;
-        return 0;
+        if (!lds_auto_) return lds_max_;
+        const u64 blocks = (u64)384 << (3 - std::min(3, e.logn1));
+        return std::max<u64>(1, blocks / ((u64)(L + 1) * (u64)L));
     }
-    bool lds_shape(const KernelEnv &e, int L, u64 nc) const { return lds_form(e, L, nc) != 0; }
+    bool lds_shape(const KernelEnv &e, int L, u64 nc) const { return e.scheme == kSchemeCKKS && ks_lds_supported(e, L) && nc <= lds_limit(e, L); }
     // scratch of the shape: the arena behind c01 (k_lds_digits' partial products; (2L + 2) L N words per ciphertext fit there for L <= 8)
     u64 *lds_part(const Scratch &S, int L, u64 nc) const
     {
@@ -791,9 +780,8 @@ public:
                 ++paths_.ks_lds;
                 LdsKsOperands src;
                 src.mode = LDSKS_MUL; src.a = a; src.b = b; src.ix = ix; src.op_offset = off;
-                const bool smaj = lds_form(env, L, nc) == 2;
-                launch_ks_lds(env, L, nc, src, d_relin_, lds_part(S, L, nc), B.c01, B.c01_item_stride, smaj);
-                if (rescale) launch_rescale_lds(env, L, 2, nc, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N, smaj);
+                launch_ks_lds(env, L, nc, src, d_relin_, lds_part(S, L, nc), B.c01, B.c01_item_stride);
+                if (rescale) launch_rescale_lds(env, L, 2, nc, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N);
                 continue;
             }
             // c0, c1 of the tensor product: written by k_k1, or (fused key switch) computed by k_k3 where it adds them in -- k_k1 is
@@ -856,9 +844,8 @@ public:
                 src.mode = LDSKS_PLAIN;
                 src.tgt = ct3 + off * 3 * LN + 2 * LN; src.tgt_op_stride = 3 * LN;
                 src.add = ct3 + off * 3 * LN; src.add_op_stride = 3 * LN;
-                const bool smaj = lds_form(env, L, nc) == 2;
-                launch_ks_lds(env, L, nc, src, d_relin_, lds_part(S, L, nc), B.c01, B.c01_item_stride, smaj);
-                if (rescale) launch_rescale_lds(env, L, 2, nc, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N, smaj);
+                launch_ks_lds(env, L, nc, src, d_relin_, lds_part(S, L, nc), B.c01, B.c01_item_stride);
+                if (rescale) launch_rescale_lds(env, L, 2, nc, B.c01, 2 * LN, out + off * 2 * (size_t)(L - 1) * N);
                 continue;
             }
             const bool in_k3 = tensor_in_k3(env, L, nc, B) && out_apart;
@@ -924,7 +911,7 @@ public:
             Scratch S = scratch(std::min<u64>(chunk, n), L); // arena sized for the batch actually processed
             const u64 *src = in + off * size * LN;
             if (lds_shape(env_, L, nc) && !ranges_overlap(in, n * size * LN, out, n * size * (size_t)(L - 1) * N)) { // (the blocks of an op read all of its input)
-                launch_rescale_lds(env_, L, size, nc, src, (u64)size * LN, out + off * size * (size_t)(L - 1) * N, lds_form(env_, L, nc) == 2);
+                launch_rescale_lds(env_, L, size, nc, src, (u64)size * LN, out + off * size * (size_t)(L - 1) * N);
                 continue;
             }
             launch_rows_inv_select(env_, L - 1, nc * size, src + (size_t)(L - 1) * N, LN, S.rlr);
@@ -980,7 +967,7 @@ public:
                 const std::array<unsigned char, 32> &rows = perm_rows_.at(elt);
                 std::copy(rows.begin(), rows.end(), src.perm_src_row);
                 src.add = addend ? addend + off * 2 * LN : nullptr; src.add_op_stride = 2 * LN;
-                launch_ks_lds(env, L, nc, src, key, lds_part(S, L, nc), B.c01, B.c01_item_stride, lds_form(env, L, nc) == 2);
+                launch_ks_lds(env, L, nc, src, key, lds_part(S, L, nc), B.c01, B.c01_item_stride);
                 continue;
             }
             // polynomial 1 of the rotated ciphertext is zero (or the addend's): on the fused path k_k1 does not write it and k_k3 takes it
@@ -2010,8 +1997,6 @@ private:
     size_t rot_tmp_bytes_ = 0;
     std::map<uint32_t, std::array<unsigned char, 32>> perm_rows_;
     he355_path_stats_t paths_{};
-    static constexpr u64 kLdsSourceRounds = 2; // (tuned on the GPU: profiles/r06_lds_shape.txt)
-    int lds_form_pin_ = [] { const char *e = getenv("HE355_LDS_FORM"); return !e ? 0 : (e[0] == 't' ? 1 : e[0] == 's' ? 2 : 0); }();
     bool lds_auto_ = !getenv("HE355_LDS_MAX");
     u64 lds_max_ = getenv("HE355_LDS_MAX") ? (u64)std::max(0, std::atoi(getenv("HE355_LDS_MAX"))) : 0;
     bool level_walk_ = !(getenv("HE355_LEVEL_WALK") && getenv("HE355_LEVEL_WALK")[0] == '0'); // he355_rotate_sum: trie levels as grouped launches
@@ -2249,10 +2234,6 @@ int he355_set_latency_max(he355_ctx *c, uint64_t n) { return guarded([&] { dev(c
 int he355_set_lds_max(he355_ctx *c, uint64_t n)
 {
     return guarded([&] { dev(c).set_lds_max(n); });
-}
-int he355_set_lds_form(he355_ctx *c, int form)
-{
-    return guarded([&] { dev(c).set_lds_form(form); });
 }
 int he355_set_level_walk(he355_ctx *c, int on) { return guarded([&] { dev(c).set_level_walk(on != 0); }); }
 int he355_set_relin_key(he355_ctx *c, const uint64_t *h_key)

@@ -473,247 +473,6 @@ __global__ void __launch_bounds__(64 << LOGN1) k_lds_floor(LdsFloorArgs A, const
     }
 }
 
-// =======================================================================================================================================
-// Source-major forms ("one inverse transform, every target"): k_lds_digits_all, k_lds_floor_all.
-// The target-major kernels above repeat the inverse transform of a digit in each of the L blocks that lift it (and the special prime's in
-// each of the L blocks that consume it): free while their grids run in ONE round of the chip, wasted issue slots once they do not.  Here a
-// block owns the SOURCE polynomial -- inverse transform once, the coefficients parked in LDS (slot A) -- and walks the target primes: lift,
-// forward column pass into a second LDS image (slot B), forward row pass, products / floor step.  L + 1 (digits) or 1 + n_tgt (floor)
-// transforms per block instead of 2 L / 2 n_tgt over L times the blocks: the shape for batches beyond one round (he355_api.hip: lds_form).
-// =======================================================================================================================================
-template <int LOGN1, class ArJ>
-__device__ __forceinline__ void block_inverse_to_coeffs(const ArJ &arJ, const PrimeDev &PJ, int wave, int lane, u64 (*A)[kLdsRow], typename ArJ::T x[kRowE],
-                                                        const Tw16 wc_inv[kTwInvC])
-{
-    constexpr int N1 = 1 << LOGN1;
-    constexpr bool kLast = LOGN1 == 0;
-    wave_rows_inv_pre(arJ, PJ, kLast, (u32)(N1 + wave), lane, A[wave], x, wc_inv); // -> layout A
-    {
-        u64 raw[kRowE];
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) raw[r] = kLast ? arJ.to_canon(x[r]) : arJ.to_raw(x[r]);
-        HE_WAVE_SYNC();
-        lds_store_A(A[wave], lane, raw);
-    }
-    __syncthreads();
-    if constexpr (!kLast) { // inverse column pass in place: slot A then holds the canonical coefficients, column by column
-        constexpr int kColsPerLane = kRowE / N1;
-#pragma unroll 1
-        for (int cc = 0; cc < kColsPerLane; ++cc) {
-            const int col = lds_pad((int)threadIdx.x + cc * 64 * N1);
-            typename ArJ::T cj[N1];
-#pragma unroll
-            for (int a = 0; a < N1; ++a) cj[a] = arJ.from_raw(A[a][col]);
-            col_inv<ArJ, LOGN1>(arJ, cj, ctw(PJ.inv), PJ.inv_w0_scaled);
-#pragma unroll
-            for (int a = 0; a < N1; ++a) A[a][col] = arJ.to_canon(cj[a]);
-        }
-    }
-    // (no barrier: the lane that wrote a column is the one that reads it in coeffs_to_target)
-}
-// slot A (canonical coefficients, this lane's columns) -> map -> forward transform under prime I: the wave's row in NTT form (layout C, lazy)
-template <int LOGN1, class ArI, class Lift, class Hook = NoHook>
-__device__ __forceinline__ void coeffs_to_target(const ArI &arI, const PrimeDev &PI, int wave, int lane, u64 (*A)[kLdsRow], u64 (*B)[kLdsRow], typename ArI::T y[kRowE],
-                                                 Lift lift, Hook before_c = Hook())
-{
-    constexpr int N1 = 1 << LOGN1;
-    constexpr bool kLast = LOGN1 == 0;
-    constexpr int kColsPerLane = kRowE / N1;
-#pragma unroll 1
-    for (int cc = 0; cc < kColsPerLane; ++cc) {
-        const int col = lds_pad((int)threadIdx.x + cc * 64 * N1);
-        typename ArI::T ci[N1];
-#pragma unroll
-        for (int a = 0; a < N1; ++a) ci[a] = arI.from_canon(lift(A[a][col]));
-        if constexpr (!kLast) col_fwd<ArI, LOGN1>(arI, ci, ctw(PI.fwd));
-#pragma unroll
-        for (int a = 0; a < N1; ++a) B[a][col] = kLast ? arI.to_canon(ci[a]) : arI.to_raw(ci[a]);
-    }
-    __syncthreads();
-    {
-        u64 raw[kRowE];
-        lds_load_A(B[wave], lane, raw);
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) y[r] = kLast ? arI.from_canon(raw[r]) : arI.from_raw(raw[r]);
-        HE_WAVE_SYNC();
-    }
-    wave_rows_fwd_n<ArI, decltype(tw_table(gtw(PI.fwd), 0u)), Hook, true>(arI, tw_table(gtw(PI.fwd), (u32)(N1 + wave)), lane, B[wave],
-                                                                          reinterpret_cast<typename ArI::T(*)[kRowE]>(y), before_c); // -> layout C
-}
-
-// ---- k_lds_digits_all: block = (op, digit j) [blocks 0 .. L-1 of an op] or (op, prime i) preparation [blocks L .. 2L-1: lds_prep_body] ----
-template <int LOGN1, class ArI>
-__device__ __forceinline__ void digits_all_target(const LdsKsArgs &A, const PrimeDev *primes, u64 op, int s, int i, int j, u64 qj, u64 (*SA)[kLdsRow], u64 (*SB)[kLdsRow])
-{
-    constexpr int N1 = 1 << LOGN1;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u64 N = (u64)N1 << kRowLog;
-    const PrimeDev &PI = primes[i];
-    const ArI arI = make_ar(PI, (ArI *)nullptr);
-    u64 kv0[kRowE], kv1[kRowE], kq0[kRowE], kq1[kRowE];
-    const int qs = ArI::kKeyQuotient ? q_slot(primes, i) : 0;
-    auto key_loads = [&]() {
-        key_rows<ArI>(A, qs, j, 0, i, N, (u64)wave << kRowLog, lane, kv0, kq0);
-        key_rows<ArI>(A, qs, j, 1, i, N, (u64)wave << kRowLog, lane, kv1, kq1);
-    };
-    const ModU64 mI = make_modu(PI);
-    const bool reduce = qj > PI.q; // (SEAL: the digit is reduced only when q_j > q_i)
-    typename ArI::T y[kRowE];
-    coeffs_to_target<LOGN1>(arI, PI, wave, lane, SA, SB, y, [&](u64 c) { return reduce ? barrett64(c, mI) : c; }, key_loads);
-    u64 *p0 = A.part + ((((op * (u64)(A.L + 2) + (u64)s) * 2 + 0) * A.L + (u64)j) * N) + ((u64)wave << kRowLog);
-    u64 *p1 = p0 + (u64)A.L * N;
-    u64 o0[kRowE], o1[kRowE];
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r) {
-        o0[r] = mul_key_canon(arI, y[r], kv0[r], kq0[r]);
-        o1[r] = mul_key_canon(arI, y[r], kv1[r], kq1[r]);
-    }
-    store_rowC(p0, lane, o0);
-    store_rowC(p1, lane, o1);
-    __syncthreads(); // slot B is rewritten for the next target
-}
-template <int LOGN1, class ArJ>
-__device__ __forceinline__ void digits_all_source(const LdsKsArgs &A, const PrimeDev *primes, u64 op, int j, u64 (*SA)[kLdsRow])
-{
-    constexpr int N1 = 1 << LOGN1;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u64 N = (u64)N1 << kRowLog;
-    const PrimeDev &PJ = primes[j];
-    const ArJ arJ = make_ar(PJ, (ArJ *)nullptr);
-    Tw16 wc_inv[kTwInvC];
-    gather_inv_C(tw_table(gtw(PJ.inv), (u32)(N1 + wave)), lane, wc_inv);
-    u64 v[kRowE];
-    target_row(A.src, arJ, A.L, N, op, j, (u32)wave, lane, SA[wave], v);
-    typename ArJ::T x[kRowE];
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r) x[r] = arJ.from_canon(v[r]);
-    block_inverse_to_coeffs<LOGN1>(arJ, PJ, wave, lane, SA, x, wc_inv);
-}
-template <int LOGN1>
-__global__ void __launch_bounds__(64 << LOGN1) k_lds_digits_all(LdsKsArgs A, const PrimeDev *primes)
-{
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    u64(*SA)[kLdsRow] = reinterpret_cast<u64(*)[kLdsRow]>(lds_raw);
-    u64(*SB)[kLdsRow] = SA + (1 << LOGN1);
-    const unsigned per_op = (unsigned)(2 * A.L);
-    const u64 op = blockIdx.x / per_op;
-    const unsigned p = blockIdx.x % per_op;
-    if (p >= (unsigned)A.L) { // preparation blocks: own-digit products and the rows the result is added into
-        const int i = (int)p - A.L;
-        if (primes[i].f64) lds_prep_body<LOGN1, ArF64>(A, primes, op, i, SA);
-        else lds_prep_body<LOGN1, ArU64>(A, primes, op, i, SA);
-        return;
-    }
-    const int j = (int)p;
-    if (primes[j].f64) digits_all_source<LOGN1, ArF64>(A, primes, op, j, SA);
-    else digits_all_source<LOGN1, ArU64>(A, primes, op, j, SA);
-    const u64 qj = primes[j].q;
-    for (int s = 0; s <= A.L; ++s) {
-        if (s == j) continue;
-        const int i = s == A.L ? A.K - 1 : s;
-        if (primes[i].f64) digits_all_target<LOGN1, ArF64>(A, primes, op, s, i, j, qj, SA, SB);
-        else digits_all_target<LOGN1, ArU64>(A, primes, op, s, i, j, qj, SA, SB);
-    }
-}
-
-// ---- k_lds_floor_all: block = (op, polynomial k): inverse transform under the source prime once, then every target prime ----
-template <int LOGN1, class ArI>
-__device__ __forceinline__ void floor_all_target(const LdsFloorArgs &A, const PrimeDev *primes, const FloorConst *fcs, u64 op, int i, int k, u64 qp, u64 (*SA)[kLdsRow],
-                                                 u64 (*SB)[kLdsRow])
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const PrimeDev &PI = primes[i];
-    const ArI arI = make_ar(PI, (ArI *)nullptr);
-    const FloorConst fc = fcs[(u64)A.src_prime * A.K + i];
-    const u64 rowoff = (u64)wave << kRowLog, qi = PI.q;
-    // c = (sum under q_i) s^-1 + addend for this target: formed now and parked in the OUTPUT row (this wave's own row of the result: written
-    // here, read back by the same wave behind the transform, then overwritten with the result) -- slot A and slot B leave no LDS for it
-    u64 *orow = A.out + op * A.out_op_stride + (u64)k * A.out_poly_stride + (u64)i * A.out_prime_stride + rowoff;
-    {
-        const u64 *pi = A.a + op * A.a_op_stride + (u64)k * A.a_poly_stride + (u64)i * A.a_prime_stride + rowoff;
-        u64 acc[kRowE], ad[kRowE];
-        load_rowC(pi, lane, acc);
-        if (A.add) load_rowC(A.add + op * A.add_op_stride + (u64)k * A.add_poly_stride + (u64)i * A.add_prime_stride + rowoff, lane, ad);
-        else {
-#pragma unroll
-            for (int r = 0; r < kRowE; ++r) ad[r] = 0;
-        }
-        for (int j = 1; j < A.a_terms; ++j) {
-            u64 w[kRowE];
-            load_rowC(pi + (u64)j * A.a_term_stride, lane, w);
-#pragma unroll
-            for (int r = 0; r < kRowE; ++r) acc[r] = addmod(acc[r], w[r], qi);
-        }
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) acc[r] = scale_add_canon(arI, acc[r], fc, ad[r]);
-        store_rowC(orow, lane, acc);
-    }
-    const ModU64 mI = make_modu(PI);
-    const u64 half_i = fc.half_mod;
-    typename ArI::T y[kRowE];
-    // (slot A holds r = (t + floor(s/2)) mod s already: floor_all_source)
-    coeffs_to_target<LOGN1>(arI, PI, wave, lane, SA, SB, y, [&](u64 r) { return submod(qp > qi ? barrett64(r, mI) : r, half_i, qi); });
-    u64 c[kRowE], o[kRowE];
-    load_rowC(orow, lane, c);
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r) o[r] = arI.floor_fin_s(c[r], lazy_to_4q(arI, y[r]), fc.inv, fc.inv_shoup, fc.inv_d, fc.inv_i);
-    store_rowC(orow, lane, o);
-    __syncthreads(); // slot B is rewritten for the next target
-}
-template <int LOGN1, class ArP>
-__device__ __forceinline__ void floor_all_source(const LdsFloorArgs &A, const PrimeDev *primes, u64 op, int k, u64 (*SA)[kLdsRow])
-{
-    constexpr int N1 = 1 << LOGN1;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const PrimeDev &PP = primes[A.src_prime];
-    const ArP arP = make_ar(PP, (ArP *)nullptr);
-    const u64 rowoff = (u64)wave << kRowLog;
-    Tw16 wc_inv[kTwInvC];
-    gather_inv_C(tw_table(gtw(PP.inv), (u32)(N1 + wave)), lane, wc_inv);
-    const u64 *sp = A.t + op * A.t_op_stride + (u64)k * A.t_poly_stride + rowoff;
-    u64 t[kRowE];
-    load_rowC(sp, lane, t);
-    for (int j = 1; j < A.t_terms; ++j) {
-        u64 u[kRowE];
-        load_rowC(sp + (u64)j * A.t_term_stride, lane, u);
-#pragma unroll
-        for (int r = 0; r < kRowE; ++r) t[r] = addmod(t[r], u[r], PP.q);
-    }
-    typename ArP::T x[kRowE];
-#pragma unroll
-    for (int r = 0; r < kRowE; ++r) x[r] = arP.from_canon(t[r]);
-    block_inverse_to_coeffs<LOGN1>(arP, PP, wave, lane, SA, x, wc_inv);
-    // r = (t + floor(s/2)) mod s, once for every target (this lane's columns, in place)
-    const u64 half = PP.q >> 1, qp = PP.q;
-    constexpr int kColsPerLane = kRowE / N1;
-#pragma unroll 1
-    for (int cc = 0; cc < kColsPerLane; ++cc) {
-        const int col = lds_pad((int)threadIdx.x + cc * 64 * N1);
-#pragma unroll
-        for (int a = 0; a < N1; ++a) {
-            u64 r = SA[a][col] + half;
-            if (r >= qp) r -= qp;
-            SA[a][col] = r;
-        }
-    }
-}
-template <int LOGN1>
-__global__ void __launch_bounds__(64 << LOGN1) k_lds_floor_all(LdsFloorArgs A, const PrimeDev *primes, const FloorConst *fcs)
-{
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    u64(*SA)[kLdsRow] = reinterpret_cast<u64(*)[kLdsRow]>(lds_raw);
-    u64(*SB)[kLdsRow] = SA + (1 << LOGN1);
-    const u64 op = blockIdx.x / (unsigned)A.n_polys;
-    const int k = (int)(blockIdx.x % (unsigned)A.n_polys);
-    if (primes[A.src_prime].f64) floor_all_source<LOGN1, ArF64>(A, primes, op, k, SA);
-    else floor_all_source<LOGN1, ArU64>(A, primes, op, k, SA);
-    const u64 qp = primes[A.src_prime].q;
-    for (int i = 0; i < A.n_tgt; ++i) {
-        if (primes[i].f64) floor_all_target<LOGN1, ArF64>(A, primes, fcs, op, i, k, qp, SA, SB);
-        else floor_all_target<LOGN1, ArU64>(A, primes, fcs, op, i, k, qp, SA, SB);
-    }
-}
-
 template <int LOGN1> void lds_attrs()
 {
     constexpr int N1 = 1 << LOGN1;
@@ -721,42 +480,37 @@ template <int LOGN1> void lds_attrs()
     static bool attr_done = false; // (per build of the device code; the attribute is per function, set once)
     if (attr_done) return;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lds_digits<LOGN1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lds_floor<LOGN1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes2) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lds_digits_all<LOGN1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_bytes)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lds_floor_all<LOGN1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_bytes)) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lds_floor<LOGN1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes2) != hipSuccess)
         throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the LDS-resident key switch");
     attr_done = true;
 }
-template <int LOGN1> void launch_floor_lds_n(const KernelEnv &env, const LdsFloorArgs &F, u64 n_ops, bool source_major)
+template <int LOGN1> void launch_floor_lds_n(const KernelEnv &env, const LdsFloorArgs &F, u64 n_ops)
 {
     constexpr int N1 = 1 << LOGN1;
-    constexpr size_t lds_bytes = (size_t)N1 * kLdsRow * sizeof(u64), lds_bytes2 = (size_t)N1 * (kLdsRow + kRowN) * sizeof(u64);
+    constexpr size_t lds_bytes2 = (size_t)N1 * (kLdsRow + kRowN) * sizeof(u64);
     lds_attrs<LOGN1>();
-    const u64 g = n_ops * (u64)F.n_polys * (source_major ? 1 : (u64)F.n_tgt);
+    const u64 g = n_ops * (u64)F.n_polys * (u64)F.n_tgt;
     if (g > 0x7fffffffull) throw std::invalid_argument("launch_floor_lds: batch too large for one grid");
-    if (!g) return;
-    if (source_major) hipLaunchKernelGGL(k_lds_floor_all<LOGN1>, dim3((unsigned)g), dim3(64 * N1), 2 * lds_bytes, env.stream, F, env.primes, env.floor_consts);
-    else hipLaunchKernelGGL(k_lds_floor<LOGN1>, dim3((unsigned)g), dim3(64 * N1), lds_bytes2, env.stream, F, env.primes, env.floor_consts);
+    if (g) hipLaunchKernelGGL(k_lds_floor<LOGN1>, dim3((unsigned)g), dim3(64 * N1), lds_bytes2, env.stream, F, env.primes, env.floor_consts);
 }
-void launch_floor_lds_any(const KernelEnv &env, const LdsFloorArgs &F, u64 n_ops, bool source_major)
+void launch_floor_lds_any(const KernelEnv &env, const LdsFloorArgs &F, u64 n_ops)
 {
     switch (env.logn1) {
-    case 0: launch_floor_lds_n<0>(env, F, n_ops, source_major); break;
-    case 1: launch_floor_lds_n<1>(env, F, n_ops, source_major); break;
-    case 2: launch_floor_lds_n<2>(env, F, n_ops, source_major); break;
-    default: launch_floor_lds_n<3>(env, F, n_ops, source_major); break;
+    case 0: launch_floor_lds_n<0>(env, F, n_ops); break;
+    case 1: launch_floor_lds_n<1>(env, F, n_ops); break;
+    case 2: launch_floor_lds_n<2>(env, F, n_ops); break;
+    default: launch_floor_lds_n<3>(env, F, n_ops); break;
     }
 }
 
-template <int LOGN1> void launch_ks_lds_n(const KernelEnv &env, const LdsKsArgs &A, u64 n_ops, bool source_major)
+template <int LOGN1> void launch_ks_lds_n(const KernelEnv &env, const LdsKsArgs &A, u64 n_ops)
 {
     constexpr int N1 = 1 << LOGN1;
     constexpr size_t lds_bytes = (size_t)N1 * kLdsRow * sizeof(u64);
     lds_attrs<LOGN1>();
-    const u64 g1 = n_ops * (source_major ? 2 * (u64)A.L : (u64)(A.L + 1) * A.L);
+    const u64 g1 = n_ops * (u64)(A.L + 1) * A.L;
     if (g1 > 0x7fffffffull) throw std::invalid_argument("launch_ks_lds: batch too large for one grid");
-    if (source_major) hipLaunchKernelGGL(k_lds_digits_all<LOGN1>, dim3((unsigned)g1), dim3(64 * N1), 2 * lds_bytes, env.stream, A, env.primes);
-    else hipLaunchKernelGGL(k_lds_digits<LOGN1>, dim3((unsigned)g1), dim3(64 * N1), lds_bytes, env.stream, A, env.primes);
+    hipLaunchKernelGGL(k_lds_digits<LOGN1>, dim3((unsigned)g1), dim3(64 * N1), lds_bytes, env.stream, A, env.primes);
     // the mod-down: a floor step by the special prime over what k_lds_digits left in `part` (slot L: its products under P; slot i: those under
     // q_i, the own digit's on the diagonal; slot L + 1: the rows the result is added into)
     const u64 N = (u64)N1 << kRowLog, L = (u64)A.L, slot_w = 2 * L * N;
@@ -766,7 +520,7 @@ template <int LOGN1> void launch_ks_lds_n(const KernelEnv &env, const LdsKsArgs 
     F.a = A.part; F.a_op_stride = (L + 2) * slot_w; F.a_poly_stride = L * N; F.a_prime_stride = slot_w; F.a_term_stride = N; F.a_terms = A.L;
     F.add = A.part + (L + 1) * slot_w; F.add_op_stride = (L + 2) * slot_w; F.add_poly_stride = L * N; F.add_prime_stride = N;
     F.out = A.out; F.out_op_stride = A.out_op_stride; F.out_poly_stride = L * N; F.out_prime_stride = N;
-    launch_floor_lds_n<LOGN1>(env, F, n_ops, source_major);
+    launch_floor_lds_n<LOGN1>(env, F, n_ops);
 #if defined(HE355_LDS_TRACE)
     static int printed = 0;
     (void)hipStreamSynchronize(env.stream);
@@ -792,7 +546,7 @@ u64 ks_lds_part_words(const KernelEnv &env, int L) { return (u64)(L + 2) * 2 * (
 
 // CKKS rescale of n_ops size-`size` ciphertexts at level L (src: [size][L][N] per op, src_op_stride words apart) into out [n_ops][size][L-1][N]:
 // one launch, block = (op, prime i < L - 1, polynomial)
-void launch_rescale_lds(const KernelEnv &env, int L, int size, u64 n_ops, const u64 *src, u64 src_op_stride, u64 *out, bool source_major)
+void launch_rescale_lds(const KernelEnv &env, int L, int size, u64 n_ops, const u64 *src, u64 src_op_stride, u64 *out)
 {
     if (!n_ops) return;
     if (!ks_lds_supported(env, L) || L < 2) throw std::invalid_argument("launch_rescale_lds: ring or level outside the LDS-resident shape");
@@ -803,10 +557,10 @@ void launch_rescale_lds(const KernelEnv &env, int L, int size, u64 n_ops, const 
     F.a = src; F.a_op_stride = src_op_stride; F.a_poly_stride = LN; F.a_prime_stride = N; F.a_term_stride = 0; F.a_terms = 1;
     F.add = nullptr; F.add_op_stride = F.add_poly_stride = F.add_prime_stride = 0;
     F.out = out; F.out_op_stride = (u64)size * L1N; F.out_poly_stride = L1N; F.out_prime_stride = N;
-    launch_floor_lds_any(env, F, n_ops, source_major);
+    launch_floor_lds_any(env, F, n_ops);
 }
 
-void launch_ks_lds(const KernelEnv &env, int L, u64 n_ops, const LdsKsOperands &src, const u64 *key, u64 *part, u64 *out, u64 out_op_stride, bool source_major)
+void launch_ks_lds(const KernelEnv &env, int L, u64 n_ops, const LdsKsOperands &src, const u64 *key, u64 *part, u64 *out, u64 out_op_stride)
 {
     int n_q = 0;
     for (int t = 0; t < env.K; ++t) n_q += env.prime_f64[t] == 0;
@@ -817,10 +571,10 @@ void launch_ks_lds(const KernelEnv &env, int L, u64 n_ops, const LdsKsOperands &
     A.src = src; A.key = key; A.part = part; A.out = out; A.out_op_stride = out_op_stride; A.L = L; A.K = env.K;
     A.trace_block = (unsigned)(L * L); // (op 0: special prime, digit 0 -- two u64-engine transforms under the reference's chains)
     switch (env.logn1) {
-    case 0: launch_ks_lds_n<0>(env, A, n_ops, source_major); break;
-    case 1: launch_ks_lds_n<1>(env, A, n_ops, source_major); break;
-    case 2: launch_ks_lds_n<2>(env, A, n_ops, source_major); break;
-    default: launch_ks_lds_n<3>(env, A, n_ops, source_major); break;
+    case 0: launch_ks_lds_n<0>(env, A, n_ops); break;
+    case 1: launch_ks_lds_n<1>(env, A, n_ops); break;
+    case 2: launch_ks_lds_n<2>(env, A, n_ops); break;
+    default: launch_ks_lds_n<3>(env, A, n_ops); break;
     }
 }
 

@@ -750,15 +750,14 @@ def test_lds_shape_equals_the_other_shapes_and_the_oracle(pair, be, n):
     want_rot_add = [o.add(want_rl[r], o.apply_galois(a[r], e3, gk3)) for r in range(n)]
     fits = N <= 8192 and L <= 8
     try:
-        for lds, form in ((64, 1), (64, 2), (64, 0), (0, 0)):  # target-major, source-major, the library's choice of form, the HBM shapes
+        for lds in (64, 0):
             g.set_lds_max(lds)
-            g.set_lds_form(form)
             g.path_stats(reset=True)
             out = g.alloc(n * 2 * L * N)
             g.multiply_relin(L, n, da, db, ix, out)
             got = out.download((n, 2, L, N))
             for r in range(n):
-                assert np.array_equal(got[r], want_rl[r]), ("multiply_relin", lds, form, r)
+                assert np.array_equal(got[r], want_rl[r]), ("multiply_relin", lds, r)
             g.relinearize(L, n, d3, out)
             got = out.download((n, 2, L, N))
             for r in range(n):
@@ -801,7 +800,6 @@ def test_lds_shape_equals_the_other_shapes_and_the_oracle(pair, be, n):
                 assert st["ks_lds"] == 0, st
     finally:
         g.set_lds_max(None)
-        g.set_lds_form(0)
 
 
 def test_pipeline_regression_fixture_gpu(be, oracle):
