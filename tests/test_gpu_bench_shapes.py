@@ -23,6 +23,11 @@ if ROOT not in sys.path:
 
 pytestmark = pytest.mark.gpu
 
+# The path-counter assertions describe the LIBRARY'S OWN choice of shape: under a run-time setting that pins another one (tools/test_matrix.sh
+# runs this module under all of them) only the bits are held to the oracle.
+_SHAPE_ENV = ("HE355_K3_FUSE", "HE355_CHUNK", "HE355_LATENCY_MAX", "HE355_LEVEL_WALK", "HE355_LDS_MAX", "HE355_DUAL_ENGINE", "HE355_FORCE_U64")
+DEFAULT_SHAPES = not any(os.environ.get(k) for k in _SHAPE_ENV)
+
 
 @pytest.fixture(scope="module")
 def be():
@@ -85,9 +90,9 @@ def test_bench_shape_first_and_last_rows_equal_the_oracle(be, oracle, name, batc
         wl.step()
         ctx.sync()
         st = ctx.path_stats()
-        if name in ("mul_relin_rescale", "mul_relin"):
+        if DEFAULT_SHAPES and name in ("mul_relin_rescale", "mul_relin"):
             assert st["ks_fused"] >= 1 and st["ks_unfused"] == 0 and st["ks_latency"] == 0, st  # the headline is the fused throughput shape
-        if name == "dot":
+        if DEFAULT_SHAPES and name == "dot":
             assert st["ks_fused"] == 13 and st["ks_latency"] == 0 and st["ks_unfused"] == 0, st  # 1 relinearization + 12 rotations, all fused at n = 64
         _check_first_and_last(oracle, _oracle_ctx(oracle, W, bits, ctx), wl, rows)
     finally:
@@ -107,12 +112,14 @@ def test_bfv_matmul_bench_shape_level_sums_inside_the_key_switch(be, oracle):
         ctx.sync()
         st = ctx.path_stats()
         assert wl.key_switches == 127
+        full = wl.result.download((64, 2, wl.L, wl.N)).copy()
+        _check_first_and_last(oracle, _oracle_ctx(oracle, W, bits, ctx), wl, 1)
+        if not DEFAULT_SHAPES:
+            return  # (another shape was pinned from outside: the bits above are what this run can hold)
         levels = st["level_sums_in_k3"] + st["level_sums_by_kernel"]
         assert levels >= 4 and st["level_sums_by_kernel"] == 0 and st["level_sums_in_k3"] == levels, st  # (the NAF trie of j * 128, j < 128, is 4 deep)
         launches_default = st["level_sum_launches_in_k3"]
         assert launches_default >= levels, st  # (a level of 13-50 nodes x 64 ciphertexts is cut at the default chunk of 1024 too: whole groups per launch)
-        full = wl.result.download((64, 2, wl.L, wl.N)).copy()
-        _check_first_and_last(oracle, _oracle_ctx(oracle, W, bits, ctx), wl, 1)
         # (a) chunk = 5 groups of 64: levels of 13-50 nodes are cut into several launches, each with its own g_op_offset, all summing in k_k3
         ctx.set_chunk(5 * 64)
         ctx.path_stats(reset=True)

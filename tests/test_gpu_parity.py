@@ -795,11 +795,54 @@ def test_lds_shape_equals_the_other_shapes_and_the_oracle(pair, be, n):
                 assert np.array_equal(got[r], want_rot_add[r]), ("rotate_add in place", lds, r)
             st = g.path_stats()
             if lds and fits:
-                assert st["ks_lds"] == (7 if L >= 2 else 5) and st["ks_fused"] == st["ks_unfused"] == st["ks_latency"] == 0, st
+                assert st["ks_lds"] >= (7 if L >= 2 else 5) and st["ks_fused"] == st["ks_unfused"] == st["ks_latency"] == 0, st
             else:
                 assert st["ks_lds"] == 0, st
     finally:
         g.set_lds_max(None)
+
+
+@pytest.mark.parametrize("N,bits,expect_lds", [
+    (4096, [60, 40, 40, 40, 40, 60], True),            # L = 5, both engines
+    (2048, [46, 36, 36, 36, 36, 36, 46], True),        # L = 6: the longest chain whose partial products fit the key-switch arena
+    (2048, [46, 36, 36, 36, 36, 36, 36, 46], False),   # L = 7: outside the shape -- the HBM shapes take it, same bits
+])
+def test_lds_shape_long_chains(be, oracle, N, bits, expect_lds):
+    """The ring-in-LDS kernels at the ends of their range: every level of a 5- and a 6-prime chain (the partial-product buffer is
+    (2L + 4) L N words carved from the arena behind c01), and one prime more, where the library must fall back."""
+    g = be.Context(be.SCHEME_CKKS, N, bit_sizes=bits, sec128=False, device=0)
+    o = oracle.Context(oracle.SCHEME_CKKS, N, bit_sizes=bits, sec128=False)
+    rng = np.random.default_rng(len(bits) * 1000 + N)
+    try:
+        g.set_lds_max(None)  # the library's own rule, whatever HE355_LDS_MAX the code-path matrix runs this module under
+        rk, gk = o.random_kswitch_key(rng), o.random_kswitch_key(rng)
+        e1 = o.galois_elt(1)
+        g.set_relin_key(rk)
+        g.set_galois_key(e1, gk)
+        n = 2
+        for L in range(g.L, 0, -1):
+            a, b = rand_cts(o, rng, n, L), rand_cts(o, rng, n, L)
+            da, db = g.to_device(a), g.to_device(b)
+            g.path_stats(reset=True)
+            out = g.alloc(n * 2 * L * N)
+            g.multiply_relin(L, n, da, db, be.Context.pairwise(), out)
+            got = out.download((n, 2, L, N))
+            for r in range(n):
+                assert np.array_equal(got[r], o.relinearize(o.multiply_ntt(a[r], b[r]), rk)), (L, r)
+            g.rotate(L, n, da, 1, out)
+            got = out.download((n, 2, L, N))
+            for r in range(n):
+                assert np.array_equal(got[r], o.apply_galois(a[r], e1, gk)), (L, r)
+            if L >= 2:
+                out2 = g.alloc(n * 2 * (L - 1) * N)
+                g.rescale(L, 2, n, da, out2)
+                got = out2.download((n, 2, L - 1, N))
+                for r in range(n):
+                    assert np.array_equal(got[r], o.rescale(a[r])), (L, r)
+            st = g.path_stats()
+            assert (st["ks_lds"] >= 2) == (expect_lds or L <= 6), (L, st)
+    finally:
+        g.close()
 
 
 def test_pipeline_regression_fixture_gpu(be, oracle):

@@ -22,6 +22,6 @@ CFGS=("HE355_NONE=1" "HE355_LDS_MAX=0" "HE355_LDS_MAX=64" "HE355_K3_FUSE=0 HE355
 FIRST=${1:-0}; COUNT=${2:-${#CFGS[@]}}
 for cfg in "${CFGS[@]:$FIRST:$COUNT}"; do
   echo "== $cfg"
-  env $cfg timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -1 || rc=1
+  env $cfg timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "^FAILED|^ERROR| passed| failed" | tail -3 || rc=1
 done
 exit $rc
