@@ -110,7 +110,8 @@ VectorBenchmark::VectorBenchmark(hebench::cpp::BaseEngine &engine, const AB::Ben
         m_p_ctx_wrapper = HeContextWrapper::createCKKSContext(poly_modulus_degree, multiplicative_depth, (int)coeff_modulus_bits, (int)extra_bits);
     else
         m_p_ctx_wrapper = HeContextWrapper::createBFVContext(poly_modulus_degree, multiplicative_depth, (int)coeff_modulus_bits, (int)extra_bits);
-    m_p_ctx_wrapper->prepareClient(256);
+    // (decode() reads n slots of every result, one for a dot product: the warm-up and the staging buffer are sized for that)
+    m_p_ctx_wrapper->prepareClient(256, bench_desc.workload == AB::Workload::DotProduct ? 1 : m_w_params.n());
     const std::size_t slot_count = m_p_ctx_wrapper->slot_count();
     if (m_w_params.n() > slot_count)
         throw HEBenchError(HEBERROR_MSG_CLASS("Vector size cannot be greater than " + std::to_string(slot_count) + "."), HEBENCH_ECODE_INVALID_ARGS);

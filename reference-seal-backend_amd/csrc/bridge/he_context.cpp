@@ -42,13 +42,15 @@ HeContextWrapper::~HeContextWrapper()
     if (m_pinned) (void)he355_host_free(m_ctx, m_pinned);
     if (m_ctx) he355_ctx_destroy(m_ctx);
 }
-// The page-locked staging buffer: 1 MiB, allocated once (prepareClient, i.e. createBenchmark) -- page-locking memory costs milliseconds, so
-// it never grows inside a phase; transfers beyond it go to pageable memory, where the copy itself dominates anyway.
-void *HeContextWrapper::pinned(std::uint64_t bytes)
+// The page-locked staging buffer: sized once at createBenchmark (prepareClient: the workload's batch x the slots its decode() reads, 1 MiB
+// at least, 64 MiB at most) -- page-locking memory costs milliseconds, so it never grows inside a phase; a transfer beyond it goes to
+// pageable memory (the runtime's own staging: 1-28 ms for 16 MiB on the MI355X box, profiles/r06_decode_probe.txt).
+void *HeContextWrapper::pinned(std::uint64_t bytes, std::uint64_t reserve)
 {
     if (!m_pinned) {
-        check(he355_host_alloc(m_ctx, (std::uint64_t)1 << 20, &m_pinned), "page-locked buffer");
-        m_pinned_bytes = (std::uint64_t)1 << 20;
+        const std::uint64_t want = std::min<std::uint64_t>((std::uint64_t)64 << 20, std::max<std::uint64_t>((std::uint64_t)1 << 20, reserve));
+        check(he355_host_alloc(m_ctx, want, &m_pinned), "page-locked buffer");
+        m_pinned_bytes = want;
     }
     return bytes <= m_pinned_bytes ? m_pinned : nullptr;
 }
@@ -65,19 +67,21 @@ template <class T> HeContextWrapper::Decoded<T> HeContextWrapper::fetchDecoded(c
     out.ptr = host;
     return out;
 }
-void HeContextWrapper::prepareClient(std::uint64_t batch_hint)
+void HeContextWrapper::prepareClient(std::uint64_t batch_hint, std::uint64_t slots_hint)
 {
     if (!clientOnDevice()) return; // (no device: the host client needs nothing prepared)
-    (void)pinned(1);
-    // one throw-away encode -> decode of `batch_hint` empty vectors sizes the client scratch and the pool's size classes, builds the encoder
-    // and CRT tables and pages the kernels in: the first real encode() then costs what the second one does
+    const std::uint64_t slots = std::max<std::uint64_t>(1, std::min<std::uint64_t>(slots_hint, slot_count()));
+    (void)pinned(1, std::max<std::uint64_t>(1, batch_hint) * slots * 8);
+    // one throw-away encode -> decode of `batch_hint` empty vectors over the slots the workload's decode() reads sizes the client scratch and
+    // the pool's size classes, builds the encoder and CRT tables and pages the kernels in: the first real encode() / decode() then cost what
+    // the second ones do
     const std::uint64_t n = std::max<std::uint64_t>(1, std::min<std::uint64_t>(batch_hint, 256));
     if (isCKKS()) {
         const std::vector<Plain> pl = encodeBatch(std::vector<std::vector<double>>(n, std::vector<double>(1, 0.0)));
-        (void)decodeSlotsCKKS(pl, SlotRanges{{0, 1}});
+        (void)decodeSlotsCKKS(pl, SlotRanges{{0, slots}});
     } else if (m_params->plain_modulus > 2 && (m_params->plain_modulus - 1) % (2 * m_params->N) == 0) {
         const std::vector<Plain> pl = encodeBatch(std::vector<std::vector<std::int64_t>>(n, std::vector<std::int64_t>(1, 0)));
-        (void)decodeSlotsBFV(pl, SlotRanges{{0, 1}});
+        (void)decodeSlotsBFV(pl, SlotRanges{{0, slots}});
     }
 }
 

@@ -116,7 +116,7 @@ public:
     // Everything the first encode() / encrypt() / decode() of a benchmark would otherwise pay for inside the call: device + streams, the
     // client keys in HBM, the encoders' tables, the client scratch for `batch_hint` objects and the page-locked staging buffer.  Called by
     // the benchmark constructors (createBenchmark is where the reference generates its keys: seal_context.cpp:46-70).
-    void prepareClient(std::uint64_t batch_hint = 1);
+    void prepareClient(std::uint64_t batch_hint = 1, std::uint64_t slots_hint = 1);
     Cipher encrypt(const Plain &plain);
     Plain decrypt(const Cipher &cipher);
     std::vector<Cipher> encryptBatch(const std::vector<Plain> &plains);   // one device call for the whole operand when a GPU is present
@@ -160,9 +160,9 @@ private:
     double m_scale = 1.0;
     bool m_device = false, m_relin = false;
     int m_client_dev = -1; // -1: not decided yet
-    void *m_pinned = nullptr; // page-locked staging of decode results / encode inputs (he355_host_alloc), grown on demand
+    void *m_pinned = nullptr; // page-locked staging of decode results / encode inputs (he355_host_alloc), sized by prepareClient, never grown inside a phase
     std::uint64_t m_pinned_bytes = 0;
-    void *pinned(std::uint64_t bytes);
+    void *pinned(std::uint64_t bytes, std::uint64_t reserve = 0);
     template <class T> Decoded<T> fetchDecoded(const void *d_src, std::uint64_t count);
     std::map<uint32_t, bool> m_galois;
 };

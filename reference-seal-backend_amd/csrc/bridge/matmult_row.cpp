@@ -88,7 +88,7 @@ MatMultRowLatencyBenchmark::MatMultRowLatencyBenchmark(hebench::cpp::BaseEngine 
     const std::uint64_t depth = m_w[MatMultRowBenchmarkDescription::Index_NumCoefficientModuli];
     const int bits = (int)m_w[MatMultRowBenchmarkDescription::Index_CoefficientModulusBits], extra = (int)m_w[MatMultRowBenchmarkDescription::Index_PlainModulusBits];
     m_p_ctx_wrapper = scheme == Scheme::CKKS ? HeContextWrapper::createCKKSContext(N, depth, bits, extra) : HeContextWrapper::createBFVContext(N, depth, bits, extra);
-    m_p_ctx_wrapper->prepareClient(256);
+    m_p_ctx_wrapper->prepareClient(256, cols_M1()); // (decode() reads dim3 slots per batching row)
     m_num_devices = DeviceGroup::resolveCount(0); // HE355_NUM_DEVICES: the declared workload parameters stay the reference's
 }
 
