@@ -50,6 +50,25 @@ def test_ckks_eltwise_multiply_offline_size3_results(backend):
     backend.destroy(hb)
 
 
+@pytest.mark.parametrize("scheme,counts", [(SCHEME_CKKS, (16, 16)), (SCHEME_CKKS, (20, 20)), (SCHEME_BFV, (20, 20))])
+def test_eltwise_add_every_slot_decoded_through_the_staging_buffer(backend, scheme, counts):
+    """decode() of whole-slot results: 16 x 16 results x 4096 slots x 8 B = 8 MiB fits the page-locked staging buffer createBenchmark sizes
+    (256 results x n slots), 20 x 20 = 12.5 MiB does not and takes the pageable path -- same values either way (he_context.cpp: pinned)."""
+    rng = np.random.default_rng(77)
+    n = 4096
+    if scheme == SCHEME_CKKS:
+        a, b = rng.uniform(-1, 1, (counts[0], n)), rng.uniform(-1, 1, (counts[1], n))
+        hb = backend.create(backend.find(W_ADD, SCHEME_CKKS, OFFLINE), ckks_params(n), counts)
+        res = backend.run(hb, [a, b], n, np.float64)
+        assert np.allclose(res, (a[:, None, :] + b[None, :, :]).reshape(-1, n), atol=1e-4)
+    else:
+        a, b = rng.integers(-1000, 1000, (counts[0], n)), rng.integers(-1000, 1000, (counts[1], n))
+        hb = backend.create(backend.find(W_ADD, SCHEME_BFV, OFFLINE), bfv_params(n), counts)
+        res = backend.run(hb, [a.astype(np.int64), b.astype(np.int64)], n, np.int64)
+        assert np.array_equal(res, (a[:, None, :] + b[None, :, :]).reshape(-1, n))
+    backend.destroy(hb)
+
+
 def test_ckks_eltwise_multiply_latency_with_indexers(backend):
     rng = np.random.default_rng(2)
     n = 10
