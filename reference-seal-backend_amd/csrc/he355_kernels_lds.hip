@@ -477,12 +477,17 @@ template <int LOGN1> void lds_attrs()
 {
     constexpr int N1 = 1 << LOGN1;
     constexpr size_t lds_bytes = (size_t)N1 * kLdsRow * sizeof(u64), lds_bytes2 = lds_bytes + (size_t)N1 * kRowN * sizeof(u64);
-    static bool attr_done = false; // (per build of the device code; the attribute is per function, set once)
+    // per build of the device code AND per device: a function's attributes belong to the device it was loaded on, and a DeviceGroup
+    // (csrc/bridge/multi_device.cpp) drives several devices from one process
+    static bool attr_done_dev[64] = {};
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) dev_id = 63; // (slot 63 is never marked done: set every time)
+    bool &attr_done = attr_done_dev[dev_id];
     if (attr_done) return;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lds_digits<LOGN1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lds_floor<LOGN1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes2) != hipSuccess)
         throw std::runtime_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the LDS-resident key switch");
-    attr_done = true;
+    attr_done = dev_id != 63;
 }
 template <int LOGN1> void launch_floor_lds_n(const KernelEnv &env, const LdsFloorArgs &F, u64 n_ops)
 {
