@@ -460,6 +460,58 @@ def dry_run(args, rank, world, dist, torch) -> int:
     return 0
 
 
+
+def sample_power(props, run_steps, step_seconds, window_seconds=1.5):
+    """Median / maximum package power (PPT) and core clock the device reports while `run_steps(k)` runs k steps, about `window_seconds` of them, read from
+    the hwmon directory of the device's PCI function; None when the files are not there or not readable (the line then carries no `power`)."""
+    import glob
+    import threading
+    try:
+        bdf = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, props.pci_device_id)
+        dirs = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+        if not dirs or not os.path.exists(os.path.join(dirs[0], "power1_input")):
+            return None
+        hw = dirs[0]
+
+        def read(name):
+            with open(os.path.join(hw, name)) as f:
+                return int(f.read().strip())
+
+        cap = read("power1_cap") / 1e6 if os.path.exists(os.path.join(hw, "power1_cap")) else None
+        idle = read("power1_input") / 1e6
+        samples, stop = [], threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                try:
+                    samples.append((read("power1_input") / 1e6, read("freq1_input") / 1e6 if os.path.exists(os.path.join(hw, "freq1_input")) else None))
+                except OSError:
+                    pass
+                stop.wait(0.02)
+
+        steps = max(3, min(20000, int(window_seconds / max(step_seconds, 1e-6))))
+        th = threading.Thread(target=poll, daemon=True)
+        t0 = time.perf_counter()
+        th.start()
+        run_steps(steps)  # queued back to back like the timed steps, one synchronisation at the end
+        window = time.perf_counter() - t0
+        stop.set()
+        th.join(timeout=2.0)
+        busy = samples[len(samples) // 3:]  # the telemetry is a moving average: the first third of the window is its ramp
+        if len(busy) < 3:
+            return None
+        watts = sorted(w for w, _ in busy)
+        mhz = sorted(m for _, m in busy if m)
+        med = watts[len(watts) // 2]
+        return {"package_w_median": round(med, 1), "package_w_max": round(watts[-1], 1), "cap_w": cap, "frac_of_cap": round(med / cap, 3) if cap else None,
+                "package_w_at_start": round(idle, 1), "sclk_mhz_median": round(mhz[len(mhz) // 2], 1) if mhz else None, "samples": len(busy),
+                "window_s": round(window, 3), "steps": steps,
+                "source": f"hwmon of PCI function {bdf}: power1_input (PPT), power1_cap, freq1_input, read every 20 ms by a host thread during an extra "
+                          "untimed run; the last two thirds of the window are used (the telemetry is a moving average)"}
+    except Exception as ex:  # noqa: BLE001 -- a missing or unreadable sensor must never cost the bench line
+        return {"error": str(ex)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -616,6 +668,12 @@ def main():
         clock = {"sustained_mhz": round(mhz, 1), "seconds_covered": round(covered, 6),
                  "source": "in-run: d(s_memtime) / d(s_memrealtime) x 100 MHz of one probe wave running beside one extra untimed step"}
 
+    # ---- package power and core clock under this load: an extra untimed run of ~1.5 s while a host thread reads the device's hwmon files
+    # (power1_input = PPT in microwatts, power1_cap, freq1_input = sclk) every 20 ms -- sysfs reads, no subprocess; rank 0 at N = 1 only ----
+    power = None
+    if n > 0 and not args.profile_mode and rank == 0 and world == 1:
+        power = sample_power(torch.cuda.get_device_properties(device), lambda k: ([wl.step() for _ in range(k)], ctx.sync()), elapsed / args.steps)
+
     # ---- dominant kernel, single stream: one extra untimed step with the two-stream schedule off, HIP events around each launch ----
     k3 = None
     if args.config in ("mul_relin_rescale", "mul_relin", "dot") and n > 0 and not args.profile_mode:
@@ -740,7 +798,7 @@ def main():
         roof = {"bound": bound, "bound_why": bound_why,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 5),
                 "traffic": traffic, "traffic_unit": "bytes per step per GPU" if traffic is not None else None, "traffic_source": traffic_src,
-                "valu": valu, "clock_probe": clock,
+                "valu": valu, "clock_probe": clock, "power": power,
                 "algorithmic_bytes_per_op": round(bytes_op, 1),
                 "compulsory_bytes_per_op": round(comp_op, 1), "frac_of_compulsory": round(comp_op * total_results / elapsed / world / HBM_PEAK, 5),
                 "kernel": "whole kernel sequence of the step (per GPU); the dominant kernel's own figures are under dominant_kernel",
